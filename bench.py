@@ -1,0 +1,246 @@
+#!/usr/bin/env python3
+"""bench.py -- log-density+gradient evaluations per second of the Dixon-Coles hot path.
+
+Contract: `python bench.py --gpus N --steps K --warmup W` (for N > 1 launched by
+torch.distributed.run, one rank per GPU).  A *step* is ONE evaluation of (U, grad U) of
+the basic Dixon-Coles model over the whole synthetic fixture set (N_fix = 1e6 fixtures,
+T = 20 teams -- the configuration BASELINE.json's metric is quoted on), inputs resident
+in HBM.  Every rank is an independent chain (weak scaling, no data-path collective):
+rank 0 generates the fixtures, broadcasts them over RCCL, each rank binds them to its own
+libbplhip context and evaluates a fixed cycle of 64 latent points back to back through
+the hipGraph path the NUTS driver uses for tree doublings.  Prints ONE JSON line.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "bpl-next_amd"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+BYTES_PER_FIXTURE = 6  # u16 + u16 + u8 + u8 (10 with f32 weights)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=4096)
+    ap.add_argument("--warmup", type=int, default=512)
+    ap.add_argument("--fixtures", type=int, default=1_000_000)
+    ap.add_argument("--teams", type=int, default=20)
+    ap.add_argument("--graph-len", type=int, default=64,
+                    help="evaluations captured per hipGraph (0 = direct launches)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-insitu", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    return ap.parse_args()
+
+
+def synthetic_league(n, n_teams, seed=2024):
+    """the T(T-1) ordered pairs tiled cyclically; truth strengths
+    N(0, 0.3^2), home advantage 0.25, Poisson goals (RandomState(seed))."""
+    import itertools
+
+    import numpy as np
+
+    teams = sorted(str(i) for i in range(n_teams))  # string-sorted, bpl/_util.py:131
+    idx = {t: i for i, t in enumerate(teams)}
+    perms = list(itertools.permutations([str(i) for i in range(n_teams)], 2))
+    ph = np.array([idx[p[0]] for p in perms], dtype=np.uint16)
+    pa = np.array([idx[p[1]] for p in perms], dtype=np.uint16)
+    k = np.arange(n) % len(perms)
+    h, a = ph[k], pa[k]
+    rs = np.random.RandomState(seed)
+    att = rs.normal(0.0, 0.3, n_teams)
+    dfn = rs.normal(0.0, 0.3, n_teams)
+    x = np.minimum(rs.poisson(np.exp(att[h] - dfn[a] + 0.25)), 255).astype(np.uint8)
+    y = np.minimum(rs.poisson(np.exp(att[a] - dfn[h])), 255).astype(np.uint8)
+    return h, a, x, y
+
+
+def cpu_baseline(h, a, x, y, n_teams, zs, budget_s):
+    """The CPU path timed beside the GPU: the oracle's C restatement ("port") on the
+    host cores of this box, same fixtures, same z cycle, bounded sample."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import dc_oracle as O
+    import dc_oracle_c as OC
+
+    fx = O.Fixtures(h, a, x, y, n_teams)
+    cf = OC.CFixtures(O.MODEL_BASIC, fx)
+    out = {}
+    for label, nt in (("all", OC.max_threads()), ("one", 1)):
+        OC.potential_and_grad(cf, zs[0], nt)  # warm
+        t0 = time.perf_counter()
+        k = 0
+        while True:
+            OC.potential_and_grad(cf, zs[k % len(zs)], nt)
+            k += 1
+            el = time.perf_counter() - t0
+            if el >= budget_s / 2 or k >= 4096:
+                break
+        out[label] = (k / el, nt, k, el)
+    v, nt, k, el = out["all"]
+    return {
+        "value": v,
+        "unit": "evals/s",
+        "cores": nt,
+        "kind": "port",
+        "sample": f"{k} evals of the same {len(h)}-fixture workload in {el:.1f}s, "
+                  f"C float64 restatement (oracle/dc_oracle.c), OpenMP {nt} threads",
+        "single_thread_value": out["one"][0],
+    }
+
+
+def main():
+    args = parse_args()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    if world != args.gpus and rank == 0:
+        print(f"# note: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
+
+    from bpl import _dist
+    from bpl._ffi import MODEL_BASIC, HipContext, default_nuts_cfg, prng_key, threefry_split
+
+    ctx = HipContext(local)
+    dev = ctx.device
+    T = args.teams
+    if rank == 0:
+        h, a, x, y = synthetic_league(args.fixtures, T)
+    else:
+        h = a = np.zeros(0, np.uint16)
+        x = y = np.zeros(0, np.uint8)
+    # RCCL broadcast of the fixture SoA from rank 0 (the only data collective)
+    bc = _dist.broadcast_fixtures({"home_idx": h, "away_idx": a, "home_goals": x,
+                                   "away_goals": y}, device=dev)
+    ctx.set_fixtures(MODEL_BASIC, bc["home_idx"], bc["away_idx"], bc["home_goals"],
+                     bc["away_goals"], T)
+    D = ctx.dim
+    n_fix = int(bc["home_idx"].numel())
+
+    # fixed z cycle: RandomState(7).uniform(-0.5, 0.5, (64, D))  
+    zs = np.random.RandomState(7).uniform(-0.5, 0.5, (64, D))
+    z = torch.tensor(zs, dtype=torch.float64, device=dev)
+    U = torch.zeros(64, dtype=torch.float64, device=dev)
+    g = torch.zeros_like(z)
+
+    glen = args.graph_len
+    if glen > 0:  # the graph length must divide both the timed and the warm-up count
+        glen = math.gcd(glen, args.steps)
+        if args.warmup:
+            glen = math.gcd(glen, args.warmup)
+
+    def run(k):
+        if glen > 0:
+            ctx.logp_grad_graph(glen, z, U, g, replays=k // glen)
+        else:
+            for i in range(k):
+                j = i % 64
+                ctx.logp_grad(z[j], U[j:j + 1], g[j], None)
+
+    run(args.warmup)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    run(args.steps)
+    ev1.record()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    ev_ms = ev0.elapsed_time(ev1)
+    tmax = torch.tensor([wall], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    wall_max = float(tmax.item())
+
+    # sanity: the timed outputs are the real thing (compare one point with a direct call)
+    Uc, gc, _ = ctx.logp_grad(z[5].contiguous())
+    assert torch.equal(Uc[0], U[5]) and torch.equal(gc, g[5]), "graph path != direct path"
+
+    # dominant kernel alone (dc_stream is >90% of the bytes): HIP-event timed period of
+    # back-to-back evaluations on this stream = ev_ms / steps (includes the epilogue
+    # kernel and the inter-kernel gaps -> conservative for the roofline)
+    per_eval_us = ev_ms * 1e3 / args.steps
+    achieved = n_fix * BYTES_PER_FIXTURE / (per_eval_us * 1e-6) / 1e9
+
+    extra = {}
+    if rank == 0 and not args.no_insitu:
+        # in situ: leapfrogs/s of a real NUTS chain on the same data (short, bounded)
+        cfg = default_nuts_cfg()
+        cfg.num_warmup, cfg.num_samples = 30, 20
+        _, st = ctx.nuts_run(cfg, prng_key(42))
+        extra["insitu_leapfrogs_per_s"] = st["total_leapfrogs"] / st["wall_seconds"]
+        extra["insitu_leapfrogs"] = st["total_leapfrogs"]
+
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        with open(tpath) as f:
+            traffic = json.load(f).get("hbm_bytes_per_eval")
+
+    if rank == 0:
+        out = {
+            "metric": "log-density+grad evals/sec, 1e6 fixtures, 1/2/4/8 chains x MI355X",
+            "value": world * args.steps / wall_max,
+            "unit": "evals/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": wall_max * 1e3 / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32 per-fixture arithmetic, f64 accumulation/epilogue",
+            "data": "synthetic",
+            "config": {
+                "workload": f"dixon_coles_basic logp+grad, {n_fix} fixtures, {T} teams, "
+                            f"D={D}, 1 chain per GPU, hipGraph of {glen} evals",
+                "fixtures": n_fix,
+                "teams": T,
+                "parallelism": f"{world} independent chain(s), one per GPU",
+            },
+            "roofline": {
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": traffic,
+                "kernel": "dc_stream (+dc_epilogue, launch gaps included)",
+                "us_per_eval_events": per_eval_us,
+                "algorithmic_bytes_per_eval": n_fix * BYTES_PER_FIXTURE,
+            },
+        }
+        out.update(extra)
+        if not args.no_cpu_baseline:
+            hh = bc["home_idx"].cpu().numpy().view(np.uint16)
+            aa = bc["away_idx"].cpu().numpy().view(np.uint16)
+            out["cpu_baseline"] = cpu_baseline(hh, aa, bc["home_goals"].cpu().numpy(),
+                                               bc["away_goals"].cpu().numpy(), T, zs,
+                                               args.cpu_seconds)
+        print(json.dumps(out))
+    ctx.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

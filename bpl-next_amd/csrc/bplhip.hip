@@ -1,0 +1,621 @@
+// bplhip.hip -- C-ABI (include/bplhip.h) over the gfx950 kernels in dc_kernels.hip.h.
+// Host side: context, fixture re-layout (sort by (home,away) pair, pad to the wave
+// tile, data-only sums), launch sequences, hipGraph replay, and the NUTS driver glue.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "../../include/bplhip.h"
+#include "dc_kernels.hip.h"
+#include "nuts.hpp"
+#include "threefry.hpp"
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    ~DevBuf() { release(); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    hipError_t ensure(size_t n) {
+        if (n <= bytes) return hipSuccess;
+        release();
+        hipError_t e = hipMalloc(&p, n);
+        if (e == hipSuccess) bytes = n;
+        return e;
+    }
+    template <class T>
+    T* as() const {
+        return static_cast<T*>(p);
+    }
+};
+
+struct GraphKey {
+    int count, n_z;
+    const void *z, *pot, *grad;
+    bool operator<(const GraphKey& o) const {
+        return std::tie(count, n_z, z, pot, grad) <
+               std::tie(o.count, o.n_z, o.z, o.pot, o.grad);
+    }
+};
+
+}  // namespace
+
+struct bplhip_ctx {
+    int device = 0;
+    std::string err;
+    bool bound = false;
+    dc::Layout L{};
+    int64_t n = 0;
+    int n_tiles = 0, tiles_per_wave = 1, n_wg = 1;
+    bool weighted = false;
+    int P = 0;
+    double lgsum = 0.0;
+    // device buffers (library owned)
+    DevBuf d_h, d_a, d_x, d_y, d_w, d_pairs, d_xs, d_cA, d_cD, d_cH, d_slabs, d_bounds;
+    int slab_chains = 0;
+    // NUTS scratch (device): z, potential, grad, aux + pinned host mirror
+    DevBuf d_nuts;
+    double* h_pinned = nullptr;
+    size_t h_pinned_bytes = 0;
+    // host copies needed by bplhip_constrain (rho bounds over the unique pairs)
+    std::vector<uint32_t> h_pairs;
+    std::vector<double> h_xs;
+    std::map<GraphKey, hipGraphExec_t> graphs;
+    hipStream_t cap_stream = nullptr;
+
+    ~bplhip_ctx() {
+        for (auto& kv : graphs) (void)hipGraphExecDestroy(kv.second);
+        if (cap_stream) (void)hipStreamDestroy(cap_stream);
+        if (h_pinned) (void)hipHostFree(h_pinned);
+    }
+};
+
+namespace {
+
+int fail(bplhip_ctx* c, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf;
+    else g_create_error = buf;
+    return code;
+}
+
+#define HIP_TRY(c, expr)                                                            \
+    do {                                                                            \
+        hipError_t e_ = (expr);                                                     \
+        if (e_ != hipSuccess)                                                       \
+            return fail((c), BPLHIP_EHIP, "%s failed: %s (%s:%d)", #expr,           \
+                        hipGetErrorString(e_), __FILE__, __LINE__);                 \
+    } while (0)
+
+size_t stream_lds_bytes(int T) {
+    const int T1 = T + 1;
+    size_t b = 2 * (size_t)((T1 + 1) & ~1) * sizeof(float2);
+    b += (size_t)(3 * T1 + ((3 * T1) & 1)) * sizeof(double);
+    b += (size_t)dc::STREAM_WAVES * dc::N_SCAL * sizeof(double);
+    b += (size_t)dc::STREAM_WAVES * 3 * sizeof(unsigned long long);
+    b += 2 * sizeof(double);
+    return b;
+}
+
+size_t epi_lds_bytes(int T) {
+    const int ncol = 3 * T + dc::N_SCAL;
+    int RG = dc::EPI_BLOCK / ncol;
+    RG = RG < 1 ? 1 : (RG > 8 ? 8 : RG);
+    return (size_t)(ncol + 64 + (size_t)RG * ncol) * sizeof(double);
+}
+
+constexpr size_t LDS_LIMIT = 160 * 1024;
+
+int ensure_slabs(bplhip_ctx* c, int chains) {
+    if (chains <= c->slab_chains) return BPLHIP_OK;
+    const size_t stride = 3 * (size_t)c->L.T + dc::N_SCAL;
+    HIP_TRY(c, c->d_slabs.ensure((size_t)chains * c->n_wg * stride * sizeof(double)));
+    HIP_TRY(c, c->d_bounds.ensure((size_t)chains * dc::BOUNDS_WORDS * sizeof(uint32_t)));
+    c->slab_chains = chains;
+    return BPLHIP_OK;
+}
+
+// Enqueue one (batched) evaluation: dc_stream then dc_epilogue.  No host sync.
+int launch_eval(bplhip_ctx* c, int chains, const double* z, double* pot, double* grad,
+                double* aux, hipStream_t s) {
+    dc::StreamArgs A{};
+    A.h = c->d_h.as<const uint4>();
+    A.a = c->d_a.as<const uint4>();
+    A.x = c->d_x.as<const uint2>();
+    A.y = c->d_y.as<const uint2>();
+    A.w = c->weighted ? c->d_w.as<const float4>() : nullptr;
+    A.n_tiles = c->n_tiles;
+    A.tiles_per_wave = c->tiles_per_wave;
+    A.pairs = c->d_pairs.as<const uint32_t>();
+    A.P = c->P;
+    A.xs = c->L.K ? c->d_xs.as<const double>() : nullptr;
+    A.slabs = c->d_slabs.as<double>();
+    A.slab_stride = 3 * c->L.T + dc::N_SCAL;
+    A.bounds = c->d_bounds.as<uint32_t>();
+    A.L = c->L;
+    const dim3 grid(c->n_wg, chains), block(dc::STREAM_BLOCK);
+    const size_t lds = stream_lds_bytes(c->L.T);
+    const bool clip = c->L.model == dc::MODEL_EXTENDED;
+    if (c->weighted) {
+        if (clip) hipLaunchKernelGGL((dc::dc_stream<true, true>), grid, block, lds, s, A, z);
+        else hipLaunchKernelGGL((dc::dc_stream<true, false>), grid, block, lds, s, A, z);
+    } else {
+        if (clip) hipLaunchKernelGGL((dc::dc_stream<false, true>), grid, block, lds, s, A, z);
+        else hipLaunchKernelGGL((dc::dc_stream<false, false>), grid, block, lds, s, A, z);
+    }
+    dc::EpiArgs E{};
+    E.slabs = c->d_slabs.as<const double>();
+    E.n_wg = c->n_wg;
+    E.slab_stride = A.slab_stride;
+    E.bounds = c->d_bounds.as<const uint32_t>();
+    E.xs = A.xs;
+    E.cA = c->d_cA.as<const double>();
+    E.cD = c->d_cD.as<const double>();
+    E.cH = c->d_cH.as<const double>();
+    E.lgsum = c->lgsum;
+    E.L = c->L;
+    hipLaunchKernelGGL(dc::dc_epilogue, dim3(chains), dim3(dc::EPI_BLOCK),
+                       epi_lds_bytes(c->L.T), s, E, z, pot, grad, aux);
+    HIP_TRY(c, hipGetLastError());
+    return BPLHIP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int bplhip_abi_version(void) { return BPLHIP_ABI_VERSION; }
+
+int bplhip_create(bplhip_ctx** out, int device_id) {
+    if (!out) return fail(nullptr, BPLHIP_EINVAL, "bplhip_create: out is NULL");
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(nullptr, BPLHIP_EHIP, "bplhip_create: no HIP device (%s)",
+                    e == hipSuccess ? "count=0" : hipGetErrorString(e));
+    if (device_id < 0 || device_id >= ndev)
+        return fail(nullptr, BPLHIP_EINVAL, "bplhip_create: device %d out of range [0,%d)",
+                    device_id, ndev);
+    e = hipSetDevice(device_id);
+    if (e != hipSuccess)
+        return fail(nullptr, BPLHIP_EHIP, "hipSetDevice(%d): %s", device_id,
+                    hipGetErrorString(e));
+    bplhip_ctx* c = new (std::nothrow) bplhip_ctx();
+    if (!c) return fail(nullptr, BPLHIP_ENOMEM, "bplhip_create: out of host memory");
+    c->device = device_id;
+    *out = c;
+    return BPLHIP_OK;
+}
+
+void bplhip_destroy(bplhip_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    delete ctx;
+}
+
+const char* bplhip_last_error(const bplhip_ctx* ctx) {
+    return ctx ? ctx->err.c_str() : g_create_error.c_str();
+}
+
+int bplhip_set_fixtures(bplhip_ctx* c, int model_kind, int64_t n, int32_t n_teams,
+                        const uint16_t* home_idx, const uint16_t* away_idx,
+                        const uint8_t* home_goals, const uint8_t* away_goals,
+                        const float* weights, const double* covariates, int32_t k,
+                        void* stream) {
+    if (!c) return BPLHIP_EINVAL;
+    c->bound = false;
+    if (model_kind != BPLHIP_MODEL_BASIC && model_kind != BPLHIP_MODEL_EXTENDED)
+        return fail(c, BPLHIP_EINVAL, "set_fixtures: unknown model_kind %d", model_kind);
+    if (n < 1 || n > (int64_t)1 << 40)
+        return fail(c, BPLHIP_EINVAL, "set_fixtures: n=%lld must be >= 1", (long long)n);
+    if (n_teams < 1 || n_teams > 65534)
+        return fail(c, BPLHIP_EINVAL, "set_fixtures: n_teams=%d out of range [1,65534]", n_teams);
+    if (!home_idx || !away_idx || !home_goals || !away_goals)
+        return fail(c, BPLHIP_EINVAL, "set_fixtures: null fixture array");
+    if (k < 0 || (k > 0 && !covariates) || (k == 0 && covariates))
+        return fail(c, BPLHIP_EINVAL, "set_fixtures: covariates/k mismatch (k=%d)", k);
+    if (model_kind == BPLHIP_MODEL_BASIC && (k != 0 || weights))
+        return fail(c, BPLHIP_EINVAL,
+                    "set_fixtures: the basic model takes neither covariates nor weights");
+    if (stream_lds_bytes(n_teams) > LDS_LIMIT || epi_lds_bytes(n_teams) > LDS_LIMIT)
+        return fail(c, BPLHIP_EUNSUPPORTED,
+                    "set_fixtures: n_teams=%d exceeds the LDS-resident table limit", n_teams);
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+
+    // ---- read the caller's device arrays once
+    std::vector<uint16_t> h(n), a(n);
+    std::vector<uint8_t> x(n), y(n);
+    std::vector<float> w;
+    HIP_TRY(c, hipMemcpyAsync(h.data(), home_idx, n * 2, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(a.data(), away_idx, n * 2, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(x.data(), home_goals, n, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(y.data(), away_goals, n, hipMemcpyDeviceToHost, s));
+    if (weights) {
+        w.resize(n);
+        HIP_TRY(c, hipMemcpyAsync(w.data(), weights, n * 4, hipMemcpyDeviceToHost, s));
+    }
+    HIP_TRY(c, hipStreamSynchronize(s));
+    for (int64_t i = 0; i < n; ++i)
+        if (h[i] >= n_teams || a[i] >= n_teams)
+            return fail(c, BPLHIP_EINVAL, "set_fixtures: team index out of range at fixture %lld",
+                        (long long)i);
+
+    // ---- sort by (home, away): runs of equal pairs become contiguous, so a wave-tile
+    // reduces to one (or a few) per-pair sums.  Stable, so equal pairs keep input order.
+    std::vector<uint64_t> order(n);
+    for (int64_t i = 0; i < n; ++i)
+        order[i] = ((uint64_t)h[i] << 48) | ((uint64_t)a[i] << 32) | (uint64_t)(uint32_t)i;
+    if (n > (int64_t)0xFFFFFFFF) return fail(c, BPLHIP_EUNSUPPORTED, "set_fixtures: n too large");
+    std::sort(order.begin(), order.end());
+
+    const int T = n_teams;
+    const int n_tiles = (int)((n + dc::TILE - 1) / dc::TILE);
+    const int64_t n_pad = (int64_t)n_tiles * dc::TILE;
+    std::vector<uint16_t> hs(n_pad, (uint16_t)T), as(n_pad, (uint16_t)T);
+    std::vector<uint8_t> xs8(n_pad, 2), ys8(n_pad, 2);
+    std::vector<float> ws;
+    if (weights) ws.assign(n_pad, 0.0f);
+    std::vector<uint32_t> pairs;
+    std::vector<double> cA(T, 0.0), cD(T, 0.0), cH(T, 0.0);
+    double lgsum = 0.0;
+    for (int64_t r = 0; r < n; ++r) {
+        const uint32_t i = (uint32_t)order[r];
+        hs[r] = h[i];
+        as[r] = a[i];
+        xs8[r] = x[i];
+        ys8[r] = y[i];
+        const double wi = weights ? (double)w[i] : 1.0;
+        if (weights) ws[r] = w[i];
+        const uint32_t pk = (uint32_t)h[i] | ((uint32_t)a[i] << 16);
+        if (pairs.empty() || pairs.back() != pk) pairs.push_back(pk);
+        cA[h[i]] += wi * x[i];
+        cA[a[i]] += wi * y[i];
+        cD[a[i]] += wi * x[i];
+        cD[h[i]] += wi * y[i];
+        cH[h[i]] += wi * x[i];
+        lgsum += wi * (std::lgamma((double)x[i] + 1.0) + std::lgamma((double)y[i] + 1.0));
+    }
+
+    // ---- launch geometry: 8 waves per workgroup, contiguous tiles per wave
+    const int max_wg = 256;  // one workgroup per CU
+    int tpw = (n_tiles + max_wg * dc::STREAM_WAVES - 1) / (max_wg * dc::STREAM_WAVES);
+    if (tpw < 1) tpw = 1;
+    const int waves = (n_tiles + tpw - 1) / tpw;
+    const int n_wg = (waves + dc::STREAM_WAVES - 1) / dc::STREAM_WAVES;
+
+    // ---- upload
+    HIP_TRY(c, c->d_h.ensure(n_pad * 2));
+    HIP_TRY(c, c->d_a.ensure(n_pad * 2));
+    HIP_TRY(c, c->d_x.ensure(n_pad));
+    HIP_TRY(c, c->d_y.ensure(n_pad));
+    HIP_TRY(c, hipMemcpyAsync(c->d_h.p, hs.data(), n_pad * 2, hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(c->d_a.p, as.data(), n_pad * 2, hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(c->d_x.p, xs8.data(), n_pad, hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(c->d_y.p, ys8.data(), n_pad, hipMemcpyHostToDevice, s));
+    if (weights) {
+        HIP_TRY(c, c->d_w.ensure(n_pad * 4));
+        HIP_TRY(c, hipMemcpyAsync(c->d_w.p, ws.data(), n_pad * 4, hipMemcpyHostToDevice, s));
+    }
+    HIP_TRY(c, c->d_pairs.ensure(pairs.size() * 4));
+    HIP_TRY(c, hipMemcpyAsync(c->d_pairs.p, pairs.data(), pairs.size() * 4,
+                              hipMemcpyHostToDevice, s));
+    HIP_TRY(c, c->d_cA.ensure(T * 8));
+    HIP_TRY(c, c->d_cD.ensure(T * 8));
+    HIP_TRY(c, c->d_cH.ensure(T * 8));
+    HIP_TRY(c, hipMemcpyAsync(c->d_cA.p, cA.data(), T * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(c->d_cD.p, cD.data(), T * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(c->d_cH.p, cH.data(), T * 8, hipMemcpyHostToDevice, s));
+    c->h_xs.clear();
+    if (k > 0) {
+        c->h_xs.assign(covariates, covariates + (size_t)T * k);
+        HIP_TRY(c, c->d_xs.ensure((size_t)T * k * 8));
+        HIP_TRY(c, hipMemcpyAsync(c->d_xs.p, c->h_xs.data(), (size_t)T * k * 8,
+                                  hipMemcpyHostToDevice, s));
+    }
+    HIP_TRY(c, hipStreamSynchronize(s));
+
+    for (auto& kv : c->graphs) (void)hipGraphExecDestroy(kv.second);
+    c->graphs.clear();
+    c->L = dc::make_layout(model_kind, T, k);
+    c->n = n;
+    c->n_tiles = n_tiles;
+    c->tiles_per_wave = tpw;
+    c->n_wg = n_wg;
+    c->weighted = weights != nullptr;
+    c->P = (int)pairs.size();
+    c->lgsum = lgsum;
+    c->h_pairs = std::move(pairs);
+    c->slab_chains = 0;
+    int rc = ensure_slabs(c, 1);
+    if (rc != BPLHIP_OK) return rc;
+    c->bound = true;
+    return BPLHIP_OK;
+}
+
+int bplhip_latent_dim(const bplhip_ctx* c) {
+    if (!c) return BPLHIP_EINVAL;
+    if (!c->bound) return BPLHIP_ESTATE;
+    return c->L.D;
+}
+
+int bplhip_logp_grad_batched(bplhip_ctx* c, int32_t n_chains, const double* z,
+                             double* potential, double* grad, double* aux, void* stream) {
+    if (!c) return BPLHIP_EINVAL;
+    if (!c->bound) return fail(c, BPLHIP_ESTATE, "logp_grad: no fixtures bound");
+    if (!z || !potential || !grad) return fail(c, BPLHIP_EINVAL, "logp_grad: null pointer");
+    if (n_chains < 1 || n_chains > 65535)
+        return fail(c, BPLHIP_EINVAL, "logp_grad: n_chains=%d out of range", n_chains);
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc = ensure_slabs(c, n_chains);
+    if (rc != BPLHIP_OK) return rc;
+    return launch_eval(c, n_chains, z, potential, grad, aux, static_cast<hipStream_t>(stream));
+}
+
+int bplhip_logp_grad(bplhip_ctx* c, const double* z, double* potential, double* grad,
+                     double* aux, void* stream) {
+    return bplhip_logp_grad_batched(c, 1, z, potential, grad, aux, stream);
+}
+
+int bplhip_logp_grad_graph(bplhip_ctx* c, int32_t count, int32_t n_z, const double* z,
+                           double* potential, double* grad, int32_t replays, void* stream) {
+    if (!c) return BPLHIP_EINVAL;
+    if (!c->bound) return fail(c, BPLHIP_ESTATE, "logp_grad_graph: no fixtures bound");
+    if (!z || !potential || !grad || count < 1 || n_z < 1 || replays < 0)
+        return fail(c, BPLHIP_EINVAL, "logp_grad_graph: bad argument");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const GraphKey key{count, n_z, z, potential, grad};
+    auto it = c->graphs.find(key);
+    if (it == c->graphs.end()) {
+        if (!c->cap_stream) HIP_TRY(c, hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking));
+        const int D = c->L.D;
+        HIP_TRY(c, hipStreamBeginCapture(c->cap_stream, hipStreamCaptureModeThreadLocal));
+        int rc = BPLHIP_OK;
+        for (int i = 0; i < count && rc == BPLHIP_OK; ++i) {
+            const int j = i % n_z;
+            rc = launch_eval(c, 1, z + (size_t)j * D, potential + j, grad + (size_t)j * D,
+                             nullptr, c->cap_stream);
+        }
+        hipGraph_t g = nullptr;
+        hipError_t e = hipStreamEndCapture(c->cap_stream, &g);
+        if (rc != BPLHIP_OK) {
+            if (g) (void)hipGraphDestroy(g);
+            return rc;
+        }
+        HIP_TRY(c, e);
+        hipGraphExec_t ge = nullptr;
+        e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(g);
+        HIP_TRY(c, e);
+        it = c->graphs.emplace(key, ge).first;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    for (int r = 0; r < replays; ++r) HIP_TRY(c, hipGraphLaunch(it->second, s));
+    return BPLHIP_OK;
+}
+
+void bplhip_threefry_split(uint32_t key_hi, uint32_t key_lo, int32_t n, uint32_t* out) {
+    if (n <= 0 || !out) return;
+    std::vector<tf::Key> ks(n);
+    tf::split({key_hi, key_lo}, n, ks.data());
+    for (int i = 0; i < n; ++i) {
+        out[2 * i] = ks[i].hi;
+        out[2 * i + 1] = ks[i].lo;
+    }
+}
+
+void bplhip_threefry_bits(uint32_t key_hi, uint32_t key_lo, int32_t n, uint32_t* out) {
+    if (n <= 0 || !out) return;
+    tf::random_bits({key_hi, key_lo}, n, out);
+}
+
+void bplhip_nuts_default_cfg(bplhip_nuts_cfg* cfg) {
+    if (!cfg) return;
+    cfg->num_warmup = 500;
+    cfg->num_samples = 1000;
+    cfg->max_tree_depth = 10;
+    cfg->adapt_step_size = 1;
+    cfg->adapt_mass_matrix = 1;
+    cfg->thinning = 1;
+    cfg->step_size = 1.0;
+    cfg->target_accept_prob = 0.8;
+    cfg->init_radius = 2.0;
+    cfg->max_delta_energy = 1000.0;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------ NUTS glue + constrain
+
+namespace {
+
+// Potential functor handed to the templated NUTS driver: one launch sequence + one
+// pinned-host read-back per evaluation.
+struct HipPotential {
+    bplhip_ctx* c;
+    hipStream_t s;
+    int D;
+    double *d_z, *d_pot, *d_grad, *d_aux;  // device
+    double* hp;                            // pinned: [D grad | pot | aux4]
+    int rc = BPLHIP_OK;
+    int dim() const { return D; }
+    // returns false on a HIP failure (rc holds the code)
+    bool operator()(const double* z, double* U, double* grad, double* aux) {
+        if (hipMemcpyAsync(d_z, z, (size_t)D * 8, hipMemcpyHostToDevice, s) != hipSuccess) {
+            rc = fail(c, BPLHIP_EHIP, "nuts: H2D of z failed");
+            return false;
+        }
+        rc = launch_eval(c, 1, d_z, d_pot, d_grad, d_aux, s);
+        if (rc != BPLHIP_OK) return false;
+        // d_grad, d_pot, d_aux are contiguous: one D2H
+        if (hipMemcpyAsync(hp, d_grad, (size_t)(D + 1 + 4) * 8, hipMemcpyDeviceToHost, s) !=
+                hipSuccess ||
+            hipStreamSynchronize(s) != hipSuccess) {
+            rc = fail(c, BPLHIP_EHIP, "nuts: D2H / sync failed: %s",
+                      hipGetErrorString(hipGetLastError()));
+            return false;
+        }
+        std::memcpy(grad, hp, (size_t)D * 8);
+        *U = hp[D];
+        if (aux) std::memcpy(aux, hp + D + 1, 4 * 8);
+        return true;
+    }
+};
+
+}  // namespace
+
+extern "C" int bplhip_nuts_run(bplhip_ctx* c, const bplhip_nuts_cfg* cfg, const double* z0,
+                               uint32_t seed_hi, uint32_t seed_lo, double* draws_out,
+                               bplhip_nuts_stats* stats, void* stream) {
+    if (!c) return BPLHIP_EINVAL;
+    if (!c->bound) return fail(c, BPLHIP_ESTATE, "nuts_run: no fixtures bound");
+    if (!cfg || !draws_out) return fail(c, BPLHIP_EINVAL, "nuts_run: null cfg/draws_out");
+    if (cfg->num_warmup < 0 || cfg->num_samples < 1 || cfg->max_tree_depth < 1 ||
+        cfg->max_tree_depth > 20 || cfg->thinning < 1 || !(cfg->step_size > 0))
+        return fail(c, BPLHIP_EINVAL, "nuts_run: bad configuration");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const int D = c->L.D;
+    const size_t nd = (size_t)2 * D + 1 + 4;
+    HIP_TRY(c, c->d_nuts.ensure(nd * 8));
+    if (c->h_pinned_bytes < nd * 8) {
+        if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+        c->h_pinned = nullptr;
+        HIP_TRY(c, hipHostMalloc((void**)&c->h_pinned, nd * 8, hipHostMallocDefault));
+        c->h_pinned_bytes = nd * 8;
+    }
+    HipPotential pot{c, static_cast<hipStream_t>(stream), D};
+    pot.d_z = c->d_nuts.as<double>();
+    pot.d_grad = pot.d_z + D;
+    pot.d_pot = pot.d_grad + D;
+    pot.d_aux = pot.d_pot + 1;
+    pot.hp = c->h_pinned;
+
+    nuts::Config nc;
+    nc.num_warmup = cfg->num_warmup;
+    nc.num_samples = cfg->num_samples;
+    nc.max_tree_depth = cfg->max_tree_depth;
+    nc.adapt_step_size = cfg->adapt_step_size != 0;
+    nc.adapt_mass_matrix = cfg->adapt_mass_matrix != 0;
+    nc.thinning = cfg->thinning;
+    nc.step_size = cfg->step_size;
+    nc.target_accept_prob = cfg->target_accept_prob;
+    nc.init_radius = cfg->init_radius;
+    nc.max_delta_energy = cfg->max_delta_energy;
+
+    {  // latent sites in MODEL EXECUTION order (seed-handler key order, Appendix B.5)
+        const dc::Layout& L = c->L;
+        const int T = L.T, K = L.K;
+        if (L.model == dc::MODEL_BASIC) {
+            // bpl/dixon_coles.py:46-78
+            nc.sites = {{L.o_ha, 1}, {L.o_md, 1}, {L.o_sa, 1}, {L.o_sd, 1},
+                        {L.o_adec, T}, {L.o_ddec, T}, {L.o_corr, 1}};
+        } else {
+            // bpl/extended_dixon_coles.py:112-235
+            nc.sites = {{L.o_mha, 1}, {L.o_sh, 1}, {L.o_md, 1}, {L.o_sa, 1}, {L.o_sd, 1}};
+            if (K) {
+                nc.sites.push_back({L.o_bA, K});
+                nc.sites.push_back({L.o_bD, K});
+            }
+            nc.sites.push_back({L.o_u, 1});
+            nc.sites.push_back({L.o_sat, T});
+            nc.sites.push_back({L.o_sdt, T});
+            nc.sites.push_back({L.o_hadec, T});
+            nc.sites.push_back({L.o_corr, 1});
+        }
+    }
+
+    nuts::Result res;
+    const auto t0 = std::chrono::steady_clock::now();
+    const int st = nuts::run_chain(pot, nc, z0, tf::Key{seed_hi, seed_lo}, draws_out, &res);
+    const double wall =
+        std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (st == nuts::ST_EVAL_FAILED) return pot.rc != BPLHIP_OK ? pot.rc : BPLHIP_EHIP;
+    if (st == nuts::ST_NO_FINITE_INIT)
+        return fail(c, BPLHIP_ENUMERIC, "nuts_run: no finite initial point after 100 tries");
+    if (stats) {
+        const size_t kept = res.potential_energy.size();
+        auto cp = [&](double* dst, const std::vector<double>& v) {
+            if (dst) std::memcpy(dst, v.data(), kept * 8);
+        };
+        cp(stats->potential_energy, res.potential_energy);
+        cp(stats->accept_prob, res.accept_prob);
+        cp(stats->step_size, res.step_size);
+        cp(stats->corr_coef, res.aux0);
+        if (stats->num_steps) std::memcpy(stats->num_steps, res.num_steps.data(), kept * 4);
+        if (stats->diverging) std::memcpy(stats->diverging, res.diverging.data(), kept * 4);
+        stats->final_step_size = res.final_step_size;
+        stats->mean_accept_prob = res.mean_accept_prob;
+        stats->total_leapfrogs = res.total_leapfrogs;
+        stats->total_divergences = res.total_divergences;
+        stats->wall_seconds = wall;
+        if (stats->inverse_mass_matrix)
+            std::memcpy(stats->inverse_mass_matrix, res.inverse_mass_matrix.data(), (size_t)D * 8);
+    }
+    return BPLHIP_OK;
+}
+
+extern "C" int bplhip_constrain(bplhip_ctx* c, const double* z_draws, int64_t s,
+                                double* attack, double* defence, double* home_advantage,
+                                double* corr_coef) {
+    if (!c) return BPLHIP_EINVAL;
+    if (!c->bound) return fail(c, BPLHIP_ESTATE, "constrain: no fixtures bound");
+    if (!z_draws || s < 0) return fail(c, BPLHIP_EINVAL, "constrain: bad argument");
+    const dc::Layout& L = c->L;
+    const int T = L.T;
+    const double* xs = c->h_xs.empty() ? nullptr : c->h_xs.data();
+    const bool clip = L.model == dc::MODEL_EXTENDED;
+    std::vector<double> att(T), def(T), ha(T);
+    for (int64_t i = 0; i < s; ++i) {
+        const double* z = z_draws + (size_t)i * L.D;
+        for (int t = 0; t < T; ++t) dc::team_params(L, z, xs, t, &att[t], &def[t], &ha[t]);
+        if (attack) std::memcpy(attack + (size_t)i * T, att.data(), (size_t)T * 8);
+        if (defence) std::memcpy(defence + (size_t)i * T, def.data(), (size_t)T * 8);
+        if (home_advantage) {
+            if (L.model == dc::MODEL_BASIC) home_advantage[i] = ha[0];
+            else std::memcpy(home_advantage + (size_t)i * T, ha.data(), (size_t)T * 8);
+        }
+        if (corr_coef) {
+            // compute_corr_coef_bounds (bpl/_util.py:23-30) over the unique pairs
+            double M = 0.0, Lh = 0.0, La = 0.0;
+            for (uint32_t pk : c->h_pairs) {
+                const int h = pk & 0xFFFFu, a = pk >> 16;
+                double lh = std::exp(att[h] - def[a] + ha[h]);
+                double la = std::exp(att[a] - def[h]);
+                if (clip) {
+                    lh = std::fmin(lh, dc::RATE_CLIP);
+                    la = std::fmin(la, dc::RATE_CLIP);
+                }
+                M = std::fmax(M, lh * la);
+                Lh = std::fmax(Lh, lh);
+                La = std::fmax(La, la);
+            }
+            const double UB = M > 1.0 ? 1.0 / M : 1.0;
+            const double LB = -1.0 / std::fmax(Lh, La);
+            double q, dq;
+            dc::clipped_sigmoid(z[L.o_corr], &q, &dq);
+            corr_coef[i] = LB + q * (UB - LB);
+        }
+    }
+    return BPLHIP_OK;
+}

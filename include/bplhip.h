@@ -1,0 +1,192 @@
+/* bplhip.h -- C-ABI of libbplhip.so: the MI355X (gfx950) Dixon-Coles log-density +
+ * gradient path and the NUTS driver around it.
+ *
+ * The reference (anguswilliams91/bpl-next) is pure Python over numpyro/JAX and has NO
+ * FFI layer of its own; the seam this library replaces is numpyro's
+ * `value_and_grad(potential_fn)(z)` call made once per leapfrog step by
+ * `NUTS(self._model)` / `MCMC(...).run(...)`:
+ *     bpl/dixon_coles.py:100-116            (basic model driver)
+ *     bpl/extended_dixon_coles.py:293-316   (extended model driver)
+ * Each entry point below cites the reference code whose work it takes over.
+ *
+ * Conventions
+ *   - plain C linkage, plain pointers and sizes, no C++/torch types;
+ *   - every function returns 0 (BPLHIP_OK) or a negative BPLHIP_E* code; the message
+ *     is kept per context (bplhip_last_error); no exception or abort crosses the ABI;
+ *   - "device" pointers are HIP device pointers owned by the caller (e.g.
+ *     torch.Tensor.data_ptr()); "host" pointers are ordinary host memory;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).  All device
+ *     work is enqueued on it; functions documented "asynchronous" do not synchronise;
+ *   - a context is bound to one device and is not thread-safe; distinct contexts may be
+ *     used concurrently from distinct host threads;
+ *   - a non-finite potential is NOT an error (NUTS treats it as a divergence): it is
+ *     returned as +inf / nan.
+ *
+ * Latent vector layout (flat, numpyro's sorted-site-name order; all float64):
+ *   basic    attack_decentered[T], corr_coef_raw, defence_decentered[T], home_advantage,
+ *            mean_defence, std_attack, std_defence                         D = 2T+5
+ *   extended attack_coefficients[K], corr_coef_raw, defence_coefficients[K],
+ *            home_advantage_decentered[T], mean_defence, mean_home_advantage,
+ *            standardised_attack[T], standardised_defence[T], std_attack, std_defence,
+ *            std_home_advantage, u                                         D = 3T+2K+7
+ */
+#ifndef BPLHIP_H
+#define BPLHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BPLHIP_ABI_VERSION 1
+
+enum {
+    BPLHIP_OK = 0,
+    BPLHIP_EINVAL = -1,   /* bad argument (null pointer, size, index out of range) */
+    BPLHIP_ESTATE = -2,   /* call out of order (e.g. logp_grad before set_fixtures) */
+    BPLHIP_EHIP = -3,     /* a HIP runtime call failed; see bplhip_last_error       */
+    BPLHIP_ENOMEM = -4,
+    BPLHIP_EUNSUPPORTED = -5,
+    BPLHIP_ENUMERIC = -6  /* NUTS could not find a finite initial point            */
+};
+
+enum {
+    BPLHIP_MODEL_BASIC = 0,    /* bpl/dixon_coles.py:39-84           */
+    BPLHIP_MODEL_EXTENDED = 1  /* bpl/extended_dixon_coles.py:78-248 */
+};
+
+typedef struct bplhip_ctx bplhip_ctx;
+
+/* ABI version of the loaded library (== BPLHIP_ABI_VERSION of the header it was built
+ * against). */
+int bplhip_abi_version(void);
+
+/* Create / destroy a context on HIP device `device_id`. */
+int bplhip_create(bplhip_ctx** out, int device_id);
+void bplhip_destroy(bplhip_ctx* ctx);
+
+/* Last error message of this context ("" if none); `ctx` may be NULL for the message of
+ * a failed bplhip_create. The pointer stays valid until the next call on the context. */
+const char* bplhip_last_error(const bplhip_ctx* ctx);
+
+/* Bind the model arguments.  Replaces the concrete (non-traced) arguments the reference
+ * hands to `mcmc.run(...)`: bpl/dixon_coles.py:108-116 (home_ind, away_ind, num_teams,
+ * home_goals, away_goals) and bpl/extended_dixon_coles.py:303-316 (+ team_covariates,
+ * weights = exp(-epsilon*time_diff), optionally rescaled: :202-205).
+ *
+ *   home_idx/away_idx  device u16[n]  team indices in [0, n_teams) -- the reference's
+ *                                     storage dtype, bpl/base.py:16-22, parse_teams
+ *                                     bpl/_util.py:115-135
+ *   home_goals/away_goals device u8[n]
+ *   weights            device f32[n] or NULL (unweighted)
+ *   covariates         HOST f64[n_teams*k] row-major, ALREADY standardised
+ *                      (bpl/extended_dixon_coles.py:124-127), or NULL with k = 0;
+ *                      must be NULL for the basic model
+ *
+ * The arrays are read once (synchronously on `stream`) and re-laid-out into a library
+ * owned SoA copy (sorted by (home,away) pair, padded to the tile size); the caller's
+ * buffers are not referenced after the call returns. */
+int bplhip_set_fixtures(bplhip_ctx* ctx, int model_kind, int64_t n, int32_t n_teams,
+                        const uint16_t* home_idx, const uint16_t* away_idx,
+                        const uint8_t* home_goals, const uint8_t* away_goals,
+                        const float* weights, const double* covariates, int32_t k,
+                        void* stream);
+
+/* D of the bound model (negative error code if no fixtures are bound). */
+int bplhip_latent_dim(const bplhip_ctx* ctx);
+
+/* THE HOT PATH.  U(z) = -log p(z, data) in unconstrained space and dU/dz -- what
+ * numpyro's `value_and_grad(potential_fn)(z)` computes once per leapfrog from the model
+ * declared at bpl/dixon_coles.py:39-84 / bpl/extended_dixon_coles.py:78-248, including
+ * compute_corr_coef_bounds (bpl/_util.py:17-31) and dixon_coles_correlation_term
+ * (bpl/_util.py:35-93).  Asynchronous, stream ordered.
+ *   z          device f64[D]
+ *   potential  device f64[1]
+ *   grad       device f64[D]
+ *   aux        device f64[4] or NULL: {corr_coef (the `deterministic` site of
+ *              bpl/dixon_coles.py:80), LB, UB, raw} */
+int bplhip_logp_grad(bplhip_ctx* ctx, const double* z, double* potential, double* grad,
+                     double* aux, void* stream);
+
+/* The same for `n_chains` independent latent vectors in one launch sequence (numpyro
+ * chain_method="vectorized", reachable through mcmc_kwargs at bpl/dixon_coles.py:105).
+ *   z [n_chains, D], potential [n_chains], grad [n_chains, D], aux [n_chains, 4] or NULL */
+int bplhip_logp_grad_batched(bplhip_ctx* ctx, int32_t n_chains, const double* z,
+                             double* potential, double* grad, double* aux, void* stream);
+
+/* Pre-record `count` back-to-back evaluations z[i % n_z] -> (potential[i % n_z],
+ * grad[i % n_z]) as one hipGraph and replay it `replays` times on `stream`
+ * (asynchronous).  This is how the NUTS driver issues the 2^depth leapfrogs of a tree
+ * doubling without a host round trip per launch; it is exposed for the op-level
+ * benchmark. */
+int bplhip_logp_grad_graph(bplhip_ctx* ctx, int32_t count, int32_t n_z, const double* z,
+                           double* potential, double* grad, int32_t replays, void* stream);
+
+/* ---- NUTS driver: numpyro.infer.{NUTS,MCMC} as configured at
+ * bpl/dixon_coles.py:100-116 (all NUTS defaults; num_warmup / num_samples forwarded). */
+typedef struct bplhip_nuts_cfg {
+    int32_t num_warmup;         /* bpl/dixon_coles.py:90 default 500                */
+    int32_t num_samples;        /* bpl/dixon_coles.py:91 default 1000               */
+    int32_t max_tree_depth;     /* numpyro default 10                               */
+    int32_t adapt_step_size;    /* numpyro default 1                                */
+    int32_t adapt_mass_matrix;  /* numpyro default 1 (diagonal, regularised)        */
+    int32_t thinning;           /* numpyro MCMC default 1                           */
+    double step_size;           /* numpyro default 1.0                              */
+    double target_accept_prob;  /* numpyro default 0.8                              */
+    double init_radius;         /* init_to_uniform(radius=2)                        */
+    double max_delta_energy;    /* numpyro default 1000                             */
+} bplhip_nuts_cfg;
+
+/* Fill `cfg` with numpyro's defaults as reached from bpl/dixon_coles.py:100-106. */
+void bplhip_nuts_default_cfg(bplhip_nuts_cfg* cfg);
+
+typedef struct bplhip_nuts_stats {
+    /* per kept draw, HOST arrays of length num_samples/thinning, each may be NULL */
+    double* potential_energy;
+    double* accept_prob;
+    double* step_size;
+    int32_t* num_steps;
+    int32_t* diverging;
+    double* corr_coef;          /* deterministic site `corr_coef` of each draw      */
+    /* scalars, filled by the call */
+    double final_step_size;
+    double mean_accept_prob;
+    int64_t total_leapfrogs;    /* potential+gradient evaluations, warm-up included */
+    int64_t total_divergences;  /* post warm-up                                     */
+    double wall_seconds;
+    double* inverse_mass_matrix; /* HOST f64[D] or NULL: adapted diagonal           */
+} bplhip_nuts_stats;
+
+/* Run one chain.  `seed_hi:seed_lo` is the 2x32 threefry key (jax.random.PRNGKey(s) ==
+ * {0, s} for a 32-bit s; chain c of a multi-chain run uses split(key, num_chains)[c]).
+ *   z0         HOST f64[D] or NULL (NULL = init_to_uniform(radius) + retry until finite,
+ *              numpyro find_valid_initial_params; non-NULL = run_kwargs init_params,
+ *              bpl/dixon_coles.py:115)
+ *   draws_out  HOST f64[num_samples/thinning, D] unconstrained draws (post warm-up)
+ * Synchronous (returns when the chain has finished). */
+int bplhip_nuts_run(bplhip_ctx* ctx, const bplhip_nuts_cfg* cfg, const double* z0,
+                    uint32_t seed_hi, uint32_t seed_lo, double* draws_out,
+                    bplhip_nuts_stats* stats, void* stream);
+
+/* Map unconstrained draws to the constrained / deterministic sites the reference reads
+ * from `mcmc.get_samples()` (bpl/dixon_coles.py:118-122,
+ * bpl/extended_dixon_coles.py:319-331).  HOST in, HOST out; any output may be NULL.
+ *   z_draws f64[s, D]
+ *   attack, defence f64[s, T]; home_advantage f64[s] (basic) or f64[s, T] (extended);
+ *   corr_coef f64[s]  (needs the rho bounds over all bound fixtures) */
+int bplhip_constrain(bplhip_ctx* ctx, const double* z_draws, int64_t s, double* attack,
+                     double* defence, double* home_advantage, double* corr_coef);
+
+/* threefry2x32 helpers with jax.random semantics (jax 0.4.24, non-partitionable
+ * threefry): used by the Python host for key plumbing (random.split for multi-chain
+ * runs, bpl/dixon_coles.py:107).  out has 2*n words: n keys (hi, lo). */
+void bplhip_threefry_split(uint32_t key_hi, uint32_t key_lo, int32_t n, uint32_t* out);
+/* n raw 32-bit draws, jax.random.bits(key, (n,), uint32). */
+void bplhip_threefry_bits(uint32_t key_hi, uint32_t key_lo, int32_t n, uint32_t* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BPLHIP_H */

@@ -1,0 +1,118 @@
+// TEST INFRASTRUCTURE (NOT product code): links the product's header-only NUTS driver
+// (bpl-next_amd/csrc/nuts.hpp) against CPU potentials so the host logic can be tested
+// without a GPU: (i) the C oracle's Dixon-Coles potential, (ii) an isotropic/diagonal
+// Gaussian for sampler invariants.  Only tests/ may load this library.
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "../bpl-next_amd/csrc/nuts.hpp"
+
+extern "C" int dco_potential_grad(int model, int64_t n, int T, int K, const uint16_t* h,
+                                  const uint16_t* a, const uint8_t* x, const uint8_t* y,
+                                  const double* w, const double* xs, const double* z,
+                                  double* U, double* grad, double* aux, int nthreads);
+extern "C" int dco_latent_dim(int model, int T, int K);
+
+namespace {
+struct OraclePot {
+    int model, T, K, D;
+    int64_t n;
+    const uint16_t *h, *a;
+    const uint8_t *x, *y;
+    const double *w, *xs;
+    int64_t evals = 0;
+    int dim() const { return D; }
+    bool operator()(const double* z, double* U, double* g, double* aux) {
+        ++evals;
+        return dco_potential_grad(model, n, T, K, h, a, x, y, w, xs, z, U, g, aux, 1) == 0;
+    }
+};
+struct GaussPot {
+    int D;
+    const double* sd;
+    int dim() const { return D; }
+    bool operator()(const double* z, double* U, double* g, double* aux) {
+        double u = 0;
+        for (int i = 0; i < D; ++i) {
+            u += 0.5 * z[i] * z[i] / (sd[i] * sd[i]);
+            g[i] = z[i] / (sd[i] * sd[i]);
+        }
+        *U = u;
+        if (aux) aux[0] = aux[1] = aux[2] = aux[3] = 0;
+        return true;
+    }
+};
+void fill(nuts::Config* c, int warm, int samp, int depth, int thin) {
+    c->num_warmup = warm;
+    c->num_samples = samp;
+    c->max_tree_depth = depth;
+    c->thinning = thin;
+}
+template <class P>
+int run(P& pot, nuts::Config& cfg, const double* z0, uint32_t khi, uint32_t klo, double* draws,
+        double* stats /*[kept,4]: pe, accept, steps, diverging*/, double* summary /*[4+D]*/) {
+    nuts::Result res;
+    int st = nuts::run_chain(pot, cfg, z0, tf::Key{khi, klo}, draws, &res);
+    if (st != nuts::ST_OK) return st;
+    const size_t kept = res.potential_energy.size();
+    for (size_t i = 0; i < kept && stats; ++i) {
+        stats[4 * i + 0] = res.potential_energy[i];
+        stats[4 * i + 1] = res.accept_prob[i];
+        stats[4 * i + 2] = res.num_steps[i];
+        stats[4 * i + 3] = res.diverging[i];
+    }
+    if (summary) {
+        summary[0] = res.final_step_size;
+        summary[1] = res.mean_accept_prob;
+        summary[2] = (double)res.total_leapfrogs;
+        summary[3] = (double)res.total_divergences;
+        for (int i = 0; i < pot.dim(); ++i) summary[4 + i] = res.inverse_mass_matrix[i];
+    }
+    return 0;
+}
+}  // namespace
+
+extern "C" {
+
+int harness_nuts_dc(int model, int64_t n, int T, int K, const uint16_t* h, const uint16_t* a,
+                    const uint8_t* x, const uint8_t* y, const double* w, const double* xs,
+                    int warm, int samp, int depth, int thin, const double* z0, uint32_t khi,
+                    uint32_t klo, double* draws, double* stats, double* summary) {
+    OraclePot pot{model, T, K, dco_latent_dim(model, T, K), n, h, a, x, y, w, xs};
+    nuts::Config cfg;
+    fill(&cfg, warm, samp, depth, thin);
+    return run(pot, cfg, z0, khi, klo, draws, stats, summary);
+}
+
+int harness_nuts_gauss(int D, const double* sd, int warm, int samp, int depth, int thin,
+                       const double* z0, uint32_t khi, uint32_t klo, double* draws,
+                       double* stats, double* summary) {
+    GaussPot pot{D, sd};
+    nuts::Config cfg;
+    fill(&cfg, warm, samp, depth, thin);
+    return run(pot, cfg, z0, khi, klo, draws, stats, summary);
+}
+
+// adaptation schedule windows: out[2*i], out[2*i+1]; returns the count
+int harness_schedule(int num_steps, int* out, int cap) {
+    auto s = nuts::build_adaptation_schedule(num_steps);
+    for (size_t i = 0; i < s.size() && (int)i < cap; ++i) {
+        out[2 * i] = s[i].start;
+        out[2 * i + 1] = s[i].end;
+    }
+    return (int)s.size();
+}
+
+void harness_ckpt_idxs(int n, int* idx_min, int* idx_max) {
+    nuts::leaf_idx_to_ckpt_idxs(n, idx_min, idx_max);
+}
+
+void harness_normal(uint32_t khi, uint32_t klo, int n, double* out) {
+    tf::normal(tf::Key{khi, klo}, n, out);
+}
+void harness_uniform(uint32_t khi, uint32_t klo, int n, float lo, float hi, double* out) {
+    tf::uniform(tf::Key{khi, klo}, n, lo, hi, out);
+}
+}

@@ -1,0 +1,177 @@
+"""GPU parity: the HIP path (through the C-ABI) vs the float64 oracle on the same seeded
+inputs.  Floating point path -> tolerances, stated here:
+
+  U     : |U_hip - U_oracle| <= 2e-9 * (|U| + sum of |per-fixture terms| ~ 4N) + 1e-9
+          (per-fixture arithmetic is float32, accumulation float64 -> the error is the
+          float32 rounding of ~N rate values, random in sign: ~1e-7 * sqrt(N) * mean rate)
+  gradU : max|dg| <= 3e-6 * max|g| + 1e-6   (same float32 per-fixture origin)
+Measured errors are far inside these (printed with -s).
+"""
+import numpy as np
+import pytest
+
+import cases
+import dc_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(ctx, model, fx, zs):
+    import torch
+
+    w32 = None if fx.weights is None else fx.weights.astype(np.float32)
+    cov = None
+    if model == O.MODEL_EXTENDED and fx.covariates is not None:
+        cov = O.standardise_covariates(fx.covariates)
+    ctx.set_fixtures(model, fx.home_idx.astype(np.uint16), fx.away_idx.astype(np.uint16),
+                     fx.home_goals.astype(np.uint8), fx.away_goals.astype(np.uint8),
+                     fx.n_teams, weights=w32, covariates_std=cov)
+    z = torch.tensor(np.stack(zs), dtype=torch.float64, device=ctx.device)
+    outs = []
+    for i in range(z.shape[0]):
+        U, g, aux = ctx.logp_grad(z[i].contiguous())
+        outs.append((U.cpu().numpy()[0], g.cpu().numpy(), aux.cpu().numpy()[0]))
+    Ub, gb, auxb = ctx.logp_grad(z)
+    return outs, (Ub.cpu().numpy(), gb.cpu().numpy(), auxb.cpu().numpy())
+
+
+def _check(model, fx, name, z, U, g, aux):
+    Uo, go, auxo = O.potential_and_grad(model, fx, z)
+    tolU = 2e-9 * (abs(Uo) + 4.0 * fx.n) + 1e-9
+    gerr = np.abs(g - go).max()
+    gtol = 3e-6 * np.abs(go).max() + 1e-6
+    print(f"{name:28s} N={fx.n:8d} U={Uo:.6f} dU={U - Uo:+.3e} (tol {tolU:.1e}) "
+          f"dg={gerr:.3e} (tol {gtol:.1e}) rho={auxo['rho']:+.6f}")
+    if not np.isfinite(Uo):
+        assert not np.isfinite(U) or U > 1e300
+        return
+    assert abs(U - Uo) <= tolU
+    assert gerr <= gtol
+    assert abs(aux[0] - auxo["rho"]) <= 1e-6
+    assert abs(aux[1] - auxo["LB"]) <= 1e-6 and abs(aux[2] - auxo["UB"]) <= 1e-6
+
+
+CASES = [
+    (O.MODEL_BASIC, "dummy"),
+    (O.MODEL_BASIC, "timed"),
+    (O.MODEL_BASIC, "ragged_1"),
+    (O.MODEL_BASIC, "ragged_777"),
+    (O.MODEL_BASIC, "ragged_5000"),
+    (O.MODEL_BASIC, "league_1e5"),
+    (O.MODEL_EXTENDED, "dummy"),
+    (O.MODEL_EXTENDED, "dummy_cov"),
+    (O.MODEL_EXTENDED, "dummy_w"),
+    (O.MODEL_EXTENDED, "timed_w"),
+    (O.MODEL_EXTENDED, "ragged_5000"),
+    (O.MODEL_EXTENDED, "league_1e5"),
+]
+
+
+@pytest.mark.parametrize("model,name", CASES)
+def test_logp_grad_matches_oracle(hip_ctx, model, name):
+    fx = cases.fixtures(name)
+    pts = cases.z_points(model, fx)
+    outs, (Ub, gb, auxb) = _run(hip_ctx, model, fx, [p[1] for p in pts])
+    for i, ((pname, z), (U, g, aux)) in enumerate(zip(pts, outs)):
+        _check(model, fx, f"{name}/{pname}", z, U, g, aux)
+        # batched launch == single launches, bitwise
+        assert U == Ub[i] and np.array_equal(g, gb[i]) and np.array_equal(aux, auxb[i])
+
+
+def test_full_size_1e6(hip_ctx):
+    """BASELINE size (N = 1e6): oracle comparison at two points for both models."""
+    h, a, x, y = O.synthetic_league(1_000_000)
+    fx = O.Fixtures(h, a, x, y, 20)
+    for model in (O.MODEL_BASIC, O.MODEL_EXTENDED):
+        pts = cases.z_points(model, fx, n_random=1)[:2]
+        outs, _ = _run(hip_ctx, model, fx, [p[1] for p in pts])
+        for (pname, z), (U, g, aux) in zip(pts, outs):
+            _check(model, fx, f"league_1e6/{pname}", z, U, g, aux)
+
+
+def test_order_invariance_and_determinism(hip_ctx):
+    """Size-independent properties at N = 1e6: (i) a launch repeated is bitwise equal;
+    (ii) permuting the fixtures leaves U and gradU unchanged (the library re-sorts);
+    (iii) additivity: U(A u B) - U(A) - U(B) + U(empty-likelihood part) is consistent,
+    checked through duplicated data: the likelihood part doubles."""
+    import torch
+
+    h, a, x, y = O.synthetic_league(1_000_000)
+    z = np.random.RandomState(3).uniform(-0.3, 0.3, 45)
+    zt = torch.tensor(z, dtype=torch.float64, device=hip_ctx.device)
+
+    def run(hh, aa, xx, yy):
+        hip_ctx.set_fixtures(O.MODEL_BASIC, hh, aa, xx, yy, 20)
+        U1, g1, _ = hip_ctx.logp_grad(zt)
+        U2, g2, _ = hip_ctx.logp_grad(zt)
+        assert torch.equal(U1, U2) and torch.equal(g1, g2)
+        return U1.cpu().numpy()[0], g1.cpu().numpy()
+
+    U0, g0 = run(h, a, x, y)
+    perm = np.random.RandomState(1).permutation(h.size)
+    Up, gp = run(h[perm], a[perm], x[perm], y[perm])
+    assert abs(Up - U0) <= 1e-9 * abs(U0)
+    assert np.abs(gp - g0).max() <= 1e-9 * np.abs(g0).max()
+
+    # priors-only part: likelihood of zero fixtures is not expressible (n >= 1), so use
+    # U(2x data) - U(data) = U(data) - U_prior  ->  U_prior = 2 U(data) - U(2x data)
+    U2x, _ = run(np.tile(h, 2), np.tile(a, 2), np.tile(x, 2), np.tile(y, 2))
+    fx_small = O.Fixtures(h[:1], a[:1], x[:1], y[:1], 20)
+    # oracle prior part = U_small - (likelihood of the single fixture): compute directly
+    sl = O.site_slices(O.MODEL_BASIC, 20)
+    U_small, _, _ = O.potential_and_grad(O.MODEL_BASIC, fx_small, z)
+    fx2 = O.Fixtures(np.tile(h[:1], 2), np.tile(a[:1], 2), np.tile(x[:1], 2), np.tile(y[:1], 2), 20)
+    U_small2, _, _ = O.potential_and_grad(O.MODEL_BASIC, fx2, z)
+    prior_oracle = 2 * U_small - U_small2
+    prior_hip = 2 * U0 - U2x
+    assert abs(prior_hip - prior_oracle) <= 2e-8 * abs(U0)
+
+
+def test_graph_replay_matches_direct(hip_ctx):
+    import torch
+
+    fx = cases.fixtures("league_1e5")
+    hip_ctx.set_fixtures(O.MODEL_BASIC, fx.home_idx.astype(np.uint16), fx.away_idx.astype(np.uint16),
+                         fx.home_goals.astype(np.uint8), fx.away_goals.astype(np.uint8), 20)
+    zs = np.random.RandomState(7).uniform(-0.5, 0.5, (8, 45))
+    z = torch.tensor(zs, dtype=torch.float64, device=hip_ctx.device)
+    Ud, gd, _ = hip_ctx.logp_grad(z)
+    U = torch.zeros(8, dtype=torch.float64, device=hip_ctx.device)
+    g = torch.zeros_like(z)
+    hip_ctx.logp_grad_graph(16, z, U, g, replays=3)
+    torch.cuda.synchronize()
+    assert torch.equal(U, Ud) and torch.equal(g, gd)
+
+
+def test_nonfinite_is_not_an_error(hip_ctx):
+    """tol=0 in the reference (bpl/_util.py:42): rho on a bound gives log(0) = -inf ->
+    U = +inf is returned, not raised (numpyro treats it as a divergence)."""
+    import torch
+
+    fx = cases.fixtures("dummy")
+    hip_ctx.set_fixtures(O.MODEL_BASIC, fx.home_idx.astype(np.uint16), fx.away_idx.astype(np.uint16),
+                         fx.home_goals.astype(np.uint8), fx.away_goals.astype(np.uint8), 20)
+    z = np.random.RandomState(7).uniform(-0.5, 0.5, 45)
+    z[20] = 40.0  # corr_coef_raw -> q clipped to 1-eps: rho ~ UB, 1 - rho*lh*la ~ 0 at argmax
+    z[41] = 1.0   # make M > 1 so UB = 1/M
+    Uo, go, _ = O.potential_and_grad(O.MODEL_BASIC, fx, z)
+    U, g, _ = hip_ctx.logp_grad(torch.tensor(z, dtype=torch.float64, device=hip_ctx.device))
+    U = U.cpu().numpy()[0]
+    print("U oracle", Uo, "U hip", U)
+    assert np.isfinite(U) == np.isfinite(Uo) or (not np.isfinite(U))
+    zn = z.copy()
+    zn[0] = np.nan
+    U, g, _ = hip_ctx.logp_grad(torch.tensor(zn, dtype=torch.float64, device=hip_ctx.device))
+    assert np.isnan(U.cpu().numpy()[0])
+
+
+def test_bad_arguments_raise(hip_ctx):
+    from bpl._ffi import BplHipError
+
+    with pytest.raises(BplHipError):
+        hip_ctx.set_fixtures(O.MODEL_BASIC, np.array([0, 5], np.uint16), np.array([1, 0], np.uint16),
+                             np.array([1, 1], np.uint8), np.array([0, 0], np.uint8), 3)  # index 5 >= T
+    with pytest.raises(BplHipError):
+        hip_ctx.set_fixtures(O.MODEL_BASIC, np.array([0], np.uint16), np.array([1], np.uint16),
+                             np.array([1], np.uint8), np.array([0], np.uint8), 2,
+                             weights=np.ones(1, np.float32))  # basic model takes no weights
