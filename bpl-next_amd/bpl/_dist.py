@@ -99,7 +99,8 @@ def broadcast_fixtures(arrays: Dict[str, Optional[np.ndarray]], device=None, src
             }[np.dtype(dt)]
             t = torch.empty(shape, dtype=tdt, device=dev)
         if ws > 1:
-            dist.broadcast(t, src=src)
+            # as raw bytes: neither RCCL nor gloo broadcasts 16-bit integer tensors
+            dist.broadcast(t.view(torch.uint8), src=src)
         out[k] = t
     return out
 

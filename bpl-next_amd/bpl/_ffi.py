@@ -26,6 +26,7 @@ ABI_SYMBOLS = (
     "bplhip_destroy",
     "bplhip_last_error",
     "bplhip_set_fixtures",
+    "bplhip_set_option",
     "bplhip_latent_dim",
     "bplhip_logp_grad",
     "bplhip_logp_grad_batched",
@@ -104,6 +105,8 @@ def load_library():
     lib.bplhip_last_error.restype = C.c_char_p
     lib.bplhip_set_fixtures.argtypes = [vp, C.c_int, i64, i32, vp, vp, vp, vp, vp, vp, i32, vp]
     lib.bplhip_set_fixtures.restype = C.c_int
+    lib.bplhip_set_option.argtypes = [vp, C.c_char_p, C.c_int]
+    lib.bplhip_set_option.restype = C.c_int
     lib.bplhip_latent_dim.argtypes = [vp]
     lib.bplhip_latent_dim.restype = C.c_int
     lib.bplhip_logp_grad.argtypes = [vp, vp, vp, vp, vp, vp]
@@ -200,6 +203,9 @@ class HipContext:
 
     def _stream(self):
         return C.c_void_p(self._torch.cuda.current_stream(self.device).cuda_stream)
+
+    def set_option(self, name: str, value: int):
+        self._check(self._lib.bplhip_set_option(self._h, name.encode(), int(value)))
 
     # -- model arguments
     def set_fixtures(

@@ -67,8 +67,14 @@ struct bplhip_ctx {
     int P = 0;
     double lgsum = 0.0;
     // device buffers (library owned)
-    DevBuf d_h, d_a, d_x, d_y, d_w, d_pairs, d_xs, d_cA, d_cD, d_cH, d_slabs, d_bounds;
+    DevBuf d_h, d_a, d_x, d_y, d_w, d_pairs, d_xs, d_cA, d_cD, d_cH, d_tickets, d_debug, d_xsf, d_zo,
+        d_compact, d_scal, d_wg_off, d_wg_slots, d_col_off, d_wg_dst;
     int slab_chains = 0;
+    int total_c = 0;      // entries of the sparse (compact) slab array
+    bool staged = true;   // the tail stages the compact array in LDS
+    // tuning options (bplhip_set_option)
+    int opt_max_wg = 255;  // streaming workgroups (+1 prior workgroup = one per CU)
+    bool lds_attr_set = false;
     // NUTS scratch (device): z, potential, grad, aux + pinned host mirror
     DevBuf d_nuts;
     double* h_pinned = nullptr;
@@ -107,38 +113,47 @@ int fail(bplhip_ctx* c, int code, const char* fmt, ...) {
                         hipGetErrorString(e_), __FILE__, __LINE__);                 \
     } while (0)
 
-size_t stream_lds_bytes(int T) {
-    const int T1 = T + 1;
-    size_t b = 2 * (size_t)((T1 + 1) & ~1) * sizeof(float2);
-    b += (size_t)(3 * T1 + ((3 * T1) & 1)) * sizeof(double);
-    b += (size_t)dc::STREAM_WAVES * dc::N_SCAL * sizeof(double);
-    b += (size_t)dc::STREAM_WAVES * 3 * sizeof(unsigned long long);
-    b += 2 * sizeof(double);
-    return b;
-}
-
-size_t epi_lds_bytes(int T) {
-    const int ncol = 3 * T + dc::N_SCAL;
-    int RG = dc::EPI_BLOCK / ncol;
-    RG = RG < 1 ? 1 : (RG > 8 ? 8 : RG);
-    return (size_t)(ncol + 64 + (size_t)RG * ncol) * sizeof(double);
-}
-
 constexpr size_t LDS_LIMIT = 160 * 1024;
+
+int zo_stride_of(const dc::Layout& L) { return (dc::ZO_HDR + L.D + 3 * L.T + 1) & ~1; }
 
 int ensure_slabs(bplhip_ctx* c, int chains) {
     if (chains <= c->slab_chains) return BPLHIP_OK;
-    const size_t stride = 3 * (size_t)c->L.T + dc::N_SCAL;
-    HIP_TRY(c, c->d_slabs.ensure((size_t)chains * c->n_wg * stride * sizeof(double)));
-    HIP_TRY(c, c->d_bounds.ensure((size_t)chains * dc::BOUNDS_WORDS * sizeof(uint32_t)));
+    HIP_TRY(c, c->d_compact.ensure((size_t)chains * std::max(c->total_c, 1) * sizeof(double)));
+    HIP_TRY(c, c->d_scal.ensure((size_t)chains * c->n_wg * dc::N_SCAL * sizeof(double)));
+    HIP_TRY(c, c->d_zo.ensure((size_t)chains * zo_stride_of(c->L) * sizeof(double)));
+    HIP_TRY(c, c->d_tickets.ensure((size_t)chains * sizeof(unsigned int)));
+    HIP_TRY(c, hipMemset(c->d_tickets.p, 0, (size_t)chains * sizeof(unsigned int)));
     c->slab_chains = chains;
     return BPLHIP_OK;
 }
 
-// Enqueue one (batched) evaluation: dc_stream then dc_epilogue.  No host sync.
+size_t ctx_lds_bytes(const bplhip_ctx* c, bool staged) {
+    return dc::eval_lds_bytes(c->L.T, c->L.D, zo_stride_of(c->L), c->n_wg, c->total_c, staged);
+}
+
+template <bool W, bool C, bool S>
+int launch_eval_s(bplhip_ctx* c, const dc::EvalArgs& A, int chains, hipStream_t s) {
+    const dim3 grid(c->n_wg + 1, chains), block(dc::BLOCK);
+    const size_t lds = ctx_lds_bytes(c, S);
+    if (!c->lds_attr_set && lds > 48 * 1024)
+        HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(dc::dc_eval<W, C, S>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    c->lds_attr_set = true;
+    hipLaunchKernelGGL((dc::dc_eval<W, C, S>), grid, block, lds, s, A);
+    HIP_TRY(c, hipGetLastError());
+    return BPLHIP_OK;
+}
+template <bool W, bool C>
+int launch_eval_t(bplhip_ctx* c, const dc::EvalArgs& A, int chains, hipStream_t s) {
+    return c->staged ? launch_eval_s<W, C, true>(c, A, chains, s)
+                     : launch_eval_s<W, C, false>(c, A, chains, s);
+}
+
+// Enqueue one (batched) evaluation: ONE launch.  No host sync.
 int launch_eval(bplhip_ctx* c, int chains, const double* z, double* pot, double* grad,
                 double* aux, hipStream_t s) {
-    dc::StreamArgs A{};
+    dc::EvalArgs A{};
     A.h = c->d_h.as<const uint4>();
     A.a = c->d_a.as<const uint4>();
     A.x = c->d_x.as<const uint2>();
@@ -149,35 +164,38 @@ int launch_eval(bplhip_ctx* c, int chains, const double* z, double* pot, double*
     A.pairs = c->d_pairs.as<const uint32_t>();
     A.P = c->P;
     A.xs = c->L.K ? c->d_xs.as<const double>() : nullptr;
-    A.slabs = c->d_slabs.as<double>();
-    A.slab_stride = 3 * c->L.T + dc::N_SCAL;
-    A.bounds = c->d_bounds.as<uint32_t>();
+    A.xsf = c->L.K ? c->d_xsf.as<const float>() : nullptr;
+    A.cA = c->d_cA.as<const double>();
+    A.cD = c->d_cD.as<const double>();
+    A.cH = c->d_cH.as<const double>();
+    A.lgsum = c->lgsum;
+    A.wg_off = c->d_wg_off.as<const int>();
+    A.wg_slots = c->d_wg_slots.as<const int>();
+    A.col_off = c->d_col_off.as<const int>();
+    A.wg_dst = c->d_wg_dst.as<const int>();
+    A.total_c = c->total_c;
+    A.compact = c->d_compact.as<double>();
+    A.scal = c->d_scal.as<double>();
+    A.zo = c->d_zo.as<double>();
+    A.n_wg = c->n_wg;
+    A.zo_stride = zo_stride_of(c->L);
+    A.tickets = c->d_tickets.as<unsigned int>();
+    A.z = z;
+    A.potential = pot;
+    A.grad = grad;
+    A.aux = aux;
+    A.debug = c->d_debug.as<unsigned long long>();
     A.L = c->L;
-    const dim3 grid(c->n_wg, chains), block(dc::STREAM_BLOCK);
-    const size_t lds = stream_lds_bytes(c->L.T);
     const bool clip = c->L.model == dc::MODEL_EXTENDED;
-    if (c->weighted) {
-        if (clip) hipLaunchKernelGGL((dc::dc_stream<true, true>), grid, block, lds, s, A, z);
-        else hipLaunchKernelGGL((dc::dc_stream<true, false>), grid, block, lds, s, A, z);
-    } else {
-        if (clip) hipLaunchKernelGGL((dc::dc_stream<false, true>), grid, block, lds, s, A, z);
-        else hipLaunchKernelGGL((dc::dc_stream<false, false>), grid, block, lds, s, A, z);
-    }
-    dc::EpiArgs E{};
-    E.slabs = c->d_slabs.as<const double>();
-    E.n_wg = c->n_wg;
-    E.slab_stride = A.slab_stride;
-    E.bounds = c->d_bounds.as<const uint32_t>();
-    E.xs = A.xs;
-    E.cA = c->d_cA.as<const double>();
-    E.cD = c->d_cD.as<const double>();
-    E.cH = c->d_cH.as<const double>();
-    E.lgsum = c->lgsum;
-    E.L = c->L;
-    hipLaunchKernelGGL(dc::dc_epilogue, dim3(chains), dim3(dc::EPI_BLOCK),
-                       epi_lds_bytes(c->L.T), s, E, z, pot, grad, aux);
-    HIP_TRY(c, hipGetLastError());
-    return BPLHIP_OK;
+    if (c->weighted) return clip ? launch_eval_t<true, true>(c, A, chains, s)
+                                 : launch_eval_t<true, false>(c, A, chains, s);
+    return clip ? launch_eval_t<false, true>(c, A, chains, s)
+                : launch_eval_t<false, false>(c, A, chains, s);
+}
+
+void drop_graphs(bplhip_ctx* c) {
+    for (auto& kv : c->graphs) (void)hipGraphExecDestroy(kv.second);
+    c->graphs.clear();
 }
 
 }  // namespace
@@ -238,7 +256,7 @@ int bplhip_set_fixtures(bplhip_ctx* c, int model_kind, int64_t n, int32_t n_team
     if (model_kind == BPLHIP_MODEL_BASIC && (k != 0 || weights))
         return fail(c, BPLHIP_EINVAL,
                     "set_fixtures: the basic model takes neither covariates nor weights");
-    if (stream_lds_bytes(n_teams) > LDS_LIMIT || epi_lds_bytes(n_teams) > LDS_LIMIT)
+    if (dc::stream_lds_bytes(n_teams) > LDS_LIMIT || dc::prior_lds_bytes(n_teams) > LDS_LIMIT)
         return fail(c, BPLHIP_EUNSUPPORTED,
                     "set_fixtures: n_teams=%d exceeds the LDS-resident table limit", n_teams);
     HIP_TRY(c, hipSetDevice(c->device));
@@ -299,13 +317,49 @@ int bplhip_set_fixtures(bplhip_ctx* c, int model_kind, int64_t n, int32_t n_team
     }
 
     // ---- launch geometry: 8 waves per workgroup, contiguous tiles per wave
-    const int max_wg = 256;  // one workgroup per CU
-    int tpw = (n_tiles + max_wg * dc::STREAM_WAVES - 1) / (max_wg * dc::STREAM_WAVES);
+    const int max_wg = c->opt_max_wg;  // one workgroup per CU by default
+    int tpw = (n_tiles + max_wg * dc::WAVES - 1) / (max_wg * dc::WAVES);
     if (tpw < 1) tpw = 1;
     const int waves = (n_tiles + tpw - 1) / tpw;
-    const int n_wg = (waves + dc::STREAM_WAVES - 1) / dc::STREAM_WAVES;
+    const int n_wg = (waves + dc::WAVES - 1) / dc::WAVES;
+
+    // ---- static sparse-slab structure: which of the 3T per-team slots each streaming
+    // workgroup's fixtures touch (att[h], ha[h], def[a], att[a], def[h]), and the
+    // transposed (per column, workgroup order) position lists for the tail's reduction
+    std::vector<int> wg_off(n_wg + 1, 0), wg_slots, col_off(3 * T + 1, 0), wg_dst;
+    {
+        std::vector<char> touched(3 * (size_t)T);
+        const int64_t per_wg = (int64_t)tpw * dc::WAVES * dc::TILE;
+        for (int w = 0; w < n_wg; ++w) {
+            std::fill(touched.begin(), touched.end(), 0);
+            const int64_t r0 = (int64_t)w * per_wg, r1 = std::min<int64_t>(n, r0 + per_wg);
+            for (int64_t r = r0; r < r1; ++r) {
+                const int hh = hs[r], aa = as[r];
+                touched[hh] = touched[2 * T + hh] = touched[T + aa] = 1;
+                touched[aa] = touched[T + hh] = 1;
+            }
+            for (int sidx = 0; sidx < 3 * T; ++sidx)
+                if (touched[sidx]) wg_slots.push_back(sidx);
+            wg_off[w + 1] = (int)wg_slots.size();
+        }
+        const int total = (int)wg_slots.size();
+        for (int k = 0; k < total; ++k) col_off[wg_slots[k] + 1] += 1;
+        for (int cidx = 0; cidx < 3 * T; ++cidx) col_off[cidx + 1] += col_off[cidx];
+        wg_dst.resize(std::max(total, 1));
+        std::vector<int> fill(col_off.begin(), col_off.end() - 1);
+        for (int k = 0; k < total; ++k) wg_dst[k] = fill[wg_slots[k]]++;  // k ascending = wg order
+        if (wg_slots.empty()) wg_slots.push_back(0);
+    }
 
     // ---- upload
+    HIP_TRY(c, c->d_wg_off.ensure(wg_off.size() * 4));
+    HIP_TRY(c, c->d_wg_slots.ensure(wg_slots.size() * 4));
+    HIP_TRY(c, c->d_col_off.ensure(col_off.size() * 4));
+    HIP_TRY(c, c->d_wg_dst.ensure(wg_dst.size() * 4));
+    HIP_TRY(c, hipMemcpyAsync(c->d_wg_off.p, wg_off.data(), wg_off.size() * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(c->d_wg_slots.p, wg_slots.data(), wg_slots.size() * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(c->d_col_off.p, col_off.data(), col_off.size() * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(c->d_wg_dst.p, wg_dst.data(), wg_dst.size() * 4, hipMemcpyHostToDevice, s));
     HIP_TRY(c, c->d_h.ensure(n_pad * 2));
     HIP_TRY(c, c->d_a.ensure(n_pad * 2));
     HIP_TRY(c, c->d_x.ensure(n_pad));
@@ -333,12 +387,15 @@ int bplhip_set_fixtures(bplhip_ctx* c, int model_kind, int64_t n, int32_t n_team
         HIP_TRY(c, c->d_xs.ensure((size_t)T * k * 8));
         HIP_TRY(c, hipMemcpyAsync(c->d_xs.p, c->h_xs.data(), (size_t)T * k * 8,
                                   hipMemcpyHostToDevice, s));
+        std::vector<float> xsf(c->h_xs.begin(), c->h_xs.end());
+        HIP_TRY(c, c->d_xsf.ensure((size_t)T * k * 4));
+        HIP_TRY(c, hipMemcpy(c->d_xsf.p, xsf.data(), (size_t)T * k * 4, hipMemcpyHostToDevice));
     }
     HIP_TRY(c, hipStreamSynchronize(s));
 
-    for (auto& kv : c->graphs) (void)hipGraphExecDestroy(kv.second);
-    c->graphs.clear();
+    drop_graphs(c);
     c->L = dc::make_layout(model_kind, T, k);
+    c->lds_attr_set = false;
     c->n = n;
     c->n_tiles = n_tiles;
     c->tiles_per_wave = tpw;
@@ -348,10 +405,25 @@ int bplhip_set_fixtures(bplhip_ctx* c, int model_kind, int64_t n, int32_t n_team
     c->lgsum = lgsum;
     c->h_pairs = std::move(pairs);
     c->slab_chains = 0;
+    c->total_c = wg_off[n_wg];
+    c->staged = ctx_lds_bytes(c, true) <= 96 * 1024;
+    if (ctx_lds_bytes(c, c->staged) > LDS_LIMIT)
+        return fail(c, BPLHIP_EUNSUPPORTED, "set_fixtures: tail LDS footprint too large");
     int rc = ensure_slabs(c, 1);
     if (rc != BPLHIP_OK) return rc;
     c->bound = true;
     return BPLHIP_OK;
+}
+
+int bplhip_set_option(bplhip_ctx* c, const char* name, int value) {
+    if (!c || !name) return BPLHIP_EINVAL;
+    const std::string n(name);
+    if (n == "max_wg") {  // takes effect at the next bplhip_set_fixtures
+        if (value < 1 || value > 1024) return fail(c, BPLHIP_EINVAL, "max_wg out of range [1,1024]");
+        c->opt_max_wg = value;
+        return BPLHIP_OK;
+    }
+    return fail(c, BPLHIP_EINVAL, "unknown option '%s'", name);
 }
 
 int bplhip_latent_dim(const bplhip_ctx* c) {
@@ -414,6 +486,23 @@ int bplhip_logp_grad_graph(bplhip_ctx* c, int32_t count, int32_t n_z, const doub
     for (int r = 0; r < replays; ++r) HIP_TRY(c, hipGraphLaunch(it->second, s));
     return BPLHIP_OK;
 }
+
+#ifdef DC_STAMPS
+// diagnostic build only: allocate / read the per-workgroup timestamp buffer [n_wg][16]
+int bplhip_debug_stamps(bplhip_ctx* c, unsigned long long* out, int n_words) {
+    if (!c || !c->bound) return BPLHIP_ESTATE;
+    const size_t bytes = (size_t)(c->n_wg + 2) * 16 * 8;
+    if (!c->d_debug.p) {
+        HIP_TRY(c, c->d_debug.ensure(bytes));
+        HIP_TRY(c, hipMemset(c->d_debug.p, 0, bytes));
+        return c->n_wg + 1;
+    }
+    HIP_TRY(c, hipDeviceSynchronize());
+    const size_t want = std::min(bytes, (size_t)n_words * 8);
+    HIP_TRY(c, hipMemcpy(out, c->d_debug.p, want, hipMemcpyDeviceToHost));
+    return c->n_wg + 1;
+}
+#endif
 
 void bplhip_threefry_split(uint32_t key_hi, uint32_t key_lo, int32_t n, uint32_t* out) {
     if (n <= 0 || !out) return;

@@ -1,16 +1,27 @@
 // dc_kernels.hip.h -- gfx950 (CDNA4, wave64) kernels for the Dixon-Coles potential
 // energy and its gradient.  No MFMA: the path is a stream + gather from an
-// LDS-resident per-team table + reduction (HBM/latency bound).
+// LDS-resident per-team table + reduction.  At the BASELINE sizes (6 MB / evaluation)
+// it is latency bound, so the design minimises the dependent chain of one launch:
 //
-//   dc_stream   : one pass over the fixture SoA (u16,u16,u8,u8[,f32] = 6 or 10 B per
-//                 fixture, 16-B / 8-B vector loads, 8 fixtures per lane).  Per
-//                 workgroup: per-team exp tables and the rho bounds are rebuilt in LDS
-//                 from z, fixtures are streamed, per-(home,away) run sums are reduced
-//                 in-lane -> across the wave (shuffles) -> into LDS per-team
-//                 accumulators -> one slab of partial sums per workgroup.
-//   dc_epilogue : one workgroup per chain; fixed-order reduction of the slabs, the
-//                 rho-bounds adjoint, priors + Jacobians and the chain rule back to the
-//                 unconstrained latent vector (float64).
+//   dc_eval   ONE launch per evaluation, grid = (1 + n_wg) x chains, 512 threads.
+//     block 0  "prior" workgroup: everything that depends on z only, in float64 and in
+//              parallel with the streaming: priors + Jacobians and their gradient, the
+//              chain-rule scalars, the exact (float64) rates of every pair -> true rho,
+//              arg-extremal pairs for the adjoint of the rho bounds, and the rounding
+//              error of every float32 table entry (for a first-order correction of U).
+//     blocks 1..n_wg  streaming workgroups:
+//       - fixture loads of the first tile are issued before anything else;
+//       - per-team tables {exp(att+ha), exp(-def)}, {exp(att), exp(-def)} rebuilt in LDS
+//         from z in float32 (v_exp_f32), rho from three DPP max reductions over the
+//         unique-pair table;
+//       - fixtures: 8 per lane from 16-B / 8-B vector loads (6 or 10 B per fixture);
+//         per fixture: 2 LDS gathers, 2 products, tau term (1 v_log_f32 + 1 v_rcp_f32);
+//         per-(home,away) run sums: in lane -> across the wave by DPP -> float64 LDS
+//         per-team accumulators; one slab of partial sums per workgroup, stored
+//         write-through (sc1).
+//     tail     the last-arriving workgroup (agent-scope ticket) reduces the slabs in a
+//              fixed order (deterministic), applies the adjoint of the bounds, the
+//              first-order value corrections and the chain rule -- adds and FMAs only.
 //
 // Mathematics: SURVEY.md Appendix A (restating bpl/dixon_coles.py:39-84,
 // bpl/extended_dixon_coles.py:78-248, bpl/_util.py:17-93 under numpyro semantics).
@@ -24,14 +35,31 @@ namespace dc {
 
 constexpr int LANE_FIX = 8;              // fixtures per lane per tile
 constexpr int TILE = 64 * LANE_FIX;      // fixtures per wave-tile
-constexpr int STREAM_BLOCK = 512;        // 8 waves per workgroup
-constexpr int STREAM_WAVES = STREAM_BLOCK / 64;
-constexpr int EPI_BLOCK = 256;
+constexpr int BLOCK = 512;               // 8 waves per workgroup
+constexpr int WAVES = BLOCK / 64;
 constexpr int N_SCAL = 4;                // SLAM, SLOG2, SU, CLIPC
-constexpr int BOUNDS_WORDS = 8;          // u32 words per chain
-constexpr uint32_t PAD_TEAM_SENTINEL = 0xFFFFu;
+constexpr int MAX_RG = 32;               // row groups of the slab reduction
+constexpr int RUN_LOOP_MAX = 4;          // runs per wave-tile handled by masked DPP sums
 
-struct StreamArgs {
+// z-only record written by the prior workgroup (doubles), per chain:
+//   [0..ZO_HDR)         scalars, see enum
+//   [ZO_HDR, +D)        gz[i]  = -dL_prior/dz_i  (everything not involving fixture sums)
+//   [ZO_HDR+D, +3T)     eps: eAg[T] | eA[T] | eDn[T]   (log(true / float32 table entry))
+enum {
+    ZO_LZ = 0,    // z-only part of L: priors + Jacobians + sum_t(att cA - def cD + ha cH)
+    ZO_SA, ZO_SD, ZO_SH,  // exp(z_std_*)
+    ZO_Q, ZO_DQ,          // corr_coef_raw (clipped sigmoid) and its derivative
+    ZO_UB, ZO_LB,         // true bounds (float64)
+    ZO_RHO,               // true rho
+    ZO_DRHO,              // rho_true - (double)rho_f32 used by the streaming workgroups
+    ZO_M, ZO_LH, ZO_LA,   // true maxima
+    ZO_PP, ZO_PQ, ZO_PR,  // arg-extremal pairs (home | away<<16, as double)
+    ZO_FLAGS,             // bit0 P home clipped, bit1 P away clipped, bit2 Q, bit3 R
+    ZO_HDR = 24
+};
+
+struct EvalArgs {
+    // fixtures (library-owned, sorted by (home,away), padded to TILE with team T)
     const uint4* h;    // [n_tiles*64]  8 x u16 home index per lane
     const uint4* a;    // [n_tiles*64]  8 x u16 away index
     const uint2* x;    // [n_tiles*64]  8 x u8 home goals
@@ -41,353 +69,113 @@ struct StreamArgs {
     int tiles_per_wave;
     const uint32_t* pairs;  // [P] unique (home | away<<16)
     int P;
-    const double* xs;       // [T,K] standardised covariates (device) or nullptr
-    double* slabs;          // [chains][n_wg][slab_stride]
-    int slab_stride;        // 3T + N_SCAL
-    uint32_t* bounds;       // [chains][BOUNDS_WORDS]
-    Layout L;
-};
-
-// ------------------------------------------------------------------ wave helpers
-
-__device__ __forceinline__ float wave_sum_f32(float v) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-    return v;
-}
-__device__ __forceinline__ double wave_sum_f64(double v) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-    return v;
-}
-__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        unsigned long long o = __shfl_xor(v, d, 64);
-        v = o > v ? o : v;
-    }
-    return v;
-}
-
-// acc layout in LDS: att[T1] | def[T1] | ha[T1]   (T1 = T+1, slot T = padding sink)
-__device__ __forceinline__ void flush_run(double* acc, int T1, uint32_t key, float sh,
-                                          float sa) {
-    const int h = key & 0xFFFFu, a = key >> 16;
-    const double dh = (double)sh, da = (double)sa;
-    atomicAdd(&acc[h], dh);            // d/d attack[home]   <- home-rate term
-    atomicAdd(&acc[2 * T1 + h], dh);   // d/d home_adv[home]
-    atomicAdd(&acc[T1 + a], dh);       // d/d defence[away]
-    atomicAdd(&acc[a], da);            // d/d attack[away]   <- away-rate term
-    atomicAdd(&acc[T1 + h], da);       // d/d defence[home]
-}
-
-// -------------------------------------------------------------------- dc_stream
-
-template <bool WEIGHTED, bool CLIP>
-__global__ __launch_bounds__(STREAM_BLOCK) void dc_stream(StreamArgs A,
-                                                          const double* __restrict__ zs) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const Layout& L = A.L;
-    const int T = L.T, T1 = T + 1;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int chain = blockIdx.y;
-    const double* z = zs + (size_t)chain * L.D;
-
-    // LDS carve (all offsets multiples of 16 B)
-    float2* tabH = reinterpret_cast<float2*>(smem);            // {exp(att+ha), exp(-def)}
-    float2* tabA = tabH + ((T1 + 1) & ~1);                     // {exp(att),    exp(-def)}
-    double* acc = reinterpret_cast<double*>(tabA + ((T1 + 1) & ~1));  // [3*T1]
-    double* red = acc + 3 * T1 + ((3 * T1) & 1);               // [STREAM_WAVES*4]
-    unsigned long long* redm =
-        reinterpret_cast<unsigned long long*>(red + STREAM_WAVES * N_SCAL);  // [W*3]
-    double* shq = reinterpret_cast<double*>(redm + STREAM_WAVES * 3);        // [2]
-
-    // ---- 0. issue the first tile's loads before anything else (latency overlap)
-    const int gw = blockIdx.x * STREAM_WAVES + wave;
-    int tile = gw * A.tiles_per_wave;
-    const int tile_end = min(tile + A.tiles_per_wave, A.n_tiles);
-    uint4 hv = make_uint4(0, 0, 0, 0), av = hv;
-    uint2 xv = make_uint2(0, 0), yv = xv;
-    float4 w0 = make_float4(0, 0, 0, 0), w1 = w0;
-    if (tile < tile_end) {
-        const size_t o = (size_t)tile * 64 + lane;
-        hv = A.h[o];
-        av = A.a[o];
-        xv = A.x[o];
-        yv = A.y[o];
-        if (WEIGHTED) {
-            w0 = A.w[2 * o];
-            w1 = A.w[2 * o + 1];
-        }
-    }
-
-    // ---- 1. per-team tables (float64 math, float32 storage) + zero accumulators
-    for (int t = tid; t < T1; t += STREAM_BLOCK) {
-        float2 vh = make_float2(0.f, 0.f), va = vh;
-        if (t < T) {
-            double att, def, ha;
-            team_params(L, z, A.xs, t, &att, &def, &ha);
-            const float edn = (float)exp(-def);
-            vh = make_float2((float)exp(att + ha), edn);
-            va = make_float2((float)exp(att), edn);
-        }
-        tabH[t] = vh;
-        tabA[t] = va;
-    }
-    for (int i = tid; i < 3 * T1; i += STREAM_BLOCK) acc[i] = 0.0;
-    if (tid == STREAM_BLOCK - 1) {
-        double q, dq;
-        clipped_sigmoid(z[L.o_corr], &q, &dq);
-        shq[0] = q;
-    }
-    __syncthreads();
-
-    // ---- 2. rho bounds over the unique-pair table (bpl/_util.py:23-30)
-    unsigned long long kP = 0, kQ = 0, kR = 0;
-    for (int p = tid; p < A.P; p += STREAM_BLOCK) {
-        const uint32_t pr = A.pairs[p];
-        const float2 th = tabH[pr & 0xFFFFu], ta = tabA[pr >> 16];
-        float lh = th.x * ta.y, la = ta.x * th.y;
-        if (CLIP) {
-            lh = fminf(lh, (float)RATE_CLIP);
-            la = fminf(la, (float)RATE_CLIP);
-        }
-        const unsigned long long idx = 0xFFFFFFFFu - (uint32_t)p;  // ties -> smallest p
-        const unsigned long long cP = ((unsigned long long)__float_as_uint(lh * la) << 32) | idx;
-        const unsigned long long cQ = ((unsigned long long)__float_as_uint(lh) << 32) | idx;
-        const unsigned long long cR = ((unsigned long long)__float_as_uint(la) << 32) | idx;
-        kP = cP > kP ? cP : kP;
-        kQ = cQ > kQ ? cQ : kQ;
-        kR = cR > kR ? cR : kR;
-    }
-    kP = wave_max_u64(kP);
-    kQ = wave_max_u64(kQ);
-    kR = wave_max_u64(kR);
-    if (lane == 0) {
-        redm[wave * 3 + 0] = kP;
-        redm[wave * 3 + 1] = kQ;
-        redm[wave * 3 + 2] = kR;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int wv = 0; wv < STREAM_WAVES; ++wv) {
-        const unsigned long long p0 = redm[wv * 3 + 0], p1 = redm[wv * 3 + 1],
-                                 p2 = redm[wv * 3 + 2];
-        kP = p0 > kP ? p0 : kP;
-        kQ = p1 > kQ ? p1 : kQ;
-        kR = p2 > kR ? p2 : kR;
-    }
-    const float Mf = __uint_as_float((uint32_t)(kP >> 32));
-    const float Lhf = __uint_as_float((uint32_t)(kQ >> 32));
-    const float Laf = __uint_as_float((uint32_t)(kR >> 32));
-    const double q = shq[0];
-    const double UB = Mf > 1.0f ? 1.0 / (double)Mf : 1.0;
-    const double LB = -1.0 / (double)fmaxf(Lhf, Laf);
-    const float rho = (float)(LB + q * (UB - LB));
-
-    if (blockIdx.x == 0 && tid == 0) {
-        uint32_t* b = A.bounds + (size_t)chain * BOUNDS_WORDS;
-        const uint32_t iP = 0xFFFFFFFFu - (uint32_t)kP, iQ = 0xFFFFFFFFu - (uint32_t)kQ,
-                       iR = 0xFFFFFFFFu - (uint32_t)kR;
-        const uint32_t pP = A.P ? A.pairs[iP] : 0, pQ = A.P ? A.pairs[iQ] : 0,
-                       pR = A.P ? A.pairs[iR] : 0;
-        uint32_t flags = 0;
-        if (CLIP) {
-            const float c = (float)RATE_CLIP;
-            if (tabH[pP & 0xFFFFu].x * tabA[pP >> 16].y > c) flags |= 1u;  // P home clipped
-            if (tabA[pP >> 16].x * tabH[pP & 0xFFFFu].y > c) flags |= 2u;  // P away clipped
-            if (tabH[pQ & 0xFFFFu].x * tabA[pQ >> 16].y > c) flags |= 4u;  // Q home clipped
-            if (tabA[pR >> 16].x * tabH[pR & 0xFFFFu].y > c) flags |= 8u;  // R away clipped
-        }
-        b[0] = __float_as_uint(Mf);
-        b[1] = __float_as_uint(Lhf);
-        b[2] = __float_as_uint(Laf);
-        b[3] = pP;
-        b[4] = pQ;
-        b[5] = pR;
-        b[6] = flags;
-        b[7] = 0;
-    }
-
-    // ---- 3. stream the fixtures
-    double dSLAM = 0.0, dSLOG = 0.0, dSU = 0.0, dCLIP = 0.0;
-    while (tile < tile_end) {
-        // prefetch the next tile
-        uint4 hn = hv, an = av;
-        uint2 xn = xv, yn = yv;
-        float4 w0n = w0, w1n = w1;
-        if (tile + 1 < tile_end) {
-            const size_t o = (size_t)(tile + 1) * 64 + lane;
-            hn = A.h[o];
-            an = A.a[o];
-            xn = A.x[o];
-            yn = A.y[o];
-            if (WEIGHTED) {
-                w0n = A.w[2 * o];
-                w1n = A.w[2 * o + 1];
-            }
-        }
-        const uint32_t hw[4] = {hv.x, hv.y, hv.z, hv.w};
-        const uint32_t aw[4] = {av.x, av.y, av.z, av.w};
-        const uint32_t xw[2] = {xv.x, xv.y};
-        const uint32_t yw[2] = {yv.x, yv.y};
-        const float wj[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
-
-        float shj[LANE_FIX], saj[LANE_FIX];
-        uint32_t keyj[LANE_FIX];
-        float slam = 0.f, slog = 0.f, su = 0.f, sclip = 0.f;
-#pragma unroll
-        for (int j = 0; j < LANE_FIX; ++j) {
-            const uint32_t hj = (hw[j >> 1] >> (16 * (j & 1))) & 0xFFFFu;
-            const uint32_t aj = (aw[j >> 1] >> (16 * (j & 1))) & 0xFFFFu;
-            const uint32_t xj = (xw[j >> 2] >> (8 * (j & 3))) & 0xFFu;
-            const uint32_t yj = (yw[j >> 2] >> (8 * (j & 3))) & 0xFFu;
-            keyj[j] = hj | (aj << 16);
-            const float2 th = tabH[hj], ta = tabA[aj];
-            float lh = th.x * ta.y;  // exp(att[h] + ha[h]) * exp(-def[a])
-            float la = ta.x * th.y;  // exp(att[a]) * exp(-def[h])
-            bool ch = false, ca = false;
-            float lh_raw = lh, la_raw = la;
-            if (CLIP) {
-                ch = lh > (float)RATE_CLIP;
-                ca = la > (float)RATE_CLIP;
-                lh = ch ? (float)RATE_CLIP : lh;
-                la = ca ? (float)RATE_CLIP : la;
-            }
-            // tau (bpl/_util.py:58-91): arg = 1 + rho*c,
-            //   c = -lh*la (0,0) | +la (1,0) | +lh (0,1) | -1 (1,1) | 0 otherwise
-            const bool x0 = xj == 0, y0 = yj == 0;
-            const bool low = (xj <= 1) & (yj <= 1);
-            float c = x0 ? (y0 ? -lh * la : lh) : (y0 ? la : -1.0f);
-            c = low ? c : 0.0f;
-            const float t = fmaf(rho, c, 1.0f);
-            const float l2 = __log2f(fmaxf(t, 0.0f));           // log(clip(.,0)): -inf at 0
-            const float u = t > 0.0f ? c * __builtin_amdgcn_rcpf(t) : 0.0f;  // dlogtau/drho
-            const float ru = rho * u;
-            // -(dL/d eta) without the data-only goal counts (added in the epilogue):
-            //   eta_h: lh - rho*u*[x==0]   (lh * dlogtau/dlh = rho*u for (0,0),(0,1))
-            float sh = lh - (x0 ? ru : 0.0f);
-            float sa = la - (y0 ? ru : 0.0f);
-            float wv = 1.0f;
-            if (WEIGHTED) wv = wj[j];
-            if (CLIP) {
-                // clipped rate: d/d eta = 0 -> cancel the goal count added later, and
-                // correct k*eta -> k*log(15) in the value
-                if (ch) {
-                    sh = (float)xj;
-                    sclip += wv * (float)xj * (__logf(lh_raw) - (float)LOG_RATE_CLIP);
-                }
-                if (ca) {
-                    sa = (float)yj;
-                    sclip += wv * (float)yj * (__logf(la_raw) - (float)LOG_RATE_CLIP);
-                }
-            }
-            if (WEIGHTED) {
-                sh *= wv;
-                sa *= wv;
-                slam += wv * (lh + la);
-                slog += wv * l2;
-                su += wv * u;
-            } else {
-                slam += lh + la;
-                slog += l2;
-                su += u;
-            }
-            shj[j] = sh;
-            saj[j] = sa;
-        }
-        dSLAM += (double)slam;
-        dSLOG += (double)slog;
-        dSU += (double)su;
-        if (CLIP) dCLIP += (double)sclip;
-
-        // ---- per-(home,away) run sums: lane -> wave -> LDS per-team accumulators
-        uint32_t diff = 0;
-        float rsh = 0.f, rsa = 0.f;
-#pragma unroll
-        for (int j = 0; j < LANE_FIX; ++j) {
-            diff |= keyj[j] ^ keyj[0];
-            rsh += shj[j];
-            rsa += saj[j];
-        }
-        uint32_t key = keyj[0];
-        if (diff != 0) {  // rare: a pair boundary inside this lane's 8 fixtures
-#pragma unroll
-            for (int j = 0; j < LANE_FIX; ++j) flush_run(acc, T1, keyj[j], shj[j], saj[j]);
-            rsh = 0.f;
-            rsa = 0.f;
-            key = keyj[LANE_FIX - 1];
-        }
-        const uint32_t k0 = __builtin_amdgcn_readfirstlane(key);
-        if (__all(key == k0)) {  // whole wave-tile on one pair (the common case: sorted)
-            rsh = wave_sum_f32(rsh);
-            rsa = wave_sum_f32(rsa);
-            if (lane == 0) flush_run(acc, T1, key, rsh, rsa);
-        } else {  // segmented inclusive scan over runs of equal keys
-            const uint32_t kprev = __shfl_up(key, 1, 64);
-            int f = (lane == 0) | (kprev != key);
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const float u0 = __shfl_up(rsh, d, 64), u1 = __shfl_up(rsa, d, 64);
-                const int fu = __shfl_up(f, d, 64);
-                if (lane >= d && !f) {
-                    rsh += u0;
-                    rsa += u1;
-                    f |= fu;
-                }
-            }
-            const uint32_t knext = __shfl_down(key, 1, 64);
-            if (lane == 63 || knext != key) flush_run(acc, T1, key, rsh, rsa);
-        }
-
-        hv = hn;
-        av = an;
-        xv = xn;
-        yv = yn;
-        w0 = w0n;
-        w1 = w1n;
-        ++tile;
-    }
-
-    // ---- 4. workgroup reduction of the scalars, then the slab
-    dSLAM = wave_sum_f64(dSLAM);
-    dSLOG = wave_sum_f64(dSLOG);
-    dSU = wave_sum_f64(dSU);
-    if (CLIP) dCLIP = wave_sum_f64(dCLIP);
-    if (lane == 0) {
-        red[wave * N_SCAL + 0] = dSLAM;
-        red[wave * N_SCAL + 1] = dSLOG;
-        red[wave * N_SCAL + 2] = dSU;
-        red[wave * N_SCAL + 3] = dCLIP;
-    }
-    __syncthreads();
-    double* slab = A.slabs + ((size_t)chain * gridDim.x + blockIdx.x) * A.slab_stride;
-    for (int i = tid; i < 3 * T; i += STREAM_BLOCK) {
-        const int which = i / T, t = i - which * T;
-        slab[i] = acc[which * T1 + t];
-    }
-    if (tid < N_SCAL) {
-        double s = 0.0;
-#pragma unroll
-        for (int wv = 0; wv < STREAM_WAVES; ++wv) s += red[wv * N_SCAL + tid];
-        slab[3 * T + tid] = s;
-    }
-}
-
-// ------------------------------------------------------------------ dc_epilogue
-
-struct EpiArgs {
-    const double* slabs;
-    int n_wg, slab_stride;
-    const uint32_t* bounds;
-    const double* xs;   // [T,K]
+    const double* xs;       // [T,K] standardised covariates (float64) or nullptr
+    const float* xsf;       // the same in float32 (streaming prologue)
+    // data-only sums
     const double* cA;   // [T] sum_{h=t} w x + sum_{a=t} w y   (coefficient of attack_t)
     const double* cD;   // [T] sum_{a=t} w x + sum_{h=t} w y   (coefficient of -defence_t)
     const double* cH;   // [T] sum_{h=t} w x                   (coefficient of home_adv_t)
     double lgsum;       // sum_i w_i (lgamma(x_i+1) + lgamma(y_i+1))
+    // static sparse-slab structure: a streaming workgroup only touches a few of the 3T
+    // per-team slots (fixtures are sorted by pair), so it publishes just those
+    const int* wg_off;      // [n_wg+1] offsets into wg_slots / the compact array
+    const int* wg_slots;    // [total_c] slot (column) index in [0, 3T) of each compact entry
+    const int* wg_dst;      // [total_c] where each entry goes in the column-major compact array
+    const int* col_off;     // [3T+1]   column c owns compact[col_off[c] .. col_off[c+1]),
+                            //          entries in workgroup order
+    int total_c;
+    // scratch
+    double* compact;        // [chains][total_c]   partial sums of the touched slots
+    double* scal;           // [chains][n_wg][N_SCAL]
+    double* zo;             // [chains][zo_stride]
+    int n_wg;               // streaming workgroups (grid.x = n_wg + 1)
+    int zo_stride;
+    unsigned int* tickets;  // [chains] arrival counters
+    // in / out
+    const double* z;        // [chains][D]
+    double* potential;      // [chains]
+    double* grad;           // [chains][D]
+    double* aux;            // [chains][4] or nullptr
+    unsigned long long* debug;  // diagnostic build only (DC_STAMPS): [n_wg+1][16]
     Layout L;
 };
 
+// Diagnostic build (make stamps): thread 0 of every workgroup stores the 100 MHz
+// s_memrealtime counter at phase boundaries into a buffer nothing else reads.
+#ifdef DC_STAMPS
+#define DC_STAMP(k)                                                                    \
+    do {                                                                               \
+        if (threadIdx.x == 0 && A.debug && blockIdx.y == 0)                            \
+            A.debug[(size_t)blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+#else
+#define DC_STAMP(k) do { } while (0)
+#endif
+
+// ------------------------------------------------------------------ wave helpers (DPP)
+
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ int dpp_i32(int old, int v) {
+    return __builtin_amdgcn_update_dpp(old, v, CTRL, ROW_MASK, 0xF, false);
+}
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ float dpp_f32(float old, float v) {
+    return __int_as_float(dpp_i32<CTRL, ROW_MASK>(__float_as_int(old), __float_as_int(v)));
+}
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ double dpp_f64(double old, double v) {
+    const long long o = __double_as_longlong(old), x = __double_as_longlong(v);
+    const int lo = dpp_i32<CTRL, ROW_MASK>((int)o, (int)x);
+    const int hi = dpp_i32<CTRL, ROW_MASK>((int)(o >> 32), (int)(x >> 32));
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+// Sum over the 64 lanes, returned wave-uniform.  quad_perm, quad_perm, row_ror:4,
+// row_ror:8 leave every lane with its 16-lane row total; row_bcast:15 / row_bcast:31
+// fold the rows so lane 63 holds the wave total.
+__device__ __forceinline__ float wave_sum_f32(float v) {
+    v += dpp_f32<0xB1>(0.f, v);        // quad_perm [1,0,3,2]
+    v += dpp_f32<0x4E>(0.f, v);        // quad_perm [2,3,0,1]
+    v += dpp_f32<0x124>(0.f, v);       // row_ror:4
+    v += dpp_f32<0x128>(0.f, v);       // row_ror:8
+    v += dpp_f32<0x142, 0xA>(0.f, v);  // row_bcast:15 into rows 1,3
+    v += dpp_f32<0x143, 0xC>(0.f, v);  // row_bcast:31 into rows 2,3
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ float wave_max_f32(float v) {  // v >= 0
+    v = fmaxf(v, dpp_f32<0xB1>(0.f, v));
+    v = fmaxf(v, dpp_f32<0x4E>(0.f, v));
+    v = fmaxf(v, dpp_f32<0x124>(0.f, v));
+    v = fmaxf(v, dpp_f32<0x128>(0.f, v));
+    v = fmaxf(v, dpp_f32<0x142, 0xA>(0.f, v));
+    v = fmaxf(v, dpp_f32<0x143, 0xC>(0.f, v));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ double readlane63_f64(double v) {
+    const long long x = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)x, 63);
+    const int hi = __builtin_amdgcn_readlane((int)(x >> 32), 63);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ double wave_sum_f64(double v) {
+    v += dpp_f64<0xB1>(0.0, v);
+    v += dpp_f64<0x4E>(0.0, v);
+    v += dpp_f64<0x124>(0.0, v);
+    v += dpp_f64<0x128>(0.0, v);
+    v += dpp_f64<0x142, 0xA>(0.0, v);
+    v += dpp_f64<0x143, 0xC>(0.0, v);
+    return readlane63_f64(v);
+}
+__device__ __forceinline__ double wave_max_f64(double v) {  // v >= 0
+    v = fmax(v, dpp_f64<0xB1>(0.0, v));
+    v = fmax(v, dpp_f64<0x4E>(0.0, v));
+    v = fmax(v, dpp_f64<0x124>(0.0, v));
+    v = fmax(v, dpp_f64<0x128>(0.0, v));
+    v = fmax(v, dpp_f64<0x142, 0xA>(0.0, v));
+    v = fmax(v, dpp_f64<0x143, 0xC>(0.0, v));
+    return readlane63_f64(v);
+}
+
+// Workgroup sum of NV doubles (all threads get the totals).  scratch: WAVES*NV doubles.
 template <int NV>
 __device__ __forceinline__ void block_sum(double (&v)[NV], double* scratch, int tid) {
     const int lane = tid & 63, wave = tid >> 6;
@@ -402,71 +190,570 @@ __device__ __forceinline__ void block_sum(double (&v)[NV], double* scratch, int 
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         double s = 0.0;
-        for (int wv = 0; wv < EPI_BLOCK / 64; ++wv) s += scratch[wv * NV + i];
+#pragma unroll
+        for (int wv = 0; wv < WAVES; ++wv) s += scratch[wv * NV + i];
         v[i] = s;
     }
 }
 
-__global__ __launch_bounds__(EPI_BLOCK) void dc_epilogue(EpiArgs A,
-                                                         const double* __restrict__ zs,
-                                                         double* __restrict__ potential,
-                                                         double* __restrict__ grads,
-                                                         double* __restrict__ auxs) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+// acc layout in LDS: att[T1] | def[T1] | ha[T1]   (T1 = T+1, slot T = padding sink)
+//   att[t] = sum_{h_i=t} sh_i + sum_{a_i=t} sa_i
+//   def[t] = sum_{a_i=t} sh_i + sum_{h_i=t} sa_i
+//   ha[t]  = sum_{h_i=t} sh_i
+__device__ __forceinline__ void flush_run(double* acc, int T1, uint32_t key, float sh,
+                                          float sa) {
+    const int h = key & 0xFFFFu, a = key >> 16;
+    const double dh = (double)sh, da = (double)sa;
+    atomicAdd(&acc[h], dh);
+    atomicAdd(&acc[2 * T1 + h], dh);
+    atomicAdd(&acc[T1 + a], dh);
+    atomicAdd(&acc[a], da);
+    atomicAdd(&acc[T1 + h], da);
+}
+
+// write-through (sc1) store / L1-bypassing (sc1) load of one double: the in-launch
+// hand-off between workgroups (cdna_hip_programming.md Guideline 16, split-K form)
+__device__ __forceinline__ double ld_sc1(const double* p) {
+    const unsigned long long u =
+        __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED,
+                          __HIP_MEMORY_SCOPE_AGENT);
+    return __longlong_as_double((long long)u);
+}
+__device__ __forceinline__ void st_sc1(double* p, double v) {
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p),
+                       (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ---------------------------------------------------------------- LDS footprints
+
+__host__ __device__ inline int tab_len(int T) { return (T + 2) & ~1; }  // >= T+1, even
+__host__ __device__ inline size_t stream_lds_bytes(int T) {
+    const int T1 = T + 1;
+    size_t b = 2 * (size_t)tab_len(T) * 8;                 // tabH, tabA (float2)
+    b += (size_t)(3 * T1 + ((3 * T1) & 1)) * 8;            // acc
+    b += (size_t)WAVES * N_SCAL * 8;                       // red
+    b += (size_t)WAVES * 4 * 4;                            // redm (float)
+    b += 16 * 4;                                           // flag
+    return b;
+}
+// tail: everything it needs is staged into LDS in one round of loads
+__host__ __device__ inline size_t tail_lds_bytes(int T, int D, int zo_stride, int n_wg,
+                                                 int total_c, bool staged) {
+    size_t d = (size_t)zo_stride + 3 * (size_t)T + D + (3 * (size_t)T + N_SCAL + 4) +
+               WAVES * 8 + (size_t)n_wg * N_SCAL;
+    size_t i = 3 * (size_t)T + 2;
+    if (staged) d += (size_t)total_c;
+    return d * 8 + ((i * 4 + 15) & ~(size_t)15) + 16;
+}
+__host__ __device__ inline size_t prior_lds_bytes(int T) {
+    size_t b = 2 * (size_t)tab_len(T) * 8;                 // tabH, tabA (float2)
+    b += 3 * (size_t)T * 8;                                // true tables (double)
+    b += 3 * (size_t)T * 8;                                // att, def, ha (double)
+    b += (32 + WAVES * 8 + WAVES * 8) * 8;                 // scalars, scratch, argmax
+    return b;
+}
+__host__ __device__ inline size_t eval_lds_bytes(int T, int D, int zo_stride, int n_wg,
+                                                 int total_c, bool staged) {
+    size_t b = stream_lds_bytes(T);
+    const size_t t = tail_lds_bytes(T, D, zo_stride, n_wg, total_c, staged),
+                 p = prior_lds_bytes(T);
+    b = b > t ? b : t;
+    return b > p ? b : p;
+}
+
+// ---------------------------------------------------------------- float32 tables
+// The streaming workgroups and the prior workgroup run exactly this code, so the prior
+// workgroup knows the table values bit for bit.
+
+struct F32Scalars {
+    float s_a, s_d, s_h, q, m, mha, gam;
+};
+__device__ __forceinline__ float exp_f32(float x) {
+    return __builtin_amdgcn_exp2f(x * 1.44269504088896341f);
+}
+__device__ __forceinline__ F32Scalars f32_scalars(const Layout& L, const double* z) {
+    F32Scalars s;
+    s.s_a = exp_f32((float)z[L.o_sa]);
+    s.s_d = exp_f32((float)z[L.o_sd]);
+    s.m = (float)z[L.o_md];
+    const float zc = (float)z[L.o_corr];
+    float q = __builtin_amdgcn_rcpf(1.0f + exp_f32(-zc));
+    s.q = fminf(fmaxf(q, (float)SIG_LO), (float)SIG_HI);
+    if (L.model == MODEL_BASIC) {
+        s.gam = (float)z[L.o_ha];
+        s.s_h = 0.f;
+        s.mha = 0.f;
+    } else {
+        s.gam = 0.f;
+        s.s_h = exp_f32((float)z[L.o_sh]);
+        s.mha = (float)z[L.o_mha];
+    }
+    return s;
+}
+__device__ __forceinline__ void f32_table_entry(const Layout& L, const F32Scalars& s,
+                                                const double* z, const float* xsf, int t,
+                                                float2* vh, float2* va) {
+    float att, def, ha;
+    if (L.model == MODEL_BASIC) {
+        att = s.s_a * (float)z[L.o_adec + t];
+        def = s.m + s.s_d * (float)z[L.o_ddec + t];
+        ha = s.gam;
+    } else {
+        float apm = 0.f, dpm = s.m;
+        for (int k = 0; k < L.K; ++k) {
+            const float xv = xsf[(size_t)t * L.K + k];
+            apm += xv * (float)z[L.o_bA + k];
+            dpm += xv * (float)z[L.o_bD + k];
+        }
+        att = apm + (float)z[L.o_sat + t] * s.s_a;
+        def = dpm + (float)z[L.o_sdt + t] * s.s_d;
+        ha = s.mha + s.s_h * (float)z[L.o_hadec + t];
+    }
+    const float edn = exp_f32(-def);
+    *vh = make_float2(exp_f32(att + ha), edn);
+    *va = make_float2(exp_f32(att), edn);
+}
+__device__ __forceinline__ void build_tables_f32(const Layout& L, const double* z,
+                                                 const float* xsf, float2* tabH, float2* tabA,
+                                                 int tid, F32Scalars* out) {
+    const F32Scalars s = f32_scalars(L, z);
+    for (int t = tid; t <= L.T; t += BLOCK) {
+        float2 vh = make_float2(0.f, 0.f), va = vh;
+        if (t < L.T) f32_table_entry(L, s, z, xsf, t, &vh, &va);
+        tabH[t] = vh;
+        tabA[t] = va;
+    }
+    *out = s;
+}
+// rho in float32 from the three float32 maxima (identical code in stream and prior)
+__device__ __forceinline__ float rho_f32(float mP, float mQ, float mR, float q) {
+    const float ub = mP > 1.0f ? __builtin_amdgcn_rcpf(mP) : 1.0f;
+    const float lb = -__builtin_amdgcn_rcpf(fmaxf(mQ, mR));
+    return fmaf(q, ub - lb, lb);
+}
+// workgroup maxima of the pair rates from the float32 tables
+template <bool CLIP>
+__device__ __forceinline__ void pair_maxima_f32(const EvalArgs& A, const float2* tabH,
+                                                const float2* tabA, uint32_t pr0, float* redm,
+                                                int tid, float* oP, float* oQ, float* oR) {
+    const int lane = tid & 63, wave = tid >> 6;
+    float mP = 0.f, mQ = 0.f, mR = 0.f;
+    for (int p = tid; p < A.P; p += BLOCK) {
+        const uint32_t pr = p == tid ? pr0 : A.pairs[p];
+        const float2 th = tabH[pr & 0xFFFFu], ta = tabA[pr >> 16];
+        float lh = th.x * ta.y, la = ta.x * th.y;
+        if (CLIP) {
+            lh = fminf(lh, (float)RATE_CLIP);
+            la = fminf(la, (float)RATE_CLIP);
+        }
+        mP = fmaxf(mP, lh * la);  // (a NaN rate reaches U through the rate sum anyway)
+        mQ = fmaxf(mQ, lh);
+        mR = fmaxf(mR, la);
+    }
+    mP = wave_max_f32(mP);
+    mQ = wave_max_f32(mQ);
+    mR = wave_max_f32(mR);
+    if (lane == 0) {
+        redm[wave * 4 + 0] = mP;
+        redm[wave * 4 + 1] = mQ;
+        redm[wave * 4 + 2] = mR;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int wv = 0; wv < WAVES; ++wv) {
+        mP = fmaxf(mP, redm[wv * 4 + 0]);
+        mQ = fmaxf(mQ, redm[wv * 4 + 1]);
+        mR = fmaxf(mR, redm[wv * 4 + 2]);
+    }
+    *oP = mP;
+    *oQ = mQ;
+    *oR = mR;
+}
+
+// ---------------------------------------------------------------- prior workgroup
+
+// sigmoid site pieces from one exp + one log1p: value (clipped), derivative, and
+// log p terms.  sp(x) = softplus(x).
+struct SigSite {
+    double v, dv, log_v, log_1mv, jac, sig;  // jac = -sp(z) - sp(-z); sig = unclipped
+};
+__device__ __forceinline__ SigSite sig_site(double zc) {
+    const double az = fabs(zc);
+    const double e = exp(-az);
+    const double l = log1p(e);            // sp(-|z|)
+    const double sp_pos = az + l;         // sp(|z|)
+    const double s_abs = 1.0 / (1.0 + e); // sigmoid(|z|)
+    const double s = zc >= 0 ? s_abs : 1.0 - s_abs;
+    SigSite r;
+    r.sig = s;
+    r.jac = -(sp_pos + l);
+    double lv = zc >= 0 ? -l : -sp_pos;       // log sigmoid(z)  = -sp(-z)
+    double l1 = zc >= 0 ? -sp_pos : -l;       // log(1-sigmoid(z)) = -sp(z)
+    if (s < SIG_LO) {
+        r.v = SIG_LO;
+        r.dv = 0.0;
+        lv = log(SIG_LO);
+        l1 = log1p(-SIG_LO);
+    } else if (s > SIG_HI) {
+        r.v = SIG_HI;
+        r.dv = 0.0;
+        lv = log(SIG_HI);
+        l1 = log1p(-SIG_HI);
+    } else {
+        r.v = s;
+        r.dv = s * (1.0 - s);
+    }
+    r.log_v = lv;
+    r.log_1mv = l1;
+    return r;
+}
+
+template <bool CLIP>
+__device__ void prior_body(const EvalArgs& A, int chain, char* smem) {
     const Layout& L = A.L;
-    const int T = L.T, K = L.K;
-    const int tid = threadIdx.x;
-    const int chain = blockIdx.x;
-    const double* z = zs + (size_t)chain * L.D;
-    double* grad = grads + (size_t)chain * L.D;
-    const int ncol = 3 * T + N_SCAL;
+    const int T = L.T, K = L.K, D = L.D;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const double* z = A.z + (size_t)chain * D;
+    double* zo = A.zo + (size_t)chain * A.zo_stride;
+    double* gz = zo + ZO_HDR;
+    double* eps = gz + D;
 
-    double* col = reinterpret_cast<double*>(smem);  // [ncol] reduced slabs
-    double* scratch = col + ncol;                   // [4*16]
-    double* part = scratch + 64;                    // [RG*ncol]
+    float2* tabH = reinterpret_cast<float2*>(smem);
+    float2* tabA = tabH + tab_len(T);
+    double* tru = reinterpret_cast<double*>(tabA + tab_len(T));  // EAg[T] | EA[T] | EDn[T]
+    double* par = tru + 3 * T;                                    // att[T] | def[T] | ha[T]
+    double* sc = par + 3 * T;                                     // [32] scalars
+    double* scratch = sc + 32;                                    // [WAVES*8]
+    double* amx = scratch + WAVES * 8;                            // [WAVES*8] argmax
 
-    // ---- 1. fixed-order reduction of the workgroup slabs
-    int RG = EPI_BLOCK / ncol;
-    RG = RG < 1 ? 1 : (RG > 8 ? 8 : RG);
-    const double* slabs = A.slabs + (size_t)chain * A.n_wg * A.slab_stride;
-    for (int idx = tid; idx < ncol * RG; idx += EPI_BLOCK) {
-        const int rg = idx / ncol, c = idx - rg * ncol;
-        double s = 0.0;
-        for (int wg = rg; wg < A.n_wg; wg += RG) s += slabs[(size_t)wg * A.slab_stride + c];
-        part[rg * ncol + c] = s;
+    // ---- float32 tables and rho exactly as the streaming workgroups build them
+    uint32_t pr0 = 0;
+    if (tid < A.P) pr0 = A.pairs[tid];
+    F32Scalars fs;
+    build_tables_f32(L, z, A.xsf, tabH, tabA, tid, &fs);
+
+    // ---- z-only scalars, one transcendental chain per wave, in parallel
+    //   0 s_a  1 s_d  2 s_h  3..8 corr site  9..14 u site
+    if (tid == 0) sc[0] = exp(z[L.o_sa]);
+    if (tid == 64) sc[1] = exp(z[L.o_sd]);
+    if (tid == 128) sc[2] = L.model == MODEL_EXTENDED ? exp(z[L.o_sh]) : 0.0;
+    if (tid == 192) {
+        const SigSite s = sig_site(z[L.o_corr]);
+        sc[3] = s.v; sc[4] = s.dv; sc[5] = s.log_v; sc[6] = s.log_1mv; sc[7] = s.jac;
+        sc[8] = s.sig;
+    }
+    if (tid == 256 && L.model == MODEL_EXTENDED) {
+        const SigSite s = sig_site(z[L.o_u]);
+        sc[9] = s.v; sc[10] = s.dv; sc[11] = s.log_v; sc[12] = s.log_1mv; sc[13] = s.jac;
+        sc[14] = s.sig;
     }
     __syncthreads();
-    for (int c = tid; c < ncol; c += EPI_BLOCK) {
-        double s = 0.0;
-        for (int rg = 0; rg < RG; ++rg) s += part[rg * ncol + c];
-        col[c] = s;
+    const double s_a = sc[0], s_d = sc[1], s_h = sc[2];
+    const double q = sc[3], dq = sc[4];
+    const double m = z[L.o_md];
+
+    // ---- per team: constrained sites, true (float64) tables, rounding errors eps
+    for (int i = tid; i < 3 * T; i += BLOCK) {
+        const int j = i / T, t = i - j * T;  // j: 0 EAg, 1 EA, 2 EDn
+        double att, def, ha;
+        if (L.model == MODEL_BASIC) {
+            att = s_a * z[L.o_adec + t];
+            def = m + s_d * z[L.o_ddec + t];
+            ha = z[L.o_ha];
+        } else {
+            double apm = 0.0, dpm = m;
+            for (int k = 0; k < K; ++k) {
+                const double xv = A.xs[(size_t)t * K + k];
+                apm += xv * z[L.o_bA + k];
+                dpm += xv * z[L.o_bD + k];
+            }
+            att = apm + z[L.o_sat + t] * s_a;
+            def = dpm + z[L.o_sdt + t] * s_d;
+            ha = z[L.o_mha] + s_h * z[L.o_hadec + t];
+        }
+        const double arg = j == 0 ? att + ha : (j == 1 ? att : -def);
+        const float tabv = j == 0 ? tabH[t].x : (j == 1 ? tabA[t].x : tabH[t].y);
+        const double tv = exp(arg);
+        tru[j * T + t] = tv;
+        // eps = log(true/table) = log1p(r), r = (true - table)/table, |r| ~ 1e-7
+        const double r = (tv - (double)tabv) / (double)tabv;
+        double e = r - 0.5 * r * r;
+        e = fabs(r) < 1e-4 ? e : 0.0;  // under/overflowed entry: no meaningful correction
+        st_sc1(&eps[j * T + t], e);
+        if (j == 0) {
+            par[t] = att;
+            par[T + t] = def;
+            par[2 * T + t] = ha;
+        }
     }
     __syncthreads();
-    double* g_att = col;          // becomes dL/d attack_t
+
+    // ---- bounds: float32 maxima (-> rho_f32 of the streaming workgroups) and the true
+    // float64 maxima with their arg-pairs (ties -> smallest pair index)
+    float* redm = reinterpret_cast<float*>(scratch);
+    float mPf, mQf, mRf;
+    pair_maxima_f32<CLIP>(A, tabH, tabA, pr0, redm, tid, &mPf, &mQf, &mRf);
+    const float rho_f = rho_f32(mPf, mQf, mRf, fs.q);
+    __syncthreads();
+
+    double mP = 0.0, mQ = 0.0, mR = 0.0;
+    int iP = 0x7FFFFFFF, iQ = 0x7FFFFFFF, iR = 0x7FFFFFFF;
+    for (int p = tid; p < A.P; p += BLOCK) {
+        const uint32_t pr = p == tid ? pr0 : A.pairs[p];
+        const int h = pr & 0xFFFFu, a = pr >> 16;
+        double lh = tru[h] * tru[2 * T + a], la = tru[T + a] * tru[2 * T + h];
+        if (CLIP) {
+            lh = fmin(lh, RATE_CLIP);
+            la = fmin(la, RATE_CLIP);
+        }
+        if (lh * la > mP) { mP = lh * la; iP = p; }
+        if (lh > mQ) { mQ = lh; iQ = p; }
+        if (la > mR) { mR = la; iR = p; }
+    }
+    {
+        const double wP = wave_max_f64(mP), wQ = wave_max_f64(mQ), wR = wave_max_f64(mR);
+        // smallest pair index among the lanes holding the wave maximum
+        int cP = mP == wP ? iP : 0x7FFFFFFF, cQ = mQ == wQ ? iQ : 0x7FFFFFFF,
+            cR = mR == wR ? iR : 0x7FFFFFFF;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            cP = min(cP, __shfl_xor(cP, d, 64));
+            cQ = min(cQ, __shfl_xor(cQ, d, 64));
+            cR = min(cR, __shfl_xor(cR, d, 64));
+        }
+        if (lane == 0) {
+            amx[wave * 8 + 0] = wP; amx[wave * 8 + 1] = wQ; amx[wave * 8 + 2] = wR;
+            amx[wave * 8 + 3] = (double)cP; amx[wave * 8 + 4] = (double)cQ;
+            amx[wave * 8 + 5] = (double)cR;
+        }
+    }
+    __syncthreads();
+
+    // ---- team sums of the z-only part of L and of its gradient (gz = -dL_prior/dz)
+    // v: 0 team part of L (priors + att cA - def cD + ha cH); extended: 1 dL/d rho_p
+    double v[2] = {0.0, 0.0};
+    double rp = 0.0, vv = 1.0;
+    if (L.model == MODEL_EXTENDED) {
+        rp = 2.0 * sc[9] - 1.0;
+        vv = 1.0 - rp * rp;
+    }
+    const double log_vv = L.model == MODEL_EXTENDED ? log(vv) : 0.0;
+    for (int t = tid; t < T; t += BLOCK) {
+        const double att = par[t], def = par[T + t], ha = par[2 * T + t];
+        const double lin = att * A.cA[t] - def * A.cD[t] + ha * A.cH[t];
+        if (L.model == MODEL_BASIC) {
+            const double ad = z[L.o_adec + t], dd = z[L.o_ddec + t];
+            v[0] += -0.5 * ad * ad - 0.5 * dd * dd - 2.0 * HALF_LOG_2PI + lin;
+            st_sc1(&gz[L.o_adec + t], ad);
+            st_sc1(&gz[L.o_ddec + t], dd);
+        } else {
+            const double sa = z[L.o_sat + t], sd = z[L.o_sdt + t], hd = z[L.o_hadec + t];
+            const double e = sd - rp * sa;
+            v[0] += -0.5 * sa * sa - 0.5 * e * e / vv - 0.5 * log_vv - 0.5 * hd * hd -
+                    3.0 * HALF_LOG_2PI + lin;
+            v[1] += e * sa / vv - rp * e * e / (vv * vv) + rp / vv;
+            st_sc1(&gz[L.o_sat + t], sa - rp * e / vv);
+            st_sc1(&gz[L.o_sdt + t], e / vv);
+            st_sc1(&gz[L.o_hadec + t], hd);
+        }
+    }
+    block_sum<2>(v, scratch, tid);
+
+    if (tid < 2 * K) {  // covariate coefficients ~ N(0,1)
+        const int o = (tid >= K ? L.o_bD + tid - K : L.o_bA + tid);
+        st_sc1(&gz[o], z[o]);
+    }
+    if (tid == 0) {
+        // combine the waves' arg-maxima
+        double M = 0.0, Lh = 0.0, La = 0.0;
+        int jP = 0x7FFFFFFF, jQ = 0x7FFFFFFF, jR = 0x7FFFFFFF;
+        for (int wv = 0; wv < WAVES; ++wv) {
+            const double a0 = amx[wv * 8 + 0], a1 = amx[wv * 8 + 1], a2 = amx[wv * 8 + 2];
+            const int i0 = (int)amx[wv * 8 + 3], i1 = (int)amx[wv * 8 + 4],
+                      i2 = (int)amx[wv * 8 + 5];
+            if (a0 > M || (a0 == M && i0 < jP)) { M = a0; jP = i0; }
+            if (a1 > Lh || (a1 == Lh && i1 < jQ)) { Lh = a1; jQ = i1; }
+            if (a2 > La || (a2 == La && i2 < jR)) { La = a2; jR = i2; }
+        }
+        const uint32_t pP = A.pairs[jP < A.P ? jP : 0], pQ = A.pairs[jQ < A.P ? jQ : 0],
+                       pR = A.pairs[jR < A.P ? jR : 0];
+        unsigned int flags = 0;
+        if (CLIP) {
+            if (tru[pP & 0xFFFFu] * tru[2 * T + (pP >> 16)] > RATE_CLIP) flags |= 1u;
+            if (tru[T + (pP >> 16)] * tru[2 * T + (pP & 0xFFFFu)] > RATE_CLIP) flags |= 2u;
+            if (tru[pQ & 0xFFFFu] * tru[2 * T + (pQ >> 16)] > RATE_CLIP) flags |= 4u;
+            if (tru[T + (pR >> 16)] * tru[2 * T + (pR & 0xFFFFu)] > RATE_CLIP) flags |= 8u;
+        }
+        const double UB = M > 1.0 ? 1.0 / M : 1.0;
+        const double LB = -1.0 / fmax(Lh, La);
+        const double rho = LB + q * (UB - LB);
+
+        // scalar priors + Jacobians (L = log density)
+        const double zsa = z[L.o_sa], zsd = z[L.o_sd];
+        double Lz = sc[5] + sc[6] + 1.791759469228055 /*log 6*/ + sc[7];  // Beta(2,2) + Jac
+        Lz += -0.5 * s_a * s_a - HALF_LOG_2PI + LN2 + zsa;  // HalfNormal(1) + Exp Jacobian
+        Lz += -0.5 * s_d * s_d - HALF_LOG_2PI + LN2 + zsd;
+        Lz += -0.5 * m * m - HALF_LOG_2PI;
+        st_sc1(&gz[L.o_corr], -((1.0 / q - 1.0 / (1.0 - q)) * dq + (1.0 - 2.0 * sc[8])));
+        st_sc1(&gz[L.o_md], m);
+        st_sc1(&gz[L.o_sa], s_a * s_a - 1.0);
+        st_sc1(&gz[L.o_sd], s_d * s_d - 1.0);
+        if (L.model == MODEL_BASIC) {
+            const double gam = z[L.o_ha], r = (gam - 0.1) / 0.2;
+            Lz += -0.5 * r * r + 1.6094379124341003 /*-log 0.2*/ - HALF_LOG_2PI;
+            st_sc1(&gz[L.o_ha], (gam - 0.1) / 0.04);
+        } else {
+            const double mha = z[L.o_mha], zsh = z[L.o_sh];
+            const double r = (mha - 0.1) / 0.2;
+            Lz += -0.5 * r * r + 1.6094379124341003 - HALF_LOG_2PI;
+            Lz += -0.5 * s_h * s_h - HALF_LOG_2PI + LN2 + zsh;
+            const double u = sc[9], du = sc[10];
+            Lz += sc[11] + 3.0 * sc[12] + 2.995732273553991 /*log 20*/ + sc[13];
+            for (int k = 0; k < K; ++k) {
+                const double ba = z[L.o_bA + k], bd = z[L.o_bD + k];
+                Lz += -0.5 * ba * ba - 0.5 * bd * bd - 2.0 * HALF_LOG_2PI;
+            }
+            st_sc1(&gz[L.o_mha], (mha - 0.1) / 0.04);
+            st_sc1(&gz[L.o_sh], s_h * s_h - 1.0);
+            st_sc1(&gz[L.o_u], -(2.0 * v[1] * du + (1.0 / u - 3.0 / (1.0 - u)) * du +
+                                 (1.0 - 2.0 * sc[14])));
+        }
+        st_sc1(&zo[ZO_LZ], Lz + v[0]);
+        st_sc1(&zo[ZO_SA], s_a);
+        st_sc1(&zo[ZO_SD], s_d);
+        st_sc1(&zo[ZO_SH], s_h);
+        st_sc1(&zo[ZO_Q], q);
+        st_sc1(&zo[ZO_DQ], dq);
+        st_sc1(&zo[ZO_UB], UB);
+        st_sc1(&zo[ZO_LB], LB);
+        st_sc1(&zo[ZO_RHO], rho);
+        st_sc1(&zo[ZO_DRHO], rho - (double)rho_f);
+        st_sc1(&zo[ZO_M], M);
+        st_sc1(&zo[ZO_LH], Lh);
+        st_sc1(&zo[ZO_LA], La);
+        st_sc1(&zo[ZO_PP], (double)pP);
+        st_sc1(&zo[ZO_PQ], (double)pQ);
+        st_sc1(&zo[ZO_PR], (double)pR);
+        st_sc1(&zo[ZO_FLAGS], (double)flags);
+    }
+}
+
+// ------------------------------------------------------------------------ tail
+
+template <bool STAGED>
+__device__ void tail_body(const EvalArgs& A, int chain, char* smem) {
+    const Layout& L = A.L;
+    const int T = L.T, K = L.K, D = L.D;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double* grad = A.grad + (size_t)chain * D;
+    const int ncol = 3 * T;
+    const int nsc = A.n_wg * N_SCAL;
+
+    // LDS carve
+    double* zoL = reinterpret_cast<double*>(smem);   // [zo_stride]  prior workgroup record
+    double* cL = zoL + A.zo_stride;                  // [3T] cA | cD | cH
+    double* zL = cL + 3 * T;                         // [D]
+    double* col = zL + D;                            // [3T + N_SCAL + 4] reduced sums
+    double* scratch = col + ncol + N_SCAL + 4;       // [WAVES*8]
+    double* scl = scratch + WAVES * 8;               // [n_wg*N_SCAL]
+    double* cmp = scl + nsc;                         // [total_c] (STAGED)
+    int* coff = reinterpret_cast<int*>(cmp + (STAGED ? A.total_c : 0));  // [3T+1]
+    DC_STAMP(7);
+
+    // ---- 1. ONE round of loads: every global value the tail needs goes to LDS now
+    const double* compact = A.compact + (size_t)chain * A.total_c;
+    const double* scal = A.scal + (size_t)chain * nsc;
+    const double* zo = A.zo + (size_t)chain * A.zo_stride;
+    const double* z = A.z + (size_t)chain * D;
+    // (loads are issued in explicit batches: a rolled load->LDS-store loop would wait
+    // for every load before issuing the next one)
+    {
+        double* dst[3] = {cmp, scl, zoL};
+        const double* src[3] = {compact, scal, zo};
+        const int cnt[3] = {STAGED ? A.total_c : 0, nsc, A.zo_stride};
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+#pragma unroll 1
+            for (int i0 = 0; i0 < cnt[a]; i0 += 8 * BLOCK) {
+                double v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int i = i0 + u * BLOCK + tid;
+                    v[u] = ld_sc1(&src[a][i < cnt[a] ? i : cnt[a] - 1]);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int i = i0 + u * BLOCK + tid;
+                    if (i < cnt[a]) dst[a][i] = v[u];
+                }
+            }
+        }
+    }
+    for (int i = tid; i < ncol; i += BLOCK)
+        cL[i] = i < T ? A.cA[i] : (i < 2 * T ? A.cD[i - T] : A.cH[i - 2 * T]);
+    for (int i = tid; i < D; i += BLOCK) zL[i] = z[i];
+    for (int i = tid; i <= ncol; i += BLOCK) coff[i] = A.col_off[i];
+    __syncthreads();
+    DC_STAMP(8);
+
+    // ---- 2. fixed-order (deterministic) column sums of the sparse slabs: the compact
+    // array is stored column-major, 8 lanes share a column, half-row DPP folds them
+    for (int c0 = 0; c0 < ncol; c0 += BLOCK / 8) {
+        const int c = c0 + (tid >> 3), j = tid & 7;
+        double s = 0.0;
+        if (c < ncol) {
+            const int k1 = coff[c + 1];
+            if (STAGED) {
+                for (int k = coff[c] + j; k < k1; k += 8) s += cmp[k];
+            } else {
+                for (int k = coff[c] + j; k < k1; k += 8) s += ld_sc1(&compact[k]);
+            }
+        }
+        s += dpp_f64<0xB1>(0.0, s);   // quad_perm [1,0,3,2]
+        s += dpp_f64<0x4E>(0.0, s);   // quad_perm [2,3,0,1]
+        s += dpp_f64<0x141>(0.0, s);  // row_half_mirror: the other quad of the 8
+        if (c < ncol && j == 0) col[c] = s;
+    }
+    if (wave < N_SCAL) {  // scalar `wave`: lanes stride the workgroups, then a DPP sum
+        double s = 0.0;
+        for (int r = lane; r < A.n_wg; r += 64) s += scl[r * N_SCAL + wave];
+        s = wave_sum_f64(s);
+        if (lane == 0) col[ncol + wave] = s;
+    }
+    __syncthreads();
+    const double* gz = zoL + ZO_HDR;
+    const double* eps = gz + D;
+    const double s_a = zoL[ZO_SA], s_d = zoL[ZO_SD], s_h = zoL[ZO_SH];
+    const double q = zoL[ZO_Q], dq = zoL[ZO_DQ], UB = zoL[ZO_UB], LB = zoL[ZO_LB];
+    const double rho = zoL[ZO_RHO], drho = zoL[ZO_DRHO];
+    const double M = zoL[ZO_M], Lh = zoL[ZO_LH], La = zoL[ZO_LA], Lz = zoL[ZO_LZ];
+    double* g_att = col;          // raw accumulators, then dL/d attack_t
     double* g_def = col + T;      // dL/d defence_t
     double* g_ha = col + 2 * T;   // dL/d home_adv_t
-    const double SLAM = col[3 * T + 0], SLOG = col[3 * T + 1], SU = col[3 * T + 2],
-                 CLIPC = col[3 * T + 3];
-    for (int t = tid; t < T; t += EPI_BLOCK) {
-        g_att[t] = A.cA[t] - g_att[t];
-        g_def[t] = -(A.cD[t] - g_def[t]);
-        g_ha[t] = A.cH[t] - g_ha[t];
+    const double SLAM = col[ncol + 0], SLOG = col[ncol + 1], SU = col[ncol + 2],
+                 CLIPC = col[ncol + 3];
+    const double G_rho = SU;  // sum_i w_i dlogtau_i/drho
+
+    // ---- 3. first-order value corrections: float32 rounding of the tables
+    //   dL = - sum_t [ ha_raw eAg_t + (att_raw - ha_raw) eA_t + def_raw eDn_t ]
+    // and of rho:  dL = G_rho (rho_true - rho_f32);  then raw sums -> dL/d(team sites)
+    double corr = 0.0;
+    for (int t = tid; t < T; t += BLOCK) {
+        const double ra = g_att[t], rd = g_def[t], rh = g_ha[t];
+        corr -= rh * eps[t] + (ra - rh) * eps[T + t] + rd * eps[2 * T + t];
     }
     __syncthreads();
-
-    // ---- 2. rho = LB + q (UB - LB) and the adjoint of the bounds (Appendix A.3)
-    const uint32_t* b = A.bounds + (size_t)chain * BOUNDS_WORDS;
-    const double M = (double)__uint_as_float(b[0]);
-    const double Lh = (double)__uint_as_float(b[1]);
-    const double La = (double)__uint_as_float(b[2]);
-    double q, dq;
-    clipped_sigmoid(z[L.o_corr], &q, &dq);
-    const double UB = M > 1.0 ? 1.0 / M : 1.0;
-    const double LB = -1.0 / fmax(Lh, La);
-    const double rho = LB + q * (UB - LB);
-    const double G_rho = SU;  // sum_i w_i dlogtau_i/drho
-    if (tid == 0) {
-        const uint32_t pP = b[3], pQ = b[4], pR = b[5], flags = b[6];
+    for (int t = tid; t < T; t += BLOCK) {
+        g_att[t] = cL[t] - g_att[t];
+        g_def[t] = -(cL[T + t] - g_def[t]);
+        g_ha[t] = cL[2 * T + t] - g_ha[t];
+    }
+    __syncthreads();
+    if (tid == 0 && A.P > 0) {  // adjoint of the bounds (Appendix A.3)
+        const uint32_t pP = (uint32_t)zoL[ZO_PP], pQ = (uint32_t)zoL[ZO_PQ],
+                       pR = (uint32_t)zoL[ZO_PR];
+        const unsigned int flags = (unsigned int)zoL[ZO_FLAGS];
         if (M > 1.0) {  // UB = 1/M : d/d eta_h[P] = d/d eta_a[P] = -1/M
             const double v = G_rho * q * (-UB);
             const int h = pP & 0xFFFFu, a = pP >> 16;
@@ -497,125 +784,338 @@ __global__ __launch_bounds__(EPI_BLOCK) void dc_epilogue(EpiArgs A,
         }
     }
     __syncthreads();
+    DC_STAMP(9);
 
-    // ---- 3. priors, Jacobians, chain rule (float64).  L = log density; U = -L.
-    const double zc = z[L.o_corr];
-    const double sigc = sigmoid(zc);
-    // Beta(2,2) on q + sigmoid Jacobian
-    double Lsc = log(q) + log1p(-q) + 1.791759469228055 /*log 6*/ - softplus(zc) - softplus(-zc);
-    const double g_corr = G_rho * (UB - LB) * dq + (1.0 / q - 1.0 / (1.0 - q)) * dq +
-                          (1.0 - 2.0 * sigc);
-    const double m = z[L.o_md];
-    const double zsa = z[L.o_sa], zsd = z[L.o_sd];
-    const double s_a = exp(zsa), s_d = exp(zsd);
-    // HalfNormal(1) on exp(z) + Exp Jacobian: -s^2/2 - log sqrt(2 pi) + log 2 + z
-    Lsc += -0.5 * s_a * s_a - HALF_LOG_2PI + LN2 + zsa;
-    Lsc += -0.5 * s_d * s_d - HALF_LOG_2PI + LN2 + zsd;
-    Lsc += -0.5 * m * m - HALF_LOG_2PI;  // mean_defence ~ N(0,1)
-
+    // ---- 4. chain rule to z (adds and FMAs only); grad = gz - (fixture-sum terms)
     if (L.model == MODEL_BASIC) {
-        const double gam = z[L.o_ha];
-        {
-            const double r = (gam - 0.1) / 0.2;
-            Lsc += -0.5 * r * r - log(0.2) - HALF_LOG_2PI;
-        }
-        // v: 0 sum g_def, 1 sum g_ha, 2 sum a~ g_att, 3 sum d~ g_def, 4 team part of L
-        double v[5] = {0, 0, 0, 0, 0};
-        for (int t = tid; t < T; t += EPI_BLOCK) {
-            const double ad = z[L.o_adec + t], dd = z[L.o_ddec + t];
+        // v: 0 sum g_def, 1 sum g_ha, 2 sum a~ g_att, 3 sum d~ g_def, 4 correction
+        double v[5] = {0, 0, 0, 0, corr};
+        for (int t = tid; t < T; t += BLOCK) {
+            const double ad = zL[L.o_adec + t], dd = zL[L.o_ddec + t];
             const double ga = g_att[t], gd = g_def[t], gh = g_ha[t];
-            grad[L.o_adec + t] = -(s_a * ga - ad);
-            grad[L.o_ddec + t] = -(s_d * gd - dd);
+            grad[L.o_adec + t] = gz[L.o_adec + t] - s_a * ga;
+            grad[L.o_ddec + t] = gz[L.o_ddec + t] - s_d * gd;
             v[0] += gd;
             v[1] += gh;
             v[2] += ad * ga;
             v[3] += dd * gd;
-            const double att = s_a * ad, def = m + s_d * dd;
-            v[4] += -0.5 * ad * ad - 0.5 * dd * dd - 2.0 * HALF_LOG_2PI + att * A.cA[t] -
-                    def * A.cD[t] + gam * A.cH[t];
         }
         block_sum<5>(v, scratch, tid);
         if (tid == 0) {
-            grad[L.o_ha] = -(v[1] - (gam - 0.1) / 0.04);
-            grad[L.o_md] = -(v[0] - m);
-            grad[L.o_sa] = -(s_a * v[2] - s_a * s_a + 1.0);
-            grad[L.o_sd] = -(s_d * v[3] - s_d * s_d + 1.0);
-            grad[L.o_corr] = -g_corr;
-            const double Ltot = Lsc + v[4] - SLAM - A.lgsum + LN2 * SLOG - CLIPC;
-            potential[chain] = -Ltot;
+            grad[L.o_ha] = gz[L.o_ha] - v[1];
+            grad[L.o_md] = gz[L.o_md] - v[0];
+            grad[L.o_sa] = gz[L.o_sa] - s_a * v[2];
+            grad[L.o_sd] = gz[L.o_sd] - s_d * v[3];
+            grad[L.o_corr] = gz[L.o_corr] - G_rho * (UB - LB) * dq;
+            const double Ltot =
+                Lz + v[4] + G_rho * drho - SLAM - A.lgsum + LN2 * SLOG - CLIPC;
+            A.potential[chain] = -Ltot;
         }
     } else {
-        const double mha = z[L.o_mha], zsh = z[L.o_sh], s_h = exp(zsh);
-        {
-            const double r = (mha - 0.1) / 0.2;
-            Lsc += -0.5 * r * r - log(0.2) - HALF_LOG_2PI;
-        }
-        Lsc += -0.5 * s_h * s_h - HALF_LOG_2PI + LN2 + zsh;
-        const double zu = z[L.o_u];
-        double u, du;
-        clipped_sigmoid(zu, &u, &du);
-        // Beta(2,4) on u + sigmoid Jacobian
-        Lsc += log(u) + 3.0 * log1p(-u) + 2.995732273553991 /*log 20*/ - softplus(zu) -
-               softplus(-zu);
-        const double rp = 2.0 * u - 1.0, vv = 1.0 - rp * rp;
-        // v: 0 sum g_def, 1 sum g_ha, 2 sum sa g_att, 3 sum sd g_def, 4 sum ha~ g_ha,
-        //    5 dL/d rho_p, 6 team part of L
-        double v[7] = {0, 0, 0, 0, 0, 0, 0};
-        for (int t = tid; t < T; t += EPI_BLOCK) {
-            const double sa = z[L.o_sat + t], sd = z[L.o_sdt + t], hd = z[L.o_hadec + t];
+        // v: 0 sum g_def, 1 sum g_ha, 2 sum sa g_att, 3 sum sd g_def, 4 sum ha~ g_ha, 5 corr
+        double v[6] = {0, 0, 0, 0, 0, corr};
+        for (int t = tid; t < T; t += BLOCK) {
+            const double sa = zL[L.o_sat + t], sd = zL[L.o_sdt + t], hd = zL[L.o_hadec + t];
             const double ga = g_att[t], gd = g_def[t], gh = g_ha[t];
-            const double e = sd - rp * sa;
-            grad[L.o_sat + t] = -(s_a * ga - sa + rp * e / vv);
-            grad[L.o_sdt + t] = -(s_d * gd - e / vv);
-            grad[L.o_hadec + t] = -(s_h * gh - hd);
+            grad[L.o_sat + t] = gz[L.o_sat + t] - s_a * ga;
+            grad[L.o_sdt + t] = gz[L.o_sdt + t] - s_d * gd;
+            grad[L.o_hadec + t] = gz[L.o_hadec + t] - s_h * gh;
             v[0] += gd;
             v[1] += gh;
             v[2] += sa * ga;
             v[3] += sd * gd;
             v[4] += hd * gh;
-            v[5] += e * sa / vv - rp * e * e / (vv * vv) + rp / vv;
-            double att, def, ha;
-            team_params(L, z, A.xs, t, &att, &def, &ha);
-            v[6] += -0.5 * sa * sa - 0.5 * e * e / vv - 0.5 * log(vv) - 0.5 * hd * hd -
-                    3.0 * HALF_LOG_2PI + att * A.cA[t] - def * A.cD[t] + ha * A.cH[t];
         }
-        block_sum<7>(v, scratch, tid);
-        // covariate coefficients: d/d beta_k = sum_t Xs[t,k] g_t - beta_k
-        for (int k = tid; k < 2 * K; k += EPI_BLOCK) {
+        block_sum<6>(v, scratch, tid);
+        for (int k = tid; k < 2 * K; k += BLOCK) {  // d/d beta_k: sum_t Xs[t,k] g_t
             const bool isd = k >= K;
             const int kk = isd ? k - K : k;
             const double* gt = isd ? g_def : g_att;
             double s = 0.0;
             for (int t = 0; t < T; ++t) s += A.xs[(size_t)t * K + kk] * gt[t];
             const int o = (isd ? L.o_bD : L.o_bA) + kk;
-            grad[o] = -(s - z[o]);
+            grad[o] = gz[o] - s;
         }
         if (tid == 0) {
-            double Lcov = 0.0;
-            for (int k = 0; k < K; ++k) {
-                const double ba = z[L.o_bA + k], bd = z[L.o_bD + k];
-                Lcov += -0.5 * ba * ba - 0.5 * bd * bd - 2.0 * HALF_LOG_2PI;
-            }
-            grad[L.o_mha] = -(v[1] - (mha - 0.1) / 0.04);
-            grad[L.o_sh] = -(s_h * v[4] - s_h * s_h + 1.0);
-            grad[L.o_md] = -(v[0] - m);
-            grad[L.o_sa] = -(s_a * v[2] - s_a * s_a + 1.0);
-            grad[L.o_sd] = -(s_d * v[3] - s_d * s_d + 1.0);
-            grad[L.o_corr] = -g_corr;
-            const double sigu = sigmoid(zu);
-            grad[L.o_u] = -(2.0 * v[5] * du + (1.0 / u - 3.0 / (1.0 - u)) * du +
-                            (1.0 - 2.0 * sigu));
-            const double Ltot = Lsc + Lcov + v[6] - SLAM - A.lgsum + LN2 * SLOG - CLIPC;
-            potential[chain] = -Ltot;
+            grad[L.o_mha] = gz[L.o_mha] - v[1];
+            grad[L.o_sh] = gz[L.o_sh] - s_h * v[4];
+            grad[L.o_md] = gz[L.o_md] - v[0];
+            grad[L.o_sa] = gz[L.o_sa] - s_a * v[2];
+            grad[L.o_sd] = gz[L.o_sd] - s_d * v[3];
+            grad[L.o_corr] = gz[L.o_corr] - G_rho * (UB - LB) * dq;
+            grad[L.o_u] = gz[L.o_u];
+            const double Ltot =
+                Lz + v[5] + G_rho * drho - SLAM - A.lgsum + LN2 * SLOG - CLIPC;
+            A.potential[chain] = -Ltot;
         }
     }
-    if (tid == 0 && auxs != nullptr) {
-        double* aux = auxs + (size_t)chain * 4;
+    DC_STAMP(10);
+    if (tid == 0 && A.aux != nullptr) {
+        double* aux = A.aux + (size_t)chain * 4;
         aux[0] = rho;
         aux[1] = LB;
         aux[2] = UB;
         aux[3] = q;
     }
+}
+
+// ------------------------------------------------------------------------- dc_eval
+
+template <bool WEIGHTED, bool CLIP, bool STAGED>
+__global__ __launch_bounds__(BLOCK) void dc_eval(EvalArgs A) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const Layout& L = A.L;
+    const int T = L.T, T1 = T + 1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int chain = blockIdx.y;
+    const double* z = A.z + (size_t)chain * L.D;
+    DC_STAMP(0);
+
+    // LDS carve of the streaming part (all offsets multiples of 16 B)
+    float2* tabH = reinterpret_cast<float2*>(smem);            // {exp(att+ha), exp(-def)}
+    float2* tabA = tabH + tab_len(T);                          // {exp(att),    exp(-def)}
+    double* acc = reinterpret_cast<double*>(tabA + tab_len(T));  // [3*T1]
+    double* red = acc + 3 * T1 + ((3 * T1) & 1);               // [WAVES*4]
+    float* redm = reinterpret_cast<float*>(red + WAVES * N_SCAL);  // [WAVES*4]
+    int* shflag = reinterpret_cast<int*>(redm + WAVES * 4);  // dynamic LDS only (G17)
+
+    if (blockIdx.x == 0) {
+        prior_body<CLIP>(A, chain, smem);
+        DC_STAMP(4);
+    } else {
+        const int wgi = blockIdx.x - 1;
+        // ---- 0. issue the first tile's loads (and this thread's pair) before anything else
+        const int gw = wgi * WAVES + wave;
+        int tile = gw * A.tiles_per_wave;
+        const int tile_end = min(tile + A.tiles_per_wave, A.n_tiles);
+        uint4 hv = make_uint4(0, 0, 0, 0), av = hv;
+        uint2 xv = make_uint2(0, 0), yv = xv;
+        float4 w0 = make_float4(0, 0, 0, 0), w1 = w0;
+        if (tile < tile_end) {
+            const size_t o = (size_t)tile * 64 + lane;
+            hv = A.h[o];
+            av = A.a[o];
+            xv = A.x[o];
+            yv = A.y[o];
+            if (WEIGHTED) {
+                w0 = A.w[2 * o];
+                w1 = A.w[2 * o + 1];
+            }
+        }
+        uint32_t pr0 = 0;
+        if (tid < A.P) pr0 = A.pairs[tid];
+        const int o0 = A.wg_off[wgi], o1 = A.wg_off[wgi + 1];  // static sparse-slab slots
+        int slot0 = 0, dst0 = 0;
+        if (o0 + tid < o1) {
+            slot0 = A.wg_slots[o0 + tid];
+            dst0 = A.wg_dst[o0 + tid];
+        }
+
+        // ---- 1. per-team tables (float32) + zero accumulators
+        F32Scalars fs;
+        build_tables_f32(L, z, A.xsf, tabH, tabA, tid, &fs);
+        for (int i = tid; i < 3 * T1; i += BLOCK) acc[i] = 0.0;
+        __syncthreads();
+        DC_STAMP(1);
+
+        // ---- 2. rho bounds over the unique-pair table (bpl/_util.py:23-30): values only
+        float mP, mQ, mR;
+        pair_maxima_f32<CLIP>(A, tabH, tabA, pr0, redm, tid, &mP, &mQ, &mR);
+        const float rho = rho_f32(mP, mQ, mR, fs.q);
+        DC_STAMP(2);
+
+        // ---- 3. stream the fixtures
+        double dSLAM = 0.0, dSLOG = 0.0, dSU = 0.0, dCLIP = 0.0;  // per lane
+        while (tile < tile_end) {
+            uint4 hn = hv, an = av;
+            uint2 xn = xv, yn = yv;
+            float4 w0n = w0, w1n = w1;
+            if (tile + 1 < tile_end) {  // prefetch the next tile
+                const size_t o = (size_t)(tile + 1) * 64 + lane;
+                hn = A.h[o];
+                an = A.a[o];
+                xn = A.x[o];
+                yn = A.y[o];
+                if (WEIGHTED) {
+                    w0n = A.w[2 * o];
+                    w1n = A.w[2 * o + 1];
+                }
+            }
+            const uint32_t hw[4] = {hv.x, hv.y, hv.z, hv.w};
+            const uint32_t aw[4] = {av.x, av.y, av.z, av.w};
+            const uint32_t xw[2] = {xv.x, xv.y};
+            const uint32_t yw[2] = {yv.x, yv.y};
+            const float wj[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+
+            float shj[LANE_FIX], saj[LANE_FIX];
+            uint32_t keyj[LANE_FIX];
+            float slam = 0.f, slog = 0.f, su = 0.f, sclip = 0.f;
+#pragma unroll
+            for (int j = 0; j < LANE_FIX; ++j) {
+                const uint32_t hj = (hw[j >> 1] >> (16 * (j & 1))) & 0xFFFFu;
+                const uint32_t aj = (aw[j >> 1] >> (16 * (j & 1))) & 0xFFFFu;
+                const uint32_t xj = (xw[j >> 2] >> (8 * (j & 3))) & 0xFFu;
+                const uint32_t yj = (yw[j >> 2] >> (8 * (j & 3))) & 0xFFu;
+                keyj[j] = hj | (aj << 16);
+                const float2 th = tabH[hj], ta = tabA[aj];
+                float lh = th.x * ta.y;  // exp(att[h] + ha[h]) * exp(-def[a])
+                float la = ta.x * th.y;  // exp(att[a]) * exp(-def[h])
+                bool ch = false, ca = false;
+                const float lh_raw = lh, la_raw = la;
+                if (CLIP) {
+                    ch = lh > (float)RATE_CLIP;
+                    ca = la > (float)RATE_CLIP;
+                    lh = ch ? (float)RATE_CLIP : lh;
+                    la = ca ? (float)RATE_CLIP : la;
+                }
+                // tau (bpl/_util.py:58-91): arg = 1 + rho*c,
+                //   c = -lh*la (0,0) | +la (1,0) | +lh (0,1) | -1 (1,1) | 0 otherwise
+                const bool x0 = xj == 0, y0 = yj == 0;
+                const bool low = (xj <= 1) & (yj <= 1);
+                float c = x0 ? (y0 ? -lh * la : lh) : (y0 ? la : -1.0f);
+                c = low ? c : 0.0f;
+                const float t = fmaf(rho, c, 1.0f);
+                const float l2 = __log2f(fmaxf(t, 0.0f));  // log(clip(., 0)): -inf at 0
+                const float u = t > 0.0f ? c * __builtin_amdgcn_rcpf(t) : 0.0f;  // dlogtau/drho
+                const float ru = rho * u;
+                // -(dL/d eta) without the data-only goal counts (added in the tail):
+                //   eta_h: lh - rho*u*[x==0]   (lh * dlogtau/dlh = rho*u for (0,0),(0,1))
+                float sh = lh - (x0 ? ru : 0.0f);
+                float sa = la - (y0 ? ru : 0.0f);
+                float wv = 1.0f;
+                if (WEIGHTED) wv = wj[j];
+                if (CLIP) {
+                    // clipped rate: d/d eta = 0 -> cancel the goal count added later, and
+                    // correct k*eta -> k*log(15) in the value
+                    if (ch) {
+                        sh = (float)xj;
+                        sclip += wv * (float)xj * (__logf(lh_raw) - (float)LOG_RATE_CLIP);
+                    }
+                    if (ca) {
+                        sa = (float)yj;
+                        sclip += wv * (float)yj * (__logf(la_raw) - (float)LOG_RATE_CLIP);
+                    }
+                }
+                if (WEIGHTED) {
+                    sh *= wv;
+                    sa *= wv;
+                    slam += wv * (lh + la);
+                    slog += wv * l2;
+                    su += wv * u;
+                } else {
+                    slam += lh + la;
+                    slog += l2;
+                    su += u;
+                }
+                shj[j] = sh;
+                saj[j] = sa;
+            }
+            // scalars: float32 over the lane's 8 fixtures only, float64 from there on
+            // (a float32 sum over the whole wave-tile would cost ~1e-4 absolute in U)
+            dSLAM += (double)slam;
+            dSLOG += (double)slog;
+            dSU += (double)su;
+            if (CLIP) dCLIP += (double)sclip;
+
+            // ---- per-(home,away) run sums: lane -> wave -> LDS per-team accumulators
+            uint32_t diff = 0;
+            float rsh = 0.f, rsa = 0.f;
+#pragma unroll
+            for (int j = 0; j < LANE_FIX; ++j) {
+                diff |= keyj[j] ^ keyj[0];
+                rsh += shj[j];
+                rsa += saj[j];
+            }
+            uint32_t key = keyj[0];
+            if (diff != 0) {  // a pair boundary inside this lane's 8 fixtures
+#pragma unroll
+                for (int j = 0; j < LANE_FIX; ++j)
+                    flush_run(acc, T1, keyj[j], shj[j], saj[j]);
+                rsh = 0.f;
+                rsa = 0.f;
+                key = keyj[LANE_FIX - 1];
+            }
+            const uint32_t kprev = __shfl_up(key, 1, 64);
+            const unsigned long long heads = __ballot(lane == 0 || kprev != key);
+            const int nruns = __popcll(heads);
+            if (nruns == 1) {  // whole wave-tile on one pair (the common case: sorted)
+                rsh = wave_sum_f32(rsh);
+                rsa = wave_sum_f32(rsa);
+                if (lane == 0) flush_run(acc, T1, key, rsh, rsa);
+            } else if (nruns <= RUN_LOOP_MAX) {  // a few runs: one masked DPP sum per run
+                unsigned long long hd = heads;
+                while (hd) {
+                    const int first = __ffsll((long long)hd) - 1;
+                    hd &= hd - 1;
+                    const int stop = hd ? __ffsll((long long)hd) - 1 : 64;
+                    const bool in = lane >= first && lane < stop;
+                    const uint32_t kk = (uint32_t)__builtin_amdgcn_readlane((int)key, first);
+                    const float s0 = wave_sum_f32(in ? rsh : 0.f);
+                    const float s1 = wave_sum_f32(in ? rsa : 0.f);
+                    if (lane == 0) flush_run(acc, T1, kk, s0, s1);
+                }
+            } else {  // many short runs: every lane adds its own sums (LDS atomics)
+                flush_run(acc, T1, key, rsh, rsa);
+            }
+
+            hv = hn;
+            av = an;
+            xv = xn;
+            yv = yn;
+            w0 = w0n;
+            w1 = w1n;
+            ++tile;
+        }
+        DC_STAMP(3);
+
+        // ---- 4. workgroup reduction of the scalars, then the slab (write-through)
+        dSLAM = wave_sum_f64(dSLAM);
+        dSLOG = wave_sum_f64(dSLOG);
+        dSU = wave_sum_f64(dSU);
+        if (CLIP) dCLIP = wave_sum_f64(dCLIP);
+        if (lane == 0) {
+            red[wave * N_SCAL + 0] = dSLAM;
+            red[wave * N_SCAL + 1] = dSLOG;
+            red[wave * N_SCAL + 2] = dSU;
+            red[wave * N_SCAL + 3] = dCLIP;
+        }
+        __syncthreads();
+        {   // publish only the slots this workgroup's fixtures touch (static list)
+            double* cmpw = A.compact + (size_t)chain * A.total_c;
+            for (int k = o0 + tid; k < o1; k += BLOCK) {
+                const int slot = k == o0 + tid ? slot0 : A.wg_slots[k];
+                const int which = slot / T, t = slot - which * T;
+                st_sc1(&cmpw[k == o0 + tid ? dst0 : A.wg_dst[k]], acc[which * T1 + t]);
+            }
+        }
+        if (tid < N_SCAL) {
+            double s = 0.0;
+#pragma unroll
+            for (int wv = 0; wv < WAVES; ++wv) s += red[wv * N_SCAL + tid];
+            st_sc1(&A.scal[((size_t)chain * A.n_wg + wgi) * N_SCAL + tid], s);
+        }
+        DC_STAMP(4);
+    }
+
+    // ---- 5. the last-arriving workgroup runs the tail.  Payloads were stored
+    // write-through (sc1); every storing wave drains, the workgroup barriers, one lane
+    // takes a ticket (relaxed, agent scope); the last arriver reads with sc1 loads.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    DC_STAMP(5);
+    if (tid == 0) {
+        const unsigned int tk = __hip_atomic_fetch_add(&A.tickets[chain], 1u, __ATOMIC_RELAXED,
+                                                       __HIP_MEMORY_SCOPE_AGENT);
+        const int last = tk == (unsigned int)A.n_wg;  // n_wg + 1 arrivals
+        if (last)  // re-arm for the next launch (stream ordered)
+            __hip_atomic_store(&A.tickets[chain], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *shflag = last;
+    }
+    __syncthreads();
+    DC_STAMP(6);
+    if (*shflag == 0) return;
+    __syncthreads();
+    tail_body<STAGED>(A, chain, smem);
 }
 
 }  // namespace dc

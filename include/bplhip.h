@@ -94,6 +94,11 @@ int bplhip_set_fixtures(bplhip_ctx* ctx, int model_kind, int64_t n, int32_t n_te
                         const float* weights, const double* covariates, int32_t k,
                         void* stream);
 
+/* Tuning knobs (no reference counterpart; defaults are the measured best):
+ *   "max_wg" streaming workgroups per evaluation (default 255: with the prior workgroup
+ *            one per CU); applies at the next bplhip_set_fixtures */
+int bplhip_set_option(bplhip_ctx* ctx, const char* name, int value);
+
 /* D of the bound model (negative error code if no fixtures are bound). */
 int bplhip_latent_dim(const bplhip_ctx* ctx);
 

@@ -1,0 +1,72 @@
+"""Generates tests/golden/*.npz -- golden input/output vectors of the hot path.
+
+PARITY UNPINNED (see oracle/dc_oracle.py): the reference's tests hold no numbers for
+this path and numpyro/jax are not installed, so these vectors come from the float64
+restatement, after it has been checked three ways (tests/test_oracle.py): against a
+literal torch-autograd transcription of the reference model, against central finite
+differences, and against the known answers of SURVEY.md Appendix C.  Inputs are the
+reference's own fixture recipes (tests/conftest.py:7-62) plus seeded synthetic leagues.
+
+Run:  python oracle/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path[:0] = [HERE, os.path.join(os.path.dirname(HERE), "tests")]
+
+import cases  # noqa: E402
+import dc_oracle as O  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+
+GOLDEN_CASES = [
+    (O.MODEL_BASIC, "dummy"),
+    (O.MODEL_BASIC, "timed"),
+    (O.MODEL_BASIC, "ragged_777"),
+    (O.MODEL_EXTENDED, "dummy"),
+    (O.MODEL_EXTENDED, "dummy_cov"),
+    (O.MODEL_EXTENDED, "dummy_w"),
+    (O.MODEL_EXTENDED, "timed_w"),
+]
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    for model, name in GOLDEN_CASES:
+        fx = cases.fixtures(name)
+        pts = cases.z_points(model, fx)
+        zs, Us, gs, rhos, lbs, ubs = [], [], [], [], [], []
+        for _, z in pts:
+            U, g, aux = O.potential_and_grad(model, fx, z)
+            zs.append(z)
+            Us.append(U)
+            gs.append(g)
+            rhos.append(aux["rho"])
+            lbs.append(aux["LB"])
+            ubs.append(aux["UB"])
+        np.savez_compressed(
+            os.path.join(OUT, f"m{model}_{name}.npz"),
+            model=model,
+            home_idx=fx.home_idx.astype(np.uint16),
+            away_idx=fx.away_idx.astype(np.uint16),
+            home_goals=fx.home_goals.astype(np.uint8),
+            away_goals=fx.away_goals.astype(np.uint8),
+            n_teams=fx.n_teams,
+            weights=np.zeros(0) if fx.weights is None else fx.weights,
+            covariates=np.zeros((0, 0)) if fx.covariates is None else fx.covariates,
+            point_names=np.array([p[0] for p in pts]),
+            z=np.stack(zs),
+            U=np.array(Us),
+            grad=np.stack(gs),
+            rho=np.array(rhos),
+            LB=np.array(lbs),
+            UB=np.array(ubs),
+        )
+        print(f"wrote m{model}_{name}.npz  ({len(pts)} points, N={fx.n})")
+
+
+if __name__ == "__main__":
+    main()

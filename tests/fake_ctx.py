@@ -1,0 +1,61 @@
+"""TEST-ONLY stand-in for bpl._ffi.HipContext: same surface, but the potential is the
+CPU oracle (through the NUTS harness).  Lets the host orchestration (bpl/_mcmc.py,
+bpl/_dist.py: chain ownership, key splitting, broadcast, gather, constrain) run under
+gloo on a box without a GPU.  Never imported by product code."""
+import numpy as np
+import torch
+
+import dc_oracle as O
+import dc_oracle_c as OC
+
+
+class FakeCtx:
+    def __init__(self, device_index=0):
+        self.device = torch.device("cpu")
+        self.dim = 0
+
+    def set_fixtures(self, model, h, a, x, y, n_teams, weights=None, covariates_std=None):
+        def np_(t, dt):
+            t = t.cpu().numpy() if isinstance(t, torch.Tensor) else np.asarray(t)
+            return t.view(np.uint16) if (dt == np.uint16 and t.dtype == np.int16) else t.astype(dt)
+
+        fx = O.Fixtures(np_(h, np.uint16), np_(a, np.uint16), np_(x, np.uint8), np_(y, np.uint8),
+                        n_teams, weights=None if weights is None else np_(weights, np.float64))
+        self.fx, self.model, self.n_teams = fx, model, n_teams
+        self.cf = OC.CFixtures(model, fx)
+        if covariates_std is not None:  # already standardised by the caller
+            self.cf.K = covariates_std.shape[1]
+            self.cf.xs = np.ascontiguousarray(covariates_std, dtype=np.float64)
+            self.cf.D = O.latent_dim(model, n_teams, self.cf.K)
+        self.dim = self.cf.D
+        return self
+
+    def nuts_run(self, cfg, key, z0=None):
+        rc, draws, stats, summ = OC.nuts_dc(self.cf, cfg.num_warmup, cfg.num_samples, key,
+                                            thin=cfg.thinning, z0=z0)
+        assert rc == 0
+        kept = draws.shape[0]
+        out = {"potential_energy": stats[:, 0], "accept_prob": stats[:, 1],
+               "step_size": np.full(kept, summ[0]), "num_steps": stats[:, 2].astype(np.int32),
+               "diverging": stats[:, 3].astype(np.int32), "corr_coef": np.zeros(kept),
+               "inverse_mass_matrix": summ[4:], "final_step_size": summ[0],
+               "mean_accept_prob": summ[1], "total_leapfrogs": int(summ[2]),
+               "total_divergences": int(summ[3]), "wall_seconds": 1.0}
+        return draws, out
+
+    def constrain(self, z):
+        T, sl = self.n_teams, O.site_slices(self.model, self.n_teams, self.cf.K)
+        s = z.shape[0]
+        att, dfn, corr = np.empty((s, T)), np.empty((s, T)), np.empty(s)
+        ha = np.empty(s) if self.model == O.MODEL_BASIC else np.empty((s, T))
+        fx = self.fx
+        if self.cf.K:  # un-standardised copy is not kept: rebuild a Fixtures with xs as raw
+            fx = O.Fixtures(fx.home_idx, fx.away_idx, fx.home_goals, fx.away_goals, T,
+                            weights=fx.weights, covariates=self.cf.xs)
+        for i in range(s):
+            _, _, aux = O.potential_and_grad(self.model, fx, z[i])
+            att[i], dfn[i], ha[i], corr[i] = aux["attack"], aux["defence"], aux["home_advantage"], aux["corr_coef"]
+        return {"attack": att, "defence": dfn, "home_advantage": ha, "corr_coef": corr}
+
+    def close(self):
+        pass

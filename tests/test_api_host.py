@@ -1,0 +1,135 @@
+"""Host-side mirror of the reference API (bpl/base.py, bpl/_util.py) on a synthetic
+posterior -- the reference's own property tests (tests/test_base_models.py:15-96) with the
+NUTS fit replaced by hand-made draws, so they run without a GPU."""
+import numpy as np
+import pytest
+
+from bpl import DixonColesMatchPredictor, ExtendedDixonColesMatchPredictor
+from bpl._util import compute_corr_coef_bounds, dixon_coles_correlation_term, parse_teams
+from bpl.base import MAX_GOALS
+
+
+def _fake_fit(cls, dummy_data, S=64, seed=0):
+    rs = np.random.RandomState(seed)
+    m = cls()
+    m.teams, m._teams_dict, _, _ = parse_teams(dummy_data["home_team"], dummy_data["away_team"], "uint16")
+    T = len(m.teams)
+    m.attack = rs.normal(0, 0.15, (S, T))
+    m.defence = rs.normal(-0.5, 0.15, (S, T))
+    m.corr_coef = rs.uniform(-0.08, 0.05, S)
+    if cls is DixonColesMatchPredictor:
+        m.home_advantage = rs.normal(0.25, 0.05, S)
+    else:
+        m.home_advantage = rs.normal(0.25, 0.05, (S, T))
+    return m
+
+
+MODELS = [DixonColesMatchPredictor, ExtendedDixonColesMatchPredictor]
+
+
+def test_parse_teams_string_sorted(dummy_data):
+    teams, d, h, a = parse_teams(dummy_data["home_team"], dummy_data["away_team"], "uint16")
+    assert list(teams[:4]) == ["0", "1", "10", "11"] and d["2"] == 12
+    assert h.dtype == np.uint16 and list(a[:3]) == [1, 12, 13]
+
+
+def test_corr_term_and_bounds_semantics():
+    lh, la = np.array([1.5, 0.8, 2.0, 1.1, 0.7]), np.array([1.1, 1.3, 0.4, 0.9, 2.5])
+    LB, UB = compute_corr_coef_bounds(lh, la)
+    assert UB == pytest.approx(1 / (0.7 * 2.5)) and LB == pytest.approx(-1 / 2.5)
+    x, y = np.array([0, 1, 0, 1, 3]), np.array([0, 0, 1, 1, 0])
+    rho = np.array([0.1, -0.2])
+    t = dixon_coles_correlation_term(x, y, np.tile(lh, (2, 1)), np.tile(la, (2, 1)), rho)
+    assert t.shape == (2, 5)
+    assert t[0, 0] == pytest.approx(np.log(1 - 0.1 * 1.5 * 1.1))
+    assert t[1, 1] == pytest.approx(np.log(1 - 0.2 * 1.3))
+    assert t[0, 2] == pytest.approx(np.log(1 + 0.1 * 2.0))
+    assert t[1, 3] == pytest.approx(np.log(1 + 0.2))
+    assert np.all(t[:, 4] == 0)
+    # tol = 0: clipped argument -> -inf, like the reference
+    t = dixon_coles_correlation_term(0, 0, np.array([[3.0]]), np.array([[3.0]]), np.array([0.5]))
+    assert np.isneginf(t[0, 0])
+
+
+@pytest.mark.parametrize("model_cls", MODELS)
+def test_predict_score_proba(dummy_data, model_cls):
+    model = _fake_fit(model_cls, dummy_data)
+    probs = model.predict_score_proba(dummy_data["home_team"], dummy_data["away_team"],
+                                      dummy_data["home_goals"], dummy_data["away_goals"])
+    assert probs.shape == (380,) and np.all((probs >= 0) & (probs <= 1))
+    prob_single = model.predict_score_proba("0", "1", 1, 0)[0]
+    assert 0 <= prob_single <= 1
+
+
+@pytest.mark.parametrize("model_cls", MODELS)
+def test_predict_outcome_proba(dummy_data, model_cls):
+    model = _fake_fit(model_cls, dummy_data)
+    probs = model.predict_outcome_proba(dummy_data["home_team"], dummy_data["away_team"])
+    total = probs["home_win"] + probs["away_win"] + probs["draw"]
+    assert np.allclose(total, 1.0, atol=1e-5)
+    p1 = model.predict_outcome_proba("0", "1")
+    assert p1["home_win"] + p1["away_win"] + p1["draw"] == pytest.approx(1.0, abs=1e-5)
+
+
+@pytest.mark.parametrize("model_cls", MODELS)
+def test_predict_score_and_concede_n_proba(dummy_data, model_cls):
+    model = _fake_fit(model_cls, dummy_data)
+    n = np.arange(MAX_GOALS + 1)
+    ph = model.predict_score_n_proba(n, "0", "1")
+    pa = model.predict_score_n_proba(n, "0", "1", home=False)
+    assert len(ph) == len(n) and np.all((ph >= 0) & (ph <= 1))
+    assert sum(ph) == pytest.approx(1.0, abs=1e-5) and sum(pa) == pytest.approx(1.0, abs=1e-5)
+    assert sum(ph * n) > sum(pa * n)  # score more at home
+    assert len(model.predict_score_n_proba(1, "0", "1")) == 1
+    ch = model.predict_concede_n_proba(n, "0", "1")
+    ca = model.predict_concede_n_proba(n, "0", "1", home=False)
+    assert sum(ch) == pytest.approx(1.0, abs=1e-5) and sum(ch * n) < sum(ca * n)
+    a = model.predict_concede_n_proba(1, "0", "1")
+    b = model.predict_score_n_proba(1, "1", "0", home=False)
+    assert a.tolist() == pytest.approx(b.tolist(), abs=1e-5)
+
+
+@pytest.mark.parametrize("model_cls", MODELS)
+def test_sampling(dummy_data, model_cls):
+    model = _fake_fit(model_cls, dummy_data)
+    s = model.sample_score(["0", "1"], ["2", "3"], num_samples=500, random_state=3)
+    assert s["home_score"].shape == (2, 500) and s["home_score"].max() <= MAX_GOALS
+    s2 = model.sample_score(["0", "1"], ["2", "3"], num_samples=500, random_state=3)
+    assert np.array_equal(s["home_score"], s2["home_score"])
+    o = model.sample_outcome(["0", "1"], ["2", "3"], num_samples=400, random_state=5)
+    assert o.shape == (2, 400) and set(np.unique(o[0])) <= {"0", "2", "Draw"}
+    p = model.predict_outcome_proba("0", "2")
+    assert abs((o[0] == "0").mean() - p["home_win"][0]) < 0.1
+
+
+def test_unknown_team_raises_keyerror(dummy_data):
+    model = _fake_fit(DixonColesMatchPredictor, dummy_data)
+    with pytest.raises(KeyError):
+        model.predict_outcome_proba("nobody", "1")
+
+
+def test_extended_fit_argument_errors(dummy_data):
+    with pytest.raises(ValueError, match="time_diff"):
+        ExtendedDixonColesMatchPredictor().fit(dummy_data, epsilon=1.0)
+    bad = dict(dummy_data)
+    bad["team_covariates"] = {"0": [1.0, 2.0]}
+    with pytest.raises(ValueError, match="team_covariates"):
+        ExtendedDixonColesMatchPredictor().fit(bad)
+
+
+def test_add_new_team(dummy_data):
+    model = _fake_fit(ExtendedDixonColesMatchPredictor, dummy_data)
+    S = model.attack.shape[0]
+    rs = np.random.RandomState(1)
+    model.attack_coefficients = None
+    model.mean_defence = rs.normal(-0.5, 0.05, S)
+    model.std_attack = np.abs(rs.normal(0.2, 0.02, S))
+    model.std_defence = np.abs(rs.normal(0.2, 0.02, S))
+    model.rho = rs.uniform(-0.5, 0.2, S)
+    model.mean_home_advantage = rs.normal(0.25, 0.02, S)
+    model.std_home_advantage = np.abs(rs.normal(0.1, 0.01, S))
+    model.add_new_team("new")
+    assert model.attack.shape == (S, 21) and model.teams[-1] == "new"
+    assert np.all(model.predict_outcome_proba("new", "0")["home_win"] > 0)
+    with pytest.raises(ValueError):
+        model.add_new_team("new")

@@ -1,0 +1,146 @@
+"""GPU end-to-end tests through the public API: the reference's own property tests
+(tests/test_dixon_coles.py:7-14, tests/test_base_models.py:15-96,
+tests/test_extended_dixon_coles.py:4-47) with the HIP path underneath, plus the
+sampler-level parity ladder of SURVEY.md §7.3-5 (L3: posterior moments of the HIP sampler
+vs the same driver on the CPU oracle potential, within Monte-Carlo error)."""
+import numpy as np
+import pytest
+
+import cases
+import dc_oracle as O
+import dc_oracle_c as OC
+
+pytestmark = pytest.mark.gpu
+
+from bpl import DixonColesMatchPredictor, ExtendedDixonColesMatchPredictor  # noqa: E402
+from bpl.base import MAX_GOALS  # noqa: E402
+
+MODELS = [DixonColesMatchPredictor, ExtendedDixonColesMatchPredictor]
+
+
+@pytest.fixture(scope="module")
+def fitted(hip_ctx):
+    """One 100+100 fit per model, shared by the property tests (the reference refits for
+    every test; the assertions are the same)."""
+    td = O.dummy_data_recipe()
+    return {cls: cls().fit(td, num_samples=100, num_warmup=100) for cls in MODELS}, td
+
+
+def test_fit_default(hip_ctx, dummy_data):  # tests/test_dixon_coles.py:7-14
+    model = DixonColesMatchPredictor().fit(dummy_data)
+    assert model.attack is not None and model.defence is not None
+    assert model.home_advantage is not None and model.teams is not None
+    assert model.corr_coef is not None
+    assert model.attack.shape == (1000, 20) and model.home_advantage.shape == (1000,)
+    info = model.mcmc_info_
+    assert info["divergences"] == 0
+    assert 0.6 < info["accept_prob"].mean() < 0.97
+    # goals are iid Poisson(2.1) / Poisson(1.7): exp(home_advantage) ~ 2.1 / 1.7
+    assert abs(model.home_advantage.mean() - np.log(2.1 / 1.7)) < 0.08
+    # corr_coef recorded on the device during sampling == host-side constrain()
+    assert np.allclose(info["corr_coef"], model.corr_coef, atol=1e-6)
+
+
+@pytest.mark.parametrize("model_cls", MODELS)
+def test_predict_score_proba(fitted, model_cls):
+    models, dd = fitted
+    model = models[model_cls]
+    probs = model.predict_score_proba(dd["home_team"], dd["away_team"], dd["home_goals"], dd["away_goals"])
+    assert np.all((probs >= 0) & (probs <= 1))
+    assert 0 <= model.predict_score_proba("0", "1", 1, 0)[0] <= 1
+
+
+@pytest.mark.parametrize("model_cls", MODELS)
+def test_predict_outcome_proba(fitted, model_cls):
+    models, dd = fitted
+    model = models[model_cls]
+    probs = model.predict_outcome_proba(dd["home_team"], dd["away_team"])
+    assert np.allclose(probs["home_win"] + probs["away_win"] + probs["draw"], 1.0, atol=1e-5)
+    p = model.predict_outcome_proba("0", "1")
+    assert p["home_win"] + p["away_win"] + p["draw"] == pytest.approx(1.0, abs=1e-5)
+
+
+@pytest.mark.parametrize("model_cls", MODELS)
+def test_predict_score_n_and_concede_n_proba(fitted, model_cls):
+    models, _ = fitted
+    model = models[model_cls]
+    n = np.arange(MAX_GOALS + 1)
+    ph, pa = model.predict_score_n_proba(n, "0", "1"), model.predict_score_n_proba(n, "0", "1", home=False)
+    assert np.all((ph >= 0) & (ph <= 1)) and sum(ph) == pytest.approx(1.0, abs=1e-5)
+    assert np.all((pa >= 0) & (pa <= 1)) and sum(pa) == pytest.approx(1.0, abs=1e-5)
+    assert sum(ph * n) > sum(pa * n)
+    ch, ca = model.predict_concede_n_proba(n, "0", "1"), model.predict_concede_n_proba(n, "0", "1", home=False)
+    assert sum(ch) == pytest.approx(1.0, abs=1e-5) and sum(ch * n) < sum(ca * n)
+    a = model.predict_concede_n_proba(1, "0", "1")
+    b = model.predict_score_n_proba(1, "1", "0", home=False)
+    assert a.tolist() == pytest.approx(b.tolist(), abs=1e-5)
+
+
+def test_time_weighted_vs_not(hip_ctx, timed_dummy_data):  # tests/test_extended_dixon_coles.py:4-25
+    m0 = ExtendedDixonColesMatchPredictor().fit(timed_dummy_data)
+    a0, d0 = m0.attack.mean(axis=0), m0.defence.mean(axis=0)
+    assert abs(a0[1] - a0[0]) < 0.05 and abs(d0[1] - d0[0]) < 0.05
+    m1 = ExtendedDixonColesMatchPredictor().fit(timed_dummy_data, epsilon=1)
+    a1, d1 = m1.attack.mean(axis=0), m1.defence.mean(axis=0)
+    assert (a1[1] - a1[0]) > 0.75 and abs(d1[1] - d1[0]) > 0.75
+
+
+def test_epsilon(hip_ctx, timed_dummy_data):  # tests/test_extended_dixon_coles.py:28-47
+    m1 = ExtendedDixonColesMatchPredictor().fit(timed_dummy_data, epsilon=1)
+    m2 = ExtendedDixonColesMatchPredictor().fit(timed_dummy_data, epsilon=2)
+    a1, a2 = m1.attack.mean(axis=0), m2.attack.mean(axis=0)
+    assert abs(a2[1] - a2[0]) > 1.5 * abs(a1[1] - a1[0])
+    d1, d2 = m1.defence.mean(axis=0), m2.defence.mean(axis=0)
+    assert abs(d2[1] - d2[0]) > 1.5 * abs(d1[1] - d1[0])
+
+
+def test_covariates_rescale_and_multichain(hip_ctx, dummy_data):
+    """Paths the reference tests never reach: team_covariates,
+    rescale_weights, num_chains > 1 (sequential chains on one GPU), thinning."""
+    td = dict(dummy_data)
+    rs = np.random.RandomState(0)
+    td["team_covariates"] = {str(i): list(rs.normal(size=3)) for i in range(20)}
+    td["time_diff"] = np.linspace(3, 0, 380)
+    m = ExtendedDixonColesMatchPredictor().fit(
+        td, num_warmup=60, num_samples=40, epsilon=0.5, rescale_weights=True,
+        mcmc_kwargs={"num_chains": 2, "thinning": 2, "progress_bar": False})
+    assert m.attack.shape == (40, 20)  # 2 chains x 40/2 draws
+    assert m.attack_coefficients.shape == (40, 3) and m.defence_coefficients.shape == (40, 3)
+    assert m.rho.shape == (40,) and np.all(np.abs(m.rho) < 1)
+    assert np.all(m.std_attack > 0) and np.isfinite(m.home_advantage).all()
+    # the two chains are keyed by split(PRNGKey(42), 2): different draws
+    assert not np.allclose(m.attack[:20], m.attack[20:])
+    with pytest.raises(TypeError):
+        DixonColesMatchPredictor().fit(dummy_data, num_warmup=1, num_samples=1, mcmc_kwargs={"bogus": 1})
+
+
+def test_init_params_and_reproducibility(hip_ctx, dummy_data):
+    z0 = np.random.RandomState(1).uniform(-0.1, 0.1, 45)
+    kw = dict(num_warmup=30, num_samples=20, run_kwargs={"init_params": z0})
+    a = DixonColesMatchPredictor().fit(dummy_data, random_state=7, **kw)
+    b = DixonColesMatchPredictor().fit(dummy_data, random_state=7, **kw)
+    c = DixonColesMatchPredictor().fit(dummy_data, random_state=8, **kw)
+    assert np.array_equal(a.attack, b.attack)  # deterministic reduction order -> bitwise
+    assert not np.array_equal(a.attack, c.attack)
+
+
+def test_hip_sampler_vs_cpu_potential_sampler(hip_ctx, dummy_data):
+    """Ladder L3: same driver, same key; the HIP potential and the float64 CPU oracle
+    potential give posteriors that agree within Monte-Carlo error (trajectories themselves
+    decorrelate after a few transitions: float32 tables vs float64)."""
+    m = DixonColesMatchPredictor().fit(dummy_data, random_state=3, num_warmup=300, num_samples=600)
+    fx = cases.fixtures("dummy")
+    rc, draws, stats, summ = OC.nuts_dc(OC.CFixtures(O.MODEL_BASIC, fx), 300, 600, (0, 3))
+    assert rc == 0
+    sl = O.site_slices(O.MODEL_BASIC, 20)
+    zh = m.mcmc_info_["unconstrained"]
+    # first transition starts from the same init point with the same momentum: identical
+    # to float32-table accuracy
+    assert np.abs(zh[0] - draws[0]).max() < 5e-2
+    for name in ("home_advantage", "mean_defence", "std_attack", "std_defence", "corr_coef_raw"):
+        a, b = zh[:, sl[name]].ravel(), draws[:, sl[name]].ravel()
+        se = np.sqrt(a.var() / 100 + b.var() / 100)  # ESS >= ~100 each, conservatively
+        assert abs(a.mean() - b.mean()) < 4 * se + 1e-3, name
+    a, b = zh[:, sl["attack_decentered"]], draws[:, sl["attack_decentered"]]
+    assert np.abs(a.mean(0) - b.mean(0)).max() < 0.45  # sd ~ 1 each, 20 comparisons
+    assert abs(m.mcmc_info_["accept_prob"].mean() - stats[:, 1].mean()) < 0.08

@@ -1,0 +1,39 @@
+"""Diagnostic: per-phase timeline of dc_eval from the stamped build (make -C bpl-next_amd/csrc stamps).
+Never used for reported numbers: the stamps perturb the kernel; read the SHARES."""
+import ctypes as C, os, sys
+ROOT = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path[:0] = [ROOT + "/bpl-next_amd", ROOT]
+import numpy as np, torch
+from bench import synthetic_league
+from bpl import _ffi
+_ffi._LIB_NAME = "libbplhip_stamps.so"
+from bpl._ffi import HipContext, MODEL_BASIC, MODEL_EXTENDED
+
+def run(n, model=MODEL_BASIC, max_wg=255):
+    h, a, x, y = synthetic_league(n, 20)
+    c = HipContext(0); c.set_option("max_wg", max_wg); c.set_fixtures(model, h, a, x, y, 20)
+    lib = c._lib
+    lib.bplhip_debug_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int]; lib.bplhip_debug_stamps.restype = C.c_int
+    nwg = lib.bplhip_debug_stamps(c._h, None, 0)
+    z = torch.tensor(np.random.RandomState(7).uniform(-.5, .5, c.dim), dtype=torch.float64, device=c.device)
+    for _ in range(5): c.logp_grad(z)
+    torch.cuda.synchronize()
+    buf = np.zeros((nwg + 1) * 16, dtype=np.uint64)
+    lib.bplhip_debug_stamps(c._h, buf.ctypes.data_as(C.c_void_p), buf.size)
+    st = buf[: nwg * 16].reshape(nwg, 16).astype(np.int64)
+    t0 = st[:, 0].min()
+    rel = (st - t0) * 0.01  # us (100 MHz)
+    names = ["entry", "tables", "bounds", "stream", "slab", "drain", "ticket", "tail:start", "tail:loads", "tail:adj", "tail:end"]
+    print(f"--- N={n} model={model} blocks={nwg} (block 0 = prior workgroup)")
+    print("  prior WG: entry=%.2f done=%.2f drain=%.2f ticket=%.2f" % (rel[0, 0], rel[0, 4], rel[0, 5], rel[0, 6]))
+    for k in range(7):
+        col = rel[1:, k][st[1:, k] > 0]
+        if col.size: print(f"  {names[k]:10s} median {np.median(col):7.2f} us  min {col.min():7.2f}  max {col.max():7.2f}")
+    last = int(np.argmax(st[:, 10]))
+    print("  tail WG", last, " ".join(f"{names[k]}={rel[last, k]:.2f}" for k in range(11)))
+    c.close()
+
+for n in (1_000_000, 100_000, 380):
+    run(n)
+run(1_000_000, MODEL_EXTENDED)
+run(1_000_000, MODEL_BASIC, 127)
