@@ -80,7 +80,7 @@ def max_threads():
     return lib().dco_max_threads()
 
 
-def nuts_dc(cf: CFixtures, warm, samp, key, depth=10, thin=1, z0=None):
+def nuts_dc(cf: CFixtures, warm, samp, key, depth=10, thin=1, z0=None, step_size=1.0):
     kept = samp // thin
     draws = np.zeros((kept, cf.D))
     stats = np.zeros((kept, 4))
@@ -89,10 +89,10 @@ def nuts_dc(cf: CFixtures, warm, samp, key, depth=10, thin=1, z0=None):
     f = harness().harness_nuts_dc
     f.restype = C.c_int
     f.argtypes = ([C.c_int, C.c_int64, C.c_int, C.c_int] + [C.c_void_p] * 6 + [C.c_int] * 4 +
-                  [C.c_void_p, C.c_uint32, C.c_uint32] + [C.c_void_p] * 3)
+                  [C.c_void_p, C.c_uint32, C.c_uint32] + [C.c_void_p] * 3 + [C.c_double])
     rc = f(cf.model, cf.n, cf.T, cf.K, _p(cf.h), _p(cf.a), _p(cf.x), _p(cf.y), _p(cf.w),
            _p(cf.xs), warm, samp, depth, thin, _p(z0), key[0], key[1], _p(draws), _p(stats),
-           _p(summ))
+           _p(summ), float(step_size))
     return rc, draws, stats, summ
 
 

@@ -44,7 +44,8 @@ struct GaussPot {
         return true;
     }
 };
-void fill(nuts::Config* c, int warm, int samp, int depth, int thin) {
+void fill(nuts::Config* c, int warm, int samp, int depth, int thin, double step = 1.0) {
+    c->step_size = step;
     c->num_warmup = warm;
     c->num_samples = samp;
     c->max_tree_depth = depth;
@@ -79,10 +80,11 @@ extern "C" {
 int harness_nuts_dc(int model, int64_t n, int T, int K, const uint16_t* h, const uint16_t* a,
                     const uint8_t* x, const uint8_t* y, const double* w, const double* xs,
                     int warm, int samp, int depth, int thin, const double* z0, uint32_t khi,
-                    uint32_t klo, double* draws, double* stats, double* summary) {
+                    uint32_t klo, double* draws, double* stats, double* summary,
+                    double step_size) {
     OraclePot pot{model, T, K, dco_latent_dim(model, T, K), n, h, a, x, y, w, xs};
     nuts::Config cfg;
-    fill(&cfg, warm, samp, depth, thin);
+    fill(&cfg, warm, samp, depth, thin, step_size > 0 ? step_size : 1.0);
     return run(pot, cfg, z0, khi, klo, draws, stats, summary);
 }
 
