@@ -15,6 +15,7 @@ import numpy as np
 
 MODEL_BASIC = 0
 MODEL_EXTENDED = 1
+MODEL_DYNAMIC = 2
 
 _LIB_NAME = "libbplhip.so"
 _lib = None
@@ -26,6 +27,8 @@ ABI_SYMBOLS = (
     "bplhip_destroy",
     "bplhip_last_error",
     "bplhip_set_fixtures",
+    "bplhip_set_fixtures_dynamic",
+    "bplhip_constrain_dynamic",
     "bplhip_set_option",
     "bplhip_latent_dim",
     "bplhip_logp_grad",
@@ -105,6 +108,10 @@ def load_library():
     lib.bplhip_last_error.restype = C.c_char_p
     lib.bplhip_set_fixtures.argtypes = [vp, C.c_int, i64, i32, vp, vp, vp, vp, vp, vp, i32, vp]
     lib.bplhip_set_fixtures.restype = C.c_int
+    lib.bplhip_set_fixtures_dynamic.argtypes = [vp, i64, i32, i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp]
+    lib.bplhip_set_fixtures_dynamic.restype = C.c_int
+    lib.bplhip_constrain_dynamic.argtypes = [vp, vp, i64, vp, vp, vp, vp, vp, vp]
+    lib.bplhip_constrain_dynamic.restype = C.c_int
     lib.bplhip_set_option.argtypes = [vp, C.c_char_p, C.c_int]
     lib.bplhip_set_option.restype = C.c_int
     lib.bplhip_latent_dim.argtypes = [vp]
@@ -265,6 +272,43 @@ class HipContext:
         self.model = model
         self.n = n
         return self
+
+    def set_fixtures_dynamic(self, home_idx, away_idx, home_goals, away_goals, gameweek,
+                             neutral_venue, n_teams: int, n_gameweeks: int,
+                             covariates_std: Optional[np.ndarray] = None, random_walk: bool = True):
+        """Bind the dynamic (time-varying) model (bpl/dynamic_dixon_coles.py)."""
+        torch = self._torch
+
+        def dev(a, np_dtype):
+            arr = np.ascontiguousarray(np.asarray(a).astype(np_dtype))
+            return torch.from_numpy(arr.view(np.int16) if np_dtype == np.uint16 else arr).to(self.device)
+
+        h, a, g = dev(home_idx, np.uint16), dev(away_idx, np.uint16), dev(gameweek, np.uint16)
+        x, y, nv = dev(home_goals, np.uint8), dev(away_goals, np.uint8), dev(neutral_venue, np.uint8)
+        n = h.numel()
+        if not (a.numel() == g.numel() == x.numel() == y.numel() == nv.numel() == n):
+            raise ValueError("fixture arrays must have equal length")
+        cov, k = None, 0
+        if covariates_std is not None:
+            cov = np.ascontiguousarray(covariates_std, dtype=np.float64)
+            k = cov.shape[1]
+        with torch.cuda.device(self.device):
+            self._check(self._lib.bplhip_set_fixtures_dynamic(
+                self._h, n, n_teams, n_gameweeks, h.data_ptr(), a.data_ptr(), x.data_ptr(),
+                y.data_ptr(), g.data_ptr(), nv.data_ptr(), _np_ptr(cov), k, int(random_walk),
+                self._stream()))
+        self.dim = self._lib.bplhip_latent_dim(self._h)
+        self.n_teams, self.n_gameweeks, self.model, self.n = n_teams, n_gameweeks, MODEL_DYNAMIC, n
+        return self
+
+    def constrain_dynamic(self, z_draws: np.ndarray):
+        z = np.ascontiguousarray(z_draws, dtype=np.float64)
+        s, g, t = z.shape[0], self.n_gameweeks, self.n_teams
+        names = ("attack", "defence", "home_attack", "away_attack", "home_defence", "away_defence")
+        out = {nm: np.empty((s, g, t)) for nm in names}
+        self._check(self._lib.bplhip_constrain_dynamic(self._h, _np_ptr(z), s,
+                                                       *[_np_ptr(out[nm]) for nm in names]))
+        return out
 
     # -- the hot path
     def logp_grad(self, z, potential=None, grad=None, aux=None):

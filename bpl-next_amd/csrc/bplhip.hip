@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "../../include/bplhip.h"
+#include "dc_dynamic.hip.h"
 #include "dc_kernels.hip.h"
 #include "nuts.hpp"
 #include "threefry.hpp"
@@ -82,6 +83,11 @@ struct bplhip_ctx {
     // host copies needed by bplhip_constrain (rho bounds over the unique pairs)
     std::vector<uint32_t> h_pairs;
     std::vector<double> h_xs;
+    // dynamic (time-varying) model: separate float64 path (dc_dynamic.hip.h)
+    bool dynamic = false;
+    dcd::DynLayout DL{};
+    int dyn_random_walk = 1;
+    DevBuf dd_gw, dd_nv, dd_cells, dd_acc, dd_lam, dd_sc, dd_hyp;
     std::map<GraphKey, hipGraphExec_t> graphs;
     hipStream_t cap_stream = nullptr;
 
@@ -151,8 +157,48 @@ int launch_eval_t(bplhip_ctx* c, const dc::EvalArgs& A, int chains, hipStream_t 
 }
 
 // Enqueue one (batched) evaluation: ONE launch.  No host sync.
+int launch_eval_dynamic(bplhip_ctx* c, int chains, const double* z, double* pot, double* grad,
+                        double* aux, hipStream_t s) {
+    const dcd::DynLayout& L = c->DL;
+    const size_t GT = (size_t)L.G * L.T;
+    for (int ch = 0; ch < chains; ++ch) {  // chains run back to back (first correct path)
+        dcd::DynArgs A{};
+        A.h = c->d_h.as<const uint16_t>();
+        A.a = c->d_a.as<const uint16_t>();
+        A.x = c->d_x.as<const uint8_t>();
+        A.y = c->d_y.as<const uint8_t>();
+        A.gw = c->dd_gw.as<const uint16_t>();
+        A.nv = c->dd_nv.as<const uint8_t>();
+        A.n = c->n;
+        A.xs = L.K ? c->d_xs.as<const double>() : nullptr;
+        A.lgsum = c->lgsum;
+        A.cells = c->dd_cells.as<double>();
+        A.acc = c->dd_acc.as<double>();
+        A.lam = c->dd_lam.as<double>();
+        A.sc = c->dd_sc.as<double>();
+        A.hyp = c->dd_hyp.as<double>();
+        A.z = z + (size_t)ch * L.D;
+        A.potential = pot + ch;
+        A.grad = grad + (size_t)ch * L.D;
+        A.aux = aux ? aux + (size_t)ch * 4 : nullptr;
+        A.random_walk = c->dyn_random_walk;
+        A.L = L;
+        HIP_TRY(c, hipMemsetAsync(A.acc, 0, GT * dcd::A_N * 8, s));
+        HIP_TRY(c, hipMemsetAsync(A.sc, 0, dcd::SC_N * 8, s));
+        hipLaunchKernelGGL(dcd::dyn_cells, dim3((L.T + 255) / 256), dim3(256), 6 * L.G * 8, s, A);
+        const int nb = (int)((c->n + 255) / 256);
+        hipLaunchKernelGGL(dcd::dyn_pass1, dim3(nb), dim3(256), 0, s, A);
+        hipLaunchKernelGGL(dcd::dyn_pass2, dim3(nb), dim3(256), 0, s, A);
+        hipLaunchKernelGGL(dcd::dyn_epilogue, dim3(1), dim3(dcd::EPI_THREADS),
+                           dcd::epi_lds_bytes(L.G, L.K), s, A);
+        HIP_TRY(c, hipGetLastError());
+    }
+    return BPLHIP_OK;
+}
+
 int launch_eval(bplhip_ctx* c, int chains, const double* z, double* pot, double* grad,
                 double* aux, hipStream_t s) {
+    if (c->dynamic) return launch_eval_dynamic(c, chains, z, pot, grad, aux, s);
     dc::EvalArgs A{};
     A.h = c->d_h.as<const uint4>();
     A.a = c->d_a.as<const uint4>();
@@ -243,6 +289,7 @@ int bplhip_set_fixtures(bplhip_ctx* c, int model_kind, int64_t n, int32_t n_team
                         void* stream) {
     if (!c) return BPLHIP_EINVAL;
     c->bound = false;
+    c->dynamic = false;
     if (model_kind != BPLHIP_MODEL_BASIC && model_kind != BPLHIP_MODEL_EXTENDED)
         return fail(c, BPLHIP_EINVAL, "set_fixtures: unknown model_kind %d", model_kind);
     if (n < 1 || n > (int64_t)1 << 40)
@@ -429,7 +476,79 @@ int bplhip_set_option(bplhip_ctx* c, const char* name, int value) {
 int bplhip_latent_dim(const bplhip_ctx* c) {
     if (!c) return BPLHIP_EINVAL;
     if (!c->bound) return BPLHIP_ESTATE;
-    return c->L.D;
+    return c->dynamic ? c->DL.D : c->L.D;
+}
+
+int bplhip_set_fixtures_dynamic(bplhip_ctx* c, int64_t n, int32_t n_teams, int32_t n_gameweeks,
+                                const uint16_t* home_idx, const uint16_t* away_idx,
+                                const uint8_t* home_goals, const uint8_t* away_goals,
+                                const uint16_t* gameweek, const uint8_t* neutral_venue,
+                                const double* covariates, int32_t k, int32_t random_walk,
+                                void* stream) {
+    if (!c) return BPLHIP_EINVAL;
+    c->bound = false;
+    if (n < 1 || n_teams < 1 || n_teams > 65534 || n_gameweeks < 1 || n_gameweeks > 65535)
+        return fail(c, BPLHIP_EINVAL, "set_fixtures_dynamic: bad sizes");
+    if (!home_idx || !away_idx || !home_goals || !away_goals || !gameweek || !neutral_venue)
+        return fail(c, BPLHIP_EINVAL, "set_fixtures_dynamic: null fixture array");
+    if (k < 0 || (k > 0 && !covariates) || (k == 0 && covariates))
+        return fail(c, BPLHIP_EINVAL, "set_fixtures_dynamic: covariates/k mismatch");
+    if ((int64_t)n_teams * n_gameweeks > (int64_t)1 << 26)
+        return fail(c, BPLHIP_EUNSUPPORTED, "set_fixtures_dynamic: too many (gameweek, team) cells");
+    if (dcd::epi_lds_bytes(n_gameweeks, k) > 64 * 1024)
+        return fail(c, BPLHIP_EUNSUPPORTED, "set_fixtures_dynamic: too many gameweeks");
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    std::vector<uint16_t> h(n), a(n), g(n);
+    std::vector<uint8_t> x(n), y(n), nv(n);
+    HIP_TRY(c, hipMemcpyAsync(h.data(), home_idx, n * 2, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(a.data(), away_idx, n * 2, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(g.data(), gameweek, n * 2, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(x.data(), home_goals, n, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(y.data(), away_goals, n, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(nv.data(), neutral_venue, n, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    double lgsum = 0.0;
+    for (int64_t i = 0; i < n; ++i) {
+        if (h[i] >= n_teams || a[i] >= n_teams || g[i] >= n_gameweeks || nv[i] > 1)
+            return fail(c, BPLHIP_EINVAL, "set_fixtures_dynamic: index out of range at fixture %lld",
+                        (long long)i);
+        lgsum += std::lgamma((double)x[i] + 1.0) + std::lgamma((double)y[i] + 1.0);
+    }
+    const size_t GT = (size_t)n_teams * n_gameweeks;
+    HIP_TRY(c, c->d_h.ensure(n * 2));
+    HIP_TRY(c, c->d_a.ensure(n * 2));
+    HIP_TRY(c, c->d_x.ensure(n));
+    HIP_TRY(c, c->d_y.ensure(n));
+    HIP_TRY(c, c->dd_gw.ensure(n * 2));
+    HIP_TRY(c, c->dd_nv.ensure(n));
+    HIP_TRY(c, hipMemcpyAsync(c->d_h.p, h.data(), n * 2, hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(c->d_a.p, a.data(), n * 2, hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(c->d_x.p, x.data(), n, hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(c->d_y.p, y.data(), n, hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(c->dd_gw.p, g.data(), n * 2, hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(c->dd_nv.p, nv.data(), n, hipMemcpyHostToDevice, s));
+    HIP_TRY(c, c->dd_cells.ensure(GT * dcd::P_N * 8));
+    HIP_TRY(c, c->dd_acc.ensure(GT * dcd::A_N * 8));
+    HIP_TRY(c, c->dd_lam.ensure((size_t)n * 2 * 8));
+    HIP_TRY(c, c->dd_sc.ensure(dcd::SC_N * 8));
+    HIP_TRY(c, c->dd_hyp.ensure((size_t)6 * n_gameweeks * 8));
+    c->h_xs.clear();
+    if (k > 0) {
+        c->h_xs.assign(covariates, covariates + (size_t)n_teams * k);
+        HIP_TRY(c, c->d_xs.ensure((size_t)n_teams * k * 8));
+        HIP_TRY(c, hipMemcpyAsync(c->d_xs.p, c->h_xs.data(), (size_t)n_teams * k * 8,
+                                  hipMemcpyHostToDevice, s));
+    }
+    HIP_TRY(c, hipStreamSynchronize(s));
+    drop_graphs(c);
+    c->DL = dcd::make_dyn_layout(n_gameweeks, n_teams, k);
+    c->dyn_random_walk = random_walk != 0;
+    c->n = n;
+    c->lgsum = lgsum;
+    c->dynamic = true;
+    c->bound = true;
+    return BPLHIP_OK;
 }
 
 int bplhip_logp_grad_batched(bplhip_ctx* c, int32_t n_chains, const double* z,
@@ -440,8 +559,10 @@ int bplhip_logp_grad_batched(bplhip_ctx* c, int32_t n_chains, const double* z,
     if (n_chains < 1 || n_chains > 65535)
         return fail(c, BPLHIP_EINVAL, "logp_grad: n_chains=%d out of range", n_chains);
     HIP_TRY(c, hipSetDevice(c->device));
-    int rc = ensure_slabs(c, n_chains);
-    if (rc != BPLHIP_OK) return rc;
+    if (!c->dynamic) {
+        int rc = ensure_slabs(c, n_chains);
+        if (rc != BPLHIP_OK) return rc;
+    }
     return launch_eval(c, n_chains, z, potential, grad, aux, static_cast<hipStream_t>(stream));
 }
 
@@ -461,7 +582,7 @@ int bplhip_logp_grad_graph(bplhip_ctx* c, int32_t count, int32_t n_z, const doub
     auto it = c->graphs.find(key);
     if (it == c->graphs.end()) {
         if (!c->cap_stream) HIP_TRY(c, hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking));
-        const int D = c->L.D;
+        const int D = c->dynamic ? c->DL.D : c->L.D;
         HIP_TRY(c, hipStreamBeginCapture(c->cap_stream, hipStreamCaptureModeThreadLocal));
         int rc = BPLHIP_OK;
         for (int i = 0; i < count && rc == BPLHIP_OK; ++i) {
@@ -584,7 +705,7 @@ extern "C" int bplhip_nuts_run(bplhip_ctx* c, const bplhip_nuts_cfg* cfg, const 
         cfg->max_tree_depth > 20 || cfg->thinning < 1 || !(cfg->step_size > 0))
         return fail(c, BPLHIP_EINVAL, "nuts_run: bad configuration");
     HIP_TRY(c, hipSetDevice(c->device));
-    const int D = c->L.D;
+    const int D = c->dynamic ? c->DL.D : c->L.D;
     const size_t nd = (size_t)2 * D + 1 + 4;
     HIP_TRY(c, c->d_nuts.ensure(nd * 8));
     if (c->h_pinned_bytes < nd * 8) {
@@ -612,7 +733,20 @@ extern "C" int bplhip_nuts_run(bplhip_ctx* c, const bplhip_nuts_cfg* cfg, const 
     nc.init_radius = cfg->init_radius;
     nc.max_delta_energy = cfg->max_delta_energy;
 
-    {  // latent sites in MODEL EXECUTION order (seed-handler key order, Appendix B.5)
+    if (c->dynamic) {  // bpl/dynamic_dixon_coles.py:74-241, model execution order
+        const dcd::DynLayout& L = c->DL;
+        const int G = L.G, GT = L.G * L.T;
+        nc.sites = {{L.o_mha, G}, {L.o_maa, G}, {L.o_mhd, G}, {L.o_mad, G}, {L.o_s_ha, G},
+                    {L.o_s_aa, G}, {L.o_s_hd, G}, {L.o_s_ad, G}, {L.o_s_att, G}, {L.o_s_def, G},
+                    {L.o_md, 1}};
+        if (L.K) {
+            nc.sites.push_back({L.o_bA, L.K});
+            nc.sites.push_back({L.o_bD, L.K});
+        }
+        for (int o : {L.o_u, L.o_sat, L.o_sdt, L.o_hat, L.o_aat, L.o_hdf, L.o_adf})
+            nc.sites.push_back({o, GT});
+        nc.sites.push_back({L.o_corr, 1});
+    } else {  // latent sites in MODEL EXECUTION order (seed-handler key order, Appendix B.5)
         const dc::Layout& L = c->L;
         const int T = L.T, K = L.K;
         if (L.model == dc::MODEL_BASIC) {
@@ -669,6 +803,7 @@ extern "C" int bplhip_constrain(bplhip_ctx* c, const double* z_draws, int64_t s,
                                 double* corr_coef) {
     if (!c) return BPLHIP_EINVAL;
     if (!c->bound) return fail(c, BPLHIP_ESTATE, "constrain: no fixtures bound");
+    if (c->dynamic) return fail(c, BPLHIP_ESTATE, "constrain: use bplhip_constrain_dynamic");
     if (!z_draws || s < 0) return fail(c, BPLHIP_EINVAL, "constrain: bad argument");
     const dc::Layout& L = c->L;
     const int T = L.T;
@@ -704,6 +839,48 @@ extern "C" int bplhip_constrain(bplhip_ctx* c, const double* z_draws, int64_t s,
             double q, dq;
             dc::clipped_sigmoid(z[L.o_corr], &q, &dq);
             corr_coef[i] = LB + q * (UB - LB);
+        }
+    }
+    return BPLHIP_OK;
+}
+
+// Dynamic model: constrained / deterministic sites per draw.  HOST in, HOST out; outputs
+// [s, G, T] each (any may be NULL): attack, defence (the walk), home_attack, away_attack,
+// home_defence, away_defence.  corr_coef comes from the sampler statistics.
+extern "C" int bplhip_constrain_dynamic(bplhip_ctx* c, const double* z_draws, int64_t s,
+                                        double* attack, double* defence, double* home_attack,
+                                        double* away_attack, double* home_defence,
+                                        double* away_defence) {
+    if (!c) return BPLHIP_EINVAL;
+    if (!c->bound || !c->dynamic) return fail(c, BPLHIP_ESTATE, "constrain_dynamic: no dynamic model bound");
+    if (!z_draws || s < 0) return fail(c, BPLHIP_EINVAL, "constrain_dynamic: bad argument");
+    const dcd::DynLayout& L = c->DL;
+    const int G = L.G, T = L.T, K = L.K;
+    const size_t GT = (size_t)G * T;
+    for (int64_t i = 0; i < s; ++i) {
+        const double* z = z_draws + (size_t)i * L.D;
+        for (int t = 0; t < T; ++t) {
+            double att = 0.0, def = z[L.o_md];
+            for (int k = 0; k < K; ++k) {
+                att += c->h_xs[(size_t)t * K + k] * z[L.o_bA + k];
+                def += c->h_xs[(size_t)t * K + k] * z[L.o_bD + k];
+            }
+            for (int g = 0; g < G; ++g) {
+                const size_t cidx = (size_t)g * T + t, o = (size_t)i * GT + cidx;
+                double a_ = 0.0, d_ = 0.0;
+                if (c->dyn_random_walk) {
+                    att += z[L.o_sat + cidx] * std::exp(z[L.o_s_att + g]);
+                    def += z[L.o_sdt + cidx] * std::exp(z[L.o_s_def + g]);
+                    a_ = att;
+                    d_ = def;
+                }
+                if (attack) attack[o] = a_;
+                if (defence) defence[o] = d_;
+                if (home_attack) home_attack[o] = z[L.o_mha + g] + std::exp(z[L.o_s_ha + g]) * z[L.o_hat + cidx];
+                if (away_attack) away_attack[o] = z[L.o_maa + g] + std::exp(z[L.o_s_aa + g]) * z[L.o_aat + cidx];
+                if (home_defence) home_defence[o] = z[L.o_mhd + g] + std::exp(z[L.o_s_hd + g]) * z[L.o_hdf + cidx];
+                if (away_defence) away_defence[o] = z[L.o_mad + g] + std::exp(z[L.o_s_ad + g]) * z[L.o_adf + cidx];
+            }
         }
     }
     return BPLHIP_OK;

@@ -54,7 +54,9 @@ enum {
 
 enum {
     BPLHIP_MODEL_BASIC = 0,    /* bpl/dixon_coles.py:39-84           */
-    BPLHIP_MODEL_EXTENDED = 1  /* bpl/extended_dixon_coles.py:78-248 */
+    BPLHIP_MODEL_EXTENDED = 1, /* bpl/extended_dixon_coles.py:78-248 */
+    BPLHIP_MODEL_DYNAMIC = 2   /* bpl/dynamic_dixon_coles.py:63-247 (bound through
+                                  bplhip_set_fixtures_dynamic)       */
 };
 
 typedef struct bplhip_ctx bplhip_ctx;
@@ -93,6 +95,34 @@ int bplhip_set_fixtures(bplhip_ctx* ctx, int model_kind, int64_t n, int32_t n_te
                         const uint8_t* home_goals, const uint8_t* away_goals,
                         const float* weights, const double* covariates, int32_t k,
                         void* stream);
+
+/* Bind the arguments of the dynamic (time-varying, neutral-venue) model,
+ * bpl/dynamic_dixon_coles.py:63-247 as run at :286-300: per-gameweek hyper-parameters,
+ * [G,T] tables, `gameweek` (0-based, device u16[n]) and `neutral_venue` (device u8[n], 0/1).
+ * Latent layout (sorted site names, D = 7GT + 10G + 2 + 2K): attack_coefficients[K],
+ * away_attack_decentered[G,T], away_defence_decentered[G,T], corr_coef_raw,
+ * defence_coefficients[K], home_attack_decentered[G,T], home_defence_decentered[G,T],
+ * mean_away_attack[G], mean_away_defence[G], mean_defence, mean_home_attack[G],
+ * mean_home_defence[G], standardised_attack[G,T], standardised_defence[G,T], std_attack[G],
+ * std_away_attack[G], std_away_defence[G], std_defence[G], std_home_attack[G],
+ * std_home_defence[G], u[G,T].  `random_walk` 1 = the INTENDED model, attack[g] = attack[g-1] +
+ * standardised_attack[g]*std_attack[g] (:192-218 discard that update);
+ * 0 = the code as written (attack = defence = 0).  After this call logp_grad / nuts_run
+ * work on the dynamic model; draws are mapped by bplhip_constrain_dynamic. */
+int bplhip_set_fixtures_dynamic(bplhip_ctx* ctx, int64_t n, int32_t n_teams,
+                                int32_t n_gameweeks, const uint16_t* home_idx,
+                                const uint16_t* away_idx, const uint8_t* home_goals,
+                                const uint8_t* away_goals, const uint16_t* gameweek,
+                                const uint8_t* neutral_venue, const double* covariates,
+                                int32_t k, int32_t random_walk, void* stream);
+
+/* Dynamic model: HOST draws f64[s, D] -> constrained/deterministic sites f64[s, G, T]
+ * (any output may be NULL): attack, defence (`attack_j`/`defence_j` of :195-218),
+ * home_attack, away_attack, home_defence, away_defence (:142-189). */
+int bplhip_constrain_dynamic(bplhip_ctx* ctx, const double* z_draws, int64_t s,
+                             double* attack, double* defence, double* home_attack,
+                             double* away_attack, double* home_defence,
+                             double* away_defence);
 
 /* Tuning knobs (no reference counterpart; defaults are the measured best):
  *   "max_wg" streaming workgroups per evaluation (default 255: with the prior workgroup

@@ -1,0 +1,87 @@
+"""GPU parity of the dynamic (time-varying) model path: HIP (float64 kernels,
+dc_dynamic.hip.h) vs the float64 oracle, BASELINE config 4 (T=100, G=50, N=2500, D=35502)
+and small ragged cases; plus a short NUTS fit through the Python class.
+Tolerance (float64 arithmetic, atomics in arbitrary order): 1e-9 relative."""
+import numpy as np
+import pytest
+
+import dc_dynamic_oracle as DO
+
+pytestmark = pytest.mark.gpu
+
+
+def _eval(ctx, fx, z, random_walk=True):
+    import torch
+
+    cov = None if fx.covariates is None else DO.standardise_covariates(fx.covariates)
+    ctx.set_fixtures_dynamic(fx.home_idx, fx.away_idx, fx.home_goals, fx.away_goals, fx.gameweek,
+                             fx.neutral, fx.n_teams, fx.n_gameweeks, covariates_std=cov,
+                             random_walk=random_walk)
+    assert ctx.dim == DO.latent_dim(fx.n_gameweeks, fx.n_teams, fx.k)
+    zt = torch.tensor(z, dtype=torch.float64, device=ctx.device)
+    U, g, aux = ctx.logp_grad(zt)
+    U2, g2, _ = ctx.logp_grad(zt)
+    assert abs(float(U2[0]) - float(U[0])) <= 1e-12 * abs(float(U[0]))
+    return float(U.cpu()[0]), g.cpu().numpy(), aux.cpu().numpy()[0]
+
+
+@pytest.mark.parametrize("random_walk", [True, False])
+@pytest.mark.parametrize("case", ["small", "small_cov", "config4"])
+def test_dynamic_logp_grad_matches_oracle(hip_ctx, case, random_walk):
+    fx = {"small": lambda: DO.small_recipe(), "small_cov": lambda: DO.small_recipe(k=3),
+          "config4": DO.config4_recipe}[case]()
+    D = DO.latent_dim(fx.n_gameweeks, fx.n_teams, fx.k)
+    sl = DO.site_slices(fx.n_gameweeks, fx.n_teams, fx.k)
+    for seed in (7, 2):
+        z = np.random.RandomState(seed).uniform(-0.3, 0.3, D)
+        if seed == 2:
+            z[sl["mean_home_attack"]] = 1.2
+        Uo, go, auxo = DO.potential_and_grad(fx, z, random_walk)
+        U, g, aux = _eval(hip_ctx, fx, z, random_walk)
+        print(f"{case} rw={random_walk} seed={seed} D={D} U={Uo:.6f} dU={U - Uo:+.2e} "
+              f"dg={np.abs(g - go).max():.2e} / {np.abs(go).max():.2e}")
+        assert abs(U - Uo) <= 1e-9 * abs(Uo)
+        assert np.abs(g - go).max() <= 1e-9 * np.abs(go).max()
+        assert abs(aux[0] - auxo["rho"]) <= 1e-12
+
+
+def test_dynamic_throughput_variant_1e6(hip_ctx):
+    """SURVEY.md §8(d) throughput variant: uniformly random (gameweek, h != a), N = 1e6."""
+    rs = np.random.RandomState(4)
+    n, T, G = 1_000_000, 100, 50
+    h = rs.randint(0, T, n)
+    a = (h + 1 + rs.randint(0, T - 1, n)) % T
+    fx = DO.DynFixtures(h, a, rs.poisson(1.5, n), rs.poisson(1.2, n), rs.randint(0, G, n),
+                        np.zeros(n, int), T, G)
+    z = np.random.RandomState(7).uniform(-0.2, 0.2, DO.latent_dim(G, T))
+    Uo, go, _ = DO.potential_and_grad(fx, z)
+    U, g, _ = _eval(hip_ctx, fx, z)
+    assert abs(U - Uo) <= 1e-9 * abs(Uo)
+    assert np.abs(g - go).max() <= 1e-9 * np.abs(go).max()
+
+
+def test_dynamic_fit_smoke(hip_ctx):
+    from bpl.dynamic_dixon_coles import DynamicNeutralDixonColesMatchPredictor
+
+    rs = np.random.RandomState(0)
+    T, G, per = 6, 4, 30
+    teams = [f"t{i}" for i in range(T)]
+    td = {"home_team": [], "away_team": [], "home_goals": [], "away_goals": [], "gameweek": [],
+          "neutral_venue": []}
+    for g in range(G):
+        for _ in range(per):
+            i, j = rs.choice(T, 2, replace=False)
+            td["home_team"].append(teams[i])
+            td["away_team"].append(teams[j])
+            td["home_goals"].append(rs.poisson(1.6))
+            td["away_goals"].append(rs.poisson(1.2))
+            td["gameweek"].append(g)
+            td["neutral_venue"].append(int(rs.rand() < 0.2))
+    z0 = np.zeros(7 * G * T + 10 * G + 2)
+    m = DynamicNeutralDixonColesMatchPredictor().fit(td, num_warmup=60, num_samples=40,
+                                                     run_kwargs={"init_params": z0})
+    assert m.attack.shape == (40, G, T) and m.home_attack.shape == (40, G, T)
+    assert m.corr_coef.shape == (40,) and np.isfinite(m.attack).all()
+    p = m.predict_outcome_proba(["t0", "t1"], ["t2", "t3"], [0, 1])
+    assert np.allclose(p["home_win"] + p["draw"] + p["away_win"], 1.0, atol=1e-5)
+    assert m.predict_score_proba("t0", "t1", 1, 0, 0).shape == (1,)
