@@ -17,7 +17,7 @@ MODEL_BASIC = 0
 MODEL_EXTENDED = 1
 MODEL_DYNAMIC = 2
 
-_LIB_NAME = "libbplhip.so"
+_LIB_NAME = os.environ.get("BPLHIP_LIB", "libbplhip.so")  # override: diagnostic builds only
 _lib = None
 
 # every symbol include/bplhip.h declares (checked by tests/test_abi.py without a GPU)

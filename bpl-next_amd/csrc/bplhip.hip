@@ -68,8 +68,8 @@ struct bplhip_ctx {
     int P = 0;
     double lgsum = 0.0;
     // device buffers (library owned)
-    DevBuf d_h, d_a, d_x, d_y, d_w, d_pairs, d_xs, d_cA, d_cD, d_cH, d_tickets, d_debug, d_xsf, d_zo,
-        d_compact, d_scal, d_wg_off, d_wg_slots, d_col_off, d_wg_dst;
+    DevBuf d_h, d_a, d_x, d_y, d_w, d_pairs, d_xs, d_cA, d_cD, d_cH, d_tickets, d_debug, d_xsf, d_hbuf,
+        d_wg_off, d_wg_slots, d_col_off, d_wg_dst;
     int slab_chains = 0;
     int total_c = 0;      // entries of the sparse (compact) slab array
     bool staged = true;   // the tail stages the compact array in LDS
@@ -123,11 +123,13 @@ constexpr size_t LDS_LIMIT = 160 * 1024;
 
 int zo_stride_of(const dc::Layout& L) { return (dc::ZO_HDR + L.D + 3 * L.T + 1) & ~1; }
 
+int hb_stride_of(const bplhip_ctx* c) {
+    return (zo_stride_of(c->L) + c->n_wg * dc::N_SCAL + c->total_c + 1) & ~1;
+}
+
 int ensure_slabs(bplhip_ctx* c, int chains) {
     if (chains <= c->slab_chains) return BPLHIP_OK;
-    HIP_TRY(c, c->d_compact.ensure((size_t)chains * std::max(c->total_c, 1) * sizeof(double)));
-    HIP_TRY(c, c->d_scal.ensure((size_t)chains * c->n_wg * dc::N_SCAL * sizeof(double)));
-    HIP_TRY(c, c->d_zo.ensure((size_t)chains * zo_stride_of(c->L) * sizeof(double)));
+    HIP_TRY(c, c->d_hbuf.ensure((size_t)chains * hb_stride_of(c) * sizeof(double)));
     HIP_TRY(c, c->d_tickets.ensure((size_t)chains * sizeof(unsigned int)));
     HIP_TRY(c, hipMemset(c->d_tickets.p, 0, (size_t)chains * sizeof(unsigned int)));
     c->slab_chains = chains;
@@ -220,9 +222,8 @@ int launch_eval(bplhip_ctx* c, int chains, const double* z, double* pot, double*
     A.col_off = c->d_col_off.as<const int>();
     A.wg_dst = c->d_wg_dst.as<const int>();
     A.total_c = c->total_c;
-    A.compact = c->d_compact.as<double>();
-    A.scal = c->d_scal.as<double>();
-    A.zo = c->d_zo.as<double>();
+    A.hbuf = c->d_hbuf.as<double>();
+    A.hb_stride = hb_stride_of(c);
     A.n_wg = c->n_wg;
     A.zo_stride = zo_stride_of(c->L);
     A.tickets = c->d_tickets.as<unsigned int>();

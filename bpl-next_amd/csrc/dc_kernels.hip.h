@@ -84,10 +84,10 @@ struct EvalArgs {
     const int* col_off;     // [3T+1]   column c owns compact[col_off[c] .. col_off[c+1]),
                             //          entries in workgroup order
     int total_c;
-    // scratch
-    double* compact;        // [chains][total_c]   partial sums of the touched slots
-    double* scal;           // [chains][n_wg][N_SCAL]
-    double* zo;             // [chains][zo_stride]
+    // scratch: ONE contiguous hand-off record per chain, read by the tail in one batch:
+    //   [ zo: zo_stride | scal: n_wg*N_SCAL | compact: total_c ]
+    double* hbuf;           // [chains][hb_stride]
+    int hb_stride;
     int n_wg;               // streaming workgroups (grid.x = n_wg + 1)
     int zo_stride;
     unsigned int* tickets;  // [chains] arrival counters
@@ -140,6 +140,21 @@ __device__ __forceinline__ float wave_sum_f32(float v) {
     v += dpp_f32<0x142, 0xA>(0.f, v);  // row_bcast:15 into rows 1,3
     v += dpp_f32<0x143, 0xC>(0.f, v);  // row_bcast:31 into rows 2,3
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+// two independent sums, interleaved step by step (twice the ILP of two calls)
+__device__ __forceinline__ void wave_sum2_f32(float& a, float& b) {
+    a += dpp_f32<0xB1>(0.f, a);        b += dpp_f32<0xB1>(0.f, b);
+    a += dpp_f32<0x4E>(0.f, a);        b += dpp_f32<0x4E>(0.f, b);
+    a += dpp_f32<0x124>(0.f, a);       b += dpp_f32<0x124>(0.f, b);
+    a += dpp_f32<0x128>(0.f, a);       b += dpp_f32<0x128>(0.f, b);
+    a += dpp_f32<0x142, 0xA>(0.f, a);  b += dpp_f32<0x142, 0xA>(0.f, b);
+    a += dpp_f32<0x143, 0xC>(0.f, a);  b += dpp_f32<0x143, 0xC>(0.f, b);
+    a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a), 63));
+    b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b), 63));
+}
+// value of the previous lane (lane 0 gets `fill`): DPP wave_shr:1, no LDS crossbar
+__device__ __forceinline__ uint32_t prev_lane_u32(uint32_t v, uint32_t fill) {
+    return (uint32_t)dpp_i32<0x138>((int)fill, (int)v);
 }
 __device__ __forceinline__ float wave_max_f32(float v) {  // v >= 0
     v = fmaxf(v, dpp_f32<0xB1>(0.f, v));
@@ -241,7 +256,7 @@ __host__ __device__ inline size_t stream_lds_bytes(int T) {
 __host__ __device__ inline size_t tail_lds_bytes(int T, int D, int zo_stride, int n_wg,
                                                  int total_c, bool staged) {
     size_t d = (size_t)zo_stride + 3 * (size_t)T + D + (3 * (size_t)T + N_SCAL + 4) +
-               WAVES * 8 + (size_t)n_wg * N_SCAL;
+               WAVES * 8 + (size_t)n_wg * N_SCAL + (size_t)T * 16 /* xs, K <= 16 staged */;
     size_t i = 3 * (size_t)T + 2;
     if (staged) d += (size_t)total_c;
     return d * 8 + ((i * 4 + 15) & ~(size_t)15) + 16;
@@ -415,7 +430,7 @@ __device__ void prior_body(const EvalArgs& A, int chain, char* smem) {
     const int T = L.T, K = L.K, D = L.D;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const double* z = A.z + (size_t)chain * D;
-    double* zo = A.zo + (size_t)chain * A.zo_stride;
+    double* zo = A.hbuf + (size_t)chain * A.hb_stride;
     double* gz = zo + ZO_HDR;
     double* eps = gz + D;
 
@@ -641,6 +656,119 @@ __device__ void prior_body(const EvalArgs& A, int chain, char* smem) {
 
 // ------------------------------------------------------------------------ tail
 
+// Per-team epilogue for T <= 64, executed by ONE wave: lane t owns team t, the adjoint of
+// the bounds is a lane-local add, sums are DPP wave reductions.  Same arithmetic and the
+// same summation order on every run (deterministic).
+__device__ void tail_one_wave(const EvalArgs& A, int chain, const double* zoL, const double* cL,
+                              const double* zL, const double* col, const double* xsL) {
+    const Layout& L = A.L;
+    const int T = L.T, K = L.K, D = L.D;
+    const int t = threadIdx.x & 63;
+    const bool on = t < T;
+    double* grad = A.grad + (size_t)chain * D;
+    const double* gz = zoL + ZO_HDR;
+    const double* eps = gz + D;
+    const int ncol = 3 * T;
+    const double s_a = zoL[ZO_SA], s_d = zoL[ZO_SD], s_h = zoL[ZO_SH];
+    const double q = zoL[ZO_Q], dq = zoL[ZO_DQ], UB = zoL[ZO_UB], LB = zoL[ZO_LB];
+    const double M = zoL[ZO_M], Lh = zoL[ZO_LH], La = zoL[ZO_LA];
+    const double SLAM = col[ncol + 0], SLOG = col[ncol + 1], SU = col[ncol + 2],
+                 CLIPC = col[ncol + 3];
+    const double G_rho = SU;
+    const double ra = on ? col[t] : 0.0, rd = on ? col[T + t] : 0.0, rh = on ? col[2 * T + t] : 0.0;
+    // first-order value correction for the float32 rounding of the tables
+    double corr = on ? -(rh * eps[t] + (ra - rh) * eps[T + t] + rd * eps[2 * T + t]) : 0.0;
+    double ga = on ? cL[t] - ra : 0.0;
+    double gd = on ? -(cL[T + t] - rd) : 0.0;
+    double gh = on ? cL[2 * T + t] - rh : 0.0;
+    if (A.P > 0) {  // adjoint of the bounds (Appendix A.3)
+        const uint32_t pP = (uint32_t)zoL[ZO_PP], pQ = (uint32_t)zoL[ZO_PQ],
+                       pR = (uint32_t)zoL[ZO_PR];
+        const unsigned int flags = (unsigned int)zoL[ZO_FLAGS];
+        if (M > 1.0) {
+            const double v = G_rho * q * (-UB);
+            const int h = pP & 0xFFFFu, a = pP >> 16;
+            if (!(flags & 1u)) {
+                if (t == h) { ga += v; gh += v; }
+                if (t == a) gd -= v;
+            }
+            if (!(flags & 2u)) {
+                if (t == a) ga += v;
+                if (t == h) gd -= v;
+            }
+        }
+        const double v = G_rho * (1.0 - q) * (-LB);
+        if (Lh >= La) {
+            const int h = pQ & 0xFFFFu, a = pQ >> 16;
+            if (!(flags & 4u)) {
+                if (t == h) { ga += v; gh += v; }
+                if (t == a) gd -= v;
+            }
+        } else {
+            const int h = pR & 0xFFFFu, a = pR >> 16;
+            if (!(flags & 8u)) {
+                if (t == a) ga += v;
+                if (t == h) gd -= v;
+            }
+        }
+    }
+    const double sum_gd = wave_sum_f64(gd), sum_gh = wave_sum_f64(gh);
+    corr = wave_sum_f64(corr);
+    const double Lz = zoL[ZO_LZ], drho = zoL[ZO_DRHO];
+    const double Ltot = Lz + corr + G_rho * drho - SLAM - A.lgsum + LN2 * SLOG - CLIPC;
+    if (L.model == MODEL_BASIC) {
+        const double ad = on ? zL[L.o_adec + t] : 0.0, dd = on ? zL[L.o_ddec + t] : 0.0;
+        if (on) {
+            grad[L.o_adec + t] = gz[L.o_adec + t] - s_a * ga;
+            grad[L.o_ddec + t] = gz[L.o_ddec + t] - s_d * gd;
+        }
+        const double dot_a = wave_sum_f64(ad * ga), dot_d = wave_sum_f64(dd * gd);
+        if (t == 0) {
+            grad[L.o_ha] = gz[L.o_ha] - sum_gh;
+            grad[L.o_md] = gz[L.o_md] - sum_gd;
+            grad[L.o_sa] = gz[L.o_sa] - s_a * dot_a;
+            grad[L.o_sd] = gz[L.o_sd] - s_d * dot_d;
+            grad[L.o_corr] = gz[L.o_corr] - G_rho * (UB - LB) * dq;
+            A.potential[chain] = -Ltot;
+        }
+    } else {
+        const double sa = on ? zL[L.o_sat + t] : 0.0, sd = on ? zL[L.o_sdt + t] : 0.0,
+                     hd = on ? zL[L.o_hadec + t] : 0.0;
+        if (on) {
+            grad[L.o_sat + t] = gz[L.o_sat + t] - s_a * ga;
+            grad[L.o_sdt + t] = gz[L.o_sdt + t] - s_d * gd;
+            grad[L.o_hadec + t] = gz[L.o_hadec + t] - s_h * gh;
+        }
+        const double dot_a = wave_sum_f64(sa * ga), dot_d = wave_sum_f64(sd * gd),
+                     dot_h = wave_sum_f64(hd * gh);
+        for (int k = 0; k < K; ++k) {  // d/d beta_k: sum_t Xs[t,k] g_t
+            const double xv = on ? (xsL ? xsL[(size_t)t * K + k] : A.xs[(size_t)t * K + k]) : 0.0;
+            const double sA = wave_sum_f64(xv * ga), sD = wave_sum_f64(xv * gd);
+            if (t == 0) {
+                grad[L.o_bA + k] = gz[L.o_bA + k] - sA;
+                grad[L.o_bD + k] = gz[L.o_bD + k] - sD;
+            }
+        }
+        if (t == 0) {
+            grad[L.o_mha] = gz[L.o_mha] - sum_gh;
+            grad[L.o_sh] = gz[L.o_sh] - s_h * dot_h;
+            grad[L.o_md] = gz[L.o_md] - sum_gd;
+            grad[L.o_sa] = gz[L.o_sa] - s_a * dot_a;
+            grad[L.o_sd] = gz[L.o_sd] - s_d * dot_d;
+            grad[L.o_corr] = gz[L.o_corr] - G_rho * (UB - LB) * dq;
+            grad[L.o_u] = gz[L.o_u];
+            A.potential[chain] = -Ltot;
+        }
+    }
+    if (t == 0 && A.aux != nullptr) {
+        double* aux = A.aux + (size_t)chain * 4;
+        aux[0] = zoL[ZO_RHO];
+        aux[1] = LB;
+        aux[2] = UB;
+        aux[3] = q;
+    }
+}
+
 template <bool STAGED>
 __device__ void tail_body(const EvalArgs& A, int chain, char* smem) {
     const Layout& L = A.L;
@@ -650,50 +778,69 @@ __device__ void tail_body(const EvalArgs& A, int chain, char* smem) {
     const int ncol = 3 * T;
     const int nsc = A.n_wg * N_SCAL;
 
-    // LDS carve
-    double* zoL = reinterpret_cast<double*>(smem);   // [zo_stride]  prior workgroup record
-    double* cL = zoL + A.zo_stride;                  // [3T] cA | cD | cH
+    // LDS carve: the hand-off record keeps its global order [zo | scal | compact]
+    double* hL = reinterpret_cast<double*>(smem);
+    double* zoL = hL;                                // [zo_stride]  prior workgroup record
+    double* scl = zoL + A.zo_stride;                 // [n_wg*N_SCAL]
+    double* cmp = scl + nsc;                         // [total_c] (STAGED)
+    double* cL = cmp + (STAGED ? A.total_c : 0);     // [3T] cA | cD | cH
     double* zL = cL + 3 * T;                         // [D]
     double* col = zL + D;                            // [3T + N_SCAL + 4] reduced sums
     double* scratch = col + ncol + N_SCAL + 4;       // [WAVES*8]
-    double* scl = scratch + WAVES * 8;               // [n_wg*N_SCAL]
-    double* cmp = scl + nsc;                         // [total_c] (STAGED)
-    int* coff = reinterpret_cast<int*>(cmp + (STAGED ? A.total_c : 0));  // [3T+1]
+    double* xsL = scratch + WAVES * 8;               // [T*K] when K <= 16
+    int* coff = reinterpret_cast<int*>(xsL + (size_t)T * 16);  // [3T+1]
     DC_STAMP(7);
 
-    // ---- 1. ONE round of loads: every global value the tail needs goes to LDS now
-    const double* compact = A.compact + (size_t)chain * A.total_c;
-    const double* scal = A.scal + (size_t)chain * nsc;
-    const double* zo = A.zo + (size_t)chain * A.zo_stride;
+    // ---- 1. ONE round of loads: every global value the tail needs is requested before
+    // the first one is used (a rolled load -> LDS-store loop would serialise them)
+    const double* hb = A.hbuf + (size_t)chain * A.hb_stride;
+    const double* compact = hb + A.zo_stride + nsc;
     const double* z = A.z + (size_t)chain * D;
-    // (loads are issued in explicit batches: a rolled load->LDS-store loop would wait
-    // for every load before issuing the next one)
+    const int nstage = A.zo_stride + nsc + (STAGED ? A.total_c : 0);
+    const bool xs_staged = K > 0 && K <= 16;
     {
-        double* dst[3] = {cmp, scl, zoL};
-        const double* src[3] = {compact, scal, zo};
-        const int cnt[3] = {STAGED ? A.total_c : 0, nsc, A.zo_stride};
+        // static / caller data first (plain loads), one element per thread per pass
+        const int i = tid;
+        const double c0 = i < ncol ? (i < T ? A.cA[i] : (i < 2 * T ? A.cD[i - T] : A.cH[i - 2 * T])) : 0.0;
+        const double z0 = i < D ? z[i] : 0.0;
+        const int o0 = i <= ncol ? A.col_off[i] : 0;
+        const double x0 = (xs_staged && i < T * K) ? A.xs[i] : 0.0;
+        double v[8];
 #pragma unroll
-        for (int a = 0; a < 3; ++a) {
+        for (int u = 0; u < 8; ++u) {
+            const int j = u * BLOCK + tid;
+            v[u] = ld_sc1(&hb[j < nstage ? j : nstage - 1]);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int j = u * BLOCK + tid;
+            if (j < nstage) hL[j] = v[u];
+        }
+        if (i < ncol) cL[i] = c0;
+        if (i < D) zL[i] = z0;
+        if (i <= ncol) coff[i] = o0;
+        if (xs_staged && i < T * K) xsL[i] = x0;
+    }
 #pragma unroll 1
-            for (int i0 = 0; i0 < cnt[a]; i0 += 8 * BLOCK) {
-                double v[8];
+    for (int i0 = 8 * BLOCK; i0 < nstage; i0 += 8 * BLOCK) {  // larger records: more batches
+        double v[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int i = i0 + u * BLOCK + tid;
-                    v[u] = ld_sc1(&src[a][i < cnt[a] ? i : cnt[a] - 1]);
-                }
+        for (int u = 0; u < 8; ++u) {
+            const int j = i0 + u * BLOCK + tid;
+            v[u] = ld_sc1(&hb[j < nstage ? j : nstage - 1]);
+        }
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int i = i0 + u * BLOCK + tid;
-                    if (i < cnt[a]) dst[a][i] = v[u];
-                }
-            }
+        for (int u = 0; u < 8; ++u) {
+            const int j = i0 + u * BLOCK + tid;
+            if (j < nstage) hL[j] = v[u];
         }
     }
-    for (int i = tid; i < ncol; i += BLOCK)
+    for (int i = tid + BLOCK; i < ncol; i += BLOCK)
         cL[i] = i < T ? A.cA[i] : (i < 2 * T ? A.cD[i - T] : A.cH[i - 2 * T]);
-    for (int i = tid; i < D; i += BLOCK) zL[i] = z[i];
-    for (int i = tid; i <= ncol; i += BLOCK) coff[i] = A.col_off[i];
+    for (int i = tid + BLOCK; i < D; i += BLOCK) zL[i] = z[i];
+    for (int i = tid + BLOCK; i <= ncol; i += BLOCK) coff[i] = A.col_off[i];
+    if (xs_staged)
+        for (int i = tid + BLOCK; i < T * K; i += BLOCK) xsL[i] = A.xs[i];
     __syncthreads();
     DC_STAMP(8);
 
@@ -722,6 +869,11 @@ __device__ void tail_body(const EvalArgs& A, int chain, char* smem) {
         if (lane == 0) col[ncol + wave] = s;
     }
     __syncthreads();
+    if (T <= 64) {  // the whole per-team epilogue fits one wave: no LDS traffic, no barriers
+        if (wave == 0) tail_one_wave(A, chain, zoL, cL, zL, col, xs_staged ? xsL : nullptr);
+        DC_STAMP(10);
+        return;
+    }
     const double* gz = zoL + ZO_HDR;
     const double* eps = gz + D;
     const double s_a = zoL[ZO_SA], s_d = zoL[ZO_SD], s_h = zoL[ZO_SH];
@@ -859,6 +1011,185 @@ __device__ void tail_body(const EvalArgs& A, int chain, char* smem) {
     }
 }
 
+// ------------------------------------------------------------ per-lane fixture math
+
+struct LaneOut {
+    uint32_t key;           // (home | away<<16) the lane's pending run sums belong to
+    float rsh, rsa;         // pending run sums: -(dL/d eta_h), -(dL/d eta_a) w/o goal counts
+    float slam, slog, su, sclip;
+};
+
+__device__ __forceinline__ float clamp0(float t) {  // max(t, 0) in one instruction
+    return __builtin_amdgcn_fmed3f(t, 0.0f, __builtin_inff());
+}
+// 0x80 in every byte of v that is zero (exact, no cross-byte carries)
+__device__ __forceinline__ uint32_t zero_bytes(uint32_t v) {
+    return ~(((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v | 0x7F7F7F7Fu);
+}
+// tau argument 1 + rho*c of one score class: log2 of its clip at 0, and dlogtau/drho
+__device__ __forceinline__ void class_terms(float rho, float c, float* l2, float* u) {
+    const float t = fmaf(rho, c, 1.0f);
+    *l2 = __log2f(clamp0(t));  // log(clip(., 0)): -inf at 0 (tol = 0, bpl/_util.py:42)
+    *u = t > 0.0f ? c * __builtin_amdgcn_rcpf(t) : 0.0f;
+}
+
+// All 8 fixtures of the lane are the pair (h, a).
+template <bool WEIGHTED, bool CLIP>
+__device__ __forceinline__ LaneOut lane_uniform(uint32_t h, uint32_t a, uint2 xv, uint2 yv,
+                                                float4 w0, float4 w1, float rho,
+                                                const float2* tabH, const float2* tabA) {
+    const float2 th = tabH[h], ta = tabA[a];
+    float lh = th.x * ta.y;  // exp(att[h] + ha[h]) * exp(-def[a])
+    float la = ta.x * th.y;  // exp(att[a]) * exp(-def[h])
+    const float lh_raw = lh, la_raw = la;
+    bool ch = false, ca = false;
+    if (CLIP) {
+        ch = lh > (float)RATE_CLIP;
+        ca = la > (float)RATE_CLIP;
+        lh = ch ? (float)RATE_CLIP : lh;
+        la = ca ? (float)RATE_CLIP : la;
+    }
+    // tau (bpl/_util.py:58-91): c = -lh*la (0,0) | +la (1,0) | +lh (0,1) | -1 (1,1)
+    float l00, u00, l10, u10, l01, u01, l11, u11;
+    class_terms(rho, -lh * la, &l00, &u00);
+    class_terms(rho, la, &l10, &u10);
+    class_terms(rho, lh, &l01, &u01);
+    class_terms(rho, -1.0f, &l11, &u11);
+    float n00, n10, n01, n11, nall, sx, sy;  // (weighted) class counts, total, goal sums
+    if (!WEIGHTED) {
+        const uint32_t one = 0x01010101u;
+        const uint32_t x0 = xv.x, x1 = xv.y, y0 = yv.x, y1 = yv.y;
+        n00 = (float)(__popc(zero_bytes(x0 | y0)) + __popc(zero_bytes(x1 | y1)));
+        n10 = (float)(__popc(zero_bytes((x0 ^ one) | y0)) + __popc(zero_bytes((x1 ^ one) | y1)));
+        n01 = (float)(__popc(zero_bytes(x0 | (y0 ^ one))) + __popc(zero_bytes(x1 | (y1 ^ one))));
+        n11 = (float)(__popc(zero_bytes((x0 ^ one) | (y0 ^ one))) +
+                      __popc(zero_bytes((x1 ^ one) | (y1 ^ one))));
+        nall = (float)LANE_FIX;
+        sx = (float)__builtin_amdgcn_sad_u8(x1, 0u, __builtin_amdgcn_sad_u8(x0, 0u, 0u));
+        sy = (float)__builtin_amdgcn_sad_u8(y1, 0u, __builtin_amdgcn_sad_u8(y0, 0u, 0u));
+    } else {
+        const uint32_t xw[2] = {xv.x, xv.y}, yw[2] = {yv.x, yv.y};
+        const float wj[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+        n00 = n10 = n01 = n11 = nall = sx = sy = 0.f;
+#pragma unroll
+        for (int j = 0; j < LANE_FIX; ++j) {
+            const uint32_t xj = (xw[j >> 2] >> (8 * (j & 3))) & 0xFFu;
+            const uint32_t yj = (yw[j >> 2] >> (8 * (j & 3))) & 0xFFu;
+            const float wv = wj[j];
+            n00 += (xj | yj) == 0 ? wv : 0.f;
+            n10 += (xj == 1 && yj == 0) ? wv : 0.f;
+            n01 += (xj == 0 && yj == 1) ? wv : 0.f;
+            n11 += (xj == 1 && yj == 1) ? wv : 0.f;
+            nall += wv;
+            if (CLIP) {
+                sx += wv * (float)xj;
+                sy += wv * (float)yj;
+            }
+        }
+    }
+    LaneOut o;
+    o.key = h | (a << 16);
+    o.slam = nall * (lh + la);
+    // a class with no fixture must not contribute (its log may be -inf): 0 * -inf = NaN
+    o.slog = (n00 != 0.f ? n00 * l00 : 0.f) + (n10 != 0.f ? n10 * l10 : 0.f) +
+             (n01 != 0.f ? n01 * l01 : 0.f) + (n11 != 0.f ? n11 * l11 : 0.f);
+    o.su = n00 * u00 + n10 * u10 + n01 * u01 + n11 * u11;
+    // -(dL/d eta) without the data-only goal counts (added in the tail):
+    //   eta_h: lh - rho*u*[x==0]   (lh * dlogtau/dlh = rho*u for (0,0),(0,1))
+    o.rsh = nall * lh - rho * (n00 * u00 + n01 * u01);
+    o.rsa = nall * la - rho * (n00 * u00 + n10 * u10);
+    o.sclip = 0.f;
+    if (CLIP) {
+        // clipped rate: d/d eta = 0 -> cancel the goal count added later, and correct
+        // k*eta -> k*log(15) in the value
+        if (ch) {
+            o.rsh = sx;
+            o.sclip += sx * (__logf(lh_raw) - (float)LOG_RATE_CLIP);
+        }
+        if (ca) {
+            o.rsa = sy;
+            o.sclip += sy * (__logf(la_raw) - (float)LOG_RATE_CLIP);
+        }
+    }
+    return o;
+}
+
+// The lane's 8 fixtures span more than one pair: per-fixture arithmetic; finished runs go
+// to the LDS accumulators, the last one stays pending like a uniform lane's.
+template <bool WEIGHTED, bool CLIP>
+__device__ __forceinline__ LaneOut lane_mixed(uint4 hv, uint4 av, uint2 xv, uint2 yv, float4 w0,
+                                              float4 w1, float rho, const float2* tabH,
+                                              const float2* tabA, double* acc, int T1) {
+    const uint32_t hw[4] = {hv.x, hv.y, hv.z, hv.w};
+    const uint32_t aw[4] = {av.x, av.y, av.z, av.w};
+    const uint32_t xw[2] = {xv.x, xv.y};
+    const uint32_t yw[2] = {yv.x, yv.y};
+    const float wj[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+    LaneOut o;
+    o.slam = o.slog = o.su = o.sclip = 0.f;
+    o.rsh = o.rsa = 0.f;
+    uint32_t kj = 0, cur = (hw[0] & 0xFFFFu) | ((aw[0] & 0xFFFFu) << 16);
+#pragma unroll
+    for (int j = 0; j < LANE_FIX; ++j) {
+        const uint32_t hj = (hw[j >> 1] >> (16 * (j & 1))) & 0xFFFFu;
+        const uint32_t aj = (aw[j >> 1] >> (16 * (j & 1))) & 0xFFFFu;
+        const uint32_t xj = (xw[j >> 2] >> (8 * (j & 3))) & 0xFFu;
+        const uint32_t yj = (yw[j >> 2] >> (8 * (j & 3))) & 0xFFu;
+        kj = hj | (aj << 16);
+        const float2 th = tabH[hj], ta = tabA[aj];
+        float lh = th.x * ta.y, la = ta.x * th.y;
+        bool ch = false, ca = false;
+        const float lh_raw = lh, la_raw = la;
+        if (CLIP) {
+            ch = lh > (float)RATE_CLIP;
+            ca = la > (float)RATE_CLIP;
+            lh = ch ? (float)RATE_CLIP : lh;
+            la = ca ? (float)RATE_CLIP : la;
+        }
+        const bool x0 = xj == 0, y0 = yj == 0;
+        const bool low = (xj <= 1) & (yj <= 1);
+        float c = x0 ? (y0 ? -lh * la : lh) : (y0 ? la : -1.0f);
+        c = low ? c : 0.0f;
+        float l2, u;
+        class_terms(rho, c, &l2, &u);
+        const float ru = rho * u;
+        float sh = lh - (x0 ? ru : 0.0f);
+        float sa = la - (y0 ? ru : 0.0f);
+        float wv = 1.0f;
+        if (WEIGHTED) wv = wj[j];
+        if (CLIP) {
+            if (ch) {
+                sh = (float)xj;
+                o.sclip += wv * (float)xj * (__logf(lh_raw) - (float)LOG_RATE_CLIP);
+            }
+            if (ca) {
+                sa = (float)yj;
+                o.sclip += wv * (float)yj * (__logf(la_raw) - (float)LOG_RATE_CLIP);
+            }
+        }
+        if (WEIGHTED) {
+            sh *= wv;
+            sa *= wv;
+            o.slam += wv * (lh + la);
+            o.slog += wv * l2;
+            o.su += wv * u;
+        } else {
+            o.slam += lh + la;
+            o.slog += l2;
+            o.su += u;
+        }
+        if (kj != cur) {  // pair boundary inside the lane: flush the finished run
+            flush_run(acc, T1, cur, o.rsh, o.rsa);
+            o.rsh = o.rsa = 0.f;
+            cur = kj;
+        }
+        o.rsh += sh;
+        o.rsa += sa;
+    }
+    o.key = cur;  // the lane's last run stays pending and merges with its neighbours
+    return o;
+}
+
 // ------------------------------------------------------------------------- dc_eval
 
 template <bool WEIGHTED, bool CLIP, bool STAGED>
@@ -924,6 +1255,9 @@ __global__ __launch_bounds__(BLOCK) void dc_eval(EvalArgs A) {
         const float rho = rho_f32(mP, mQ, mR, fs.q);
         DC_STAMP(2);
 
+#ifdef DC_STAMPS
+        float rho_dbg = 0.f;
+#endif
         // ---- 3. stream the fixtures
         double dSLAM = 0.0, dSLOG = 0.0, dSU = 0.0, dCLIP = 0.0;  // per lane
         while (tile < tile_end) {
@@ -941,106 +1275,47 @@ __global__ __launch_bounds__(BLOCK) void dc_eval(EvalArgs A) {
                     w1n = A.w[2 * o + 1];
                 }
             }
-            const uint32_t hw[4] = {hv.x, hv.y, hv.z, hv.w};
-            const uint32_t aw[4] = {av.x, av.y, av.z, av.w};
-            const uint32_t xw[2] = {xv.x, xv.y};
-            const uint32_t yw[2] = {yv.x, yv.y};
-            const float wj[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
-
-            float shj[LANE_FIX], saj[LANE_FIX];
-            uint32_t keyj[LANE_FIX];
-            float slam = 0.f, slog = 0.f, su = 0.f, sclip = 0.f;
-#pragma unroll
-            for (int j = 0; j < LANE_FIX; ++j) {
-                const uint32_t hj = (hw[j >> 1] >> (16 * (j & 1))) & 0xFFFFu;
-                const uint32_t aj = (aw[j >> 1] >> (16 * (j & 1))) & 0xFFFFu;
-                const uint32_t xj = (xw[j >> 2] >> (8 * (j & 3))) & 0xFFu;
-                const uint32_t yj = (yw[j >> 2] >> (8 * (j & 3))) & 0xFFu;
-                keyj[j] = hj | (aj << 16);
-                const float2 th = tabH[hj], ta = tabA[aj];
-                float lh = th.x * ta.y;  // exp(att[h] + ha[h]) * exp(-def[a])
-                float la = ta.x * th.y;  // exp(att[a]) * exp(-def[h])
-                bool ch = false, ca = false;
-                const float lh_raw = lh, la_raw = la;
-                if (CLIP) {
-                    ch = lh > (float)RATE_CLIP;
-                    ca = la > (float)RATE_CLIP;
-                    lh = ch ? (float)RATE_CLIP : lh;
-                    la = ca ? (float)RATE_CLIP : la;
-                }
-                // tau (bpl/_util.py:58-91): arg = 1 + rho*c,
-                //   c = -lh*la (0,0) | +la (1,0) | +lh (0,1) | -1 (1,1) | 0 otherwise
-                const bool x0 = xj == 0, y0 = yj == 0;
-                const bool low = (xj <= 1) & (yj <= 1);
-                float c = x0 ? (y0 ? -lh * la : lh) : (y0 ? la : -1.0f);
-                c = low ? c : 0.0f;
-                const float t = fmaf(rho, c, 1.0f);
-                const float l2 = __log2f(fmaxf(t, 0.0f));  // log(clip(., 0)): -inf at 0
-                const float u = t > 0.0f ? c * __builtin_amdgcn_rcpf(t) : 0.0f;  // dlogtau/drho
-                const float ru = rho * u;
-                // -(dL/d eta) without the data-only goal counts (added in the tail):
-                //   eta_h: lh - rho*u*[x==0]   (lh * dlogtau/dlh = rho*u for (0,0),(0,1))
-                float sh = lh - (x0 ? ru : 0.0f);
-                float sa = la - (y0 ? ru : 0.0f);
-                float wv = 1.0f;
-                if (WEIGHTED) wv = wj[j];
-                if (CLIP) {
-                    // clipped rate: d/d eta = 0 -> cancel the goal count added later, and
-                    // correct k*eta -> k*log(15) in the value
-                    if (ch) {
-                        sh = (float)xj;
-                        sclip += wv * (float)xj * (__logf(lh_raw) - (float)LOG_RATE_CLIP);
-                    }
-                    if (ca) {
-                        sa = (float)yj;
-                        sclip += wv * (float)yj * (__logf(la_raw) - (float)LOG_RATE_CLIP);
-                    }
-                }
-                if (WEIGHTED) {
-                    sh *= wv;
-                    sa *= wv;
-                    slam += wv * (lh + la);
-                    slog += wv * l2;
-                    su += wv * u;
-                } else {
-                    slam += lh + la;
-                    slog += l2;
-                    su += u;
-                }
-                shj[j] = sh;
-                saj[j] = sa;
+            // One lane = 8 consecutive fixtures.  Sorted by pair, they almost always share
+            // ONE (home, away): then the two rates and the four score-class tau terms are
+            // computed once for the lane and each fixture is only classified; a lane that
+            // straddles a pair boundary takes the per-fixture path.
+            LaneOut lo;
+            {
+                const uint32_t hrep = (hv.x & 0xFFFFu) * 0x00010001u;
+                const uint32_t arep = (av.x & 0xFFFFu) * 0x00010001u;
+                const uint32_t mixed = (hv.x ^ hrep) | (hv.y ^ hrep) | (hv.z ^ hrep) |
+                                       (hv.w ^ hrep) | (av.x ^ arep) | (av.y ^ arep) |
+                                       (av.z ^ arep) | (av.w ^ arep);
+#ifdef DC_STAMPS
+                if (mixed == 0xFFFFFFFFu) rho_dbg += 1.0f;  // forces the loads to have landed
+                DC_STAMP(12);
+#endif
+                if (mixed == 0)
+                    lo = lane_uniform<WEIGHTED, CLIP>(hv.x & 0xFFFFu, av.x & 0xFFFFu, xv, yv, w0,
+                                                      w1, rho, tabH, tabA);
+                else
+                    lo = lane_mixed<WEIGHTED, CLIP>(hv, av, xv, yv, w0, w1, rho, tabH, tabA, acc,
+                                                    T1);
             }
             // scalars: float32 over the lane's 8 fixtures only, float64 from there on
             // (a float32 sum over the whole wave-tile would cost ~1e-4 absolute in U)
-            dSLAM += (double)slam;
-            dSLOG += (double)slog;
-            dSU += (double)su;
-            if (CLIP) dCLIP += (double)sclip;
+            dSLAM += (double)lo.slam;
+            dSLOG += (double)lo.slog;
+            dSU += (double)lo.su;
+            if (CLIP) dCLIP += (double)lo.sclip;
+            float rsh = lo.rsh, rsa = lo.rsa;
+            const uint32_t key = lo.key;
+#ifdef DC_STAMPS
+            if (rsh == 12345.678f) rho_dbg += 1.0f;
+            DC_STAMP(13);
+#endif
 
             // ---- per-(home,away) run sums: lane -> wave -> LDS per-team accumulators
-            uint32_t diff = 0;
-            float rsh = 0.f, rsa = 0.f;
-#pragma unroll
-            for (int j = 0; j < LANE_FIX; ++j) {
-                diff |= keyj[j] ^ keyj[0];
-                rsh += shj[j];
-                rsa += saj[j];
-            }
-            uint32_t key = keyj[0];
-            if (diff != 0) {  // a pair boundary inside this lane's 8 fixtures
-#pragma unroll
-                for (int j = 0; j < LANE_FIX; ++j)
-                    flush_run(acc, T1, keyj[j], shj[j], saj[j]);
-                rsh = 0.f;
-                rsa = 0.f;
-                key = keyj[LANE_FIX - 1];
-            }
-            const uint32_t kprev = __shfl_up(key, 1, 64);
-            const unsigned long long heads = __ballot(lane == 0 || kprev != key);
+            const uint32_t kprev = prev_lane_u32(key, ~key);
+            const unsigned long long heads = __ballot(kprev != key);  // lane 0 always a head
             const int nruns = __popcll(heads);
             if (nruns == 1) {  // whole wave-tile on one pair (the common case: sorted)
-                rsh = wave_sum_f32(rsh);
-                rsa = wave_sum_f32(rsa);
+                wave_sum2_f32(rsh, rsa);
                 if (lane == 0) flush_run(acc, T1, key, rsh, rsa);
             } else if (nruns <= RUN_LOOP_MAX) {  // a few runs: one masked DPP sum per run
                 unsigned long long hd = heads;
@@ -1050,8 +1325,8 @@ __global__ __launch_bounds__(BLOCK) void dc_eval(EvalArgs A) {
                     const int stop = hd ? __ffsll((long long)hd) - 1 : 64;
                     const bool in = lane >= first && lane < stop;
                     const uint32_t kk = (uint32_t)__builtin_amdgcn_readlane((int)key, first);
-                    const float s0 = wave_sum_f32(in ? rsh : 0.f);
-                    const float s1 = wave_sum_f32(in ? rsa : 0.f);
+                    float s0 = in ? rsh : 0.f, s1 = in ? rsa : 0.f;
+                    wave_sum2_f32(s0, s1);
                     if (lane == 0) flush_run(acc, T1, kk, s0, s1);
                 }
             } else {  // many short runs: every lane adds its own sums (LDS atomics)
@@ -1067,6 +1342,9 @@ __global__ __launch_bounds__(BLOCK) void dc_eval(EvalArgs A) {
             ++tile;
         }
         DC_STAMP(3);
+#ifdef DC_STAMPS
+        if (rho_dbg == 77.f) dSLAM += 1.0;
+#endif
 
         // ---- 4. workgroup reduction of the scalars, then the slab (write-through)
         dSLAM = wave_sum_f64(dSLAM);
@@ -1081,7 +1359,7 @@ __global__ __launch_bounds__(BLOCK) void dc_eval(EvalArgs A) {
         }
         __syncthreads();
         {   // publish only the slots this workgroup's fixtures touch (static list)
-            double* cmpw = A.compact + (size_t)chain * A.total_c;
+            double* cmpw = A.hbuf + (size_t)chain * A.hb_stride + A.zo_stride + A.n_wg * N_SCAL;
             for (int k = o0 + tid; k < o1; k += BLOCK) {
                 const int slot = k == o0 + tid ? slot0 : A.wg_slots[k];
                 const int which = slot / T, t = slot - which * T;
@@ -1092,7 +1370,7 @@ __global__ __launch_bounds__(BLOCK) void dc_eval(EvalArgs A) {
             double s = 0.0;
 #pragma unroll
             for (int wv = 0; wv < WAVES; ++wv) s += red[wv * N_SCAL + tid];
-            st_sc1(&A.scal[((size_t)chain * A.n_wg + wgi) * N_SCAL + tid], s);
+            st_sc1(&A.hbuf[(size_t)chain * A.hb_stride + A.zo_stride + wgi * N_SCAL + tid], s);
         }
         DC_STAMP(4);
     }

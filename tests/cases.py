@@ -33,6 +33,12 @@ def fixtures(name):
         fx = fixtures("timed")
         fx.weights = float32_weights(O.timed_dummy_data_recipe()["time_diff"], 1.0, True)
         return fx
+    if name.startswith("leaguew"):  # long runs per pair AND time weights (uniform-lane path)
+        n = int(float(name.split("_")[1]))
+        h, a, x, y = O.synthetic_league(n)
+        fx = O.Fixtures(h, a, x, y, 20)
+        fx.weights = float32_weights(np.linspace(5, 0, n), 1.0)
+        return fx
     if name.startswith("league"):
         n = int(float(name.split("_")[1]))
         h, a, x, y = O.synthetic_league(n)

@@ -70,6 +70,7 @@ CASES = [
     (O.MODEL_EXTENDED, "timed_w"),
     (O.MODEL_EXTENDED, "ragged_5000"),
     (O.MODEL_EXTENDED, "league_1e5"),
+    (O.MODEL_EXTENDED, "leaguew_3e4"),
 ]
 
 

@@ -23,17 +23,15 @@ def run(n, model=MODEL_BASIC, max_wg=255):
     st = buf[: nwg * 16].reshape(nwg, 16).astype(np.int64)
     t0 = st[:, 0].min()
     rel = (st - t0) * 0.01  # us (100 MHz)
-    names = ["entry", "tables", "bounds", "stream", "slab", "drain", "ticket", "tail:start", "tail:loads", "tail:adj", "tail:end"]
+    names = ["entry", "tables", "bounds", "stream", "slab", "drain", "ticket", "tail:start", "tail:loads", "tail:adj", "tail:end", "-", "loads-landed", "lane-math"]
     print(f"--- N={n} model={model} blocks={nwg} (block 0 = prior workgroup)")
     print("  prior WG: entry=%.2f done=%.2f drain=%.2f ticket=%.2f" % (rel[0, 0], rel[0, 4], rel[0, 5], rel[0, 6]))
-    for k in range(7):
+    for k in list(range(7)) + [12, 13]:
         col = rel[1:, k][st[1:, k] > 0]
         if col.size: print(f"  {names[k]:10s} median {np.median(col):7.2f} us  min {col.min():7.2f}  max {col.max():7.2f}")
     last = int(np.argmax(st[:, 10]))
     print("  tail WG", last, " ".join(f"{names[k]}={rel[last, k]:.2f}" for k in range(11)))
     c.close()
 
-for n in (1_000_000, 100_000, 380):
+for n in (1_000_000, 250_000, 100_000, 20_000):
     run(n)
-run(1_000_000, MODEL_EXTENDED)
-run(1_000_000, MODEL_BASIC, 127)
