@@ -74,10 +74,11 @@ struct bplhip_ctx {
     int total_c = 0;      // entries of the sparse (compact) slab array
     bool staged = true;   // the tail stages the compact array in LDS
     // tuning options (bplhip_set_option)
+    int opt_device_nuts = 1;  // 1: tree builder on the device (nuts_dev.hip.h) when supported
     int opt_max_wg = 255;  // streaming workgroups (+1 prior workgroup = one per CU)
     bool lds_attr_set = false;
     // NUTS scratch (device): z, potential, grad, aux + pinned host mirror
-    DevBuf d_nuts;
+    DevBuf d_nuts, d_ns;
     double* h_pinned = nullptr;
     size_t h_pinned_bytes = 0;
     // host copies needed by bplhip_constrain (rho bounds over the unique pairs)
@@ -199,14 +200,14 @@ int launch_eval_dynamic(bplhip_ctx* c, int chains, const double* z, double* pot,
 }
 
 int launch_eval(bplhip_ctx* c, int chains, const double* z, double* pot, double* grad,
-                double* aux, hipStream_t s) {
+                double* aux, hipStream_t s, double* nuts_state = nullptr, int nuts_depth = 0) {
     if (c->dynamic) return launch_eval_dynamic(c, chains, z, pot, grad, aux, s);
     dc::EvalArgs A{};
-    A.h = c->d_h.as<const uint4>();
-    A.a = c->d_a.as<const uint4>();
-    A.x = c->d_x.as<const uint2>();
-    A.y = c->d_y.as<const uint2>();
-    A.w = c->weighted ? c->d_w.as<const float4>() : nullptr;
+    A.h = c->d_h.as<const uint32_t>();
+    A.a = c->d_a.as<const uint32_t>();
+    A.x = c->d_x.as<const uint32_t>();
+    A.y = c->d_y.as<const uint32_t>();
+    A.w = c->weighted ? c->d_w.as<const float>() : nullptr;
     A.n_tiles = c->n_tiles;
     A.tiles_per_wave = c->tiles_per_wave;
     A.pairs = c->d_pairs.as<const uint32_t>();
@@ -232,6 +233,8 @@ int launch_eval(bplhip_ctx* c, int chains, const double* z, double* pot, double*
     A.grad = grad;
     A.aux = aux;
     A.debug = c->d_debug.as<unsigned long long>();
+    A.nuts = nuts_state;
+    A.nuts_max_depth = nuts_depth;
     A.L = c->L;
     const bool clip = c->L.model == dc::MODEL_EXTENDED;
     if (c->weighted) return clip ? launch_eval_t<true, true>(c, A, chains, s)
@@ -466,6 +469,10 @@ int bplhip_set_fixtures(bplhip_ctx* c, int model_kind, int64_t n, int32_t n_team
 int bplhip_set_option(bplhip_ctx* c, const char* name, int value) {
     if (!c || !name) return BPLHIP_EINVAL;
     const std::string n(name);
+    if (n == "device_nuts") {
+        c->opt_device_nuts = value != 0;
+        return BPLHIP_OK;
+    }
     if (n == "max_wg") {  // takes effect at the next bplhip_set_fixtures
         if (value < 1 || value > 1024) return fail(c, BPLHIP_EINVAL, "max_wg out of range [1,1024]");
         c->opt_max_wg = value;
@@ -696,6 +703,124 @@ struct HipPotential {
 
 }  // namespace
 
+namespace {
+
+// Tree builder on the device: per doubling the host enqueues k_begin, 2^j dc_eval launches
+// (leaf bookkeeping in their tails) and k_end, and synchronises once per batch of
+// doublings; the first batch of a transition speculates on the previous tree's depth.
+struct DeviceEngine {
+    bplhip_ctx* c;
+    hipStream_t s;
+    const nuts::Config& cfg;
+    int D, max_depth;
+    double* ns;        // device state (nuts_dev.hip.h)
+    double* hp;        // pinned: [r: D | hdr: H_N | z: D]
+    int64_t evals = 0;
+    int last_depth = 1;
+    int rc = BPLHIP_OK;
+    int dim() const { return D; }
+    int64_t leapfrogs() const { return evals; }
+    bool hip_ok(hipError_t e, const char* what) {
+        if (e == hipSuccess) return true;
+        rc = fail(c, BPLHIP_EHIP, "device nuts: %s: %s", what, hipGetErrorString(e));
+        return false;
+    }
+    bool set_state(const double* z, double* pe_out, bool* finite) {
+        std::memcpy(hp, z, (size_t)D * 8);
+        double* zn = nd::vec(ns, D, nd::V_ZN);
+        double* gr = nd::vec(ns, D, nd::V_GRAD);
+        if (!hip_ok(hipMemcpyAsync(zn, hp, (size_t)D * 8, hipMemcpyHostToDevice, s), "H2D z")) return false;
+        rc = launch_eval(c, 1, zn, ns + nd::H_LEAF_PE, gr, ns + nd::H_LEAF_AUX0, s);
+        if (rc != BPLHIP_OK) return false;
+        // adopt as the current state of the chain
+        (void)hipMemcpyAsync(nd::vec(ns, D, nd::V_Z), zn, (size_t)D * 8, hipMemcpyDeviceToDevice, s);
+        (void)hipMemcpyAsync(nd::vec(ns, D, nd::V_G), gr, (size_t)D * 8, hipMemcpyDeviceToDevice, s);
+        (void)hipMemcpyAsync(ns + nd::H_CUR_PE, ns + nd::H_LEAF_PE, 8, hipMemcpyDeviceToDevice, s);
+        (void)hipMemcpyAsync(ns + nd::H_T_AUX0, ns + nd::H_LEAF_AUX0, 32, hipMemcpyDeviceToDevice, s);
+        double* h_hdr = hp + D;
+        (void)hipMemcpyAsync(h_hdr, ns, (size_t)nd::H_N * 8, hipMemcpyDeviceToHost, s);
+        (void)hipMemcpyAsync(hp + D + nd::H_N, gr, (size_t)D * 8, hipMemcpyDeviceToHost, s);
+        if (!hip_ok(hipStreamSynchronize(s), "sync(set_state)")) return false;
+        const double pe = h_hdr[nd::H_LEAF_PE];
+        bool ok = std::isfinite(pe);
+        for (int i = 0; i < D && ok; ++i) ok = std::isfinite(hp[D + nd::H_N + i]);
+        *finite = ok;
+        *pe_out = pe;
+        evals += 1;
+        return true;
+    }
+    bool transition(const double* r, tf::Key key, double step_size, const nuts::vec& inv_mass,
+                    bool mass_changed, double* z_out, nuts::TransitionOut* out) {
+        double* h_hdr = hp + D;
+        if (mass_changed) {
+            // (pinned staging reused: the copy is ordered before the momentum copy)
+            std::memcpy(hp + D + nd::H_N, inv_mass.data(), (size_t)D * 8);
+            if (!hip_ok(hipMemcpyAsync(nd::vec(ns, D, nd::V_INVM), hp + D + nd::H_N, (size_t)D * 8,
+                                       hipMemcpyHostToDevice, s), "H2D inv_mass")) return false;
+        }
+        std::memcpy(hp, r, (size_t)D * 8);
+        if (!hip_ok(hipMemcpyAsync(nd::vec(ns, D, nd::V_TL_R), hp, (size_t)D * 8,
+                                   hipMemcpyHostToDevice, s), "H2D r")) return false;
+        hipLaunchKernelGGL(nd::k_init, dim3(1), dim3(64), 0, s, ns, D, step_size, cfg.max_delta_energy);
+        double* zn = nd::vec(ns, D, nd::V_ZN);
+        double* gr = nd::vec(ns, D, nd::V_GRAD);
+        int depth = 0;
+        bool stop = false;
+        double evals_before = 0.0;
+        bool first_batch = true;
+        while (!stop && depth < max_depth) {
+            int nb = first_batch ? std::max(1, std::min(last_depth, max_depth)) : 1;
+            nb = std::min(nb, max_depth - depth);
+            for (int j = depth; j < depth + nb; ++j) {
+                // numpyro build_tree: key, direction_key, doubling_key = split(key, 3);
+                // _double_tree: key, transition_key = split(doubling_key)
+                tf::Key k_next, k_dir, k_dbl, k_sub, k_tr;
+                tf::split3(key, &k_next, &k_dir, &k_dbl);
+                key = k_next;
+                const int going_right = tf::bernoulli(k_dir, 0.5) ? 1 : 0;
+                tf::split2(k_dbl, &k_sub, &k_tr);
+                hipLaunchKernelGGL(nd::k_begin, dim3(1), dim3(64), 0, s, ns, D, j, going_right,
+                                   k_sub.hi, k_sub.lo);
+                const int leaves = 1 << j;
+                for (int l = 0; l < leaves; ++l) {
+                    rc = launch_eval(c, 1, zn, ns + nd::H_LEAF_PE, gr, ns + nd::H_LEAF_AUX0, s, ns,
+                                     max_depth);
+                    if (rc != BPLHIP_OK) return false;
+                }
+                hipLaunchKernelGGL(nd::k_end, dim3(1), dim3(64), 0, s, ns, D, max_depth, k_tr.hi,
+                                   k_tr.lo);
+            }
+            (void)hipMemcpyAsync(h_hdr, ns, (size_t)nd::H_N * 8, hipMemcpyDeviceToHost, s);
+            if (!hip_ok(hipStreamSynchronize(s), "sync(doubling)")) return false;
+            if (first_batch) evals_before = 0.0;
+            first_batch = false;
+            depth = (int)h_hdr[nd::H_T_DEPTH];
+            stop = h_hdr[nd::H_STOP] != 0.0;
+        }
+        (void)evals_before;
+        hipLaunchKernelGGL(nd::k_finish, dim3(1), dim3(64), 0, s, ns, D);
+        (void)hipMemcpyAsync(hp + D + nd::H_N, nd::vec(ns, D, nd::V_TP_Z), (size_t)D * 8,
+                       hipMemcpyDeviceToHost, s);
+        if (!hip_ok(hipStreamSynchronize(s), "sync(finish)")) return false;
+        if (!hip_ok(hipGetLastError(), "launch")) return false;
+        const double num = h_hdr[nd::H_T_NUM];
+        out->accept_prob = num > 0 ? h_hdr[nd::H_T_SUMACC] / num : 0.0;
+        out->num_steps = (int)num;
+        out->diverging = h_hdr[nd::H_T_DIV] != 0.0;
+        out->pe = h_hdr[nd::H_T_PE];
+        out->aux[0] = h_hdr[nd::H_T_AUX0];
+        out->aux[1] = h_hdr[nd::H_T_AUX1];
+        out->aux[2] = h_hdr[nd::H_T_AUX2];
+        out->aux[3] = h_hdr[nd::H_T_AUX3];
+        std::memcpy(z_out, hp + D + nd::H_N, (size_t)D * 8);
+        evals += (int64_t)num;
+        last_depth = std::max(1, depth);
+        return true;
+    }
+};
+
+}  // namespace
+
 extern "C" int bplhip_nuts_run(bplhip_ctx* c, const bplhip_nuts_cfg* cfg, const double* z0,
                                uint32_t seed_hi, uint32_t seed_lo, double* draws_out,
                                bplhip_nuts_stats* stats, void* stream) {
@@ -771,10 +896,36 @@ extern "C" int bplhip_nuts_run(bplhip_ctx* c, const bplhip_nuts_cfg* cfg, const 
 
     nuts::Result res;
     const auto t0 = std::chrono::steady_clock::now();
-    const int st = nuts::run_chain(pot, nc, z0, tf::Key{seed_hi, seed_lo}, draws_out, &res);
+    int st;
+    int dev_rc = BPLHIP_OK;
+    const bool device_tree = c->opt_device_nuts && !c->dynamic && c->L.T <= 64 && c->staged;
+    if (device_tree) {
+        const size_t nsd = nd::ns_doubles(D, nc.max_tree_depth);
+        HIP_TRY(c, c->d_ns.ensure(nsd * 8));
+        HIP_TRY(c, hipMemsetAsync(c->d_ns.p, 0, nsd * 8, static_cast<hipStream_t>(stream)));
+        const size_t need = ((size_t)2 * D + nd::H_N) * 8;
+        if (c->h_pinned_bytes < need) {
+            if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+            c->h_pinned = nullptr;
+            HIP_TRY(c, hipHostMalloc((void**)&c->h_pinned, need, hipHostMallocDefault));
+            c->h_pinned_bytes = need;
+        }
+        int rc1 = ensure_slabs(c, 1);
+        if (rc1 != BPLHIP_OK) return rc1;
+        DeviceEngine E{c, static_cast<hipStream_t>(stream), nc, D, nc.max_tree_depth,
+                       c->d_ns.as<double>(), c->h_pinned};
+        // identity mass matrix until adapted
+        std::vector<double> ones(D, 1.0);
+        HIP_TRY(c, hipMemcpy(nd::vec(E.ns, D, nd::V_INVM), ones.data(), (size_t)D * 8, hipMemcpyHostToDevice));
+        st = nuts::run_chain_engine(E, nc, z0, tf::Key{seed_hi, seed_lo}, draws_out, &res);
+        dev_rc = E.rc;
+    } else {
+        st = nuts::run_chain(pot, nc, z0, tf::Key{seed_hi, seed_lo}, draws_out, &res);
+        dev_rc = pot.rc;
+    }
     const double wall =
         std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    if (st == nuts::ST_EVAL_FAILED) return pot.rc != BPLHIP_OK ? pot.rc : BPLHIP_EHIP;
+    if (st == nuts::ST_EVAL_FAILED) return dev_rc != BPLHIP_OK ? dev_rc : BPLHIP_EHIP;
     if (st == nuts::ST_NO_FINITE_INIT)
         return fail(c, BPLHIP_ENUMERIC, "nuts_run: no finite initial point after 100 tries");
     if (stats) {

@@ -30,10 +30,17 @@
 #include <stdint.h>
 
 #include "dc_layout.h"
+#include "nuts_dev.hip.h"
 
 namespace dc {
 
-constexpr int LANE_FIX = 8;              // fixtures per lane per tile
+#ifndef DC_LANE_FIX
+#define DC_LANE_FIX 8
+#endif
+constexpr int LANE_FIX = DC_LANE_FIX;    // fixtures per lane per tile (4 or 8)
+static_assert(LANE_FIX == 4 || LANE_FIX == 8, "LANE_FIX must be 4 or 8");
+constexpr int HWORDS = LANE_FIX / 2;     // packed u16 pairs per lane
+constexpr int XWORDS = LANE_FIX / 4;     // packed u8 quads per lane
 constexpr int TILE = 64 * LANE_FIX;      // fixtures per wave-tile
 constexpr int BLOCK = 512;               // 8 waves per workgroup
 constexpr int WAVES = BLOCK / 64;
@@ -60,11 +67,11 @@ enum {
 
 struct EvalArgs {
     // fixtures (library-owned, sorted by (home,away), padded to TILE with team T)
-    const uint4* h;    // [n_tiles*64]  8 x u16 home index per lane
-    const uint4* a;    // [n_tiles*64]  8 x u16 away index
-    const uint2* x;    // [n_tiles*64]  8 x u8 home goals
-    const uint2* y;    // [n_tiles*64]  8 x u8 away goals
-    const float4* w;   // [n_tiles*128] 8 x f32 weights, or nullptr
+    const uint32_t* h;  // [n_tiles*64*HWORDS]  LANE_FIX x u16 home index per lane
+    const uint32_t* a;  // [n_tiles*64*HWORDS]  LANE_FIX x u16 away index
+    const uint32_t* x;  // [n_tiles*64*XWORDS]  LANE_FIX x u8 home goals
+    const uint32_t* y;  // [n_tiles*64*XWORDS]  LANE_FIX x u8 away goals
+    const float* w;     // [n_tiles*64*LANE_FIX] f32 weights, or nullptr
     int n_tiles;
     int tiles_per_wave;
     const uint32_t* pairs;  // [P] unique (home | away<<16)
@@ -97,6 +104,11 @@ struct EvalArgs {
     double* grad;           // [chains][D]
     double* aux;            // [chains][4] or nullptr
     unsigned long long* debug;  // diagnostic build only (DC_STAMPS): [n_wg+1][16]
+    // device-resident NUTS (nuts_dev.hip.h): when set, z/potential/grad/aux point into this
+    // state buffer, a finished subtree makes the launch return at once, and the tail runs
+    // the leaf bookkeeping and writes the next leapfrog's position
+    double* nuts;
+    int nuts_max_depth;
     Layout L;
 };
 
@@ -256,7 +268,8 @@ __host__ __device__ inline size_t stream_lds_bytes(int T) {
 __host__ __device__ inline size_t tail_lds_bytes(int T, int D, int zo_stride, int n_wg,
                                                  int total_c, bool staged) {
     size_t d = (size_t)zo_stride + 3 * (size_t)T + D + (3 * (size_t)T + N_SCAL + 4) +
-               WAVES * 8 + (size_t)n_wg * N_SCAL + (size_t)T * 16 /* xs, K <= 16 staged */;
+               WAVES * 8 + (size_t)n_wg * N_SCAL + (size_t)T * 16 /* xs, K <= 16 staged */ +
+               (size_t)D + 8 /* hand-over to the NUTS leaf */;
     size_t i = 3 * (size_t)T + 2;
     if (staged) d += (size_t)total_c;
     return d * 8 + ((i * 4 + 15) & ~(size_t)15) + 16;
@@ -464,6 +477,7 @@ __device__ void prior_body(const EvalArgs& A, int chain, char* smem) {
         sc[14] = s.sig;
     }
     __syncthreads();
+    DC_STAMP(1);
     const double s_a = sc[0], s_d = sc[1], s_h = sc[2];
     const double q = sc[3], dq = sc[4];
     const double m = z[L.o_md];
@@ -503,6 +517,7 @@ __device__ void prior_body(const EvalArgs& A, int chain, char* smem) {
         }
     }
     __syncthreads();
+    DC_STAMP(2);
 
     // ---- bounds: float32 maxima (-> rho_f32 of the streaming workgroups) and the true
     // float64 maxima with their arg-pairs (ties -> smallest pair index)
@@ -544,6 +559,7 @@ __device__ void prior_body(const EvalArgs& A, int chain, char* smem) {
         }
     }
     __syncthreads();
+    DC_STAMP(3);
 
     // ---- team sums of the z-only part of L and of its gradient (gz = -dL_prior/dz)
     // v: 0 team part of L (priors + att cA - def cD + ha cH); extended: 1 dL/d rho_p
@@ -574,6 +590,7 @@ __device__ void prior_body(const EvalArgs& A, int chain, char* smem) {
         }
     }
     block_sum<2>(v, scratch, tid);
+    DC_STAMP(12);
 
     if (tid < 2 * K) {  // covariate coefficients ~ N(0,1)
         const int o = (tid >= K ? L.o_bD + tid - K : L.o_bA + tid);
@@ -660,12 +677,18 @@ __device__ void prior_body(const EvalArgs& A, int chain, char* smem) {
 // the bounds is a lane-local add, sums are DPP wave reductions.  Same arithmetic and the
 // same summation order on every run (deterministic).
 __device__ void tail_one_wave(const EvalArgs& A, int chain, const double* zoL, const double* cL,
-                              const double* zL, const double* col, const double* xsL) {
+                              const double* zL, const double* col, const double* xsL,
+                              double* gradL) {
     const Layout& L = A.L;
     const int T = L.T, K = L.K, D = L.D;
     const int t = threadIdx.x & 63;
     const bool on = t < T;
     double* grad = A.grad + (size_t)chain * D;
+    const bool nuts = A.nuts != nullptr;
+    auto put = [&](int o, double v) {
+        grad[o] = v;
+        if (nuts) gradL[o] = v;
+    };
     const double* gz = zoL + ZO_HDR;
     const double* eps = gz + D;
     const int ncol = 3 * T;
@@ -719,25 +742,25 @@ __device__ void tail_one_wave(const EvalArgs& A, int chain, const double* zoL, c
     if (L.model == MODEL_BASIC) {
         const double ad = on ? zL[L.o_adec + t] : 0.0, dd = on ? zL[L.o_ddec + t] : 0.0;
         if (on) {
-            grad[L.o_adec + t] = gz[L.o_adec + t] - s_a * ga;
-            grad[L.o_ddec + t] = gz[L.o_ddec + t] - s_d * gd;
+            put(L.o_adec + t, gz[L.o_adec + t] - s_a * ga);
+            put(L.o_ddec + t, gz[L.o_ddec + t] - s_d * gd);
         }
         const double dot_a = wave_sum_f64(ad * ga), dot_d = wave_sum_f64(dd * gd);
         if (t == 0) {
-            grad[L.o_ha] = gz[L.o_ha] - sum_gh;
-            grad[L.o_md] = gz[L.o_md] - sum_gd;
-            grad[L.o_sa] = gz[L.o_sa] - s_a * dot_a;
-            grad[L.o_sd] = gz[L.o_sd] - s_d * dot_d;
-            grad[L.o_corr] = gz[L.o_corr] - G_rho * (UB - LB) * dq;
+            put(L.o_ha, gz[L.o_ha] - sum_gh);
+            put(L.o_md, gz[L.o_md] - sum_gd);
+            put(L.o_sa, gz[L.o_sa] - s_a * dot_a);
+            put(L.o_sd, gz[L.o_sd] - s_d * dot_d);
+            put(L.o_corr, gz[L.o_corr] - G_rho * (UB - LB) * dq);
             A.potential[chain] = -Ltot;
         }
     } else {
         const double sa = on ? zL[L.o_sat + t] : 0.0, sd = on ? zL[L.o_sdt + t] : 0.0,
                      hd = on ? zL[L.o_hadec + t] : 0.0;
         if (on) {
-            grad[L.o_sat + t] = gz[L.o_sat + t] - s_a * ga;
-            grad[L.o_sdt + t] = gz[L.o_sdt + t] - s_d * gd;
-            grad[L.o_hadec + t] = gz[L.o_hadec + t] - s_h * gh;
+            put(L.o_sat + t, gz[L.o_sat + t] - s_a * ga);
+            put(L.o_sdt + t, gz[L.o_sdt + t] - s_d * gd);
+            put(L.o_hadec + t, gz[L.o_hadec + t] - s_h * gh);
         }
         const double dot_a = wave_sum_f64(sa * ga), dot_d = wave_sum_f64(sd * gd),
                      dot_h = wave_sum_f64(hd * gh);
@@ -745,18 +768,18 @@ __device__ void tail_one_wave(const EvalArgs& A, int chain, const double* zoL, c
             const double xv = on ? (xsL ? xsL[(size_t)t * K + k] : A.xs[(size_t)t * K + k]) : 0.0;
             const double sA = wave_sum_f64(xv * ga), sD = wave_sum_f64(xv * gd);
             if (t == 0) {
-                grad[L.o_bA + k] = gz[L.o_bA + k] - sA;
-                grad[L.o_bD + k] = gz[L.o_bD + k] - sD;
+                put(L.o_bA + k, gz[L.o_bA + k] - sA);
+                put(L.o_bD + k, gz[L.o_bD + k] - sD);
             }
         }
         if (t == 0) {
-            grad[L.o_mha] = gz[L.o_mha] - sum_gh;
-            grad[L.o_sh] = gz[L.o_sh] - s_h * dot_h;
-            grad[L.o_md] = gz[L.o_md] - sum_gd;
-            grad[L.o_sa] = gz[L.o_sa] - s_a * dot_a;
-            grad[L.o_sd] = gz[L.o_sd] - s_d * dot_d;
-            grad[L.o_corr] = gz[L.o_corr] - G_rho * (UB - LB) * dq;
-            grad[L.o_u] = gz[L.o_u];
+            put(L.o_mha, gz[L.o_mha] - sum_gh);
+            put(L.o_sh, gz[L.o_sh] - s_h * dot_h);
+            put(L.o_md, gz[L.o_md] - sum_gd);
+            put(L.o_sa, gz[L.o_sa] - s_a * dot_a);
+            put(L.o_sd, gz[L.o_sd] - s_d * dot_d);
+            put(L.o_corr, gz[L.o_corr] - G_rho * (UB - LB) * dq);
+            put(L.o_u, gz[L.o_u]);
             A.potential[chain] = -Ltot;
         }
     }
@@ -766,6 +789,19 @@ __device__ void tail_one_wave(const EvalArgs& A, int chain, const double* zoL, c
         aux[1] = LB;
         aux[2] = UB;
         aux[3] = q;
+    }
+    if (nuts) {  // device-resident NUTS: this wave finishes the leapfrog and books the leaf
+        if (t == 0) {
+            gradL[D] = -Ltot;
+            gradL[D + 1] = zoL[ZO_RHO];
+            gradL[D + 2] = LB;
+            gradL[D + 3] = UB;
+            gradL[D + 4] = q;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        nd::nuts_leaf(A.nuts, D, A.nuts_max_depth, t, gradL);
     }
 }
 
@@ -788,7 +824,8 @@ __device__ void tail_body(const EvalArgs& A, int chain, char* smem) {
     double* col = zL + D;                            // [3T + N_SCAL + 4] reduced sums
     double* scratch = col + ncol + N_SCAL + 4;       // [WAVES*8]
     double* xsL = scratch + WAVES * 8;               // [T*K] when K <= 16
-    int* coff = reinterpret_cast<int*>(xsL + (size_t)T * 16);  // [3T+1]
+    double* gradL = xsL + (size_t)T * 16;             // [D+8] grad | U | aux (NUTS hand-over)
+    int* coff = reinterpret_cast<int*>(gradL + D + 8);  // [3T+1]
     DC_STAMP(7);
 
     // ---- 1. ONE round of loads: every global value the tail needs is requested before
@@ -870,7 +907,7 @@ __device__ void tail_body(const EvalArgs& A, int chain, char* smem) {
     }
     __syncthreads();
     if (T <= 64) {  // the whole per-team epilogue fits one wave: no LDS traffic, no barriers
-        if (wave == 0) tail_one_wave(A, chain, zoL, cL, zL, col, xs_staged ? xsL : nullptr);
+        if (wave == 0) tail_one_wave(A, chain, zoL, cL, zL, col, xs_staged ? xsL : nullptr, gradL);
         DC_STAMP(10);
         return;
     }
@@ -1013,6 +1050,43 @@ __device__ void tail_body(const EvalArgs& A, int chain, char* smem) {
 
 // ------------------------------------------------------------ per-lane fixture math
 
+// the lane's LANE_FIX consecutive fixtures, still packed as loaded (16-B / 8-B / 4-B loads)
+struct LaneData {
+    uint32_t hw[HWORDS], aw[HWORDS], xw[XWORDS], yw[XWORDS];
+    float wj[LANE_FIX];
+};
+template <int NW>
+__device__ __forceinline__ void load_words(const uint32_t* p, uint32_t (&d)[NW]) {
+    if (NW == 4) {
+        const uint4 v = *reinterpret_cast<const uint4*>(p);
+        d[0] = v.x; d[1] = v.y; d[NW > 2 ? 2 : 0] = v.z; d[NW > 3 ? 3 : 0] = v.w;
+    } else if (NW == 2) {
+        const uint2 v = *reinterpret_cast<const uint2*>(p);
+        d[0] = v.x; d[1] = v.y;
+    } else {
+        d[0] = *p;
+    }
+}
+template <bool WEIGHTED>
+__device__ __forceinline__ LaneData load_lane(const EvalArgs& A, size_t o /* tile*64 + lane */) {
+    LaneData L;
+    load_words<HWORDS>(A.h + o * HWORDS, L.hw);
+    load_words<HWORDS>(A.a + o * HWORDS, L.aw);
+    load_words<XWORDS>(A.x + o * XWORDS, L.xw);
+    load_words<XWORDS>(A.y + o * XWORDS, L.yw);
+    if (WEIGHTED) {
+#pragma unroll
+        for (int q = 0; q < LANE_FIX / 4; ++q) {
+            const float4 v = *reinterpret_cast<const float4*>(A.w + o * LANE_FIX + 4 * q);
+            L.wj[4 * q] = v.x; L.wj[4 * q + 1] = v.y; L.wj[4 * q + 2] = v.z; L.wj[4 * q + 3] = v.w;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < LANE_FIX; ++j) L.wj[j] = 1.0f;
+    }
+    return L;
+}
+
 struct LaneOut {
     uint32_t key;           // (home | away<<16) the lane's pending run sums belong to
     float rsh, rsa;         // pending run sums: -(dL/d eta_h), -(dL/d eta_a) w/o goal counts
@@ -1035,9 +1109,9 @@ __device__ __forceinline__ void class_terms(float rho, float c, float* l2, float
 
 // All 8 fixtures of the lane are the pair (h, a).
 template <bool WEIGHTED, bool CLIP>
-__device__ __forceinline__ LaneOut lane_uniform(uint32_t h, uint32_t a, uint2 xv, uint2 yv,
-                                                float4 w0, float4 w1, float rho,
+__device__ __forceinline__ LaneOut lane_uniform(const LaneData& Ld, float rho,
                                                 const float2* tabH, const float2* tabA) {
+    const uint32_t h = Ld.hw[0] & 0xFFFFu, a = Ld.aw[0] & 0xFFFFu;
     const float2 th = tabH[h], ta = tabA[a];
     float lh = th.x * ta.y;  // exp(att[h] + ha[h]) * exp(-def[a])
     float la = ta.x * th.y;  // exp(att[a]) * exp(-def[h])
@@ -1058,24 +1132,29 @@ __device__ __forceinline__ LaneOut lane_uniform(uint32_t h, uint32_t a, uint2 xv
     float n00, n10, n01, n11, nall, sx, sy;  // (weighted) class counts, total, goal sums
     if (!WEIGHTED) {
         const uint32_t one = 0x01010101u;
-        const uint32_t x0 = xv.x, x1 = xv.y, y0 = yv.x, y1 = yv.y;
-        n00 = (float)(__popc(zero_bytes(x0 | y0)) + __popc(zero_bytes(x1 | y1)));
-        n10 = (float)(__popc(zero_bytes((x0 ^ one) | y0)) + __popc(zero_bytes((x1 ^ one) | y1)));
-        n01 = (float)(__popc(zero_bytes(x0 | (y0 ^ one))) + __popc(zero_bytes(x1 | (y1 ^ one))));
-        n11 = (float)(__popc(zero_bytes((x0 ^ one) | (y0 ^ one))) +
-                      __popc(zero_bytes((x1 ^ one) | (y1 ^ one))));
+        int c00 = 0, c10 = 0, c01 = 0, c11 = 0;
+        uint32_t ax = 0, ay = 0;
+#pragma unroll
+        for (int q = 0; q < XWORDS; ++q) {
+            const uint32_t x = Ld.xw[q], y = Ld.yw[q];
+            c00 += __popc(zero_bytes(x | y));
+            c10 += __popc(zero_bytes((x ^ one) | y));
+            c01 += __popc(zero_bytes(x | (y ^ one)));
+            c11 += __popc(zero_bytes((x ^ one) | (y ^ one)));
+            ax = __builtin_amdgcn_sad_u8(x, 0u, ax);
+            ay = __builtin_amdgcn_sad_u8(y, 0u, ay);
+        }
+        n00 = (float)c00; n10 = (float)c10; n01 = (float)c01; n11 = (float)c11;
         nall = (float)LANE_FIX;
-        sx = (float)__builtin_amdgcn_sad_u8(x1, 0u, __builtin_amdgcn_sad_u8(x0, 0u, 0u));
-        sy = (float)__builtin_amdgcn_sad_u8(y1, 0u, __builtin_amdgcn_sad_u8(y0, 0u, 0u));
+        sx = (float)ax;
+        sy = (float)ay;
     } else {
-        const uint32_t xw[2] = {xv.x, xv.y}, yw[2] = {yv.x, yv.y};
-        const float wj[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
         n00 = n10 = n01 = n11 = nall = sx = sy = 0.f;
 #pragma unroll
         for (int j = 0; j < LANE_FIX; ++j) {
-            const uint32_t xj = (xw[j >> 2] >> (8 * (j & 3))) & 0xFFu;
-            const uint32_t yj = (yw[j >> 2] >> (8 * (j & 3))) & 0xFFu;
-            const float wv = wj[j];
+            const uint32_t xj = (Ld.xw[j >> 2] >> (8 * (j & 3))) & 0xFFu;
+            const uint32_t yj = (Ld.yw[j >> 2] >> (8 * (j & 3))) & 0xFFu;
+            const float wv = Ld.wj[j];
             n00 += (xj | yj) == 0 ? wv : 0.f;
             n10 += (xj == 1 && yj == 0) ? wv : 0.f;
             n01 += (xj == 0 && yj == 1) ? wv : 0.f;
@@ -1117,14 +1196,13 @@ __device__ __forceinline__ LaneOut lane_uniform(uint32_t h, uint32_t a, uint2 xv
 // The lane's 8 fixtures span more than one pair: per-fixture arithmetic; finished runs go
 // to the LDS accumulators, the last one stays pending like a uniform lane's.
 template <bool WEIGHTED, bool CLIP>
-__device__ __forceinline__ LaneOut lane_mixed(uint4 hv, uint4 av, uint2 xv, uint2 yv, float4 w0,
-                                              float4 w1, float rho, const float2* tabH,
+__device__ __forceinline__ LaneOut lane_mixed(const LaneData& Ld, float rho, const float2* tabH,
                                               const float2* tabA, double* acc, int T1) {
-    const uint32_t hw[4] = {hv.x, hv.y, hv.z, hv.w};
-    const uint32_t aw[4] = {av.x, av.y, av.z, av.w};
-    const uint32_t xw[2] = {xv.x, xv.y};
-    const uint32_t yw[2] = {yv.x, yv.y};
-    const float wj[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+    const uint32_t* hw = Ld.hw;
+    const uint32_t* aw = Ld.aw;
+    const uint32_t* xw = Ld.xw;
+    const uint32_t* yw = Ld.yw;
+    const float* wj = Ld.wj;
     LaneOut o;
     o.slam = o.slog = o.su = o.sclip = 0.f;
     o.rsh = o.rsa = 0.f;
@@ -1192,8 +1270,13 @@ __device__ __forceinline__ LaneOut lane_mixed(uint4 hv, uint4 av, uint2 xv, uint
 
 // ------------------------------------------------------------------------- dc_eval
 
+#ifdef DC_MIN_WAVES  // waves per SIMD the register allocation must allow (2 workgroups per CU = 4)
+#define DC_LAUNCH_BOUNDS __launch_bounds__(BLOCK, DC_MIN_WAVES)
+#else
+#define DC_LAUNCH_BOUNDS __launch_bounds__(BLOCK)
+#endif
 template <bool WEIGHTED, bool CLIP, bool STAGED>
-__global__ __launch_bounds__(BLOCK) void dc_eval(EvalArgs A) {
+__global__ DC_LAUNCH_BOUNDS void dc_eval(EvalArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const Layout& L = A.L;
     const int T = L.T, T1 = T + 1;
@@ -1201,6 +1284,8 @@ __global__ __launch_bounds__(BLOCK) void dc_eval(EvalArgs A) {
     const int chain = blockIdx.y;
     const double* z = A.z + (size_t)chain * L.D;
     DC_STAMP(0);
+    // device-resident NUTS: the subtree this launch belonged to may already be complete
+    const double nuts_done = A.nuts ? A.nuts[nd::H_S_DONE] : 0.0;
 
     // LDS carve of the streaming part (all offsets multiples of 16 B)
     float2* tabH = reinterpret_cast<float2*>(smem);            // {exp(att+ha), exp(-def)}
@@ -1211,6 +1296,7 @@ __global__ __launch_bounds__(BLOCK) void dc_eval(EvalArgs A) {
     int* shflag = reinterpret_cast<int*>(redm + WAVES * 4);  // dynamic LDS only (G17)
 
     if (blockIdx.x == 0) {
+        if (nuts_done != 0.0) return;
         prior_body<CLIP>(A, chain, smem);
         DC_STAMP(4);
     } else {
@@ -1219,20 +1305,8 @@ __global__ __launch_bounds__(BLOCK) void dc_eval(EvalArgs A) {
         const int gw = wgi * WAVES + wave;
         int tile = gw * A.tiles_per_wave;
         const int tile_end = min(tile + A.tiles_per_wave, A.n_tiles);
-        uint4 hv = make_uint4(0, 0, 0, 0), av = hv;
-        uint2 xv = make_uint2(0, 0), yv = xv;
-        float4 w0 = make_float4(0, 0, 0, 0), w1 = w0;
-        if (tile < tile_end) {
-            const size_t o = (size_t)tile * 64 + lane;
-            hv = A.h[o];
-            av = A.a[o];
-            xv = A.x[o];
-            yv = A.y[o];
-            if (WEIGHTED) {
-                w0 = A.w[2 * o];
-                w1 = A.w[2 * o + 1];
-            }
-        }
+        LaneData cur{};
+        if (tile < tile_end) cur = load_lane<WEIGHTED>(A, (size_t)tile * 64 + lane);
         uint32_t pr0 = 0;
         if (tid < A.P) pr0 = A.pairs[tid];
         const int o0 = A.wg_off[wgi], o1 = A.wg_off[wgi + 1];  // static sparse-slab slots
@@ -1241,6 +1315,7 @@ __global__ __launch_bounds__(BLOCK) void dc_eval(EvalArgs A) {
             slot0 = A.wg_slots[o0 + tid];
             dst0 = A.wg_dst[o0 + tid];
         }
+        if (nuts_done != 0.0) return;  // (uniform over the whole grid)
 
         // ---- 1. per-team tables (float32) + zero accumulators
         F32Scalars fs;
@@ -1261,41 +1336,28 @@ __global__ __launch_bounds__(BLOCK) void dc_eval(EvalArgs A) {
         // ---- 3. stream the fixtures
         double dSLAM = 0.0, dSLOG = 0.0, dSU = 0.0, dCLIP = 0.0;  // per lane
         while (tile < tile_end) {
-            uint4 hn = hv, an = av;
-            uint2 xn = xv, yn = yv;
-            float4 w0n = w0, w1n = w1;
-            if (tile + 1 < tile_end) {  // prefetch the next tile
-                const size_t o = (size_t)(tile + 1) * 64 + lane;
-                hn = A.h[o];
-                an = A.a[o];
-                xn = A.x[o];
-                yn = A.y[o];
-                if (WEIGHTED) {
-                    w0n = A.w[2 * o];
-                    w1n = A.w[2 * o + 1];
-                }
-            }
-            // One lane = 8 consecutive fixtures.  Sorted by pair, they almost always share
+            LaneData nxt = cur;
+            if (tile + 1 < tile_end)  // prefetch the next tile
+                nxt = load_lane<WEIGHTED>(A, (size_t)(tile + 1) * 64 + lane);
+            // One lane = LANE_FIX consecutive fixtures.  Sorted by pair, they almost always share
             // ONE (home, away): then the two rates and the four score-class tau terms are
             // computed once for the lane and each fixture is only classified; a lane that
             // straddles a pair boundary takes the per-fixture path.
             LaneOut lo;
             {
-                const uint32_t hrep = (hv.x & 0xFFFFu) * 0x00010001u;
-                const uint32_t arep = (av.x & 0xFFFFu) * 0x00010001u;
-                const uint32_t mixed = (hv.x ^ hrep) | (hv.y ^ hrep) | (hv.z ^ hrep) |
-                                       (hv.w ^ hrep) | (av.x ^ arep) | (av.y ^ arep) |
-                                       (av.z ^ arep) | (av.w ^ arep);
+                const uint32_t hrep = (cur.hw[0] & 0xFFFFu) * 0x00010001u;
+                const uint32_t arep = (cur.aw[0] & 0xFFFFu) * 0x00010001u;
+                uint32_t mixed = 0;
+#pragma unroll
+                for (int q = 0; q < HWORDS; ++q) mixed |= (cur.hw[q] ^ hrep) | (cur.aw[q] ^ arep);
 #ifdef DC_STAMPS
                 if (mixed == 0xFFFFFFFFu) rho_dbg += 1.0f;  // forces the loads to have landed
                 DC_STAMP(12);
 #endif
                 if (mixed == 0)
-                    lo = lane_uniform<WEIGHTED, CLIP>(hv.x & 0xFFFFu, av.x & 0xFFFFu, xv, yv, w0,
-                                                      w1, rho, tabH, tabA);
+                    lo = lane_uniform<WEIGHTED, CLIP>(cur, rho, tabH, tabA);
                 else
-                    lo = lane_mixed<WEIGHTED, CLIP>(hv, av, xv, yv, w0, w1, rho, tabH, tabA, acc,
-                                                    T1);
+                    lo = lane_mixed<WEIGHTED, CLIP>(cur, rho, tabH, tabA, acc, T1);
             }
             // scalars: float32 over the lane's 8 fixtures only, float64 from there on
             // (a float32 sum over the whole wave-tile would cost ~1e-4 absolute in U)
@@ -1333,12 +1395,7 @@ __global__ __launch_bounds__(BLOCK) void dc_eval(EvalArgs A) {
                 flush_run(acc, T1, key, rsh, rsa);
             }
 
-            hv = hn;
-            av = an;
-            xv = xn;
-            yv = yn;
-            w0 = w0n;
-            w1 = w1n;
+            cur = nxt;
             ++tile;
         }
         DC_STAMP(3);

@@ -344,36 +344,89 @@ inline void draw_init(tf::Key subkey, const std::vector<Site>& sites, double rad
     }
 }
 
+// What one NUTS transition reports back to the adaptation / collection loop.
+struct TransitionOut {
+    double accept_prob = 0, pe = 0, aux[4] = {0, 0, 0, 0};
+    int num_steps = 0;
+    bool diverging = false;
+};
+
+// Engine concept (the tree builder behind run_chain_engine):
+//   int  dim() const;
+//   bool set_state(const double* z, double* pe, bool* finite);   // evaluate + adopt z
+//   bool transition(const double* r, tf::Key key, double step_size, const vec& inv_mass,
+//                   bool mass_changed, double* z_out, TransitionOut* out);
+//   int64_t leapfrogs() const;
+// `false` = backend failure.
+
+// Host tree builder over a potential functor (one evaluation + read-back per leapfrog).
 template <class Pot>
-int run_chain(Pot& pot, const Config& cfg, const double* z0, tf::Key key, double* draws_out,
-              Result* res) {
-    const int D = pot.dim();
-    Sampler<Pot> S(pot, cfg);
+struct HostEngine {
+    Pot& pot;
+    const Config& cfg;
+    Sampler<Pot> S;
+    vec z, g;
+    double pe = 0, aux[4] = {0, 0, 0, 0};
+    HostEngine(Pot& p, const Config& c) : pot(p), cfg(c), S(p, c), z(p.dim()), g(p.dim()) {}
+    int dim() const { return S.D; }
+    int64_t leapfrogs() const { return S.leapfrogs; }
+    bool set_state(const double* z0, double* pe_out, bool* finite) {
+        for (int i = 0; i < S.D; ++i) z[i] = z0[i];
+        if (!pot(z.data(), &pe, g.data(), aux)) return false;
+        bool ok = std::isfinite(pe);
+        for (int i = 0; i < S.D && ok; ++i) ok = std::isfinite(g[i]);
+        *finite = ok;
+        *pe_out = pe;
+        return true;
+    }
+    bool transition(const double* r, tf::Key key, double step_size, const vec& inv_mass,
+                    bool /*mass_changed*/, double* z_out, TransitionOut* out) {
+        S.step_size = step_size;
+        S.inv_mass = inv_mass;
+        vec rv(r, r + S.D);
+        Tree tree = S.build_tree(z, rv, pe, g, aux, key);
+        if (S.eval_failed) return false;
+        z = tree.z_prop;
+        g = tree.g_prop;
+        pe = tree.pe_prop;
+        for (int i = 0; i < 4; ++i) aux[i] = tree.aux_prop[i];
+        out->accept_prob = tree.sum_accept / tree.num_proposals;
+        out->num_steps = tree.num_proposals;
+        out->diverging = tree.diverging;
+        out->pe = pe;
+        for (int i = 0; i < 4; ++i) out->aux[i] = aux[i];
+        for (int i = 0; i < S.D; ++i) z_out[i] = z[i];
+        return true;
+    }
+};
+
+template <class Engine>
+int run_chain_engine(Engine& E, const Config& cfg, const double* z0, tf::Key key,
+                     double* draws_out, Result* res) {
+    const int D = E.dim();
     std::vector<Site> sites = cfg.sites;
     if (sites.empty()) sites.push_back({0, D});
 
     // NUTS.init: key, key_init_model = split(key)
     tf::Key key_init;
     tf::split2(key, &key, &key_init);
-    vec z(D), g(D);
-    double pe = 0, aux[4] = {0, 0, 0, 0};
+    vec z(D);
+    double pe = 0;
+    bool finite = false;
     if (z0) {
         for (int i = 0; i < D; ++i) z[i] = z0[i];
-        if (!pot(z.data(), &pe, g.data(), aux)) return ST_EVAL_FAILED;
+        if (!E.set_state(z.data(), &pe, &finite)) return ST_EVAL_FAILED;
     } else {
-        bool ok = false;
         tf::Key k = key_init;
-        for (int attempt = 0; attempt < 100 && !ok; ++attempt) {
+        for (int attempt = 0; attempt < 100 && !finite; ++attempt) {
             tf::Key sub;
             tf::split2(k, &k, &sub);
             draw_init(sub, sites, cfg.init_radius, &z);
-            if (!pot(z.data(), &pe, g.data(), aux)) return ST_EVAL_FAILED;
-            ok = std::isfinite(pe);
-            for (int i = 0; i < D && ok; ++i) ok = std::isfinite(g[i]);
+            if (!E.set_state(z.data(), &pe, &finite)) return ST_EVAL_FAILED;
         }
-        if (!ok) return ST_NO_FINITE_INIT;
+        if (!finite) return ST_NO_FINITE_INIT;
     }
-    S.leapfrogs = 0;
+    const int64_t leap0 = E.leapfrogs();
 
     // init_kernel: key_hmc, key_wa, key_momentum = split(key, 3)
     tf::Key key_hmc, key_wa, key_mom0;
@@ -381,8 +434,11 @@ int run_chain(Pot& pot, const Config& cfg, const double* z0, tf::Key key, double
 
     const std::vector<Window> sched = build_adaptation_schedule(cfg.num_warmup);
     const int num_windows = (int)sched.size();
+    double step_size = cfg.step_size;
+    vec inv_mass(D, 1.0), mass_sqrt(D, 1.0);
+    bool mass_changed = true;
     DualAveraging ss;
-    ss.init(std::log(10.0 * S.step_size));
+    ss.init(std::log(10.0 * step_size));
     Welford mm;
     mm.init(D);
     int window_idx = 0;
@@ -404,15 +460,13 @@ int run_chain(Pot& pot, const Config& cfg, const double* z0, tf::Key key, double
         tf::Key k_mom, k_tr;
         tf::split3(key_hmc, &key_hmc, &k_mom, &k_tr);
         tf::normal(k_mom, D, eps_n.data());
-        for (int i = 0; i < D; ++i) r[i] = S.mass_sqrt[i] * eps_n[i];
-        const double used_step = S.step_size;
-        Tree tree = S.build_tree(z, r, pe, g, aux, k_tr);
-        if (S.eval_failed) return ST_EVAL_FAILED;
-        const double accept_prob = tree.sum_accept / tree.num_proposals;
-        z = tree.z_prop;
-        g = tree.g_prop;
-        pe = tree.pe_prop;
-        for (int i = 0; i < 4; ++i) aux[i] = tree.aux_prop[i];
+        for (int i = 0; i < D; ++i) r[i] = mass_sqrt[i] * eps_n[i];
+        const double used_step = step_size;
+        TransitionOut out;
+        if (!E.transition(r.data(), k_tr, step_size, inv_mass, mass_changed, z.data(), &out))
+            return ST_EVAL_FAILED;
+        mass_changed = false;
+        const double accept_prob = out.accept_prob;
 
         if (it < cfg.num_warmup) {  // warmup_adapter.update_fn
             const int t = it;
@@ -420,7 +474,7 @@ int run_chain(Pot& pot, const Config& cfg, const double* z0, tf::Key key, double
                 ss.update(cfg.target_accept_prob - accept_prob);
                 double s = (t == cfg.num_warmup - 1) ? std::exp(ss.x_avg) : std::exp(ss.x_t);
                 const double tiny = 1.1754943508222875e-38;
-                S.step_size = s < tiny ? tiny : s;
+                step_size = s < tiny ? tiny : s;
             }
             const bool is_middle = (0 < window_idx) && (window_idx < num_windows - 1);
             if (cfg.adapt_mass_matrix && is_middle) mm.update(z);
@@ -428,33 +482,41 @@ int run_chain(Pot& pot, const Config& cfg, const double* z0, tf::Key key, double
             if (at_end) window_idx += 1;
             if (at_end && is_middle) {
                 if (cfg.adapt_mass_matrix) {
-                    mm.final_regularized(&S.inv_mass);
-                    for (int i = 0; i < D; ++i) S.mass_sqrt[i] = 1.0 / std::sqrt(S.inv_mass[i]);
+                    mm.final_regularized(&inv_mass);
+                    for (int i = 0; i < D; ++i) mass_sqrt[i] = 1.0 / std::sqrt(inv_mass[i]);
                     mm.init(D);
+                    mass_changed = true;
                 }
-                if (cfg.adapt_step_size) ss.init(std::log(10.0 * S.step_size));
+                if (cfg.adapt_step_size) ss.init(std::log(10.0 * step_size));
             }
         } else {
             const int n = it - cfg.num_warmup + 1;
             mean_accept += (accept_prob - mean_accept) / n;
-            if (tree.diverging) res->total_divergences += 1;
+            if (out.diverging) res->total_divergences += 1;
             if (it >= start_idx && (it - start_idx) % cfg.thinning == cfg.thinning - 1) {
                 const int idx = (it - start_idx) / cfg.thinning;
                 for (int i = 0; i < D; ++i) draws_out[(size_t)idx * D + i] = z[i];
-                res->potential_energy[idx] = pe;
+                res->potential_energy[idx] = out.pe;
                 res->accept_prob[idx] = accept_prob;
                 res->step_size[idx] = used_step;
-                res->aux0[idx] = aux[0];
-                res->num_steps[idx] = tree.num_proposals;
-                res->diverging[idx] = tree.diverging ? 1 : 0;
+                res->aux0[idx] = out.aux[0];
+                res->num_steps[idx] = out.num_steps;
+                res->diverging[idx] = out.diverging ? 1 : 0;
             }
         }
     }
-    res->final_step_size = S.step_size;
+    res->final_step_size = step_size;
     res->mean_accept_prob = mean_accept;
-    res->total_leapfrogs = S.leapfrogs;
-    res->inverse_mass_matrix = S.inv_mass;
+    res->total_leapfrogs = E.leapfrogs() - leap0;
+    res->inverse_mass_matrix = inv_mass;
     return ST_OK;
+}
+
+template <class Pot>
+int run_chain(Pot& pot, const Config& cfg, const double* z0, tf::Key key, double* draws_out,
+              Result* res) {
+    HostEngine<Pot> E(pot, cfg);
+    return run_chain_engine(E, cfg, z0, key, draws_out, res);
 }
 
 }  // namespace nuts

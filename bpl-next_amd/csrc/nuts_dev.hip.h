@@ -1,0 +1,367 @@
+// nuts_dev.hip.h -- device-resident half of the NUTS transition (numpyro 0.13.2 iterative
+// tree; host half and adaptation in nuts.hpp / bplhip.hip).
+//
+// Why: with a host-side tree every leapfrog costs a launch + a device->host read-back
+// (~45 us at N = 1e6 against ~11 us of kernel).  Here the leaf bookkeeping (velocity-Verlet
+// half steps, energy, uniform multinomial transition with threefry, checkpointed U-turn
+// test) runs in the tail of dc_eval itself, on the wave that has just produced the
+// gradient, and writes the NEXT leapfrog's position; the host enqueues the 2^j launches of
+// a doubling (or of several doublings) without reading anything back and synchronises once
+// per batch.  Launches that come after the subtree has finished return at once.
+//
+// All state lives in one device buffer ("NS"); one wave works on it, lanes stride over D.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace nd {
+
+// The integrator arithmetic below must round exactly like the host driver's (nuts.hpp,
+// compiled without FMA): no contraction, so both tree builders walk the same trajectory.
+#pragma clang fp contract(off)
+
+// ---- header words (doubles unless noted)
+enum {
+    H_EPS = 0,        // step size (positive)
+    H_DIR,            // +1 / -1 direction of the current doubling
+    H_E0,             // energy at the start of the transition
+    H_MAXDE,          // divergence threshold
+    // tree (whole transition)
+    H_T_DEPTH, H_T_WEIGHT, H_T_TURN, H_T_DIV, H_T_SUMACC, H_T_NUM, H_T_PE, H_T_EPROP,
+    // subtree of the current doubling
+    H_S_MAX,          // leaves wanted = 2^depth
+    H_S_NUM, H_S_WEIGHT, H_S_TURN, H_S_DIV, H_S_SUMACC, H_S_PE, H_S_EPROP,
+    H_S_DONE,         // 1: remaining launches of this doubling return at once
+    H_S_ACTIVE,       // 0: this doubling was enqueued speculatively and must not run
+    H_KEY_HI, H_KEY_LO,  // threefry key of the subtree (as doubles holding u32)
+    H_CUR_PE,         // potential of the current state (start of transition)
+    H_STOP,           // 1: the tree is complete (turning / diverging / max depth)
+    H_T_AUX0, H_T_AUX1, H_T_AUX2, H_T_AUX3,
+    H_S_AUX0, H_S_AUX1, H_S_AUX2, H_S_AUX3,
+    H_LEAF_AUX0, H_LEAF_AUX1, H_LEAF_AUX2, H_LEAF_AUX3,  // aux written by the evaluation
+    H_LEAF_PE,        // potential written by the evaluation
+    H_EVALS,          // evaluations actually performed (counter)
+    H_N = 48
+};
+
+// ---- vectors of length D, in this order after the header
+enum {
+    V_INVM = 0,
+    V_Z, V_G,                      // current state of the chain (start of the transition)
+    V_ZN,                          // position of the NEXT evaluation (read by dc_eval)
+    V_RH,                          // momentum after the first half step of that leapfrog
+    V_GRAD,                        // gradient written by the evaluation
+    V_TL_Z, V_TL_R, V_TL_G, V_TR_Z, V_TR_R, V_TR_G, V_TP_Z, V_TP_G, V_T_RSUM,   // tree
+    V_SL_Z, V_SL_R, V_SL_G, V_SR_Z, V_SR_R, V_SR_G, V_SP_Z, V_SP_G, V_S_RSUM,   // subtree
+    V_CKPT                         // 2 * max_depth vectors: r_ckpts | r_sum_ckpts
+};
+
+__host__ __device__ inline size_t ns_doubles(int D, int max_depth) {
+    return (size_t)H_N + (size_t)(V_CKPT + 2 * max_depth) * D;
+}
+__host__ __device__ inline double* vec(double* ns, int D, int which) {
+    return ns + H_N + (size_t)which * D;
+}
+
+// ---------------------------------------------------------------- threefry (device)
+__device__ __forceinline__ uint32_t rotl32(uint32_t v, int r) { return (v << r) | (v >> (32 - r)); }
+__device__ inline void tf_block(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t* o0,
+                                uint32_t* o1) {
+    const int R0[4] = {13, 15, 26, 6}, R1[4] = {17, 29, 16, 24};
+    const uint32_t ks[3] = {k0, k1, k0 ^ k1 ^ 0x1BD11BDAu};
+    uint32_t x0 = c0 + ks[0], x1 = c1 + ks[1];
+#pragma unroll
+    for (int g = 0; g < 5; ++g) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            x0 += x1;
+            x1 = rotl32(x1, (g & 1) ? R1[i] : R0[i]);
+            x1 ^= x0;
+        }
+        x0 += ks[(g + 1) % 3];
+        x1 += ks[(g + 2) % 3] + (uint32_t)(g + 1);
+    }
+    *o0 = x0;
+    *o1 = x1;
+}
+// jax.random.split(key, 2): counts [0,1,2,3] -> blocks (0,2), (1,3)
+__device__ inline void tf_split2(uint32_t khi, uint32_t klo, uint32_t* a_hi, uint32_t* a_lo,
+                                 uint32_t* b_hi, uint32_t* b_lo) {
+    uint32_t p0, q0, p1, q1;
+    tf_block(khi, klo, 0u, 2u, &p0, &q0);
+    tf_block(khi, klo, 1u, 3u, &p1, &q1);
+    *a_hi = p0; *a_lo = p1;
+    *b_hi = q0; *b_lo = q1;
+}
+// jax.random.bernoulli(key, p): uniform(key, ()) < p, float32 mantissa trick
+__device__ inline bool tf_bernoulli(uint32_t khi, uint32_t klo, double p) {
+    uint32_t b0, b1;
+    tf_block(khi, klo, 0u, 0u, &b0, &b1);
+    const float u = __uint_as_float((b0 >> 9) | 0x3F800000u) - 1.0f;
+    return (double)u < p;
+}
+
+// ---------------------------------------------------------------- wave helpers
+__device__ __forceinline__ double nd_wave_sum(double v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+// numpyro _is_turning with a diagonal inverse mass matrix
+__device__ inline bool is_turning(const double* invM, const double* r_left, const double* r_right,
+                                  const double* r_sum, int D, int lane) {
+    double dl = 0.0, dr = 0.0;
+    for (int i = lane; i < D; i += 64) {
+        const double rs = r_sum[i] - 0.5 * (r_left[i] + r_right[i]);
+        dl += invM[i] * r_left[i] * rs;
+        dr += invM[i] * r_right[i] * rs;
+    }
+    dl = nd_wave_sum(dl);
+    dr = nd_wave_sum(dr);
+    return (dl <= 0.0) | (dr <= 0.0);
+}
+__device__ __forceinline__ void vcopy(double* dst, const double* src, int D, int lane) {
+    for (int i = lane; i < D; i += 64) dst[i] = src[i];
+}
+__device__ __forceinline__ double logaddexp(double a, double b) {
+    if (a == b) return a + 0.6931471805599453;
+    const double m = fmax(a, b);
+    return m + log1p(exp(-fabs(a - b)));
+}
+
+// ---------------------------------------------------------------- leaf (one wave)
+// Called by the wave that has just computed potential, aux and gradient of the position
+// V_ZN (reached with half-stepped momentum V_RH); it hands them over in LDS:
+// gL = grad[D] | potential | aux[4].
+__device__ inline void nuts_leaf(double* ns, int D, int max_depth, int lane, const double* gL) {
+    const double eps = ns[H_EPS] * ns[H_DIR];
+    const bool going_right = ns[H_DIR] > 0.0;
+    double* invM = vec(ns, D, V_INVM);
+    double* zn = vec(ns, D, V_ZN);
+    double* rh = vec(ns, D, V_RH);
+    const double* gr = gL;
+    const double pe = gL[D];
+    // second half step, kinetic energy
+    double kin = 0.0;
+    for (int i = lane; i < D; i += 64) {
+        const double r = rh[i] - 0.5 * eps * gr[i];
+        rh[i] = r;  // V_RH now holds the leaf's full-step momentum
+        kin += invM[i] * r * r;
+    }
+    kin = 0.5 * nd_wave_sum(kin);
+    const double e_new = pe + kin;
+    double delta = e_new - ns[H_E0];
+    if (delta != delta) delta = __builtin_inf();
+    const double w_leaf = -delta;
+    const bool div_leaf = delta > ns[H_MAXDE];
+    const double acc_leaf = fmin(1.0, exp(-delta));
+
+    const int num = (int)ns[H_S_NUM];  // leaves so far = index of this leaf
+    double* sl_z = vec(ns, D, V_SL_Z); double* sl_r = vec(ns, D, V_SL_R); double* sl_g = vec(ns, D, V_SL_G);
+    double* sr_z = vec(ns, D, V_SR_Z); double* sr_r = vec(ns, D, V_SR_R); double* sr_g = vec(ns, D, V_SR_G);
+    double* sp_z = vec(ns, D, V_SP_Z); double* sp_g = vec(ns, D, V_SP_G);
+    double* s_rsum = vec(ns, D, V_S_RSUM);
+    uint32_t khi = (uint32_t)ns[H_KEY_HI], klo = (uint32_t)ns[H_KEY_LO];
+    uint32_t nhi, nlo, thi, tlo;
+    tf_split2(khi, klo, &nhi, &nlo, &thi, &tlo);  // rng_key, transition_rng_key = split(rng_key)
+
+    bool take = true;
+    double w_sub = w_leaf, sum_acc = acc_leaf;
+    if (num == 0) {
+        vcopy(sl_z, zn, D, lane); vcopy(sl_r, rh, D, lane); vcopy(sl_g, gr, D, lane);
+        vcopy(sr_z, zn, D, lane); vcopy(sr_r, rh, D, lane); vcopy(sr_g, gr, D, lane);
+        vcopy(s_rsum, rh, D, lane);
+    } else {
+        // _combine_tree(current, leaf, biased_transition=False)
+        if (going_right) { vcopy(sr_z, zn, D, lane); vcopy(sr_r, rh, D, lane); vcopy(sr_g, gr, D, lane); }
+        else { vcopy(sl_z, zn, D, lane); vcopy(sl_r, rh, D, lane); vcopy(sl_g, gr, D, lane); }
+        for (int i = lane; i < D; i += 64) s_rsum[i] += rh[i];
+        const double w_cur = ns[H_S_WEIGHT];
+        const double prob = 1.0 / (1.0 + exp(-(w_leaf - w_cur)));  // expit: uniform transition
+        take = tf_bernoulli(thi, tlo, prob);
+        w_sub = logaddexp(w_cur, w_leaf);
+        sum_acc = ns[H_S_SUMACC] + acc_leaf;
+    }
+    if (take) {
+        vcopy(sp_z, zn, D, lane);
+        vcopy(sp_g, gr, D, lane);
+    }
+    // checkpoints (numpyro _leaf_idx_to_ckpt_idxs / _is_iterative_turning)
+    int idx_max = 0, trail = 0;
+    for (int v = num >> 1; v > 0; v >>= 1) idx_max += v & 1;
+    for (int v = num; v & 1; v >>= 1) trail += 1;
+    const int idx_min = idx_max - trail + 1;
+    double* ck_r = vec(ns, D, V_CKPT);
+    double* ck_s = ck_r + (size_t)max_depth * D;
+    if ((num & 1) == 0) {
+        vcopy(ck_r + (size_t)idx_max * D, rh, D, lane);
+        vcopy(ck_s + (size_t)idx_max * D, s_rsum, D, lane);
+    }
+    bool turning = false;
+    for (int i = idx_max; i >= idx_min && !turning; --i) {
+        const double* cr = ck_r + (size_t)i * D;
+        const double* cs = ck_s + (size_t)i * D;
+        double dl = 0.0, dr = 0.0;
+        for (int k = lane; k < D; k += 64) {
+            const double sub = s_rsum[k] - cs[k] + cr[k];
+            const double rs = sub - 0.5 * (cr[k] + rh[k]);
+            dl += invM[k] * cr[k] * rs;
+            dr += invM[k] * rh[k] * rs;
+        }
+        dl = nd_wave_sum(dl);
+        dr = nd_wave_sum(dr);
+        turning = (dl <= 0.0) | (dr <= 0.0);
+    }
+    const int new_num = num + 1;
+    const bool done = turning || div_leaf || new_num >= (int)ns[H_S_MAX];
+    // next leapfrog starts from this leaf (the subtree grows in one direction)
+    if (!done) {
+        double* zn2 = zn;
+        for (int i = lane; i < D; i += 64) {
+            const double r = rh[i] - 0.5 * eps * gr[i];
+            zn2[i] = zn[i] + eps * invM[i] * r;
+            rh[i] = r;
+        }
+    }
+    if (lane == 0) {
+        ns[H_S_NUM] = (double)new_num;
+        ns[H_S_WEIGHT] = w_sub;
+        ns[H_S_SUMACC] = sum_acc;
+        ns[H_S_DIV] = div_leaf ? 1.0 : 0.0;
+        ns[H_S_TURN] = turning ? 1.0 : 0.0;
+        ns[H_S_DONE] = done ? 1.0 : 0.0;
+        ns[H_KEY_HI] = (double)nhi;
+        ns[H_KEY_LO] = (double)nlo;
+        ns[H_EVALS] += 1.0;
+        if (take) {
+            ns[H_S_PE] = pe;
+            ns[H_S_EPROP] = e_new;
+            ns[H_S_AUX0] = gL[D + 1]; ns[H_S_AUX1] = gL[D + 2];
+            ns[H_S_AUX2] = gL[D + 3]; ns[H_S_AUX3] = gL[D + 4];
+        }
+    }
+}
+
+// ---------------------------------------------------------------- small kernels (1 wave)
+
+// start of a transition: tree = the current state with momentum r (uploaded to V_TL_R)
+__global__ __launch_bounds__(64) void k_init(double* ns, int D, double eps, double max_de) {
+    const int lane = threadIdx.x;
+    double* invM = vec(ns, D, V_INVM);
+    double* r = vec(ns, D, V_TL_R);
+    double kin = 0.0;
+    for (int i = lane; i < D; i += 64) kin += invM[i] * r[i] * r[i];
+    kin = 0.5 * nd_wave_sum(kin);
+    vcopy(vec(ns, D, V_TL_Z), vec(ns, D, V_Z), D, lane);
+    vcopy(vec(ns, D, V_TL_G), vec(ns, D, V_G), D, lane);
+    vcopy(vec(ns, D, V_TR_Z), vec(ns, D, V_Z), D, lane);
+    vcopy(vec(ns, D, V_TR_R), r, D, lane);
+    vcopy(vec(ns, D, V_TR_G), vec(ns, D, V_G), D, lane);
+    vcopy(vec(ns, D, V_TP_Z), vec(ns, D, V_Z), D, lane);
+    vcopy(vec(ns, D, V_TP_G), vec(ns, D, V_G), D, lane);
+    vcopy(vec(ns, D, V_T_RSUM), r, D, lane);
+    if (lane == 0) {
+        const double e0 = ns[H_CUR_PE] + kin;
+        ns[H_EPS] = eps;
+        ns[H_MAXDE] = max_de;
+        ns[H_E0] = e0;
+        ns[H_T_DEPTH] = 0.0; ns[H_T_WEIGHT] = 0.0; ns[H_T_TURN] = 0.0; ns[H_T_DIV] = 0.0;
+        ns[H_T_SUMACC] = 0.0; ns[H_T_NUM] = 0.0; ns[H_T_PE] = ns[H_CUR_PE]; ns[H_T_EPROP] = e0;
+        ns[H_STOP] = 0.0;
+        ns[H_S_DONE] = 1.0; ns[H_S_ACTIVE] = 0.0;
+    }
+}
+
+// start of doubling `j`: runs only if the tree is still at depth j and not finished
+__global__ __launch_bounds__(64) void k_begin(double* ns, int D, int j, int going_right,
+                                              uint32_t khi, uint32_t klo) {
+    const int lane = threadIdx.x;
+    const bool active = ns[H_STOP] == 0.0 && (int)ns[H_T_DEPTH] == j;
+    if (!active) {
+        if (lane == 0) { ns[H_S_ACTIVE] = 0.0; ns[H_S_DONE] = 1.0; }
+        return;
+    }
+    const double dir = going_right ? 1.0 : -1.0;
+    const double eps = ns[H_EPS] * dir;
+    const double* invM = vec(ns, D, V_INVM);
+    const double* ez = vec(ns, D, going_right ? V_TR_Z : V_TL_Z);
+    const double* er = vec(ns, D, going_right ? V_TR_R : V_TL_R);
+    const double* eg = vec(ns, D, going_right ? V_TR_G : V_TL_G);
+    double* zn = vec(ns, D, V_ZN);
+    double* rh = vec(ns, D, V_RH);
+    for (int i = lane; i < D; i += 64) {
+        const double r = er[i] - 0.5 * eps * eg[i];
+        rh[i] = r;
+        zn[i] = ez[i] + eps * invM[i] * r;
+    }
+    if (lane == 0) {
+        ns[H_DIR] = dir;
+        ns[H_S_MAX] = (double)(1 << j);
+        ns[H_S_NUM] = 0.0; ns[H_S_WEIGHT] = 0.0; ns[H_S_TURN] = 0.0; ns[H_S_DIV] = 0.0;
+        ns[H_S_SUMACC] = 0.0;
+        ns[H_S_DONE] = 0.0; ns[H_S_ACTIVE] = 1.0;
+        ns[H_KEY_HI] = (double)khi; ns[H_KEY_LO] = (double)klo;
+    }
+}
+
+// end of a doubling: _combine_tree(tree, subtree, biased_transition=True)
+__global__ __launch_bounds__(64) void k_end(double* ns, int D, int max_depth, uint32_t thi,
+                                            uint32_t tlo) {
+    const int lane = threadIdx.x;
+    if (ns[H_S_ACTIVE] == 0.0) return;
+    const bool going_right = ns[H_DIR] > 0.0;
+    const double* invM = vec(ns, D, V_INVM);
+    // outer leaves of the combined tree
+    if (going_right) {
+        vcopy(vec(ns, D, V_TR_Z), vec(ns, D, V_SR_Z), D, lane);
+        vcopy(vec(ns, D, V_TR_R), vec(ns, D, V_SR_R), D, lane);
+        vcopy(vec(ns, D, V_TR_G), vec(ns, D, V_SR_G), D, lane);
+    } else {
+        vcopy(vec(ns, D, V_TL_Z), vec(ns, D, V_SL_Z), D, lane);
+        vcopy(vec(ns, D, V_TL_R), vec(ns, D, V_SL_R), D, lane);
+        vcopy(vec(ns, D, V_TL_G), vec(ns, D, V_SL_G), D, lane);
+    }
+    double* t_rsum = vec(ns, D, V_T_RSUM);
+    const double* s_rsum = vec(ns, D, V_S_RSUM);
+    for (int i = lane; i < D; i += 64) t_rsum[i] += s_rsum[i];
+    const bool s_turn = ns[H_S_TURN] != 0.0, s_div = ns[H_S_DIV] != 0.0;
+    const double w_cur = ns[H_T_WEIGHT], w_new = ns[H_S_WEIGHT];
+    double prob = exp(w_new - w_cur);
+    if (s_turn || s_div) prob = 0.0;
+    prob = fmin(prob, 1.0);
+    const bool turning =
+        s_turn | is_turning(invM, vec(ns, D, V_TL_R), vec(ns, D, V_TR_R), t_rsum, D, lane);
+    const bool take = tf_bernoulli(thi, tlo, prob);
+    if (take) {
+        vcopy(vec(ns, D, V_TP_Z), vec(ns, D, V_SP_Z), D, lane);
+        vcopy(vec(ns, D, V_TP_G), vec(ns, D, V_SP_G), D, lane);
+    }
+    if (lane == 0) {
+        if (take) {
+            ns[H_T_PE] = ns[H_S_PE];
+            ns[H_T_EPROP] = ns[H_S_EPROP];
+            ns[H_T_AUX0] = ns[H_S_AUX0]; ns[H_T_AUX1] = ns[H_S_AUX1];
+            ns[H_T_AUX2] = ns[H_S_AUX2]; ns[H_T_AUX3] = ns[H_S_AUX3];
+        }
+        const double depth = ns[H_T_DEPTH] + 1.0;
+        ns[H_T_DEPTH] = depth;
+        ns[H_T_WEIGHT] = logaddexp(w_cur, w_new);
+        ns[H_T_TURN] = turning ? 1.0 : 0.0;
+        ns[H_T_DIV] = s_div ? 1.0 : 0.0;
+        ns[H_T_SUMACC] += ns[H_S_SUMACC];
+        ns[H_T_NUM] += ns[H_S_NUM];
+        ns[H_STOP] = (turning || s_div || (int)depth >= max_depth) ? 1.0 : 0.0;
+        ns[H_S_ACTIVE] = 0.0;
+        ns[H_S_DONE] = 1.0;
+    }
+}
+
+// end of the transition: the proposal becomes the current state
+__global__ __launch_bounds__(64) void k_finish(double* ns, int D) {
+    const int lane = threadIdx.x;
+    vcopy(vec(ns, D, V_Z), vec(ns, D, V_TP_Z), D, lane);
+    vcopy(vec(ns, D, V_G), vec(ns, D, V_TP_G), D, lane);
+    if (lane == 0) ns[H_CUR_PE] = ns[H_T_PE];
+}
+
+}  // namespace nd

@@ -125,6 +125,10 @@ int bplhip_constrain_dynamic(bplhip_ctx* ctx, const double* z_draws, int64_t s,
                              double* away_defence);
 
 /* Tuning knobs (no reference counterpart; defaults are the measured best):
+ *   "device_nuts" 1 (default) = NUTS tree builder on the device: leaf bookkeeping in the
+ *            tail of the evaluation kernel, one host synchronisation per batch of
+ *            doublings; 0 = host tree builder (one read-back per leapfrog).  The device
+ *            builder is used for the basic/extended models with n_teams <= 64.
  *   "max_wg" streaming workgroups per evaluation (default 255: with the prior workgroup
  *            one per CU); applies at the next bplhip_set_fixtures */
 int bplhip_set_option(bplhip_ctx* ctx, const char* name, int value);
