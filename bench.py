@@ -184,7 +184,7 @@ def main():
     if rank == 0 and not args.no_insitu:
         # in situ: leapfrogs/s of a real NUTS chain on the same data (short, bounded)
         cfg = default_nuts_cfg()
-        cfg.num_warmup, cfg.num_samples = 30, 20
+        cfg.num_warmup, cfg.num_samples = 150, 100
         _, st = ctx.nuts_run(cfg, prng_key(42))
         extra["insitu_leapfrogs_per_s"] = st["total_leapfrogs"] / st["wall_seconds"]
         extra["insitu_leapfrogs"] = st["total_leapfrogs"]
@@ -223,7 +223,7 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
-                "kernel": "dc_stream (+dc_epilogue, launch gaps included)",
+                "kernel": "dc_eval (one launch per evaluation: streaming + prior + tail)",
                 "us_per_eval_events": per_eval_us,
                 "algorithmic_bytes_per_eval": n_fix * BYTES_PER_FIXTURE,
             },

@@ -37,6 +37,8 @@ ABI_SYMBOLS = (
     "bplhip_nuts_default_cfg",
     "bplhip_nuts_run",
     "bplhip_constrain",
+    "bplhip_predict_set_posterior",
+    "bplhip_predict_score_proba",
     "bplhip_threefry_split",
     "bplhip_threefry_bits",
 )
@@ -130,6 +132,10 @@ def load_library():
     lib.bplhip_nuts_run.restype = C.c_int
     lib.bplhip_constrain.argtypes = [vp, vp, i64, vp, vp, vp, vp]
     lib.bplhip_constrain.restype = C.c_int
+    lib.bplhip_predict_set_posterior.argtypes = [vp, i32, i32, vp, vp, vp, i32, vp]
+    lib.bplhip_predict_set_posterior.restype = C.c_int
+    lib.bplhip_predict_score_proba.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp]
+    lib.bplhip_predict_score_proba.restype = C.c_int
     lib.bplhip_threefry_split.argtypes = [u32, u32, i32, C.POINTER(u32)]
     lib.bplhip_threefry_split.restype = None
     lib.bplhip_threefry_bits.argtypes = [u32, u32, i32, C.POINTER(u32)]
@@ -342,6 +348,33 @@ class HipContext:
                 grad.data_ptr(), replays, self._stream(),
             )
         )
+
+    # -- predict path on the device
+    def predict_set_posterior(self, attack, defence, home_advantage, corr_coef):
+        att = np.ascontiguousarray(attack, dtype=np.float64)
+        dfn = np.ascontiguousarray(defence, dtype=np.float64)
+        ha = np.ascontiguousarray(home_advantage, dtype=np.float64)
+        cc = np.ascontiguousarray(corr_coef, dtype=np.float64)
+        s, t = att.shape
+        if dfn.shape != (s, t) or cc.shape != (s,) or ha.shape not in ((s,), (s, t)):
+            raise ValueError("posterior arrays have inconsistent shapes")
+        with self._torch.cuda.device(self.device):
+            self._check(self._lib.bplhip_predict_set_posterior(
+                self._h, s, t, _np_ptr(att), _np_ptr(dfn), _np_ptr(ha), int(ha.ndim == 2), _np_ptr(cc)))
+
+    def predict_score_proba(self, home_idx, away_idx, home_goals, away_goals) -> np.ndarray:
+        h = np.ascontiguousarray(home_idx, dtype=np.uint16)
+        a = np.ascontiguousarray(away_idx, dtype=np.uint16)
+        x = np.ascontiguousarray(home_goals, dtype=np.uint16)
+        y = np.ascontiguousarray(away_goals, dtype=np.uint16)
+        m = h.size
+        if not (a.size == x.size == y.size == m):
+            raise ValueError("query arrays must have equal length")
+        out = np.empty(m, dtype=np.float64)
+        with self._torch.cuda.device(self.device):
+            self._check(self._lib.bplhip_predict_score_proba(
+                self._h, m, _np_ptr(h), _np_ptr(a), _np_ptr(x), _np_ptr(y), _np_ptr(out), self._stream()))
+        return out
 
     # -- sampler
     def nuts_run(self, cfg: NutsCfg, key: Tuple[int, int], z0: Optional[np.ndarray] = None):

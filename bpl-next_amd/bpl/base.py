@@ -38,6 +38,28 @@ class BaseMatchPredictor:
         # unique team names (sorted) and the name -> integer index map
         self.teams = None
         self._teams_dict = None
+        # True: predict_score_proba (and everything built on it) runs on the GPU through
+        # libbplhip's predict kernel instead of host numpy (same results to ~1e-13)
+        self.predict_on_device = False
+        self._predict_ctx = None
+        self._predict_key = None
+
+    def _device_score_proba(self, home_ind, away_ind, home_goals, away_goals) -> np.ndarray:
+        """predict_score_proba on the device for index arrays; scalars are broadcast."""
+        from bpl._ffi import HipContext
+
+        m = len(home_ind)
+        hg = np.broadcast_to(np.asarray(home_goals), (m,)) if np.ndim(home_goals) == 0 else np.asarray(home_goals)
+        ag = np.broadcast_to(np.asarray(away_goals), (m,)) if np.ndim(away_goals) == 0 else np.asarray(away_goals)
+        if self._predict_ctx is None:
+            self._predict_ctx = HipContext(0)
+        key = (id(self.attack), id(self.defence), id(self.home_advantage), id(self.corr_coef),
+               np.shape(self.attack))
+        if key != self._predict_key:
+            self._predict_ctx.predict_set_posterior(self.attack, self.defence,
+                                                    self.home_advantage, self.corr_coef)
+            self._predict_key = key
+        return self._predict_ctx.predict_score_proba(home_ind, away_ind, hg, ag)
 
     @abstractmethod
     def fit(

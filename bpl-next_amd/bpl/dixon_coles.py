@@ -82,6 +82,8 @@ class DixonColesMatchPredictor(BaseMatchPredictor):
         away_goals: Union[int, Iterable[int]],
     ) -> np.ndarray:
         home_team, away_team = self._parse_fixture_args(home_team, away_team)
+        if self.predict_on_device:
+            return self._device_score_proba(home_team, away_team, home_goals, away_goals)
 
         expected_home_goals, expected_away_goals = self._calculate_expected_goals(
             home_team, away_team

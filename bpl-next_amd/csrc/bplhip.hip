@@ -17,6 +17,7 @@
 #include "../../include/bplhip.h"
 #include "dc_dynamic.hip.h"
 #include "dc_kernels.hip.h"
+#include "dc_predict.hip.h"
 #include "nuts.hpp"
 #include "threefry.hpp"
 
@@ -79,6 +80,9 @@ struct bplhip_ctx {
     bool lds_attr_set = false;
     // NUTS scratch (device): z, potential, grad, aux + pinned host mirror
     DevBuf d_nuts, d_ns;
+    // posterior draws for the device predict path (dc_predict.hip.h)
+    DevBuf dp_att, dp_def, dp_ha, dp_corr, dp_q;
+    int pred_S = 0, pred_T = 0, pred_ha_stride = 0;
     double* h_pinned = nullptr;
     size_t h_pinned_bytes = 0;
     // host copies needed by bplhip_constrain (rho bounds over the unique pairs)
@@ -141,17 +145,24 @@ size_t ctx_lds_bytes(const bplhip_ctx* c, bool staged) {
     return dc::eval_lds_bytes(c->L.T, c->L.D, zo_stride_of(c->L), c->n_wg, c->total_c, staged);
 }
 
-template <bool W, bool C, bool S>
-int launch_eval_s(bplhip_ctx* c, const dc::EvalArgs& A, int chains, hipStream_t s) {
+template <bool W, bool C, bool S, bool N>
+int launch_eval_n(bplhip_ctx* c, const dc::EvalArgs& A, int chains, hipStream_t s) {
     const dim3 grid(c->n_wg + 1, chains), block(dc::BLOCK);
     const size_t lds = ctx_lds_bytes(c, S);
-    if (!c->lds_attr_set && lds > 48 * 1024)
-        HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(dc::dc_eval<W, C, S>),
+    if (lds > 48 * 1024) {  // (idempotent; only for large team counts)
+        HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(dc::dc_eval<W, C, S, N>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    c->lds_attr_set = true;
-    hipLaunchKernelGGL((dc::dc_eval<W, C, S>), grid, block, lds, s, A);
+    }
+    hipLaunchKernelGGL((dc::dc_eval<W, C, S, N>), grid, block, lds, s, A);
     HIP_TRY(c, hipGetLastError());
     return BPLHIP_OK;
+}
+template <bool W, bool C, bool S>
+int launch_eval_s(bplhip_ctx* c, const dc::EvalArgs& A, int chains, hipStream_t s) {
+    // the NUTS-aware instantiation is a separate kernel: the plain evaluation carries none
+    // of its code (instruction-cache footprint matters at ~11 us per launch)
+    return A.nuts ? launch_eval_n<W, C, S, true>(c, A, chains, s)
+                  : launch_eval_n<W, C, S, false>(c, A, chains, s);
 }
 template <bool W, bool C>
 int launch_eval_t(bplhip_ctx* c, const dc::EvalArgs& A, int chains, hipStream_t s) {
@@ -766,7 +777,6 @@ struct DeviceEngine {
         double* gr = nd::vec(ns, D, nd::V_GRAD);
         int depth = 0;
         bool stop = false;
-        double evals_before = 0.0;
         bool first_batch = true;
         while (!stop && depth < max_depth) {
             int nb = first_batch ? std::max(1, std::min(last_depth, max_depth)) : 1;
@@ -790,18 +800,17 @@ struct DeviceEngine {
                 hipLaunchKernelGGL(nd::k_end, dim3(1), dim3(64), 0, s, ns, D, max_depth, k_tr.hi,
                                    k_tr.lo);
             }
+            // one read-back per batch: header + the tree's current proposal (final if STOP)
             (void)hipMemcpyAsync(h_hdr, ns, (size_t)nd::H_N * 8, hipMemcpyDeviceToHost, s);
+            (void)hipMemcpyAsync(hp + D + nd::H_N, nd::vec(ns, D, nd::V_TP_Z), (size_t)D * 8,
+                                 hipMemcpyDeviceToHost, s);
             if (!hip_ok(hipStreamSynchronize(s), "sync(doubling)")) return false;
-            if (first_batch) evals_before = 0.0;
             first_batch = false;
             depth = (int)h_hdr[nd::H_T_DEPTH];
             stop = h_hdr[nd::H_STOP] != 0.0;
         }
-        (void)evals_before;
+        // the proposal becomes the chain's current state (no host wait needed)
         hipLaunchKernelGGL(nd::k_finish, dim3(1), dim3(64), 0, s, ns, D);
-        (void)hipMemcpyAsync(hp + D + nd::H_N, nd::vec(ns, D, nd::V_TP_Z), (size_t)D * 8,
-                       hipMemcpyDeviceToHost, s);
-        if (!hip_ok(hipStreamSynchronize(s), "sync(finish)")) return false;
         if (!hip_ok(hipGetLastError(), "launch")) return false;
         const double num = h_hdr[nd::H_T_NUM];
         out->accept_prob = num > 0 ? h_hdr[nd::H_T_SUMACC] / num : 0.0;
@@ -1035,5 +1044,72 @@ extern "C" int bplhip_constrain_dynamic(bplhip_ctx* c, const double* z_draws, in
             }
         }
     }
+    return BPLHIP_OK;
+}
+
+// ---- predict path on the device (row f-2)
+extern "C" int bplhip_predict_set_posterior(bplhip_ctx* c, int32_t s, int32_t t,
+                                            const double* attack, const double* defence,
+                                            const double* home_advantage,
+                                            int32_t home_advantage_per_team,
+                                            const double* corr_coef) {
+    if (!c) return BPLHIP_EINVAL;
+    if (s < 1 || t < 1 || !attack || !defence || !home_advantage || !corr_coef)
+        return fail(c, BPLHIP_EINVAL, "predict_set_posterior: bad argument");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t st = (size_t)s * t * 8, hb = home_advantage_per_team ? st : (size_t)s * 8;
+    HIP_TRY(c, c->dp_att.ensure(st));
+    HIP_TRY(c, c->dp_def.ensure(st));
+    HIP_TRY(c, c->dp_ha.ensure(hb));
+    HIP_TRY(c, c->dp_corr.ensure((size_t)s * 8));
+    HIP_TRY(c, hipMemcpy(c->dp_att.p, attack, st, hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->dp_def.p, defence, st, hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->dp_ha.p, home_advantage, hb, hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->dp_corr.p, corr_coef, (size_t)s * 8, hipMemcpyHostToDevice));
+    c->pred_S = s;
+    c->pred_T = t;
+    c->pred_ha_stride = home_advantage_per_team ? t : 0;
+    return BPLHIP_OK;
+}
+
+extern "C" int bplhip_predict_score_proba(bplhip_ctx* c, int64_t m, const uint16_t* home_idx,
+                                          const uint16_t* away_idx, const uint16_t* home_goals,
+                                          const uint16_t* away_goals, double* out, void* stream) {
+    if (!c) return BPLHIP_EINVAL;
+    if (c->pred_S == 0) return fail(c, BPLHIP_ESTATE, "predict_score_proba: no posterior set");
+    if (m < 0 || (m > 0 && (!home_idx || !away_idx || !home_goals || !away_goals || !out)))
+        return fail(c, BPLHIP_EINVAL, "predict_score_proba: bad argument");
+    if (m == 0) return BPLHIP_OK;
+    for (int64_t i = 0; i < m; ++i)
+        if (home_idx[i] >= c->pred_T || away_idx[i] >= c->pred_T)
+            return fail(c, BPLHIP_EINVAL, "predict_score_proba: team index out of range at %lld",
+                        (long long)i);
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    HIP_TRY(c, c->dp_q.ensure((size_t)m * (4 * 2 + 8)));
+    uint16_t* q = c->dp_q.as<uint16_t>();
+    double* d_out = reinterpret_cast<double*>(c->dp_q.as<char>() + (((size_t)m * 8 + 7) & ~(size_t)7));
+    HIP_TRY(c, hipMemcpyAsync(q, home_idx, (size_t)m * 2, hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(q + m, away_idx, (size_t)m * 2, hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(q + 2 * m, home_goals, (size_t)m * 2, hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(q + 3 * m, away_goals, (size_t)m * 2, hipMemcpyHostToDevice, s));
+    dcp::PredictArgs A{};
+    A.S = c->pred_S;
+    A.T = c->pred_T;
+    A.attack = c->dp_att.as<const double>();
+    A.defence = c->dp_def.as<const double>();
+    A.home_adv = c->dp_ha.as<const double>();
+    A.ha_stride = c->pred_ha_stride;
+    A.corr = c->dp_corr.as<const double>();
+    A.M = m;
+    A.h = q;
+    A.a = q + m;
+    A.x = q + 2 * m;
+    A.y = q + 3 * m;
+    A.out = d_out;
+    hipLaunchKernelGGL(dcp::predict_score_proba, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, A);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(out, d_out, (size_t)m * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
     return BPLHIP_OK;
 }

@@ -676,6 +676,7 @@ __device__ void prior_body(const EvalArgs& A, int chain, char* smem) {
 // Per-team epilogue for T <= 64, executed by ONE wave: lane t owns team t, the adjoint of
 // the bounds is a lane-local add, sums are DPP wave reductions.  Same arithmetic and the
 // same summation order on every run (deterministic).
+template <bool NUTS>
 __device__ void tail_one_wave(const EvalArgs& A, int chain, const double* zoL, const double* cL,
                               const double* zL, const double* col, const double* xsL,
                               double* gradL) {
@@ -684,7 +685,7 @@ __device__ void tail_one_wave(const EvalArgs& A, int chain, const double* zoL, c
     const int t = threadIdx.x & 63;
     const bool on = t < T;
     double* grad = A.grad + (size_t)chain * D;
-    const bool nuts = A.nuts != nullptr;
+    constexpr bool nuts = NUTS;
     auto put = [&](int o, double v) {
         grad[o] = v;
         if (nuts) gradL[o] = v;
@@ -805,7 +806,7 @@ __device__ void tail_one_wave(const EvalArgs& A, int chain, const double* zoL, c
     }
 }
 
-template <bool STAGED>
+template <bool STAGED, bool NUTS>
 __device__ void tail_body(const EvalArgs& A, int chain, char* smem) {
     const Layout& L = A.L;
     const int T = L.T, K = L.K, D = L.D;
@@ -907,7 +908,8 @@ __device__ void tail_body(const EvalArgs& A, int chain, char* smem) {
     }
     __syncthreads();
     if (T <= 64) {  // the whole per-team epilogue fits one wave: no LDS traffic, no barriers
-        if (wave == 0) tail_one_wave(A, chain, zoL, cL, zL, col, xs_staged ? xsL : nullptr, gradL);
+        if (wave == 0)
+            tail_one_wave<NUTS>(A, chain, zoL, cL, zL, col, xs_staged ? xsL : nullptr, gradL);
         DC_STAMP(10);
         return;
     }
@@ -1275,7 +1277,7 @@ __device__ __forceinline__ LaneOut lane_mixed(const LaneData& Ld, float rho, con
 #else
 #define DC_LAUNCH_BOUNDS __launch_bounds__(BLOCK)
 #endif
-template <bool WEIGHTED, bool CLIP, bool STAGED>
+template <bool WEIGHTED, bool CLIP, bool STAGED, bool NUTS>
 __global__ DC_LAUNCH_BOUNDS void dc_eval(EvalArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const Layout& L = A.L;
@@ -1285,7 +1287,7 @@ __global__ DC_LAUNCH_BOUNDS void dc_eval(EvalArgs A) {
     const double* z = A.z + (size_t)chain * L.D;
     DC_STAMP(0);
     // device-resident NUTS: the subtree this launch belonged to may already be complete
-    const double nuts_done = A.nuts ? A.nuts[nd::H_S_DONE] : 0.0;
+    const double nuts_done = NUTS ? A.nuts[nd::H_S_DONE] : 0.0;
 
     // LDS carve of the streaming part (all offsets multiples of 16 B)
     float2* tabH = reinterpret_cast<float2*>(smem);            // {exp(att+ha), exp(-def)}
@@ -1296,7 +1298,7 @@ __global__ DC_LAUNCH_BOUNDS void dc_eval(EvalArgs A) {
     int* shflag = reinterpret_cast<int*>(redm + WAVES * 4);  // dynamic LDS only (G17)
 
     if (blockIdx.x == 0) {
-        if (nuts_done != 0.0) return;
+        if (NUTS && nuts_done != 0.0) return;
         prior_body<CLIP>(A, chain, smem);
         DC_STAMP(4);
     } else {
@@ -1315,7 +1317,7 @@ __global__ DC_LAUNCH_BOUNDS void dc_eval(EvalArgs A) {
             slot0 = A.wg_slots[o0 + tid];
             dst0 = A.wg_dst[o0 + tid];
         }
-        if (nuts_done != 0.0) return;  // (uniform over the whole grid)
+        if (NUTS && nuts_done != 0.0) return;  // (uniform over the whole grid)
 
         // ---- 1. per-team tables (float32) + zero accumulators
         F32Scalars fs;
@@ -1450,7 +1452,7 @@ __global__ DC_LAUNCH_BOUNDS void dc_eval(EvalArgs A) {
     DC_STAMP(6);
     if (*shflag == 0) return;
     __syncthreads();
-    tail_body<STAGED>(A, chain, smem);
+    tail_body<STAGED, NUTS>(A, chain, smem);
 }
 
 }  // namespace dc

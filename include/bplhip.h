@@ -218,6 +218,21 @@ int bplhip_nuts_run(bplhip_ctx* ctx, const bplhip_nuts_cfg* cfg, const double* z
 int bplhip_constrain(bplhip_ctx* ctx, const double* z_draws, int64_t s, double* attack,
                      double* defence, double* home_advantage, double* corr_coef);
 
+/* ---- predict path on the device (post-fit).
+ * bplhip_predict_set_posterior uploads the posterior draws the reference keeps as
+ * attributes after fit (bpl/dixon_coles.py:118-122): attack/defence f64[s,t],
+ * home_advantage f64[s] (basic) or f64[s,t] (extended, home_advantage_per_team = 1),
+ * corr_coef f64[s] -- HOST pointers.  bplhip_predict_score_proba evaluates
+ * `predict_score_proba` (bpl/dixon_coles.py:139-163, bpl/extended_dixon_coles.py:360-399):
+ * out[i] = mean over draws of exp(tau term) * Poisson(x_i; home rate) * Poisson(y_i; away
+ * rate), HOST u16[m] in, HOST f64[m] out, synchronous.  No fixtures need to be bound. */
+int bplhip_predict_set_posterior(bplhip_ctx* ctx, int32_t s, int32_t t, const double* attack,
+                                 const double* defence, const double* home_advantage,
+                                 int32_t home_advantage_per_team, const double* corr_coef);
+int bplhip_predict_score_proba(bplhip_ctx* ctx, int64_t m, const uint16_t* home_idx,
+                               const uint16_t* away_idx, const uint16_t* home_goals,
+                               const uint16_t* away_goals, double* out, void* stream);
+
 /* threefry2x32 helpers with jax.random semantics (jax 0.4.24, non-partitionable
  * threefry): used by the Python host for key plumbing (random.split for multi-chain
  * runs, bpl/dixon_coles.py:107).  out has 2*n words: n keys (hi, lo). */

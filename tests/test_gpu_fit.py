@@ -210,3 +210,33 @@ def test_device_tree_matches_host_tree(hip_ctx):
             assert np.isfinite(d).all() and st["total_divergences"] == 0
             assert 0.55 < st["mean_accept_prob"] <= 1.0
         hip_ctx.set_option("device_nuts", 1)
+
+
+@pytest.mark.parametrize("model_cls", MODELS)
+def test_device_predict_matches_host_predict(fitted, model_cls):
+    """Row f-2: predict_score_proba / outcome / n-goals through the HIP predict kernel equal
+    the host numpy path (float64 both; tolerance 1e-12)."""
+    models, dd = fitted
+    model = models[model_cls]
+    host = {
+        "score": model.predict_score_proba(dd["home_team"], dd["away_team"], dd["home_goals"], dd["away_goals"]),
+        "single": model.predict_score_proba("0", "1", 1, 0),
+        "outcome": model.predict_outcome_proba(dd["home_team"][:40], dd["away_team"][:40]),
+        "n": model.predict_score_n_proba(np.arange(MAX_GOALS + 1), "0", "1"),
+    }
+    model.predict_on_device = True
+    try:
+        dev = {
+            "score": model.predict_score_proba(dd["home_team"], dd["away_team"], dd["home_goals"], dd["away_goals"]),
+            "single": model.predict_score_proba("0", "1", 1, 0),
+            "outcome": model.predict_outcome_proba(dd["home_team"][:40], dd["away_team"][:40]),
+            "n": model.predict_score_n_proba(np.arange(MAX_GOALS + 1), "0", "1"),
+        }
+    finally:
+        model.predict_on_device = False
+    assert np.abs(dev["score"] - host["score"]).max() < 1e-12
+    assert np.abs(dev["single"] - host["single"]).max() < 1e-12
+    assert np.abs(dev["n"] - host["n"]).max() < 1e-12
+    for k in ("home_win", "draw", "away_win"):
+        assert np.abs(dev["outcome"][k] - host["outcome"][k]).max() < 1e-12
+    assert np.allclose(dev["outcome"]["home_win"] + dev["outcome"]["draw"] + dev["outcome"]["away_win"], 1.0, atol=1e-5)
