@@ -18,6 +18,7 @@
 #include "dc_dynamic.hip.h"
 #include "dc_kernels.hip.h"
 #include "dc_predict.hip.h"
+#include "dc_vec.hip.h"
 #include "nuts.hpp"
 #include "threefry.hpp"
 
@@ -77,6 +78,14 @@ struct bplhip_ctx {
     // tuning options (bplhip_set_option)
     int opt_device_nuts = 1;  // 1: tree builder on the device (nuts_dev.hip.h) when supported
     int opt_max_wg = 255;  // streaming workgroups (+1 prior workgroup = one per CU)
+    int opt_vec_min_chains = 4;  // batched calls with at least this many chains use dc_vec (0: never)
+    int opt_vec_tpw = 2;         // minimum tiles per wave of the chain-vectorised partition
+    // chain-vectorised partition (dc_vec.hip.h): fewer, fatter workgroups, own sparse structure
+    struct VecPart {
+        bool ok = false, staged = true;
+        int tpw = 1, n_wg = 1, total_c = 0, slab_chains = 0;
+        DevBuf d_wg_off, d_wg_slots, d_col_off, d_wg_dst, d_hbuf;
+    } vp;
     bool lds_attr_set = false;
     // NUTS scratch (device): z, potential, grad, aux + pinned host mirror
     DevBuf d_nuts, d_ns;
@@ -210,9 +219,8 @@ int launch_eval_dynamic(bplhip_ctx* c, int chains, const double* z, double* pot,
     return BPLHIP_OK;
 }
 
-int launch_eval(bplhip_ctx* c, int chains, const double* z, double* pot, double* grad,
-                double* aux, hipStream_t s, double* nuts_state = nullptr, int nuts_depth = 0) {
-    if (c->dynamic) return launch_eval_dynamic(c, chains, z, pot, grad, aux, s);
+dc::EvalArgs eval_args(bplhip_ctx* c, int chains, const double* z, double* pot, double* grad,
+                       double* aux) {
     dc::EvalArgs A{};
     A.h = c->d_h.as<const uint32_t>();
     A.a = c->d_a.as<const uint32_t>();
@@ -239,19 +247,121 @@ int launch_eval(bplhip_ctx* c, int chains, const double* z, double* pot, double*
     A.n_wg = c->n_wg;
     A.zo_stride = zo_stride_of(c->L);
     A.tickets = c->d_tickets.as<unsigned int>();
+    A.chains = chains;
     A.z = z;
     A.potential = pot;
     A.grad = grad;
     A.aux = aux;
     A.debug = c->d_debug.as<unsigned long long>();
+    A.L = c->L;
+    return A;
+}
+
+int launch_eval(bplhip_ctx* c, int chains, const double* z, double* pot, double* grad,
+                double* aux, hipStream_t s, double* nuts_state = nullptr, int nuts_depth = 0) {
+    if (c->dynamic) return launch_eval_dynamic(c, chains, z, pot, grad, aux, s);
+    dc::EvalArgs A = eval_args(c, chains, z, pot, grad, aux);
     A.nuts = nuts_state;
     A.nuts_max_depth = nuts_depth;
-    A.L = c->L;
     const bool clip = c->L.model == dc::MODEL_EXTENDED;
     if (c->weighted) return clip ? launch_eval_t<true, true>(c, A, chains, s)
                                  : launch_eval_t<true, false>(c, A, chains, s);
     return clip ? launch_eval_t<false, true>(c, A, chains, s)
                 : launch_eval_t<false, false>(c, A, chains, s);
+}
+
+// ---- chain-vectorised evaluation (dc_vec.hip.h): stream launch + tail launch
+int vec_hb_stride(const bplhip_ctx* c) {
+    return (zo_stride_of(c->L) + c->vp.n_wg * dc::N_SCAL + c->vp.total_c + 1) & ~1;
+}
+size_t vec_tail_lds(const bplhip_ctx* c, bool staged) {
+    return dc::tail_lds_bytes(c->L.T, c->L.D, zo_stride_of(c->L), c->vp.n_wg, c->vp.total_c, staged);
+}
+template <bool W, bool C>
+int launch_vec_t(bplhip_ctx* c, const dc::EvalArgs& A, int chains, hipStream_t s) {
+    const int groups = (chains + dc::CB - 1) / dc::CB;
+    const size_t lds = std::max(dc::vec_stream_lds_bytes(c->L.T), dc::prior_lds_bytes(c->L.T));
+    if (lds > 48 * 1024)
+        HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(dc::dc_vec_stream<W, C>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((dc::dc_vec_stream<W, C>), dim3(dc::CB + c->vp.n_wg, groups),
+                       dim3(dc::BLOCK), lds, s, A);
+    const size_t tl = vec_tail_lds(c, c->vp.staged);
+    if (c->vp.staged) {
+        if (tl > 48 * 1024)
+            HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(dc::dc_vec_tail<true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)tl));
+        hipLaunchKernelGGL((dc::dc_vec_tail<true>), dim3(chains), dim3(dc::BLOCK), tl, s, A);
+    } else {
+        if (tl > 48 * 1024)
+            HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(dc::dc_vec_tail<false>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)tl));
+        hipLaunchKernelGGL((dc::dc_vec_tail<false>), dim3(chains), dim3(dc::BLOCK), tl, s, A);
+    }
+    HIP_TRY(c, hipGetLastError());
+    return BPLHIP_OK;
+}
+int launch_eval_vec(bplhip_ctx* c, int chains, const double* z, double* pot, double* grad,
+                    double* aux, hipStream_t s) {
+    if (chains > c->vp.slab_chains) {
+        HIP_TRY(c, c->vp.d_hbuf.ensure((size_t)chains * vec_hb_stride(c) * sizeof(double)));
+        c->vp.slab_chains = chains;
+    }
+    dc::EvalArgs A = eval_args(c, chains, z, pot, grad, aux);
+    A.tiles_per_wave = c->vp.tpw;
+    A.wg_off = c->vp.d_wg_off.as<const int>();
+    A.wg_slots = c->vp.d_wg_slots.as<const int>();
+    A.col_off = c->vp.d_col_off.as<const int>();
+    A.wg_dst = c->vp.d_wg_dst.as<const int>();
+    A.total_c = c->vp.total_c;
+    A.hbuf = c->vp.d_hbuf.as<double>();
+    A.hb_stride = vec_hb_stride(c);
+    A.n_wg = c->vp.n_wg;
+    A.tickets = nullptr;
+    const bool clip = c->L.model == dc::MODEL_EXTENDED;
+    if (c->weighted) return clip ? launch_vec_t<true, true>(c, A, chains, s)
+                                 : launch_vec_t<true, false>(c, A, chains, s);
+    return clip ? launch_vec_t<false, true>(c, A, chains, s)
+                : launch_vec_t<false, false>(c, A, chains, s);
+}
+
+bool use_vec(const bplhip_ctx* c, int chains) {
+    return !c->dynamic && c->vp.ok && c->opt_vec_min_chains > 0 && chains >= c->opt_vec_min_chains;
+}
+
+// Static sparse-slab structure: which of the 3T per-team slots each streaming workgroup's
+// fixtures touch (att[h], ha[h], def[a], att[a], def[h]), and the transposed (per column,
+// workgroup order) position lists for the tail's reduction.
+struct SparseSlabs {
+    std::vector<int> wg_off, wg_slots, col_off, wg_dst;
+};
+SparseSlabs build_sparse_slabs(const std::vector<uint16_t>& hs, const std::vector<uint16_t>& as,
+                               int64_t n, int T, int tpw, int n_wg) {
+    SparseSlabs o;
+    o.wg_off.assign(n_wg + 1, 0);
+    o.col_off.assign(3 * T + 1, 0);
+    std::vector<char> touched(3 * (size_t)T);
+    const int64_t per_wg = (int64_t)tpw * dc::WAVES * dc::TILE;
+    for (int w = 0; w < n_wg; ++w) {
+        std::fill(touched.begin(), touched.end(), 0);
+        const int64_t r0 = (int64_t)w * per_wg, r1 = std::min<int64_t>(n, r0 + per_wg);
+        for (int64_t r = r0; r < r1; ++r) {
+            const int hh = hs[r], aa = as[r];
+            touched[hh] = touched[2 * T + hh] = touched[T + aa] = 1;
+            touched[aa] = touched[T + hh] = 1;
+        }
+        for (int sidx = 0; sidx < 3 * T; ++sidx)
+            if (touched[sidx]) o.wg_slots.push_back(sidx);
+        o.wg_off[w + 1] = (int)o.wg_slots.size();
+    }
+    const int total = (int)o.wg_slots.size();
+    for (int k = 0; k < total; ++k) o.col_off[o.wg_slots[k] + 1] += 1;
+    for (int cidx = 0; cidx < 3 * T; ++cidx) o.col_off[cidx + 1] += o.col_off[cidx];
+    o.wg_dst.resize(std::max(total, 1));
+    std::vector<int> fill(o.col_off.begin(), o.col_off.end() - 1);
+    for (int k = 0; k < total; ++k) o.wg_dst[k] = fill[o.wg_slots[k]]++;  // k ascending = wg order
+    if (o.wg_slots.empty()) o.wg_slots.push_back(0);
+    return o;
 }
 
 void drop_graphs(bplhip_ctx* c) {
@@ -385,33 +495,9 @@ int bplhip_set_fixtures(bplhip_ctx* c, int model_kind, int64_t n, int32_t n_team
     const int waves = (n_tiles + tpw - 1) / tpw;
     const int n_wg = (waves + dc::WAVES - 1) / dc::WAVES;
 
-    // ---- static sparse-slab structure: which of the 3T per-team slots each streaming
-    // workgroup's fixtures touch (att[h], ha[h], def[a], att[a], def[h]), and the
-    // transposed (per column, workgroup order) position lists for the tail's reduction
-    std::vector<int> wg_off(n_wg + 1, 0), wg_slots, col_off(3 * T + 1, 0), wg_dst;
-    {
-        std::vector<char> touched(3 * (size_t)T);
-        const int64_t per_wg = (int64_t)tpw * dc::WAVES * dc::TILE;
-        for (int w = 0; w < n_wg; ++w) {
-            std::fill(touched.begin(), touched.end(), 0);
-            const int64_t r0 = (int64_t)w * per_wg, r1 = std::min<int64_t>(n, r0 + per_wg);
-            for (int64_t r = r0; r < r1; ++r) {
-                const int hh = hs[r], aa = as[r];
-                touched[hh] = touched[2 * T + hh] = touched[T + aa] = 1;
-                touched[aa] = touched[T + hh] = 1;
-            }
-            for (int sidx = 0; sidx < 3 * T; ++sidx)
-                if (touched[sidx]) wg_slots.push_back(sidx);
-            wg_off[w + 1] = (int)wg_slots.size();
-        }
-        const int total = (int)wg_slots.size();
-        for (int k = 0; k < total; ++k) col_off[wg_slots[k] + 1] += 1;
-        for (int cidx = 0; cidx < 3 * T; ++cidx) col_off[cidx + 1] += col_off[cidx];
-        wg_dst.resize(std::max(total, 1));
-        std::vector<int> fill(col_off.begin(), col_off.end() - 1);
-        for (int k = 0; k < total; ++k) wg_dst[k] = fill[wg_slots[k]]++;  // k ascending = wg order
-        if (wg_slots.empty()) wg_slots.push_back(0);
-    }
+    SparseSlabs sp = build_sparse_slabs(hs, as, n, T, tpw, n_wg);
+    std::vector<int>&wg_off = sp.wg_off, &wg_slots = sp.wg_slots, &col_off = sp.col_off,
+    &wg_dst = sp.wg_dst;
 
     // ---- upload
     HIP_TRY(c, c->d_wg_off.ensure(wg_off.size() * 4));
@@ -473,6 +559,29 @@ int bplhip_set_fixtures(bplhip_ctx* c, int model_kind, int64_t n, int32_t n_team
         return fail(c, BPLHIP_EUNSUPPORTED, "set_fixtures: tail LDS footprint too large");
     int rc = ensure_slabs(c, 1);
     if (rc != BPLHIP_OK) return rc;
+
+    // ---- chain-vectorised partition: fewer, fatter workgroups (the per-workgroup prologue
+    // of 8 chains' tables is amortised over more tiles)
+    {
+        auto& vp = c->vp;
+        vp.ok = false;
+        vp.slab_chains = 0;
+        vp.tpw = std::max(tpw, c->opt_vec_tpw);
+        const int vwaves = (n_tiles + vp.tpw - 1) / vp.tpw;
+        vp.n_wg = (vwaves + dc::WAVES - 1) / dc::WAVES;
+        const SparseSlabs vs = build_sparse_slabs(hs, as, n, T, vp.tpw, vp.n_wg);
+        vp.total_c = vs.wg_off[vp.n_wg];
+        HIP_TRY(c, vp.d_wg_off.ensure(vs.wg_off.size() * 4));
+        HIP_TRY(c, vp.d_wg_slots.ensure(vs.wg_slots.size() * 4));
+        HIP_TRY(c, vp.d_col_off.ensure(vs.col_off.size() * 4));
+        HIP_TRY(c, vp.d_wg_dst.ensure(vs.wg_dst.size() * 4));
+        HIP_TRY(c, hipMemcpy(vp.d_wg_off.p, vs.wg_off.data(), vs.wg_off.size() * 4, hipMemcpyHostToDevice));
+        HIP_TRY(c, hipMemcpy(vp.d_wg_slots.p, vs.wg_slots.data(), vs.wg_slots.size() * 4, hipMemcpyHostToDevice));
+        HIP_TRY(c, hipMemcpy(vp.d_col_off.p, vs.col_off.data(), vs.col_off.size() * 4, hipMemcpyHostToDevice));
+        HIP_TRY(c, hipMemcpy(vp.d_wg_dst.p, vs.wg_dst.data(), vs.wg_dst.size() * 4, hipMemcpyHostToDevice));
+        vp.staged = vec_tail_lds(c, true) <= 96 * 1024;
+        vp.ok = dc::vec_stream_lds_bytes(T) <= 64 * 1024 && vec_tail_lds(c, vp.staged) <= LDS_LIMIT;
+    }
     c->bound = true;
     return BPLHIP_OK;
 }
@@ -482,6 +591,16 @@ int bplhip_set_option(bplhip_ctx* c, const char* name, int value) {
     const std::string n(name);
     if (n == "device_nuts") {
         c->opt_device_nuts = value != 0;
+        return BPLHIP_OK;
+    }
+    if (n == "vec_min_chains") {  // batched calls with >= value chains use the vectorised kernel
+        if (value < 0) return fail(c, BPLHIP_EINVAL, "vec_min_chains must be >= 0");
+        c->opt_vec_min_chains = value;
+        return BPLHIP_OK;
+    }
+    if (n == "vec_tiles_per_wave") {  // takes effect at the next bplhip_set_fixtures
+        if (value < 1 || value > 4096) return fail(c, BPLHIP_EINVAL, "vec_tiles_per_wave out of range");
+        c->opt_vec_tpw = value;
         return BPLHIP_OK;
     }
     if (n == "max_wg") {  // takes effect at the next bplhip_set_fixtures
@@ -578,6 +697,8 @@ int bplhip_logp_grad_batched(bplhip_ctx* c, int32_t n_chains, const double* z,
     if (n_chains < 1 || n_chains > 65535)
         return fail(c, BPLHIP_EINVAL, "logp_grad: n_chains=%d out of range", n_chains);
     HIP_TRY(c, hipSetDevice(c->device));
+    if (use_vec(c, n_chains))
+        return launch_eval_vec(c, n_chains, z, potential, grad, aux, static_cast<hipStream_t>(stream));
     if (!c->dynamic) {
         int rc = ensure_slabs(c, n_chains);
         if (rc != BPLHIP_OK) return rc;

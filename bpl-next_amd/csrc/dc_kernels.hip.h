@@ -98,6 +98,7 @@ struct EvalArgs {
     int n_wg;               // streaming workgroups (grid.x = n_wg + 1)
     int zo_stride;
     unsigned int* tickets;  // [chains] arrival counters
+    int chains;             // number of chains of this launch (dc_vec.hip.h)
     // in / out
     const double* z;        // [chains][D]
     double* potential;      // [chains]

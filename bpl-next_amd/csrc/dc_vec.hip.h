@@ -1,0 +1,345 @@
+// dc_vec.hip.h -- chain-vectorised evaluation (numpyro chain_method="vectorized",
+// bplhip_logp_grad_batched): one streaming workgroup carries CB = 8 chains through its
+// fixtures at once.
+//
+// Everything that depends on the fixtures only is done ONCE per lane and shared by the
+// chains: the loads, the unpacking, the pair of the lane's run and its score-class counts
+// (SWAR classification).  Per chain and lane what remains is two LDS gathers, two
+// products, three tau terms and a handful of FMAs -- about 9 VALU operations per
+// (fixture, chain) instead of ~45 for one chain alone, and the fixture bytes cross HBM/L2
+// once per 8 chains.
+//
+//   dc_vec_stream  grid = (CB + n_wg) x ceil(chains / CB), 512 threads.
+//     blocks 0..CB-1   prior workgroup of chain group*CB + blockIdx.x (prior_body, unchanged)
+//     blocks CB..      streaming: wave b builds chain b's float32 tables and rho (no
+//                      cross-wave reduction), then all 8 waves stream the workgroup's
+//                      tiles for all 8 chains.  A lane whose 8 fixtures span several
+//                      pairs is processed run by run (masked classification), so the
+//                      per-chain arithmetic is always the run-level one.
+//   dc_vec_tail    grid = chains: tail_body of dc_kernels.hip.h, one workgroup per chain
+//                  (a kernel boundary replaces the ticket of the single-chain launch).
+//
+// Same hand-off record per chain as dc_eval ([zo | scal | compact]), same arithmetic per
+// run; only the grouping of the float32 partial sums differs.
+#pragma once
+#include "dc_kernels.hip.h"
+
+namespace dc {
+
+constexpr int CB = WAVES;  // chains per streaming workgroup (wave b prepares chain b)
+
+__host__ __device__ inline int vec_acc_len(int T) { return (3 * (T + 1) + 1) & ~1; }
+__host__ __device__ inline size_t vec_stream_lds_bytes(int T) {
+    size_t b = (size_t)CB * 2 * tab_len(T) * 8;   // tables (float2)
+    b += (size_t)CB * vec_acc_len(T) * 8;         // accumulators (double)
+    b += (size_t)WAVES * CB * 2 * 8;              // red: V, SU per wave and chain
+    b += (size_t)CB * 4 + 32;                     // rho
+    return b;
+}
+
+// what a lane knows about one run of equal (home, away) among its fixtures: shared by
+// all chains
+struct LaneClass {
+    uint32_t key;                              // home | away << 16
+    float n00, n10, n01, n11, nall, sx, sy;    // (weighted) score-class counts, goal sums
+};
+
+// Take the first not yet processed run of the lane (fixtures in `rem`), classify its
+// fixtures, and remove them from `rem`.  A lane with rem == 0 returns an empty run on the
+// sentinel team (zero table entries: contributes exactly 0).
+template <bool WEIGHTED>
+__device__ __forceinline__ LaneClass classify(const LaneData& Ld, uint32_t& rem, uint32_t sentinel) {
+    LaneClass c;
+    constexpr uint32_t ALL = (1u << LANE_FIX) - 1u;
+    const uint32_t h0 = Ld.hw[0] & 0xFFFFu, a0 = Ld.aw[0] & 0xFFFFu;
+    uint32_t mixed = 0;
+#pragma unroll
+    for (int q = 0; q < HWORDS; ++q)
+        mixed |= (Ld.hw[q] ^ (h0 * 0x00010001u)) | (Ld.aw[q] ^ (a0 * 0x00010001u));
+    if (!WEIGHTED && rem == ALL && mixed == 0) {  // the common case: one pair, SWAR counts
+        const uint32_t one = 0x01010101u;
+        int c00 = 0, c10 = 0, c01 = 0, c11 = 0;
+        uint32_t ax = 0, ay = 0;
+#pragma unroll
+        for (int q = 0; q < XWORDS; ++q) {
+            const uint32_t x = Ld.xw[q], y = Ld.yw[q];
+            c00 += __popc(zero_bytes(x | y));
+            c10 += __popc(zero_bytes((x ^ one) | y));
+            c01 += __popc(zero_bytes(x | (y ^ one)));
+            c11 += __popc(zero_bytes((x ^ one) | (y ^ one)));
+            ax = __builtin_amdgcn_sad_u8(x, 0u, ax);
+            ay = __builtin_amdgcn_sad_u8(y, 0u, ay);
+        }
+        c.key = h0 | (a0 << 16);
+        c.n00 = (float)c00; c.n10 = (float)c10; c.n01 = (float)c01; c.n11 = (float)c11;
+        c.nall = (float)LANE_FIX;
+        c.sx = (float)ax;
+        c.sy = (float)ay;
+        rem = 0;
+        return c;
+    }
+    uint32_t key = sentinel | (sentinel << 16);
+    bool have = false;
+    uint32_t members = 0;
+    c.n00 = c.n10 = c.n01 = c.n11 = c.nall = c.sx = c.sy = 0.f;
+#pragma unroll
+    for (int j = 0; j < LANE_FIX; ++j) {
+        const uint32_t hj = (Ld.hw[j >> 1] >> (16 * (j & 1))) & 0xFFFFu;
+        const uint32_t aj = (Ld.aw[j >> 1] >> (16 * (j & 1))) & 0xFFFFu;
+        const uint32_t xj = (Ld.xw[j >> 2] >> (8 * (j & 3))) & 0xFFu;
+        const uint32_t yj = (Ld.yw[j >> 2] >> (8 * (j & 3))) & 0xFFu;
+        const uint32_t kj = hj | (aj << 16);
+        const bool r = (rem >> j) & 1u;
+        if (r && !have) {
+            key = kj;
+            have = true;
+        }
+        const bool m = r && kj == key;
+        members |= m ? (1u << j) : 0u;
+        const float wv = m ? (WEIGHTED ? Ld.wj[j] : 1.0f) : 0.0f;
+        c.n00 += (xj | yj) == 0 ? wv : 0.f;
+        c.n10 += (xj == 1 && yj == 0) ? wv : 0.f;
+        c.n01 += (xj == 0 && yj == 1) ? wv : 0.f;
+        c.n11 += (xj == 1 && yj == 1) ? wv : 0.f;
+        c.nall += wv;
+        c.sx += wv * (float)xj;
+        c.sy += wv * (float)yj;
+    }
+    c.key = key;
+    rem &= ~members;
+    return c;
+}
+
+struct ChainOut {
+    float rsh, rsa;  // -(dL/d eta_h), -(dL/d eta_a) of the run, without the goal counts
+    float slam, slog, su, sclip;
+};
+
+// one chain's terms of one run (same arithmetic as lane_uniform of dc_kernels.hip.h)
+template <bool CLIP>
+__device__ __forceinline__ ChainOut chain_terms(const LaneClass& c, float rho, const float2* tabH,
+                                                const float2* tabA, float l11, float u11) {
+    const float2 th = tabH[c.key & 0xFFFFu], ta = tabA[c.key >> 16];
+    float lh = th.x * ta.y;  // exp(att[h] + ha[h]) * exp(-def[a])
+    float la = ta.x * th.y;  // exp(att[a]) * exp(-def[h])
+    const float lh_raw = lh, la_raw = la;
+    bool ch = false, ca = false;
+    if (CLIP) {
+        ch = lh > (float)RATE_CLIP;
+        ca = la > (float)RATE_CLIP;
+        lh = ch ? (float)RATE_CLIP : lh;
+        la = ca ? (float)RATE_CLIP : la;
+    }
+    float l00, u00, l10, u10, l01, u01;
+    class_terms(rho, -lh * la, &l00, &u00);
+    class_terms(rho, la, &l10, &u10);
+    class_terms(rho, lh, &l01, &u01);
+    ChainOut o;
+    o.slam = c.nall * (lh + la);
+    o.slog = (c.n00 != 0.f ? c.n00 * l00 : 0.f) + (c.n10 != 0.f ? c.n10 * l10 : 0.f) +
+             (c.n01 != 0.f ? c.n01 * l01 : 0.f) + (c.n11 != 0.f ? c.n11 * l11 : 0.f);
+    o.su = c.n00 * u00 + c.n10 * u10 + c.n01 * u01 + c.n11 * u11;
+    o.rsh = c.nall * lh - rho * (c.n00 * u00 + c.n01 * u01);
+    o.rsa = c.nall * la - rho * (c.n00 * u00 + c.n10 * u10);
+    o.sclip = 0.f;
+    if (CLIP) {
+        if (ch) {
+            o.rsh = c.sx;
+            o.sclip += c.sx * (__logf(lh_raw) - (float)LOG_RATE_CLIP);
+        }
+        if (ca) {
+            o.rsa = c.sy;
+            o.sclip += c.sy * (__logf(la_raw) - (float)LOG_RATE_CLIP);
+        }
+    }
+    return o;
+}
+
+// value of chain `lane` out of CB wave-uniform values (lanes >= CB get the last one)
+__device__ __forceinline__ float pick_chain(const float (&v)[CB], int lane) {
+    float r = v[CB - 1];
+#pragma unroll
+    for (int b = CB - 2; b >= 0; --b) r = lane == b ? v[b] : r;
+    return r;
+}
+
+template <bool WEIGHTED, bool CLIP>
+__global__ __launch_bounds__(BLOCK) void dc_vec_stream(EvalArgs A) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const Layout& L = A.L;
+    const int T = L.T, T1 = T + 1, tl = tab_len(T), accn = vec_acc_len(T);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int chain0 = blockIdx.y * CB;
+
+    if (blockIdx.x < CB) {  // prior workgroups of this group's chains
+        const int chain = chain0 + blockIdx.x;
+        if (chain < A.chains) prior_body<CLIP>(A, chain, smem);
+        return;
+    }
+    const int wgi = blockIdx.x - CB;
+
+    // ---- 0. the first tile's loads before anything else
+    const int gw = wgi * WAVES + wave;
+    int tile = gw * A.tiles_per_wave;
+    const int tile_end = min(tile + A.tiles_per_wave, A.n_tiles);
+    LaneData cur{};
+    if (tile < tile_end) cur = load_lane<WEIGHTED>(A, (size_t)tile * 64 + lane);
+    const int o0 = A.wg_off[wgi], o1 = A.wg_off[wgi + 1];
+
+    float2* tab = reinterpret_cast<float2*>(smem);                   // [CB][2][tl]
+    double* acc = reinterpret_cast<double*>(tab + (size_t)CB * 2 * tl);  // [CB][accn]
+    double* red = acc + (size_t)CB * accn;                           // [WAVES][CB][2]
+    float* rhoL = reinterpret_cast<float*>(red + WAVES * CB * 2);    // [CB]
+
+    // ---- 1. wave b: chain b's float32 tables, zeroed accumulators, rho
+    {
+        const int b = wave;
+        const int chain = min(chain0 + b, A.chains - 1);  // (a padding chain repeats the last)
+        const double* z = A.z + (size_t)chain * L.D;
+        const F32Scalars fs = f32_scalars(L, z);
+        float2* tH = tab + (size_t)(2 * b) * tl;
+        float2* tA = tH + tl;
+        for (int t = lane; t <= T; t += 64) {
+            float2 vh = make_float2(0.f, 0.f), va = vh;
+            if (t < T) f32_table_entry(L, fs, z, A.xsf, t, &vh, &va);
+            tH[t] = vh;
+            tA[t] = va;
+        }
+        for (int i = lane; i < accn; i += 64) acc[(size_t)b * accn + i] = 0.0;
+        __syncthreads();
+        float mP = 0.f, mQ = 0.f, mR = 0.f;  // bpl/_util.py:23-30 over the unique pairs
+        for (int p = lane; p < A.P; p += 64) {
+            const uint32_t pr = A.pairs[p];
+            const float2 th = tH[pr & 0xFFFFu], ta = tA[pr >> 16];
+            float lh = th.x * ta.y, la = ta.x * th.y;
+            if (CLIP) {
+                lh = fminf(lh, (float)RATE_CLIP);
+                la = fminf(la, (float)RATE_CLIP);
+            }
+            mP = fmaxf(mP, lh * la);
+            mQ = fmaxf(mQ, lh);
+            mR = fmaxf(mR, la);
+        }
+        mP = wave_max_f32(mP);
+        mQ = wave_max_f32(mQ);
+        mR = wave_max_f32(mR);
+        if (lane == 0) rhoL[b] = rho_f32(mP, mQ, mR, fs.q);
+        __syncthreads();
+    }
+    float rho[CB], l11[CB], u11[CB];
+#pragma unroll
+    for (int b = 0; b < CB; ++b) {
+        rho[b] = rhoL[b];
+        class_terms(rho[b], -1.0f, &l11[b], &u11[b]);
+    }
+
+    // ---- 2. stream the fixtures, all chains per lane
+    double dV[CB], dSU[CB];  // per lane: ln2*SLOG - SLAM - CLIPC, and SU
+#pragma unroll
+    for (int b = 0; b < CB; ++b) dV[b] = dSU[b] = 0.0;
+    const uint32_t sentinel = (uint32_t)T;
+    while (tile < tile_end) {
+        LaneData nxt = cur;
+        if (tile + 1 < tile_end) nxt = load_lane<WEIGHTED>(A, (size_t)(tile + 1) * 64 + lane);
+
+        float prs[CB], pra[CB];  // the lane's last run stays pending (merges across lanes)
+        uint32_t pkey = sentinel | (sentinel << 16);
+#pragma unroll
+        for (int b = 0; b < CB; ++b) prs[b] = pra[b] = 0.f;
+        uint32_t rem = (1u << LANE_FIX) - 1u;
+        do {
+            const bool act = rem != 0;
+            const LaneClass lc = classify<WEIGHTED>(cur, rem, sentinel);
+            const bool more = rem != 0;  // further runs in this lane: this one is complete
+#pragma unroll
+            for (int b = 0; b < CB; ++b) {
+                const float2* tH = tab + (size_t)(2 * b) * tl;
+                const ChainOut o = chain_terms<CLIP>(lc, rho[b], tH, tH + tl, l11[b], u11[b]);
+                double v = fma((double)LN2, (double)o.slog, -(double)o.slam);
+                if (CLIP) v -= (double)o.sclip;
+                dV[b] += v;
+                dSU[b] += (double)o.su;
+                prs[b] = act ? o.rsh : prs[b];
+                pra[b] = act ? o.rsa : pra[b];
+            }
+            pkey = act ? lc.key : pkey;
+            if (more) {  // (rare) a finished run inside the lane goes straight to LDS
+#pragma unroll
+                for (int b = 0; b < CB; ++b)
+                    flush_run(acc + (size_t)b * accn, T1, pkey, prs[b], pra[b]);
+            }
+        } while (__ballot(rem != 0) != 0ull);
+
+        // ---- per-(home,away) run sums across the wave: DPP, then float64 LDS accumulators
+        const uint32_t kprev = prev_lane_u32(pkey, ~pkey);
+        const unsigned long long heads = __ballot(kprev != pkey);  // lane 0 always a head
+        const int nruns = __popcll(heads);
+        if (nruns <= RUN_LOOP_MAX) {
+            unsigned long long hd = heads;
+            while (hd) {
+                const int first = __ffsll((long long)hd) - 1;
+                hd &= hd - 1;
+                const int stop = hd ? __ffsll((long long)hd) - 1 : 64;
+                const bool in = lane >= first && lane < stop;
+                const uint32_t kk = (uint32_t)__builtin_amdgcn_readlane((int)pkey, first);
+                float sh[CB], sa[CB];
+#pragma unroll
+                for (int b = 0; b < CB; ++b) {
+                    sh[b] = in ? prs[b] : 0.f;
+                    sa[b] = in ? pra[b] : 0.f;
+                    wave_sum2_f32(sh[b], sa[b]);
+                }
+                // lane b adds chain b's run sums
+                const float vh = pick_chain(sh, lane), va = pick_chain(sa, lane);
+                if (lane < CB) flush_run(acc + (size_t)lane * accn, T1, kk, vh, va);
+            }
+        } else {  // many short runs: every lane adds its own sums
+#pragma unroll
+            for (int b = 0; b < CB; ++b)
+                flush_run(acc + (size_t)b * accn, T1, pkey, prs[b], pra[b]);
+        }
+        cur = nxt;
+        ++tile;
+    }
+
+    // ---- 3. workgroup reduction of the scalars, then the slabs of all chains
+#pragma unroll
+    for (int b = 0; b < CB; ++b) {
+        const double v = wave_sum_f64(dV[b]), u = wave_sum_f64(dSU[b]);
+        if (lane == 0) {
+            red[(wave * CB + b) * 2 + 0] = v;
+            red[(wave * CB + b) * 2 + 1] = u;
+        }
+    }
+    __syncthreads();
+    const int cnt = o1 - o0;
+    const int nvalid = min(CB, A.chains - chain0);
+    for (int i = tid; i < cnt * nvalid; i += BLOCK) {
+        const int b = i / cnt, k = o0 + (i - b * cnt);
+        const int slot = A.wg_slots[k];
+        const int which = slot / T, t = slot - which * T;
+        double* cmpw = A.hbuf + (size_t)(chain0 + b) * A.hb_stride + A.zo_stride + A.n_wg * N_SCAL;
+        st_sc1(&cmpw[A.wg_dst[k]], acc[(size_t)b * accn + which * T1 + t]);
+    }
+    if (tid < CB * N_SCAL) {
+        const int b = tid / N_SCAL, j = tid - b * N_SCAL;
+        if (b < nvalid) {
+            // the tail forms  -SLAM + ln2*SLOG - CLIPC: hand it V as -SLAM, and SU
+            double s = 0.0;
+            if (j == 0 || j == 2) {
+#pragma unroll
+                for (int wv = 0; wv < WAVES; ++wv) s += red[(wv * CB + b) * 2 + (j == 0 ? 0 : 1)];
+                if (j == 0) s = -s;
+            }
+            st_sc1(&A.hbuf[(size_t)(chain0 + b) * A.hb_stride + A.zo_stride + wgi * N_SCAL + j], s);
+        }
+    }
+}
+
+template <bool STAGED>
+__global__ __launch_bounds__(BLOCK) void dc_vec_tail(EvalArgs A) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    tail_body<STAGED, false>(A, blockIdx.x, smem);
+}
+
+}  // namespace dc

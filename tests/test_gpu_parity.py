@@ -34,15 +34,20 @@ def _run(ctx, model, fx, zs):
     for i in range(z.shape[0]):
         U, g, aux = ctx.logp_grad(z[i].contiguous())
         outs.append((U.cpu().numpy()[0], g.cpu().numpy(), aux.cpu().numpy()[0]))
+    ctx.set_option("vec_min_chains", 0)      # batched = grid.y copies of the single launch
     Ub, gb, auxb = ctx.logp_grad(z)
-    return outs, (Ub.cpu().numpy(), gb.cpu().numpy(), auxb.cpu().numpy())
+    ctx.set_option("vec_min_chains", 1)      # chain-vectorised kernel (dc_vec.hip.h)
+    Uv, gv, auxv = ctx.logp_grad(z)
+    ctx.set_option("vec_min_chains", 4)
+    return outs, (Ub.cpu().numpy(), gb.cpu().numpy(), auxb.cpu().numpy()), \
+        (Uv.cpu().numpy(), gv.cpu().numpy(), auxv.cpu().numpy())
 
 
 def _check(model, fx, name, z, U, g, aux):
     Uo, go, auxo = O.potential_and_grad(model, fx, z)
     P = len(set(zip(fx.home_idx.tolist(), fx.away_idx.tolist())))
     tolU = 3e-7 * (abs(Uo) + 4.0 * fx.n) / np.sqrt(P) + 1e-9
-    if name.endswith("/clip"):
+    if "/clip" in name:
         tolU *= 20
     gerr = np.abs(g - go).max()
     gtol = 3e-6 * np.abs(go).max() + 1e-6
@@ -78,11 +83,13 @@ CASES = [
 def test_logp_grad_matches_oracle(hip_ctx, model, name):
     fx = cases.fixtures(name)
     pts = cases.z_points(model, fx)
-    outs, (Ub, gb, auxb) = _run(hip_ctx, model, fx, [p[1] for p in pts])
+    outs, (Ub, gb, auxb), (Uv, gv, auxv) = _run(hip_ctx, model, fx, [p[1] for p in pts])
     for i, ((pname, z), (U, g, aux)) in enumerate(zip(pts, outs)):
         _check(model, fx, f"{name}/{pname}", z, U, g, aux)
         # batched launch == single launches, bitwise
         assert U == Ub[i] and np.array_equal(g, gb[i]) and np.array_equal(aux, auxb[i])
+        # chain-vectorised kernel: same tolerances against the oracle
+        _check(model, fx, f"{name}/{pname} [vec]", z, Uv[i], gv[i], auxv[i])
 
 
 def test_full_size_1e6(hip_ctx):
@@ -91,9 +98,38 @@ def test_full_size_1e6(hip_ctx):
     fx = O.Fixtures(h, a, x, y, 20)
     for model in (O.MODEL_BASIC, O.MODEL_EXTENDED):
         pts = cases.z_points(model, fx, n_random=1)[:2]
-        outs, _ = _run(hip_ctx, model, fx, [p[1] for p in pts])
-        for (pname, z), (U, g, aux) in zip(pts, outs):
+        outs, _, (Uv, gv, auxv) = _run(hip_ctx, model, fx, [p[1] for p in pts])
+        for i, ((pname, z), (U, g, aux)) in enumerate(zip(pts, outs)):
             _check(model, fx, f"league_1e6/{pname}", z, U, g, aux)
+            _check(model, fx, f"league_1e6/{pname} [vec]", z, Uv[i], gv[i], auxv[i])
+
+
+@pytest.mark.parametrize("name,model,chains", [("league_1e5", O.MODEL_BASIC, 19),
+                                               ("leaguew_3e4", O.MODEL_EXTENDED, 9),
+                                               ("ragged_777", O.MODEL_EXTENDED, 8)])
+def test_chain_vectorised_matches_single(hip_ctx, name, model, chains):
+    """dc_vec (8 chains per workgroup, partial last group) vs the single-chain launch on the
+    same points: same arithmetic per run, different grouping of float32 partial sums."""
+    import torch
+
+    fx = cases.fixtures(name)
+    D = O.latent_dim(model, fx.n_teams, 0 if fx.covariates is None else fx.covariates.shape[1])
+    zs = [np.random.RandomState(100 + i).uniform(-0.5, 0.5, D) for i in range(chains)]
+    outs, _, (Uv, gv, auxv) = _run(hip_ctx, model, fx, zs)
+    P = len(set(zip(fx.home_idx.tolist(), fx.away_idx.tolist())))
+    for i, (U, g, aux) in enumerate(outs):
+        print(f"chain {i}: U={U:.6f} dU={Uv[i] - U:+.3e} dg={np.abs(gv[i] - g).max():.3e} "
+              f"|g|={np.abs(g).max():.3e}")
+        assert abs(Uv[i] - U) <= 2 * (3e-7 * (abs(U) + 4.0 * fx.n) / np.sqrt(P) + 1e-9)
+        assert np.abs(gv[i] - g).max() <= 1e-6 * np.abs(g).max()
+        assert np.array_equal(auxv[i], aux)
+    # deterministic
+    z = torch.tensor(np.stack(zs), dtype=torch.float64, device=hip_ctx.device)
+    hip_ctx.set_option("vec_min_chains", 1)
+    U1, g1, _ = hip_ctx.logp_grad(z)
+    U2, g2, _ = hip_ctx.logp_grad(z)
+    hip_ctx.set_option("vec_min_chains", 4)
+    assert torch.equal(U1, U2) and torch.equal(g1, g2)
 
 
 def test_order_invariance_and_determinism(hip_ctx):

@@ -5,9 +5,13 @@ import numpy as np, torch
 from bench import synthetic_league
 from bpl._ffi import HipContext, MODEL_BASIC
 h,a,x,y = synthetic_league(1_000_000, 20)
-c=HipContext(0); c.set_fixtures(MODEL_BASIC,h,a,x,y,20)
+c=HipContext(0)
+VEC=int(os.environ.get('VEC','1')); TPW=int(os.environ.get('VEC_TPW','2'))
+c.set_option('vec_tiles_per_wave',TPW); c.set_option('vec_min_chains', 1 if VEC else 0)
+c.set_fixtures(MODEL_BASIC,h,a,x,y,20)
+print(f"vec={VEC} vec_tiles_per_wave={TPW}")
 res={}
-for C in (1,2,4,8,16,32,64):
+for C in [int(v) for v in os.environ.get('CHAINS','1,2,4,8,16,32,64,128,256').split(',')]:
     z=torch.tensor(np.random.RandomState(7).uniform(-.5,.5,(C,45)),dtype=torch.float64,device=c.device)
     U=torch.zeros(C,dtype=torch.float64,device=c.device); g=torch.zeros_like(z); aux=torch.zeros((C,4),dtype=torch.float64,device=c.device)
     for _ in range(20): c.logp_grad(z,U,g,aux)
