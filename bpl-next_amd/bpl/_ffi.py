@@ -16,6 +16,7 @@ import numpy as np
 MODEL_BASIC = 0
 MODEL_EXTENDED = 1
 MODEL_DYNAMIC = 2
+BPLHIP_EUNSUPPORTED = -5  # include/bplhip.h
 
 _LIB_NAME = os.environ.get("BPLHIP_LIB", "libbplhip.so")  # override: diagnostic builds only
 _lib = None
@@ -36,6 +37,7 @@ ABI_SYMBOLS = (
     "bplhip_logp_grad_graph",
     "bplhip_nuts_default_cfg",
     "bplhip_nuts_run",
+    "bplhip_nuts_run_chains",
     "bplhip_constrain",
     "bplhip_predict_set_posterior",
     "bplhip_predict_score_proba",
@@ -130,6 +132,10 @@ def load_library():
         vp, C.POINTER(NutsCfg), vp, u32, u32, vp, C.POINTER(NutsStats), vp,
     ]
     lib.bplhip_nuts_run.restype = C.c_int
+    lib.bplhip_nuts_run_chains.argtypes = [
+        vp, C.POINTER(NutsCfg), i32, vp, vp, vp, C.POINTER(NutsStats), vp,
+    ]
+    lib.bplhip_nuts_run_chains.restype = C.c_int
     lib.bplhip_constrain.argtypes = [vp, vp, i64, vp, vp, vp, vp]
     lib.bplhip_constrain.restype = C.c_int
     lib.bplhip_predict_set_posterior.argtypes = [vp, i32, i32, vp, vp, vp, i32, vp]
@@ -377,10 +383,8 @@ class HipContext:
         return out
 
     # -- sampler
-    def nuts_run(self, cfg: NutsCfg, key: Tuple[int, int], z0: Optional[np.ndarray] = None):
-        kept = cfg.num_samples // cfg.thinning
-        d = self.dim
-        draws = np.empty((kept, d), dtype=np.float64)
+    @staticmethod
+    def _stats_buffers(kept: int, d: int):
         out = {
             "potential_energy": np.empty(kept),
             "accept_prob": np.empty(kept),
@@ -400,6 +404,23 @@ class HipContext:
         st.diverging = out["diverging"].ctypes.data_as(ip)
         st.corr_coef = out["corr_coef"].ctypes.data_as(dp)
         st.inverse_mass_matrix = out["inverse_mass_matrix"].ctypes.data_as(dp)
+        return out, st
+
+    @staticmethod
+    def _stats_scalars(out, st):
+        out.update(
+            final_step_size=st.final_step_size,
+            mean_accept_prob=st.mean_accept_prob,
+            total_leapfrogs=int(st.total_leapfrogs),
+            total_divergences=int(st.total_divergences),
+            wall_seconds=st.wall_seconds,
+        )
+
+    def nuts_run(self, cfg: NutsCfg, key: Tuple[int, int], z0: Optional[np.ndarray] = None):
+        kept = cfg.num_samples // cfg.thinning
+        d = self.dim
+        draws = np.empty((kept, d), dtype=np.float64)
+        out, st = self._stats_buffers(kept, d)
         z0c = None if z0 is None else np.ascontiguousarray(z0, dtype=np.float64)
         if z0c is not None and z0c.shape != (d,):
             raise ValueError(f"init_params must have shape ({d},)")
@@ -410,14 +431,40 @@ class HipContext:
                     draws.ctypes.data_as(C.c_void_p), C.byref(st), self._stream(),
                 )
             )
-        out.update(
-            final_step_size=st.final_step_size,
-            mean_accept_prob=st.mean_accept_prob,
-            total_leapfrogs=int(st.total_leapfrogs),
-            total_divergences=int(st.total_divergences),
-            wall_seconds=st.wall_seconds,
-        )
+        self._stats_scalars(out, st)
         return draws, out
+
+    def nuts_run_chains(self, cfg: NutsCfg, keys, z0: Optional[np.ndarray] = None):
+        """Lock-step chains on this GPU (numpyro chain_method="vectorized").  Returns a list
+        of (draws, stats) per chain, same content as nuts_run.  Raises BplHipError with
+        code EUNSUPPORTED when the bound model cannot run in lock step."""
+        n = len(keys)
+        kept = cfg.num_samples // cfg.thinning
+        d = self.dim
+        draws = np.empty((n, kept, d), dtype=np.float64)
+        bufs = [self._stats_buffers(kept, d) for _ in range(n)]
+        st_arr = (NutsStats * n)()
+        for i, (_, st) in enumerate(bufs):
+            st_arr[i] = st
+        seeds = np.ascontiguousarray(np.asarray(keys, dtype=np.uint32).reshape(n, 2))
+        z0c = None if z0 is None else np.ascontiguousarray(z0, dtype=np.float64)
+        if z0c is not None:
+            if z0c.shape == (d,):
+                z0c = np.ascontiguousarray(np.tile(z0c, (n, 1)))
+            if z0c.shape != (n, d):
+                raise ValueError(f"init_params must have shape ({n}, {d})")
+        with self._torch.cuda.device(self.device):
+            self._check(
+                self._lib.bplhip_nuts_run_chains(
+                    self._h, C.byref(cfg), n, _np_ptr(z0c), _np_ptr(seeds),
+                    draws.ctypes.data_as(C.c_void_p), st_arr, self._stream(),
+                )
+            )
+        res = []
+        for i, (out, _) in enumerate(bufs):
+            self._stats_scalars(out, st_arr[i])
+            res.append((draws[i], out))
+        return res
 
     def constrain(self, z_draws: np.ndarray):
         z = np.ascontiguousarray(z_draws, dtype=np.float64)

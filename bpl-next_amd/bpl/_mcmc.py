@@ -152,9 +152,29 @@ def run_mcmc(
                       "diverging", "corr_coef")
         stats = np.empty((len(mine), kept, len(stat_names)))
         scal = np.zeros((len(mine), 4))
+        # chains that share this GPU run in lock step (numpyro chain_method="vectorized":
+        # one chain-vectorised evaluation per leapfrog of all of them) unless
+        # chain_method="sequential" or the bound model does not support it
+        results = None
+        method = mcmc_kwargs.get("chain_method", "parallel")
+        if method not in ("parallel", "sequential", "vectorized"):
+            raise ValueError("Only supporting the following methods to draw chains: "
+                             '"sequential", "parallel", or "vectorized"')
+        if len(mine) > 1 and method != "sequential" and hasattr(ctx, "nuts_run_chains"):
+            from bpl._ffi import BPLHIP_EUNSUPPORTED, BplHipError
+
+            zm = None if z0 is None else (z0[list(mine)] if z0.ndim == 2 else z0)
+            try:
+                results = ctx.nuts_run_chains(cfg, [keys[c] for c in mine], zm)
+            except BplHipError as e:
+                if e.code != BPLHIP_EUNSUPPORTED:
+                    raise
         for j, c in enumerate(mine):
-            zc = None if z0 is None else (z0[c] if z0.ndim == 2 else z0)
-            d, st = ctx.nuts_run(cfg, keys[c], zc)
+            if results is not None:
+                d, st = results[j]
+            else:
+                zc = None if z0 is None else (z0[c] if z0.ndim == 2 else z0)
+                d, st = ctx.nuts_run(cfg, keys[c], zc)
             draws[j] = d
             for i, nm in enumerate(stat_names):
                 stats[j, :, i] = st[nm]

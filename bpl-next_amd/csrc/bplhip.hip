@@ -252,6 +252,10 @@ dc::EvalArgs eval_args(bplhip_ctx* c, int chains, const double* z, double* pot, 
     A.potential = pot;
     A.grad = grad;
     A.aux = aux;
+    A.z_stride = c->L.D;
+    A.g_stride = c->L.D;
+    A.p_stride = 1;
+    A.aux_stride = 4;
     A.debug = c->d_debug.as<unsigned long long>();
     A.L = c->L;
     return A;
@@ -277,37 +281,51 @@ int vec_hb_stride(const bplhip_ctx* c) {
 size_t vec_tail_lds(const bplhip_ctx* c, bool staged) {
     return dc::tail_lds_bytes(c->L.T, c->L.D, zo_stride_of(c->L), c->vp.n_wg, c->vp.total_c, staged);
 }
-template <bool W, bool C>
-int launch_vec_t(bplhip_ctx* c, const dc::EvalArgs& A, int chains, hipStream_t s) {
+template <bool S, bool N>
+int launch_vec_tail(bplhip_ctx* c, const dc::EvalArgs& A, int chains, hipStream_t s) {
+    const size_t tl = vec_tail_lds(c, S);
+    if (tl > 48 * 1024)
+        HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(dc::dc_vec_tail<S, N>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)tl));
+    hipLaunchKernelGGL((dc::dc_vec_tail<S, N>), dim3(chains), dim3(dc::BLOCK), tl, s, A);
+    return BPLHIP_OK;
+}
+template <bool W, bool C, bool N>
+int launch_vec_n(bplhip_ctx* c, const dc::EvalArgs& A, int chains, hipStream_t s) {
     const int groups = (chains + dc::CB - 1) / dc::CB;
     const size_t lds = std::max(dc::vec_stream_lds_bytes(c->L.T), dc::prior_lds_bytes(c->L.T));
     if (lds > 48 * 1024)
-        HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(dc::dc_vec_stream<W, C>),
+        HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(dc::dc_vec_stream<W, C, N>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((dc::dc_vec_stream<W, C>), dim3(dc::CB + c->vp.n_wg, groups),
+    hipLaunchKernelGGL((dc::dc_vec_stream<W, C, N>), dim3(dc::CB + c->vp.n_wg, groups),
                        dim3(dc::BLOCK), lds, s, A);
-    const size_t tl = vec_tail_lds(c, c->vp.staged);
-    if (c->vp.staged) {
-        if (tl > 48 * 1024)
-            HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(dc::dc_vec_tail<true>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)tl));
-        hipLaunchKernelGGL((dc::dc_vec_tail<true>), dim3(chains), dim3(dc::BLOCK), tl, s, A);
-    } else {
-        if (tl > 48 * 1024)
-            HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(dc::dc_vec_tail<false>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)tl));
-        hipLaunchKernelGGL((dc::dc_vec_tail<false>), dim3(chains), dim3(dc::BLOCK), tl, s, A);
-    }
+    const int rc = c->vp.staged ? launch_vec_tail<true, N>(c, A, chains, s)
+                                : launch_vec_tail<false, N>(c, A, chains, s);
+    if (rc != BPLHIP_OK) return rc;
     HIP_TRY(c, hipGetLastError());
     return BPLHIP_OK;
 }
+template <bool W, bool C>
+int launch_vec_t(bplhip_ctx* c, const dc::EvalArgs& A, int chains, hipStream_t s) {
+    return A.nuts ? launch_vec_n<W, C, true>(c, A, chains, s)
+                  : launch_vec_n<W, C, false>(c, A, chains, s);
+}
+// nuts != nullptr: lock-step device NUTS; chain c's state at nuts + c*nuts_stride, and
+// z / pot / grad / aux point into chain 0's state (strides = nuts_stride)
 int launch_eval_vec(bplhip_ctx* c, int chains, const double* z, double* pot, double* grad,
-                    double* aux, hipStream_t s) {
+                    double* aux, hipStream_t s, double* nuts = nullptr, int nuts_stride = 0,
+                    int nuts_depth = 0) {
     if (chains > c->vp.slab_chains) {
         HIP_TRY(c, c->vp.d_hbuf.ensure((size_t)chains * vec_hb_stride(c) * sizeof(double)));
         c->vp.slab_chains = chains;
     }
     dc::EvalArgs A = eval_args(c, chains, z, pot, grad, aux);
+    if (nuts) {
+        A.nuts = nuts;
+        A.nuts_stride = nuts_stride;
+        A.nuts_max_depth = nuts_depth;
+        A.z_stride = A.g_stride = A.p_stride = A.aux_stride = nuts_stride;
+    }
     A.tiles_per_wave = c->vp.tpw;
     A.wg_off = c->vp.d_wg_off.as<const int>();
     A.wg_slots = c->vp.d_wg_slots.as<const int>();
@@ -949,34 +967,136 @@ struct DeviceEngine {
     }
 };
 
-}  // namespace
 
-extern "C" int bplhip_nuts_run(bplhip_ctx* c, const bplhip_nuts_cfg* cfg, const double* z0,
-                               uint32_t seed_hi, uint32_t seed_lo, double* draws_out,
-                               bplhip_nuts_stats* stats, void* stream) {
-    if (!c) return BPLHIP_EINVAL;
-    if (!c->bound) return fail(c, BPLHIP_ESTATE, "nuts_run: no fixtures bound");
-    if (!cfg || !draws_out) return fail(c, BPLHIP_EINVAL, "nuts_run: null cfg/draws_out");
-    if (cfg->num_warmup < 0 || cfg->num_samples < 1 || cfg->max_tree_depth < 1 ||
-        cfg->max_tree_depth > 20 || cfg->thinning < 1 || !(cfg->step_size > 0))
-        return fail(c, BPLHIP_EINVAL, "nuts_run: bad configuration");
-    HIP_TRY(c, hipSetDevice(c->device));
-    const int D = c->dynamic ? c->DL.D : c->L.D;
-    const size_t nd = (size_t)2 * D + 1 + 4;
-    HIP_TRY(c, c->d_nuts.ensure(nd * 8));
-    if (c->h_pinned_bytes < nd * 8) {
-        if (c->h_pinned) (void)hipHostFree(c->h_pinned);
-        c->h_pinned = nullptr;
-        HIP_TRY(c, hipHostMalloc((void**)&c->h_pinned, nd * 8, hipHostMallocDefault));
-        c->h_pinned_bytes = nd * 8;
+// Lock-step chains (numpyro chain_method="vectorized"): all chains' trees are built
+// together; every leapfrog of the batch is ONE chain-vectorised evaluation (dc_vec.hip.h)
+// whose tail books each chain's leaf.  Chains whose subtree / tree is complete idle.
+struct VecDeviceEngine {
+    bplhip_ctx* c;
+    hipStream_t s;
+    const nuts::Config& cfg;
+    int D, max_depth, C;
+    double* ns;       // device [C][stride]
+    size_t stride;
+    double* par;      // device [C][par_stride]
+    int par_stride;
+    // pinned staging: r [C][D] | inv_mass [C][D] | hdr [C][H_N] | prop [C][D] | par [C][par_stride]
+    double *h_r, *h_m, *h_hdr, *h_prop, *h_par;
+    int last_depth = 1;
+    int rc = BPLHIP_OK;
+    int dim() const { return D; }
+    bool hip_ok(hipError_t e, const char* what) {
+        if (e == hipSuccess) return true;
+        rc = fail(c, BPLHIP_EHIP, "lock-step nuts: %s: %s", what, hipGetErrorString(e));
+        return false;
     }
-    HipPotential pot{c, static_cast<hipStream_t>(stream), D};
-    pot.d_z = c->d_nuts.as<double>();
-    pot.d_grad = pot.d_z + D;
-    pot.d_pot = pot.d_grad + D;
-    pot.d_aux = pot.d_pot + 1;
-    pot.hp = c->h_pinned;
+    bool set_state(int ch, const double* z, double* pe_out, bool* finite) {
+        double* nsc = ns + (size_t)ch * stride;
+        std::memcpy(h_r, z, (size_t)D * 8);
+        double* zn = nd::vec(nsc, D, nd::V_ZN);
+        double* gr = nd::vec(nsc, D, nd::V_GRAD);
+        if (!hip_ok(hipMemcpyAsync(zn, h_r, (size_t)D * 8, hipMemcpyHostToDevice, s), "H2D z")) return false;
+        rc = launch_eval(c, 1, zn, nsc + nd::H_LEAF_PE, gr, nsc + nd::H_LEAF_AUX0, s);
+        if (rc != BPLHIP_OK) return false;
+        (void)hipMemcpyAsync(nd::vec(nsc, D, nd::V_Z), zn, (size_t)D * 8, hipMemcpyDeviceToDevice, s);
+        (void)hipMemcpyAsync(nd::vec(nsc, D, nd::V_G), gr, (size_t)D * 8, hipMemcpyDeviceToDevice, s);
+        (void)hipMemcpyAsync(nsc + nd::H_CUR_PE, nsc + nd::H_LEAF_PE, 8, hipMemcpyDeviceToDevice, s);
+        (void)hipMemcpyAsync(nsc + nd::H_T_AUX0, nsc + nd::H_LEAF_AUX0, 32, hipMemcpyDeviceToDevice, s);
+        (void)hipMemcpyAsync(h_hdr, nsc, (size_t)nd::H_N * 8, hipMemcpyDeviceToHost, s);
+        (void)hipMemcpyAsync(h_prop, gr, (size_t)D * 8, hipMemcpyDeviceToHost, s);
+        if (!hip_ok(hipStreamSynchronize(s), "sync(set_state)")) return false;
+        const double pe = h_hdr[nd::H_LEAF_PE];
+        bool ok = std::isfinite(pe);
+        for (int i = 0; i < D && ok; ++i) ok = std::isfinite(h_prop[i]);
+        *finite = ok;
+        *pe_out = pe;
+        return true;
+    }
+    bool transition_all(std::vector<nuts::ChainDriver>& cds, std::vector<nuts::TransitionOut>* outs) {
+        bool any_mass = false;
+        for (int ch = 0; ch < C; ++ch) {
+            nuts::ChainDriver& cd = cds[ch];
+            std::memcpy(h_r + (size_t)ch * D, cd.r.data(), (size_t)D * 8);
+            std::memcpy(h_m + (size_t)ch * D, cd.inv_mass.data(), (size_t)D * 8);
+            any_mass = any_mass || cd.mass_changed;
+            // numpyro build_tree: key, direction_key, doubling_key = split(key, 3);
+            // _double_tree: key, transition_key = split(doubling_key) -- data independent,
+            // so all doublings' directions and keys are known up front
+            double* p = h_par + (size_t)ch * par_stride;
+            p[0] = cd.step_size;
+            tf::Key key = cd.k_tr;
+            for (int j = 0; j < max_depth; ++j) {
+                tf::Key k_next, k_dir, k_dbl, k_sub, k_tr;
+                tf::split3(key, &k_next, &k_dir, &k_dbl);
+                key = k_next;
+                tf::split2(k_dbl, &k_sub, &k_tr);
+                double* q = p + 1 + 5 * j;
+                q[0] = tf::bernoulli(k_dir, 0.5) ? 1.0 : 0.0;
+                q[1] = (double)k_sub.hi; q[2] = (double)k_sub.lo;
+                q[3] = (double)k_tr.hi;  q[4] = (double)k_tr.lo;
+            }
+        }
+        const size_t pitch = stride * 8, row = (size_t)D * 8;
+        if (any_mass &&
+            !hip_ok(hipMemcpy2DAsync(nd::vec(ns, D, nd::V_INVM), pitch, h_m, row, row, C,
+                                     hipMemcpyHostToDevice, s), "H2D inv_mass")) return false;
+        if (!hip_ok(hipMemcpy2DAsync(nd::vec(ns, D, nd::V_TL_R), pitch, h_r, row, row, C,
+                                     hipMemcpyHostToDevice, s), "H2D r")) return false;
+        if (!hip_ok(hipMemcpyAsync(par, h_par, (size_t)C * par_stride * 8, hipMemcpyHostToDevice, s),
+                    "H2D par")) return false;
+        hipLaunchKernelGGL(nd::kv_init, dim3(C), dim3(64), 0, s, ns, stride, D, par, par_stride,
+                           cfg.max_delta_energy);
+        int depth = 0;
+        bool stop = false, first_batch = true;
+        while (!stop && depth < max_depth) {
+            int nb = first_batch ? std::max(1, std::min(last_depth, max_depth)) : 1;
+            nb = std::min(nb, max_depth - depth);
+            for (int j = depth; j < depth + nb; ++j) {
+                hipLaunchKernelGGL(nd::kv_begin, dim3(C), dim3(64), 0, s, ns, stride, D, j, par,
+                                   par_stride);
+                const int leaves = 1 << j;
+                for (int l = 0; l < leaves; ++l) {
+                    rc = launch_eval_vec(c, C, nd::vec(ns, D, nd::V_ZN), ns + nd::H_LEAF_PE,
+                                         nd::vec(ns, D, nd::V_GRAD), ns + nd::H_LEAF_AUX0, s, ns,
+                                         (int)stride, max_depth);
+                    if (rc != BPLHIP_OK) return false;
+                }
+                hipLaunchKernelGGL(nd::kv_end, dim3(C), dim3(64), 0, s, ns, stride, D, j, max_depth,
+                                   par, par_stride);
+            }
+            // one read-back per batch: every chain's header + current proposal
+            (void)hipMemcpy2DAsync(h_hdr, (size_t)nd::H_N * 8, ns, pitch, (size_t)nd::H_N * 8, C,
+                                   hipMemcpyDeviceToHost, s);
+            (void)hipMemcpy2DAsync(h_prop, row, nd::vec(ns, D, nd::V_TP_Z), pitch, row, C,
+                                   hipMemcpyDeviceToHost, s);
+            if (!hip_ok(hipStreamSynchronize(s), "sync(doubling)")) return false;
+            first_batch = false;
+            depth += nb;
+            stop = true;
+            for (int ch = 0; ch < C; ++ch) stop = stop && h_hdr[(size_t)ch * nd::H_N + nd::H_STOP] != 0.0;
+        }
+        hipLaunchKernelGGL(nd::kv_finish, dim3(C), dim3(64), 0, s, ns, stride, D);
+        if (!hip_ok(hipGetLastError(), "launch")) return false;
+        int dmax = 1;
+        for (int ch = 0; ch < C; ++ch) {
+            const double* hd = h_hdr + (size_t)ch * nd::H_N;
+            nuts::TransitionOut& o = (*outs)[ch];
+            const double num = hd[nd::H_T_NUM];
+            o.accept_prob = num > 0 ? hd[nd::H_T_SUMACC] / num : 0.0;
+            o.num_steps = (int)num;
+            o.diverging = hd[nd::H_T_DIV] != 0.0;
+            o.pe = hd[nd::H_T_PE];
+            for (int i = 0; i < 4; ++i) o.aux[i] = hd[nd::H_T_AUX0 + i];
+            std::memcpy(cds[ch].z.data(), h_prop + (size_t)ch * D, (size_t)D * 8);
+            dmax = std::max(dmax, (int)hd[nd::H_T_DEPTH]);
+        }
+        last_depth = dmax;
+        return true;
+    }
+};
 
+// numpyro's configuration + the latent sites in model execution order (init key order)
+nuts::Config make_nuts_config(const bplhip_ctx* c, const bplhip_nuts_cfg* cfg) {
     nuts::Config nc;
     nc.num_warmup = cfg->num_warmup;
     nc.num_samples = cfg->num_samples;
@@ -1024,6 +1144,60 @@ extern "C" int bplhip_nuts_run(bplhip_ctx* c, const bplhip_nuts_cfg* cfg, const 
         }
     }
 
+    return nc;
+}
+
+void fill_stats(bplhip_nuts_stats* stats, const nuts::Result& res, double wall, int D) {
+    if (!stats) return;
+    const size_t kept = res.potential_energy.size();
+    auto cp = [&](double* dst, const std::vector<double>& v) {
+        if (dst) std::memcpy(dst, v.data(), kept * 8);
+    };
+    cp(stats->potential_energy, res.potential_energy);
+    cp(stats->accept_prob, res.accept_prob);
+    cp(stats->step_size, res.step_size);
+    cp(stats->corr_coef, res.aux0);
+    if (stats->num_steps) std::memcpy(stats->num_steps, res.num_steps.data(), kept * 4);
+    if (stats->diverging) std::memcpy(stats->diverging, res.diverging.data(), kept * 4);
+    stats->final_step_size = res.final_step_size;
+    stats->mean_accept_prob = res.mean_accept_prob;
+    stats->total_leapfrogs = res.total_leapfrogs;
+    stats->total_divergences = res.total_divergences;
+    stats->wall_seconds = wall;
+    if (stats->inverse_mass_matrix)
+        std::memcpy(stats->inverse_mass_matrix, res.inverse_mass_matrix.data(), (size_t)D * 8);
+}
+
+}  // namespace
+
+extern "C" int bplhip_nuts_run(bplhip_ctx* c, const bplhip_nuts_cfg* cfg, const double* z0,
+                               uint32_t seed_hi, uint32_t seed_lo, double* draws_out,
+                               bplhip_nuts_stats* stats, void* stream) {
+    if (!c) return BPLHIP_EINVAL;
+    if (!c->bound) return fail(c, BPLHIP_ESTATE, "nuts_run: no fixtures bound");
+    if (!cfg || !draws_out) return fail(c, BPLHIP_EINVAL, "nuts_run: null cfg/draws_out");
+    if (cfg->num_warmup < 0 || cfg->num_samples < 1 || cfg->max_tree_depth < 1 ||
+        cfg->max_tree_depth > 20 || cfg->thinning < 1 || !(cfg->step_size > 0))
+        return fail(c, BPLHIP_EINVAL, "nuts_run: bad configuration");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const int D = c->dynamic ? c->DL.D : c->L.D;
+    const size_t nd = (size_t)2 * D + 1 + 4;
+    HIP_TRY(c, c->d_nuts.ensure(nd * 8));
+    if (c->h_pinned_bytes < nd * 8) {
+        if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+        c->h_pinned = nullptr;
+        HIP_TRY(c, hipHostMalloc((void**)&c->h_pinned, nd * 8, hipHostMallocDefault));
+        c->h_pinned_bytes = nd * 8;
+    }
+    HipPotential pot{c, static_cast<hipStream_t>(stream), D};
+    pot.d_z = c->d_nuts.as<double>();
+    pot.d_grad = pot.d_z + D;
+    pot.d_pot = pot.d_grad + D;
+    pot.d_aux = pot.d_pot + 1;
+    pot.hp = c->h_pinned;
+
+    nuts::Config nc = make_nuts_config(c, cfg);
+
     nuts::Result res;
     const auto t0 = std::chrono::steady_clock::now();
     int st;
@@ -1058,25 +1232,71 @@ extern "C" int bplhip_nuts_run(bplhip_ctx* c, const bplhip_nuts_cfg* cfg, const 
     if (st == nuts::ST_EVAL_FAILED) return dev_rc != BPLHIP_OK ? dev_rc : BPLHIP_EHIP;
     if (st == nuts::ST_NO_FINITE_INIT)
         return fail(c, BPLHIP_ENUMERIC, "nuts_run: no finite initial point after 100 tries");
-    if (stats) {
-        const size_t kept = res.potential_energy.size();
-        auto cp = [&](double* dst, const std::vector<double>& v) {
-            if (dst) std::memcpy(dst, v.data(), kept * 8);
-        };
-        cp(stats->potential_energy, res.potential_energy);
-        cp(stats->accept_prob, res.accept_prob);
-        cp(stats->step_size, res.step_size);
-        cp(stats->corr_coef, res.aux0);
-        if (stats->num_steps) std::memcpy(stats->num_steps, res.num_steps.data(), kept * 4);
-        if (stats->diverging) std::memcpy(stats->diverging, res.diverging.data(), kept * 4);
-        stats->final_step_size = res.final_step_size;
-        stats->mean_accept_prob = res.mean_accept_prob;
-        stats->total_leapfrogs = res.total_leapfrogs;
-        stats->total_divergences = res.total_divergences;
-        stats->wall_seconds = wall;
-        if (stats->inverse_mass_matrix)
-            std::memcpy(stats->inverse_mass_matrix, res.inverse_mass_matrix.data(), (size_t)D * 8);
+    fill_stats(stats, res, wall, D);
+    return BPLHIP_OK;
+}
+
+extern "C" int bplhip_nuts_run_chains(bplhip_ctx* c, const bplhip_nuts_cfg* cfg, int32_t n_chains,
+                                      const double* z0, const uint32_t* seeds, double* draws_out,
+                                      bplhip_nuts_stats* stats, void* stream) {
+    if (!c) return BPLHIP_EINVAL;
+    if (!c->bound) return fail(c, BPLHIP_ESTATE, "nuts_run_chains: no fixtures bound");
+    if (!cfg || !draws_out || !seeds) return fail(c, BPLHIP_EINVAL, "nuts_run_chains: null argument");
+    if (n_chains < 1 || n_chains > 4096) return fail(c, BPLHIP_EINVAL, "nuts_run_chains: bad n_chains");
+    if (cfg->num_warmup < 0 || cfg->num_samples < 1 || cfg->max_tree_depth < 1 ||
+        cfg->max_tree_depth > 20 || cfg->thinning < 1 || !(cfg->step_size > 0))
+        return fail(c, BPLHIP_EINVAL, "nuts_run_chains: bad configuration");
+    if (c->dynamic || !c->vp.ok || c->L.T > 64 || !c->vp.staged)
+        return fail(c, BPLHIP_EUNSUPPORTED,
+                    "nuts_run_chains: lock-step chains need the basic/extended model with <= 64 teams");
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int D = c->L.D, C = n_chains;
+    const nuts::Config nc = make_nuts_config(c, cfg);
+    const size_t stride = (nd::ns_doubles(D, nc.max_tree_depth) + 1) & ~(size_t)1;
+    const int par_stride = nd::par_doubles(nc.max_tree_depth);
+    DevBuf d_ns, d_par;
+    HIP_TRY(c, d_ns.ensure((size_t)C * stride * 8));
+    HIP_TRY(c, d_par.ensure((size_t)C * par_stride * 8));
+    HIP_TRY(c, hipMemsetAsync(d_ns.p, 0, (size_t)C * stride * 8, s));
+    const size_t pinned = ((size_t)C * (3 * D + nd::H_N + par_stride)) * 8;
+    double* hp = nullptr;
+    HIP_TRY(c, hipHostMalloc((void**)&hp, pinned, hipHostMallocDefault));
+    int rc1 = ensure_slabs(c, 1);
+    if (rc1 != BPLHIP_OK) {
+        (void)hipHostFree(hp);
+        return rc1;
     }
+    VecDeviceEngine E{c, s, nc, D, nc.max_tree_depth, C, d_ns.as<double>(), stride,
+                      d_par.as<double>(), par_stride};
+    E.h_r = hp;
+    E.h_m = E.h_r + (size_t)C * D;
+    E.h_hdr = E.h_m + (size_t)C * D;
+    E.h_prop = E.h_hdr + (size_t)C * nd::H_N;
+    E.h_par = E.h_prop + (size_t)C * D;
+    {   // identity mass matrices until adapted
+        std::vector<double> ones((size_t)C * D, 1.0);
+        hipError_t e = hipMemcpy2D(nd::vec(E.ns, D, nd::V_INVM), stride * 8, ones.data(), (size_t)D * 8,
+                                   (size_t)D * 8, C, hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            (void)hipHostFree(hp);
+            return fail(c, BPLHIP_EHIP, "nuts_run_chains: H2D mass: %s", hipGetErrorString(e));
+        }
+    }
+    std::vector<tf::Key> keys(C);
+    for (int ch = 0; ch < C; ++ch) keys[ch] = tf::Key{seeds[2 * ch], seeds[2 * ch + 1]};
+    std::vector<nuts::Result> res;
+    const auto t0 = std::chrono::steady_clock::now();
+    const int st = nuts::run_chains_lockstep(E, nc, C, z0, keys.data(), draws_out, &res);
+    (void)hipStreamSynchronize(s);
+    const double wall =
+        std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    (void)hipHostFree(hp);
+    if (st == nuts::ST_EVAL_FAILED) return E.rc != BPLHIP_OK ? E.rc : BPLHIP_EHIP;
+    if (st == nuts::ST_NO_FINITE_INIT)
+        return fail(c, BPLHIP_ENUMERIC, "nuts_run_chains: no finite initial point after 100 tries");
+    if (stats)
+        for (int ch = 0; ch < C; ++ch) fill_stats(&stats[ch], res[ch], wall, D);
     return BPLHIP_OK;
 }
 

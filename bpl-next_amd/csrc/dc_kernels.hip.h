@@ -99,19 +99,27 @@ struct EvalArgs {
     int zo_stride;
     unsigned int* tickets;  // [chains] arrival counters
     int chains;             // number of chains of this launch (dc_vec.hip.h)
-    // in / out
+    // in / out: chain c at z + c*z_stride, potential + c*p_stride, grad + c*g_stride,
+    // aux + c*aux_stride (plain batches: D, 1, D, 4; device NUTS: all inside the state buffer)
     const double* z;        // [chains][D]
     double* potential;      // [chains]
     double* grad;           // [chains][D]
     double* aux;            // [chains][4] or nullptr
+    int z_stride, p_stride, g_stride, aux_stride;
     unsigned long long* debug;  // diagnostic build only (DC_STAMPS): [n_wg+1][16]
     // device-resident NUTS (nuts_dev.hip.h): when set, z/potential/grad/aux point into this
     // state buffer, a finished subtree makes the launch return at once, and the tail runs
     // the leaf bookkeeping and writes the next leapfrog's position
-    double* nuts;
+    double* nuts;           // chain c at nuts + c*nuts_stride
+    int nuts_stride;
     int nuts_max_depth;
     Layout L;
 };
+__device__ __forceinline__ const double* z_of(const EvalArgs& A, int c) { return A.z + (size_t)c * A.z_stride; }
+__device__ __forceinline__ double* grad_of(const EvalArgs& A, int c) { return A.grad + (size_t)c * A.g_stride; }
+__device__ __forceinline__ double* pot_of(const EvalArgs& A, int c) { return A.potential + (size_t)c * A.p_stride; }
+__device__ __forceinline__ double* aux_of(const EvalArgs& A, int c) { return A.aux + (size_t)c * A.aux_stride; }
+__device__ __forceinline__ double* nuts_of(const EvalArgs& A, int c) { return A.nuts + (size_t)c * A.nuts_stride; }
 
 // Diagnostic build (make stamps): thread 0 of every workgroup stores the 100 MHz
 // s_memrealtime counter at phase boundaries into a buffer nothing else reads.
@@ -443,7 +451,7 @@ __device__ void prior_body(const EvalArgs& A, int chain, char* smem) {
     const Layout& L = A.L;
     const int T = L.T, K = L.K, D = L.D;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const double* z = A.z + (size_t)chain * D;
+    const double* z = z_of(A, chain);
     double* zo = A.hbuf + (size_t)chain * A.hb_stride;
     double* gz = zo + ZO_HDR;
     double* eps = gz + D;
@@ -685,7 +693,7 @@ __device__ void tail_one_wave(const EvalArgs& A, int chain, const double* zoL, c
     const int T = L.T, K = L.K, D = L.D;
     const int t = threadIdx.x & 63;
     const bool on = t < T;
-    double* grad = A.grad + (size_t)chain * D;
+    double* grad = grad_of(A, chain);
     constexpr bool nuts = NUTS;
     auto put = [&](int o, double v) {
         grad[o] = v;
@@ -754,7 +762,7 @@ __device__ void tail_one_wave(const EvalArgs& A, int chain, const double* zoL, c
             put(L.o_sa, gz[L.o_sa] - s_a * dot_a);
             put(L.o_sd, gz[L.o_sd] - s_d * dot_d);
             put(L.o_corr, gz[L.o_corr] - G_rho * (UB - LB) * dq);
-            A.potential[chain] = -Ltot;
+            *pot_of(A, chain) = -Ltot;
         }
     } else {
         const double sa = on ? zL[L.o_sat + t] : 0.0, sd = on ? zL[L.o_sdt + t] : 0.0,
@@ -782,11 +790,11 @@ __device__ void tail_one_wave(const EvalArgs& A, int chain, const double* zoL, c
             put(L.o_sd, gz[L.o_sd] - s_d * dot_d);
             put(L.o_corr, gz[L.o_corr] - G_rho * (UB - LB) * dq);
             put(L.o_u, gz[L.o_u]);
-            A.potential[chain] = -Ltot;
+            *pot_of(A, chain) = -Ltot;
         }
     }
     if (t == 0 && A.aux != nullptr) {
-        double* aux = A.aux + (size_t)chain * 4;
+        double* aux = aux_of(A, chain);
         aux[0] = zoL[ZO_RHO];
         aux[1] = LB;
         aux[2] = UB;
@@ -803,7 +811,7 @@ __device__ void tail_one_wave(const EvalArgs& A, int chain, const double* zoL, c
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        nd::nuts_leaf(A.nuts, D, A.nuts_max_depth, t, gradL);
+        nd::nuts_leaf(nuts_of(A, chain), D, A.nuts_max_depth, t, gradL);
     }
 }
 
@@ -812,7 +820,7 @@ __device__ void tail_body(const EvalArgs& A, int chain, char* smem) {
     const Layout& L = A.L;
     const int T = L.T, K = L.K, D = L.D;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    double* grad = A.grad + (size_t)chain * D;
+    double* grad = grad_of(A, chain);
     const int ncol = 3 * T;
     const int nsc = A.n_wg * N_SCAL;
 
@@ -834,7 +842,7 @@ __device__ void tail_body(const EvalArgs& A, int chain, char* smem) {
     // the first one is used (a rolled load -> LDS-store loop would serialise them)
     const double* hb = A.hbuf + (size_t)chain * A.hb_stride;
     const double* compact = hb + A.zo_stride + nsc;
-    const double* z = A.z + (size_t)chain * D;
+    const double* z = z_of(A, chain);
     const int nstage = A.zo_stride + nsc + (STAGED ? A.total_c : 0);
     const bool xs_staged = K > 0 && K <= 16;
     {
@@ -1001,7 +1009,7 @@ __device__ void tail_body(const EvalArgs& A, int chain, char* smem) {
             grad[L.o_corr] = gz[L.o_corr] - G_rho * (UB - LB) * dq;
             const double Ltot =
                 Lz + v[4] + G_rho * drho - SLAM - A.lgsum + LN2 * SLOG - CLIPC;
-            A.potential[chain] = -Ltot;
+            *pot_of(A, chain) = -Ltot;
         }
     } else {
         // v: 0 sum g_def, 1 sum g_ha, 2 sum sa g_att, 3 sum sd g_def, 4 sum ha~ g_ha, 5 corr
@@ -1038,12 +1046,12 @@ __device__ void tail_body(const EvalArgs& A, int chain, char* smem) {
             grad[L.o_u] = gz[L.o_u];
             const double Ltot =
                 Lz + v[5] + G_rho * drho - SLAM - A.lgsum + LN2 * SLOG - CLIPC;
-            A.potential[chain] = -Ltot;
+            *pot_of(A, chain) = -Ltot;
         }
     }
     DC_STAMP(10);
     if (tid == 0 && A.aux != nullptr) {
-        double* aux = A.aux + (size_t)chain * 4;
+        double* aux = aux_of(A, chain);
         aux[0] = rho;
         aux[1] = LB;
         aux[2] = UB;
@@ -1285,10 +1293,10 @@ __global__ DC_LAUNCH_BOUNDS void dc_eval(EvalArgs A) {
     const int T = L.T, T1 = T + 1;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int chain = blockIdx.y;
-    const double* z = A.z + (size_t)chain * L.D;
+    const double* z = z_of(A, chain);
     DC_STAMP(0);
     // device-resident NUTS: the subtree this launch belonged to may already be complete
-    const double nuts_done = NUTS ? A.nuts[nd::H_S_DONE] : 0.0;
+    const double nuts_done = NUTS ? nuts_of(A, chain)[nd::H_S_DONE] : 0.0;
 
     // LDS carve of the streaming part (all offsets multiples of 16 B)
     float2* tabH = reinterpret_cast<float2*>(smem);            // {exp(att+ha), exp(-def)}

@@ -163,7 +163,7 @@ __device__ __forceinline__ float pick_chain(const float (&v)[CB], int lane) {
     return r;
 }
 
-template <bool WEIGHTED, bool CLIP>
+template <bool WEIGHTED, bool CLIP, bool NUTS>
 __global__ __launch_bounds__(BLOCK) void dc_vec_stream(EvalArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const Layout& L = A.L;
@@ -173,10 +173,18 @@ __global__ __launch_bounds__(BLOCK) void dc_vec_stream(EvalArgs A) {
 
     if (blockIdx.x < CB) {  // prior workgroups of this group's chains
         const int chain = chain0 + blockIdx.x;
-        if (chain < A.chains) prior_body<CLIP>(A, chain, smem);
+        if (chain >= A.chains) return;
+        if (NUTS && nuts_of(A, chain)[nd::H_S_DONE] != 0.0) return;  // subtree already complete
+        prior_body<CLIP>(A, chain, smem);
         return;
     }
     const int wgi = blockIdx.x - CB;
+    if (NUTS) {  // lock-step chains: nothing to do once every chain of the group has finished
+        bool all_done = true;
+        for (int b = 0; b < CB && chain0 + b < A.chains; ++b)
+            all_done = all_done && nuts_of(A, chain0 + b)[nd::H_S_DONE] != 0.0;
+        if (all_done) return;
+    }
 
     // ---- 0. the first tile's loads before anything else
     const int gw = wgi * WAVES + wave;
@@ -195,7 +203,7 @@ __global__ __launch_bounds__(BLOCK) void dc_vec_stream(EvalArgs A) {
     {
         const int b = wave;
         const int chain = min(chain0 + b, A.chains - 1);  // (a padding chain repeats the last)
-        const double* z = A.z + (size_t)chain * L.D;
+        const double* z = z_of(A, chain);
         const F32Scalars fs = f32_scalars(L, z);
         float2* tH = tab + (size_t)(2 * b) * tl;
         float2* tA = tH + tl;
@@ -336,10 +344,11 @@ __global__ __launch_bounds__(BLOCK) void dc_vec_stream(EvalArgs A) {
     }
 }
 
-template <bool STAGED>
+template <bool STAGED, bool NUTS>
 __global__ __launch_bounds__(BLOCK) void dc_vec_tail(EvalArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    tail_body<STAGED, false>(A, blockIdx.x, smem);
+    if (NUTS && nuts_of(A, blockIdx.x)[nd::H_S_DONE] != 0.0) return;
+    tail_body<STAGED, NUTS>(A, blockIdx.x, smem);
 }
 
 }  // namespace dc

@@ -400,74 +400,84 @@ struct HostEngine {
     }
 };
 
-template <class Engine>
-int run_chain_engine(Engine& E, const Config& cfg, const double* z0, tf::Key key,
-                     double* draws_out, Result* res) {
-    const int D = E.dim();
-    std::vector<Site> sites = cfg.sites;
-    if (sites.empty()) sites.push_back({0, D});
-
-    // NUTS.init: key, key_init_model = split(key)
-    tf::Key key_init;
-    tf::split2(key, &key, &key_init);
-    vec z(D);
-    double pe = 0;
-    bool finite = false;
-    if (z0) {
-        for (int i = 0; i < D; ++i) z[i] = z0[i];
-        if (!E.set_state(z.data(), &pe, &finite)) return ST_EVAL_FAILED;
-    } else {
-        tf::Key k = key_init;
-        for (int attempt = 0; attempt < 100 && !finite; ++attempt) {
-            tf::Key sub;
-            tf::split2(k, &k, &sub);
-            draw_init(sub, sites, cfg.init_radius, &z);
-            if (!E.set_state(z.data(), &pe, &finite)) return ST_EVAL_FAILED;
-        }
-        if (!finite) return ST_NO_FINITE_INIT;
-    }
-    const int64_t leap0 = E.leapfrogs();
-
-    // init_kernel: key_hmc, key_wa, key_momentum = split(key, 3)
-    tf::Key key_hmc, key_wa, key_mom0;
-    tf::split3(key, &key_hmc, &key_wa, &key_mom0);
-
-    const std::vector<Window> sched = build_adaptation_schedule(cfg.num_warmup);
-    const int num_windows = (int)sched.size();
-    double step_size = cfg.step_size;
-    vec inv_mass(D, 1.0), mass_sqrt(D, 1.0);
+// One chain's loop state around the tree builder: key plumbing, momentum draws, warm-up
+// adaptation and draw collection (numpyro hmc.py init_kernel / sample_kernel,
+// hmc_util.py warmup_adapter).  A tree engine runs between begin() and end(); several
+// ChainDrivers can share one lock-step engine.
+struct ChainDriver {
+    const Config& cfg;
+    int D;
+    double* draws_out;
+    Result* res;
+    vec z, r, eps_n, inv_mass, mass_sqrt;
+    tf::Key key_hmc{}, k_tr{};
+    std::vector<Window> sched;
+    int num_windows = 0, window_idx = 0, total = 0, kept = 0, start_idx = 0;
+    double step_size = 1.0, used_step = 1.0, mean_accept = 0.0;
     bool mass_changed = true;
     DualAveraging ss;
-    ss.init(std::log(10.0 * step_size));
     Welford mm;
-    mm.init(D);
-    int window_idx = 0;
 
-    const int total = cfg.num_warmup + cfg.num_samples;
-    const int kept = cfg.num_samples / cfg.thinning;
-    const int start_idx = cfg.num_warmup + cfg.num_samples % cfg.thinning;
-    res->potential_energy.assign(kept, 0.0);
-    res->accept_prob.assign(kept, 0.0);
-    res->step_size.assign(kept, 0.0);
-    res->aux0.assign(kept, 0.0);
-    res->num_steps.assign(kept, 0);
-    res->diverging.assign(kept, 0);
-    double mean_accept = 0.0;
-    vec r(D), eps_n(D);
+    ChainDriver(const Config& c, int dim, double* draws, Result* r_)
+        : cfg(c), D(dim), draws_out(draws), res(r_), z(dim), r(dim), eps_n(dim),
+          inv_mass(dim, 1.0), mass_sqrt(dim, 1.0) {}
 
-    for (int it = 0; it < total; ++it) {
-        // sample_kernel: key, key_momentum, key_transition = split(key, 3)
-        tf::Key k_mom, k_tr;
+    // initial state (z0 or init_to_uniform with retries) through set_state(z, &pe, &finite)
+    template <class SetState>
+    int init(SetState&& set_state, const double* z0, tf::Key key) {
+        std::vector<Site> sites = cfg.sites;
+        if (sites.empty()) sites.push_back({0, D});
+        // NUTS.init: key, key_init_model = split(key)
+        tf::Key key_init;
+        tf::split2(key, &key, &key_init);
+        double pe = 0;
+        bool finite = false;
+        if (z0) {
+            for (int i = 0; i < D; ++i) z[i] = z0[i];
+            if (!set_state(z.data(), &pe, &finite)) return ST_EVAL_FAILED;
+        } else {
+            tf::Key k = key_init;
+            for (int attempt = 0; attempt < 100 && !finite; ++attempt) {
+                tf::Key sub;
+                tf::split2(k, &k, &sub);
+                draw_init(sub, sites, cfg.init_radius, &z);
+                if (!set_state(z.data(), &pe, &finite)) return ST_EVAL_FAILED;
+            }
+            if (!finite) return ST_NO_FINITE_INIT;
+        }
+        // init_kernel: key_hmc, key_wa, key_momentum = split(key, 3)
+        tf::Key key_wa, key_mom0;
+        tf::split3(key, &key_hmc, &key_wa, &key_mom0);
+        sched = build_adaptation_schedule(cfg.num_warmup);
+        num_windows = (int)sched.size();
+        step_size = cfg.step_size;
+        ss.init(std::log(10.0 * step_size));
+        mm.init(D);
+        total = cfg.num_warmup + cfg.num_samples;
+        kept = cfg.num_samples / cfg.thinning;
+        start_idx = cfg.num_warmup + cfg.num_samples % cfg.thinning;
+        res->potential_energy.assign(kept, 0.0);
+        res->accept_prob.assign(kept, 0.0);
+        res->step_size.assign(kept, 0.0);
+        res->aux0.assign(kept, 0.0);
+        res->num_steps.assign(kept, 0);
+        res->diverging.assign(kept, 0);
+        return ST_OK;
+    }
+
+    // sample_kernel: key, key_momentum, key_transition = split(key, 3); momentum r
+    void begin() {
+        tf::Key k_mom;
         tf::split3(key_hmc, &key_hmc, &k_mom, &k_tr);
         tf::normal(k_mom, D, eps_n.data());
         for (int i = 0; i < D; ++i) r[i] = mass_sqrt[i] * eps_n[i];
-        const double used_step = step_size;
-        TransitionOut out;
-        if (!E.transition(r.data(), k_tr, step_size, inv_mass, mass_changed, z.data(), &out))
-            return ST_EVAL_FAILED;
+        used_step = step_size;
+    }
+
+    // after the transition (z already holds the new state)
+    void end(int it, const TransitionOut& out) {
         mass_changed = false;
         const double accept_prob = out.accept_prob;
-
         if (it < cfg.num_warmup) {  // warmup_adapter.update_fn
             const int t = it;
             if (cfg.adapt_step_size) {
@@ -505,10 +515,64 @@ int run_chain_engine(Engine& E, const Config& cfg, const double* z0, tf::Key key
             }
         }
     }
-    res->final_step_size = step_size;
-    res->mean_accept_prob = mean_accept;
-    res->total_leapfrogs = E.leapfrogs() - leap0;
-    res->inverse_mass_matrix = inv_mass;
+
+    void finish(int64_t leapfrogs) {
+        res->final_step_size = step_size;
+        res->mean_accept_prob = mean_accept;
+        res->total_leapfrogs = leapfrogs;
+        res->inverse_mass_matrix = inv_mass;
+    }
+};
+
+template <class Engine>
+int run_chain_engine(Engine& E, const Config& cfg, const double* z0, tf::Key key,
+                     double* draws_out, Result* res) {
+    ChainDriver cd(cfg, E.dim(), draws_out, res);
+    const int st = cd.init(
+        [&](const double* zz, double* pe, bool* fin) { return E.set_state(zz, pe, fin); }, z0, key);
+    if (st != ST_OK) return st;
+    const int64_t leap0 = E.leapfrogs();
+    for (int it = 0; it < cd.total; ++it) {
+        cd.begin();
+        TransitionOut out;
+        if (!E.transition(cd.r.data(), cd.k_tr, cd.step_size, cd.inv_mass, cd.mass_changed,
+                          cd.z.data(), &out))
+            return ST_EVAL_FAILED;
+        cd.end(it, out);
+    }
+    cd.finish(E.leapfrogs() - leap0);
+    return ST_OK;
+}
+
+// Lock-step chains on one engine: every iteration all chains draw their momenta, the
+// engine builds all trees together (VecEngine::transition_all), then every chain adapts.
+template <class VecEngine>
+int run_chains_lockstep(VecEngine& E, const Config& cfg, int n_chains, const double* z0,
+                        const tf::Key* keys, double* draws_out, std::vector<Result>* res) {
+    const int D = E.dim();
+    const int kept = cfg.num_samples / cfg.thinning;
+    res->assign(n_chains, Result{});
+    std::vector<ChainDriver> cds;
+    cds.reserve(n_chains);
+    for (int c = 0; c < n_chains; ++c)
+        cds.emplace_back(cfg, D, draws_out + (size_t)c * kept * D, &(*res)[c]);
+    for (int c = 0; c < n_chains; ++c) {
+        const int st = cds[c].init(
+            [&](const double* zz, double* pe, bool* fin) { return E.set_state(c, zz, pe, fin); },
+            z0 ? z0 + (size_t)c * D : nullptr, keys[c]);
+        if (st != ST_OK) return st;
+    }
+    std::vector<TransitionOut> outs(n_chains);
+    std::vector<int64_t> leaps(n_chains, 0);
+    for (int it = 0; it < cds[0].total; ++it) {
+        for (auto& cd : cds) cd.begin();
+        if (!E.transition_all(cds, &outs)) return ST_EVAL_FAILED;
+        for (int c = 0; c < n_chains; ++c) {
+            cds[c].end(it, outs[c]);
+            leaps[c] += outs[c].num_steps;
+        }
+    }
+    for (int c = 0; c < n_chains; ++c) cds[c].finish(leaps[c]);
     return ST_OK;
 }
 

@@ -245,8 +245,7 @@ __device__ inline void nuts_leaf(double* ns, int D, int max_depth, int lane, con
 // ---------------------------------------------------------------- small kernels (1 wave)
 
 // start of a transition: tree = the current state with momentum r (uploaded to V_TL_R)
-__global__ __launch_bounds__(64) void k_init(double* ns, int D, double eps, double max_de) {
-    const int lane = threadIdx.x;
+__device__ inline void init_body(double* ns, int D, double eps, double max_de, int lane) {
     double* invM = vec(ns, D, V_INVM);
     double* r = vec(ns, D, V_TL_R);
     double kin = 0.0;
@@ -273,9 +272,8 @@ __global__ __launch_bounds__(64) void k_init(double* ns, int D, double eps, doub
 }
 
 // start of doubling `j`: runs only if the tree is still at depth j and not finished
-__global__ __launch_bounds__(64) void k_begin(double* ns, int D, int j, int going_right,
-                                              uint32_t khi, uint32_t klo) {
-    const int lane = threadIdx.x;
+__device__ inline void begin_body(double* ns, int D, int j, int going_right, uint32_t khi,
+                                  uint32_t klo, int lane) {
     const bool active = ns[H_STOP] == 0.0 && (int)ns[H_T_DEPTH] == j;
     if (!active) {
         if (lane == 0) { ns[H_S_ACTIVE] = 0.0; ns[H_S_DONE] = 1.0; }
@@ -305,9 +303,8 @@ __global__ __launch_bounds__(64) void k_begin(double* ns, int D, int j, int goin
 }
 
 // end of a doubling: _combine_tree(tree, subtree, biased_transition=True)
-__global__ __launch_bounds__(64) void k_end(double* ns, int D, int max_depth, uint32_t thi,
-                                            uint32_t tlo) {
-    const int lane = threadIdx.x;
+__device__ inline void end_body(double* ns, int D, int max_depth, uint32_t thi, uint32_t tlo,
+                                int lane) {
     if (ns[H_S_ACTIVE] == 0.0) return;
     const bool going_right = ns[H_DIR] > 0.0;
     const double* invM = vec(ns, D, V_INVM);
@@ -357,11 +354,49 @@ __global__ __launch_bounds__(64) void k_end(double* ns, int D, int max_depth, ui
 }
 
 // end of the transition: the proposal becomes the current state
-__global__ __launch_bounds__(64) void k_finish(double* ns, int D) {
-    const int lane = threadIdx.x;
+__device__ inline void finish_body(double* ns, int D, int lane) {
     vcopy(vec(ns, D, V_Z), vec(ns, D, V_TP_Z), D, lane);
     vcopy(vec(ns, D, V_G), vec(ns, D, V_TP_G), D, lane);
     if (lane == 0) ns[H_CUR_PE] = ns[H_T_PE];
+}
+
+// ---- one chain
+__global__ __launch_bounds__(64) void k_init(double* ns, int D, double eps, double max_de) {
+    init_body(ns, D, eps, max_de, threadIdx.x);
+}
+__global__ __launch_bounds__(64) void k_begin(double* ns, int D, int j, int going_right,
+                                              uint32_t khi, uint32_t klo) {
+    begin_body(ns, D, j, going_right, khi, klo, threadIdx.x);
+}
+__global__ __launch_bounds__(64) void k_end(double* ns, int D, int max_depth, uint32_t thi,
+                                            uint32_t tlo) {
+    end_body(ns, D, max_depth, thi, tlo, threadIdx.x);
+}
+__global__ __launch_bounds__(64) void k_finish(double* ns, int D) { finish_body(ns, D, threadIdx.x); }
+
+// ---- lock-step chains: block c works on chain c's state (ns + c*stride); its step size and
+// per-doubling directions / keys come from a parameter table uploaded once per transition:
+//   par[c] = { eps, (going_right, sub_hi, sub_lo, tr_hi, tr_lo) x max_depth }   (doubles)
+__host__ __device__ inline int par_doubles(int max_depth) { return 1 + 5 * max_depth; }
+__global__ __launch_bounds__(64) void kv_init(double* ns, size_t stride, int D, const double* par,
+                                              int par_stride, double max_de) {
+    const int c = blockIdx.x;
+    init_body(ns + c * stride, D, par[(size_t)c * par_stride], max_de, threadIdx.x);
+}
+__global__ __launch_bounds__(64) void kv_begin(double* ns, size_t stride, int D, int j,
+                                               const double* par, int par_stride) {
+    const int c = blockIdx.x;
+    const double* p = par + (size_t)c * par_stride + 1 + 5 * j;
+    begin_body(ns + c * stride, D, j, p[0] != 0.0, (uint32_t)p[1], (uint32_t)p[2], threadIdx.x);
+}
+__global__ __launch_bounds__(64) void kv_end(double* ns, size_t stride, int D, int j, int max_depth,
+                                             const double* par, int par_stride) {
+    const int c = blockIdx.x;
+    const double* p = par + (size_t)c * par_stride + 1 + 5 * j;
+    end_body(ns + c * stride, D, max_depth, (uint32_t)p[3], (uint32_t)p[4], threadIdx.x);
+}
+__global__ __launch_bounds__(64) void kv_finish(double* ns, size_t stride, int D) {
+    finish_body(ns + blockIdx.x * stride, D, threadIdx.x);
 }
 
 }  // namespace nd

@@ -209,6 +209,18 @@ int bplhip_nuts_run(bplhip_ctx* ctx, const bplhip_nuts_cfg* cfg, const double* z
                     uint32_t seed_hi, uint32_t seed_lo, double* draws_out,
                     bplhip_nuts_stats* stats, void* stream);
 
+/* Run `n_chains` chains in lock step on this GPU (numpyro chain_method="vectorized",
+ * MCMC(num_chains=...) at bpl/dixon_coles.py:101-106): every leapfrog of all chains is one
+ * chain-vectorised evaluation.  Basic / extended model, n_teams <= 64; otherwise
+ * BPLHIP_EUNSUPPORTED (run the chains one after another with bplhip_nuts_run).
+ *   z0        HOST f64[n_chains, D] or NULL       seeds  HOST u32[n_chains, 2] (hi, lo)
+ *   draws_out HOST f64[n_chains, num_samples/thinning, D]
+ *   stats     n_chains statistics records, or NULL; wall_seconds is the whole run's.
+ * Chain c follows the same key sequence as bplhip_nuts_run with seeds[c]. */
+int bplhip_nuts_run_chains(bplhip_ctx* ctx, const bplhip_nuts_cfg* cfg, int32_t n_chains,
+                           const double* z0, const uint32_t* seeds, double* draws_out,
+                           bplhip_nuts_stats* stats, void* stream);
+
 /* Map unconstrained draws to the constrained / deterministic sites the reference reads
  * from `mcmc.get_samples()` (bpl/dixon_coles.py:118-122,
  * bpl/extended_dixon_coles.py:319-331).  HOST in, HOST out; any output may be NULL.

@@ -212,6 +212,64 @@ def test_device_tree_matches_host_tree(hip_ctx):
         hip_ctx.set_option("device_nuts", 1)
 
 
+def test_lockstep_chains_match_single_chains(hip_ctx):
+    """Lock-step chains (bplhip_nuts_run_chains: one chain-vectorised evaluation per leapfrog
+    of all chains, numpyro chain_method="vectorized") follow the same key sequences and the
+    same algorithm as bplhip_nuts_run chain by chain.  The vectorised kernel groups its
+    float32 partial sums differently (1e-10 relative in U), so with a fixed step size the
+    trees coincide and the first draws agree closely; the difference then grows with the
+    chaotic trajectories, as between the host and device tree builders."""
+    from bpl._ffi import MODEL_BASIC, MODEL_EXTENDED, default_nuts_cfg
+
+    for model, name, nch in ((MODEL_BASIC, "dummy", 5), (MODEL_EXTENDED, "dummy_cov", 9)):
+        fx = cases.fixtures(name)
+        cov = None if fx.covariates is None or model == MODEL_BASIC else O.standardise_covariates(fx.covariates)
+        hip_ctx.set_fixtures(model, fx.home_idx.astype(np.uint16), fx.away_idx.astype(np.uint16),
+                             fx.home_goals.astype(np.uint8), fx.away_goals.astype(np.uint8), 20,
+                             covariates_std=cov)
+        D = hip_ctx.dim
+        z0 = np.random.RandomState(2).uniform(-0.2, 0.2, (nch, D))
+        keys = [(0, 11 + c) for c in range(nch)]
+        cfg = default_nuts_cfg()
+        cfg.num_warmup, cfg.num_samples, cfg.step_size = 0, 6, 0.02
+        multi = hip_ctx.nuts_run_chains(cfg, keys, z0)
+        for c in range(nch):
+            d1, s1 = hip_ctx.nuts_run(cfg, keys[c], z0[c])
+            dm, sm = multi[c]
+            assert sm["num_steps"][:3].tolist() == s1["num_steps"][:3].tolist()
+            assert np.abs(dm[:3] - d1[:3]).max() < 1e-5
+            assert np.abs(sm["potential_energy"][:3] - s1["potential_energy"][:3]).max() < 1e-4
+            assert sm["total_leapfrogs"] > 50
+        # adaptation on, init_to_uniform: healthy statistics for every chain
+        cfg.num_warmup, cfg.num_samples, cfg.step_size = 150, 40, 1.0
+        multi = hip_ctx.nuts_run_chains(cfg, keys)
+        for d, st in multi:
+            assert np.isfinite(d).all() and st["total_divergences"] <= 2
+            assert 0.55 < st["mean_accept_prob"] <= 1.0
+        # distinct keys -> distinct chains
+        assert np.abs(multi[0][0] - multi[1][0]).max() > 1e-3
+
+
+def test_fit_num_chains_lockstep_vs_sequential(dummy_data):
+    """fit(mcmc_kwargs={"num_chains": 4}): the lock-step default and chain_method="sequential"
+    sample the same posterior (shapes, chain-major order, means within Monte-Carlo error)."""
+    from bpl import DixonColesMatchPredictor
+
+    fits = {}
+    for method in ("vectorized", "sequential"):
+        m = DixonColesMatchPredictor().fit(dummy_data, random_state=3, num_warmup=200, num_samples=200,
+                                           mcmc_kwargs={"num_chains": 4, "chain_method": method})
+        assert m.attack.shape == (800, 20) and m.corr_coef.shape == (800,)
+        assert m.mcmc_info_["divergences"] == 0
+        fits[method] = m
+    a, b = fits["vectorized"], fits["sequential"]
+    sd = np.sqrt(a.attack.var(0) + b.attack.var(0))
+    assert (np.abs(a.attack.mean(0) - b.attack.mean(0)) < 0.35 * sd).all()
+    assert abs(a.home_advantage.mean() - b.home_advantage.mean()) < 0.05
+    # chains are distinct and chain-major
+    assert np.abs(a.attack[:200].mean(0) - a.attack[200:400].mean(0)).max() > 1e-6
+
+
 @pytest.mark.parametrize("model_cls", MODELS)
 def test_device_predict_matches_host_predict(fitted, model_cls):
     """Row f-2: predict_score_proba / outcome / n-goals through the HIP predict kernel equal
