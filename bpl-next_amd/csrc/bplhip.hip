@@ -1202,7 +1202,8 @@ extern "C" int bplhip_nuts_run(bplhip_ctx* c, const bplhip_nuts_cfg* cfg, const 
     const auto t0 = std::chrono::steady_clock::now();
     int st;
     int dev_rc = BPLHIP_OK;
-    const bool device_tree = c->opt_device_nuts && !c->dynamic && c->L.T <= 64 && c->staged;
+    const bool device_tree = c->opt_device_nuts && !c->dynamic && c->L.T <= 64 && c->staged &&
+                             c->L.D <= 64 * nd::LEAF_NE;
     if (device_tree) {
         const size_t nsd = nd::ns_doubles(D, nc.max_tree_depth);
         HIP_TRY(c, c->d_ns.ensure(nsd * 8));
@@ -1246,7 +1247,7 @@ extern "C" int bplhip_nuts_run_chains(bplhip_ctx* c, const bplhip_nuts_cfg* cfg,
     if (cfg->num_warmup < 0 || cfg->num_samples < 1 || cfg->max_tree_depth < 1 ||
         cfg->max_tree_depth > 20 || cfg->thinning < 1 || !(cfg->step_size > 0))
         return fail(c, BPLHIP_EINVAL, "nuts_run_chains: bad configuration");
-    if (c->dynamic || !c->vp.ok || c->L.T > 64 || !c->vp.staged)
+    if (c->dynamic || !c->vp.ok || c->L.T > 64 || !c->vp.staged || c->L.D > 64 * nd::LEAF_NE)
         return fail(c, BPLHIP_EUNSUPPORTED,
                     "nuts_run_chains: lock-step chains need the basic/extended model with <= 64 teams");
     HIP_TRY(c, hipSetDevice(c->device));

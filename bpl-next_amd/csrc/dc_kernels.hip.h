@@ -536,8 +536,10 @@ __device__ void prior_body(const EvalArgs& A, int chain, char* smem) {
     const float rho_f = rho_f32(mPf, mQf, mRf, fs.q);
     __syncthreads();
 
+    // (ties: the pair with the smallest index wins; a thread sees its pairs in ascending
+    // order and keeps the first, lanes and waves are in ascending pair order too)
     double mP = 0.0, mQ = 0.0, mR = 0.0;
-    int iP = 0x7FFFFFFF, iQ = 0x7FFFFFFF, iR = 0x7FFFFFFF;
+    uint32_t aP = 0, aQ = 0, aR = 0;  // arg-pairs (home | away << 16)
     for (int p = tid; p < A.P; p += BLOCK) {
         const uint32_t pr = p == tid ? pr0 : A.pairs[p];
         const int h = pr & 0xFFFFu, a = pr >> 16;
@@ -546,25 +548,22 @@ __device__ void prior_body(const EvalArgs& A, int chain, char* smem) {
             lh = fmin(lh, RATE_CLIP);
             la = fmin(la, RATE_CLIP);
         }
-        if (lh * la > mP) { mP = lh * la; iP = p; }
-        if (lh > mQ) { mQ = lh; iQ = p; }
-        if (la > mR) { mR = la; iR = p; }
+        if (lh * la > mP) { mP = lh * la; aP = pr; }
+        if (lh > mQ) { mQ = lh; aQ = pr; }
+        if (la > mR) { mR = la; aR = pr; }
     }
     {
         const double wP = wave_max_f64(mP), wQ = wave_max_f64(mQ), wR = wave_max_f64(mR);
-        // smallest pair index among the lanes holding the wave maximum
-        int cP = mP == wP ? iP : 0x7FFFFFFF, cQ = mQ == wQ ? iQ : 0x7FFFFFFF,
-            cR = mR == wR ? iR : 0x7FFFFFFF;
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) {
-            cP = min(cP, __shfl_xor(cP, d, 64));
-            cQ = min(cQ, __shfl_xor(cQ, d, 64));
-            cR = min(cR, __shfl_xor(cR, d, 64));
-        }
+        // first lane holding the wave maximum (no cross-lane min-reduction, no reload)
+        const unsigned long long bP = __ballot(mP == wP), bQ = __ballot(mQ == wQ),
+                                 bR = __ballot(mR == wR);
+        const uint32_t pP = (uint32_t)__builtin_amdgcn_readlane((int)aP, bP ? __ffsll((long long)bP) - 1 : 0);
+        const uint32_t pQ = (uint32_t)__builtin_amdgcn_readlane((int)aQ, bQ ? __ffsll((long long)bQ) - 1 : 0);
+        const uint32_t pR = (uint32_t)__builtin_amdgcn_readlane((int)aR, bR ? __ffsll((long long)bR) - 1 : 0);
         if (lane == 0) {
             amx[wave * 8 + 0] = wP; amx[wave * 8 + 1] = wQ; amx[wave * 8 + 2] = wR;
-            amx[wave * 8 + 3] = (double)cP; amx[wave * 8 + 4] = (double)cQ;
-            amx[wave * 8 + 5] = (double)cR;
+            amx[wave * 8 + 3] = (double)pP; amx[wave * 8 + 4] = (double)pQ;
+            amx[wave * 8 + 5] = (double)pR;
         }
     }
     __syncthreads();
@@ -606,19 +605,15 @@ __device__ void prior_body(const EvalArgs& A, int chain, char* smem) {
         st_sc1(&gz[o], z[o]);
     }
     if (tid == 0) {
-        // combine the waves' arg-maxima
+        // combine the waves' arg-maxima (strict >: the lowest wave wins ties)
         double M = 0.0, Lh = 0.0, La = 0.0;
-        int jP = 0x7FFFFFFF, jQ = 0x7FFFFFFF, jR = 0x7FFFFFFF;
+        uint32_t pP = 0, pQ = 0, pR = 0;
         for (int wv = 0; wv < WAVES; ++wv) {
             const double a0 = amx[wv * 8 + 0], a1 = amx[wv * 8 + 1], a2 = amx[wv * 8 + 2];
-            const int i0 = (int)amx[wv * 8 + 3], i1 = (int)amx[wv * 8 + 4],
-                      i2 = (int)amx[wv * 8 + 5];
-            if (a0 > M || (a0 == M && i0 < jP)) { M = a0; jP = i0; }
-            if (a1 > Lh || (a1 == Lh && i1 < jQ)) { Lh = a1; jQ = i1; }
-            if (a2 > La || (a2 == La && i2 < jR)) { La = a2; jR = i2; }
+            if (a0 > M) { M = a0; pP = (uint32_t)amx[wv * 8 + 3]; }
+            if (a1 > Lh) { Lh = a1; pQ = (uint32_t)amx[wv * 8 + 4]; }
+            if (a2 > La) { La = a2; pR = (uint32_t)amx[wv * 8 + 5]; }
         }
-        const uint32_t pP = A.pairs[jP < A.P ? jP : 0], pQ = A.pairs[jQ < A.P ? jQ : 0],
-                       pR = A.pairs[jR < A.P ? jR : 0];
         unsigned int flags = 0;
         if (CLIP) {
             if (tru[pP & 0xFFFFu] * tru[2 * T + (pP >> 16)] > RATE_CLIP) flags |= 1u;
@@ -749,6 +744,7 @@ __device__ void tail_one_wave(const EvalArgs& A, int chain, const double* zoL, c
     corr = wave_sum_f64(corr);
     const double Lz = zoL[ZO_LZ], drho = zoL[ZO_DRHO];
     const double Ltot = Lz + corr + G_rho * drho - SLAM - A.lgsum + LN2 * SLOG - CLIPC;
+    DC_STAMP(11);
     if (L.model == MODEL_BASIC) {
         const double ad = on ? zL[L.o_adec + t] : 0.0, dd = on ? zL[L.o_ddec + t] : 0.0;
         if (on) {
@@ -793,6 +789,7 @@ __device__ void tail_one_wave(const EvalArgs& A, int chain, const double* zoL, c
             *pot_of(A, chain) = -Ltot;
         }
     }
+    DC_STAMP(14);
     if (t == 0 && A.aux != nullptr) {
         double* aux = aux_of(A, chain);
         aux[0] = zoL[ZO_RHO];
@@ -916,6 +913,7 @@ __device__ void tail_body(const EvalArgs& A, int chain, char* smem) {
         if (lane == 0) col[ncol + wave] = s;
     }
     __syncthreads();
+    DC_STAMP(9);
     if (T <= 64) {  // the whole per-team epilogue fits one wave: no LDS traffic, no barriers
         if (wave == 0)
             tail_one_wave<NUTS>(A, chain, zoL, cL, zL, col, xs_staged ? xsL : nullptr, gradL);
@@ -984,7 +982,6 @@ __device__ void tail_body(const EvalArgs& A, int chain, char* smem) {
         }
     }
     __syncthreads();
-    DC_STAMP(9);
 
     // ---- 4. chain rule to z (adds and FMAs only); grad = gz - (fixture-sum terms)
     if (L.model == MODEL_BASIC) {

@@ -133,94 +133,142 @@ __device__ __forceinline__ double logaddexp(double a, double b) {
 // Called by the wave that has just computed potential, aux and gradient of the position
 // V_ZN (reached with half-stepped momentum V_RH); it hands them over in LDS:
 // gL = grad[D] | potential | aux[4].
+//
+// The leaf sits on the serial path of the chain (the next evaluation needs the position it
+// writes), so it is organised by memory round trips, not by statement order: (A) the whole
+// header (one word per lane) and every vector it reads are requested at once; (B) all
+// arithmetic runs from registers; (C) the checkpoint reads -- their address depends on the
+// leaf index from the header -- are the second and last dependent round; (D) stores.
+constexpr int LEAF_NE = 4;  // vector elements per lane: D <= 256
+__device__ __forceinline__ double hdr_word(double hv, int k) {  // k wave-uniform constant
+    const long long x = __double_as_longlong(hv);
+    const int lo = __builtin_amdgcn_readlane((int)x, k);
+    const int hi = __builtin_amdgcn_readlane((int)(x >> 32), k);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
 __device__ inline void nuts_leaf(double* ns, int D, int max_depth, int lane, const double* gL) {
-    const double eps = ns[H_EPS] * ns[H_DIR];
-    const bool going_right = ns[H_DIR] > 0.0;
-    double* invM = vec(ns, D, V_INVM);
-    double* zn = vec(ns, D, V_ZN);
-    double* rh = vec(ns, D, V_RH);
-    const double* gr = gL;
+    // ---- (A) one round of loads
+    const double hv = lane < H_N ? ns[lane] : 0.0;
+    double* p_invM = vec(ns, D, V_INVM);
+    double* p_zn = vec(ns, D, V_ZN);
+    double* p_rh = vec(ns, D, V_RH);
+    double* p_rsum = vec(ns, D, V_S_RSUM);
+    double invM[LEAF_NE], zn[LEAF_NE], r[LEAF_NE], rs[LEAF_NE], g[LEAF_NE];
+#pragma unroll
+    for (int e = 0; e < LEAF_NE; ++e) {
+        const int i = lane + 64 * e;
+        const bool ok = i < D;
+        invM[e] = ok ? p_invM[i] : 0.0;
+        zn[e] = ok ? p_zn[i] : 0.0;
+        r[e] = ok ? p_rh[i] : 0.0;
+        rs[e] = ok ? p_rsum[i] : 0.0;
+        g[e] = ok ? gL[i] : 0.0;
+    }
     const double pe = gL[D];
-    // second half step, kinetic energy
-    double kin = 0.0;
-    for (int i = lane; i < D; i += 64) {
-        const double r = rh[i] - 0.5 * eps * gr[i];
-        rh[i] = r;  // V_RH now holds the leaf's full-step momentum
-        kin += invM[i] * r * r;
-    }
-    kin = 0.5 * nd_wave_sum(kin);
-    const double e_new = pe + kin;
-    double delta = e_new - ns[H_E0];
-    if (delta != delta) delta = __builtin_inf();
-    const double w_leaf = -delta;
-    const bool div_leaf = delta > ns[H_MAXDE];
-    const double acc_leaf = fmin(1.0, exp(-delta));
-
-    const int num = (int)ns[H_S_NUM];  // leaves so far = index of this leaf
-    double* sl_z = vec(ns, D, V_SL_Z); double* sl_r = vec(ns, D, V_SL_R); double* sl_g = vec(ns, D, V_SL_G);
-    double* sr_z = vec(ns, D, V_SR_Z); double* sr_r = vec(ns, D, V_SR_R); double* sr_g = vec(ns, D, V_SR_G);
-    double* sp_z = vec(ns, D, V_SP_Z); double* sp_g = vec(ns, D, V_SP_G);
-    double* s_rsum = vec(ns, D, V_S_RSUM);
-    uint32_t khi = (uint32_t)ns[H_KEY_HI], klo = (uint32_t)ns[H_KEY_LO];
-    uint32_t nhi, nlo, thi, tlo;
-    tf_split2(khi, klo, &nhi, &nlo, &thi, &tlo);  // rng_key, transition_rng_key = split(rng_key)
-
-    bool take = true;
-    double w_sub = w_leaf, sum_acc = acc_leaf;
-    if (num == 0) {
-        vcopy(sl_z, zn, D, lane); vcopy(sl_r, rh, D, lane); vcopy(sl_g, gr, D, lane);
-        vcopy(sr_z, zn, D, lane); vcopy(sr_r, rh, D, lane); vcopy(sr_g, gr, D, lane);
-        vcopy(s_rsum, rh, D, lane);
-    } else {
-        // _combine_tree(current, leaf, biased_transition=False)
-        if (going_right) { vcopy(sr_z, zn, D, lane); vcopy(sr_r, rh, D, lane); vcopy(sr_g, gr, D, lane); }
-        else { vcopy(sl_z, zn, D, lane); vcopy(sl_r, rh, D, lane); vcopy(sl_g, gr, D, lane); }
-        for (int i = lane; i < D; i += 64) s_rsum[i] += rh[i];
-        const double w_cur = ns[H_S_WEIGHT];
-        const double prob = 1.0 / (1.0 + exp(-(w_leaf - w_cur)));  // expit: uniform transition
-        take = tf_bernoulli(thi, tlo, prob);
-        w_sub = logaddexp(w_cur, w_leaf);
-        sum_acc = ns[H_S_SUMACC] + acc_leaf;
-    }
-    if (take) {
-        vcopy(sp_z, zn, D, lane);
-        vcopy(sp_g, gr, D, lane);
-    }
-    // checkpoints (numpyro _leaf_idx_to_ckpt_idxs / _is_iterative_turning)
+    const double h_eps = hdr_word(hv, H_EPS), h_dir = hdr_word(hv, H_DIR);
+    const double eps = h_eps * h_dir;
+    const bool going_right = h_dir > 0.0;
+    const int num = (int)hdr_word(hv, H_S_NUM);  // leaves so far = index of this leaf
+    // checkpoint indices (numpyro _leaf_idx_to_ckpt_idxs)
     int idx_max = 0, trail = 0;
     for (int v = num >> 1; v > 0; v >>= 1) idx_max += v & 1;
     for (int v = num; v & 1; v >>= 1) trail += 1;
     const int idx_min = idx_max - trail + 1;
     double* ck_r = vec(ns, D, V_CKPT);
     double* ck_s = ck_r + (size_t)max_depth * D;
-    if ((num & 1) == 0) {
-        vcopy(ck_r + (size_t)idx_max * D, rh, D, lane);
-        vcopy(ck_s + (size_t)idx_max * D, s_rsum, D, lane);
+    // ---- (C, issued early) the first checkpoint an odd leaf compares against
+    double c_r[LEAF_NE], c_s[LEAF_NE];
+    const bool has_ck = idx_max >= idx_min;
+#pragma unroll
+    for (int e = 0; e < LEAF_NE; ++e) {
+        const int i = lane + 64 * e;
+        const bool ok = has_ck && i < D;
+        c_r[e] = ok ? ck_r[(size_t)idx_max * D + i] : 0.0;
+        c_s[e] = ok ? ck_s[(size_t)idx_max * D + i] : 0.0;
     }
+
+    // ---- (B) second half step, kinetic energy
+    double kin = 0.0;
+#pragma unroll
+    for (int e = 0; e < LEAF_NE; ++e) {
+        r[e] = r[e] - 0.5 * eps * g[e];  // the leaf's full-step momentum
+        kin += invM[e] * r[e] * r[e];
+    }
+    kin = 0.5 * nd_wave_sum(kin);
+    const double e_new = pe + kin;
+    double delta = e_new - hdr_word(hv, H_E0);
+    if (delta != delta) delta = __builtin_inf();
+    const double w_leaf = -delta;
+    const bool div_leaf = delta > hdr_word(hv, H_MAXDE);
+    const double acc_leaf = fmin(1.0, exp(-delta));
+
+    uint32_t khi = (uint32_t)hdr_word(hv, H_KEY_HI), klo = (uint32_t)hdr_word(hv, H_KEY_LO);
+    uint32_t nhi, nlo, thi, tlo;
+    tf_split2(khi, klo, &nhi, &nlo, &thi, &tlo);  // rng_key, transition_rng_key = split(rng_key)
+
+    bool take = true;
+    double w_sub = w_leaf, sum_acc = acc_leaf;
+    if (num == 0) {
+#pragma unroll
+        for (int e = 0; e < LEAF_NE; ++e) rs[e] = r[e];
+    } else {
+        // _combine_tree(current, leaf, biased_transition=False)
+#pragma unroll
+        for (int e = 0; e < LEAF_NE; ++e) rs[e] += r[e];
+        const double w_cur = hdr_word(hv, H_S_WEIGHT);
+        const double prob = 1.0 / (1.0 + exp(-(w_leaf - w_cur)));  // expit: uniform transition
+        take = tf_bernoulli(thi, tlo, prob);
+        w_sub = logaddexp(w_cur, w_leaf);
+        sum_acc = hdr_word(hv, H_S_SUMACC) + acc_leaf;
+    }
+    // checkpointed U-turn test (numpyro _is_iterative_turning)
     bool turning = false;
-    for (int i = idx_max; i >= idx_min && !turning; --i) {
-        const double* cr = ck_r + (size_t)i * D;
-        const double* cs = ck_s + (size_t)i * D;
+    for (int ci = idx_max; ci >= idx_min && !turning; --ci) {
+        if (ci != idx_max) {  // (a leaf closing several subtrees: one more round per level)
+#pragma unroll
+            for (int e = 0; e < LEAF_NE; ++e) {
+                const int i = lane + 64 * e;
+                c_r[e] = i < D ? ck_r[(size_t)ci * D + i] : 0.0;
+                c_s[e] = i < D ? ck_s[(size_t)ci * D + i] : 0.0;
+            }
+        }
         double dl = 0.0, dr = 0.0;
-        for (int k = lane; k < D; k += 64) {
-            const double sub = s_rsum[k] - cs[k] + cr[k];
-            const double rs = sub - 0.5 * (cr[k] + rh[k]);
-            dl += invM[k] * cr[k] * rs;
-            dr += invM[k] * rh[k] * rs;
+#pragma unroll
+        for (int e = 0; e < LEAF_NE; ++e) {
+            const double sub = rs[e] - c_s[e] + c_r[e];
+            const double rsm = sub - 0.5 * (c_r[e] + r[e]);
+            dl += invM[e] * c_r[e] * rsm;
+            dr += invM[e] * r[e] * rsm;
         }
         dl = nd_wave_sum(dl);
         dr = nd_wave_sum(dr);
         turning = (dl <= 0.0) | (dr <= 0.0);
     }
     const int new_num = num + 1;
-    const bool done = turning || div_leaf || new_num >= (int)ns[H_S_MAX];
-    // next leapfrog starts from this leaf (the subtree grows in one direction)
-    if (!done) {
-        double* zn2 = zn;
-        for (int i = lane; i < D; i += 64) {
-            const double r = rh[i] - 0.5 * eps * gr[i];
-            zn2[i] = zn[i] + eps * invM[i] * r;
-            rh[i] = r;
+    const bool done = turning || div_leaf || new_num >= (int)hdr_word(hv, H_S_MAX);
+
+    // ---- (D) stores
+    double* sl_z = vec(ns, D, V_SL_Z); double* sl_r = vec(ns, D, V_SL_R); double* sl_g = vec(ns, D, V_SL_G);
+    double* sr_z = vec(ns, D, V_SR_Z); double* sr_r = vec(ns, D, V_SR_R); double* sr_g = vec(ns, D, V_SR_G);
+    double* sp_z = vec(ns, D, V_SP_Z); double* sp_g = vec(ns, D, V_SP_G);
+    const bool wl = num == 0 || !going_right, wr = num == 0 || going_right;
+    const bool wck = (num & 1) == 0;
+#pragma unroll
+    for (int e = 0; e < LEAF_NE; ++e) {
+        const int i = lane + 64 * e;
+        if (i < D) {
+            // next leapfrog starts from this leaf (the subtree grows in one direction)
+            const double rn = r[e] - 0.5 * eps * g[e];
+            p_zn[i] = done ? zn[e] : zn[e] + eps * invM[e] * rn;
+            p_rh[i] = done ? r[e] : rn;
+            p_rsum[i] = rs[e];
+            if (wl) { sl_z[i] = zn[e]; sl_r[i] = r[e]; sl_g[i] = g[e]; }
+            if (wr) { sr_z[i] = zn[e]; sr_r[i] = r[e]; sr_g[i] = g[e]; }
+            if (take) { sp_z[i] = zn[e]; sp_g[i] = g[e]; }
+            if (wck) {
+                ck_r[(size_t)idx_max * D + i] = r[e];
+                ck_s[(size_t)idx_max * D + i] = rs[e];
+            }
         }
     }
     if (lane == 0) {
@@ -232,7 +280,7 @@ __device__ inline void nuts_leaf(double* ns, int D, int max_depth, int lane, con
         ns[H_S_DONE] = done ? 1.0 : 0.0;
         ns[H_KEY_HI] = (double)nhi;
         ns[H_KEY_LO] = (double)nlo;
-        ns[H_EVALS] += 1.0;
+        ns[H_EVALS] = hdr_word(hv, H_EVALS) + 1.0;
         if (take) {
             ns[H_S_PE] = pe;
             ns[H_S_EPROP] = e_new;

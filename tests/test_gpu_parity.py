@@ -178,7 +178,9 @@ def test_graph_replay_matches_direct(hip_ctx):
                          fx.home_goals.astype(np.uint8), fx.away_goals.astype(np.uint8), 20)
     zs = np.random.RandomState(7).uniform(-0.5, 0.5, (8, 45))
     z = torch.tensor(zs, dtype=torch.float64, device=hip_ctx.device)
+    hip_ctx.set_option("vec_min_chains", 0)  # direct = 8 single-chain launches (grid.y)
     Ud, gd, _ = hip_ctx.logp_grad(z)
+    hip_ctx.set_option("vec_min_chains", 4)
     U = torch.zeros(8, dtype=torch.float64, device=hip_ctx.device)
     g = torch.zeros_like(z)
     hip_ctx.logp_grad_graph(16, z, U, g, replays=3)

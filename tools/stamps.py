@@ -30,7 +30,8 @@ def run(n, model=MODEL_BASIC, max_wg=255):
         col = rel[1:, k][st[1:, k] > 0]
         if col.size: print(f"  {names[k]:10s} median {np.median(col):7.2f} us  min {col.min():7.2f}  max {col.max():7.2f}")
     last = int(np.argmax(st[:, 10]))
-    print("  tail WG", last, " ".join(f"{names[k]}={rel[last, k]:.2f}" for k in range(11)))
+    print("  tail WG", last, " ".join(f"{names[k]}={rel[last, k]:.2f}" for k in range(11)),
+          f"epi:sums={rel[last, 11]:.2f} epi:puts={rel[last, 14]:.2f}")
     c.close()
 
 for n in (1_000_000,):
