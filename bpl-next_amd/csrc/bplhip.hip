@@ -101,7 +101,7 @@ struct bplhip_ctx {
     bool dynamic = false;
     dcd::DynLayout DL{};
     int dyn_random_walk = 1;
-    DevBuf dd_gw, dd_nv, dd_cells, dd_acc, dd_lam, dd_sc, dd_hyp;
+    DevBuf dd_gw, dd_nv, dd_cells, dd_acc, dd_hyp;
     std::map<GraphKey, hipGraphExec_t> graphs;
     hipStream_t cap_stream = nullptr;
 
@@ -184,7 +184,7 @@ int launch_eval_dynamic(bplhip_ctx* c, int chains, const double* z, double* pot,
                         double* aux, hipStream_t s) {
     const dcd::DynLayout& L = c->DL;
     const size_t GT = (size_t)L.G * L.T;
-    for (int ch = 0; ch < chains; ++ch) {  // chains run back to back (first correct path)
+    for (int ch = 0; ch < chains; ++ch) {  // chains run back to back
         dcd::DynArgs A{};
         A.h = c->d_h.as<const uint16_t>();
         A.a = c->d_a.as<const uint16_t>();
@@ -197,8 +197,10 @@ int launch_eval_dynamic(bplhip_ctx* c, int chains, const double* z, double* pot,
         A.lgsum = c->lgsum;
         A.cells = c->dd_cells.as<double>();
         A.acc = c->dd_acc.as<double>();
-        A.lam = c->dd_lam.as<double>();
-        A.sc = c->dd_sc.as<double>();
+        A.sc = A.acc + GT * dcd::A_N;
+        A.gsum = A.sc + dcd::SC_N;
+        A.red = A.gsum + 10 * (size_t)L.G;
+        A.cov = A.red + dcd::R_N;
         A.hyp = c->dd_hyp.as<double>();
         A.z = z + (size_t)ch * L.D;
         A.potential = pot + ch;
@@ -206,14 +208,25 @@ int launch_eval_dynamic(bplhip_ctx* c, int chains, const double* z, double* pot,
         A.aux = aux ? aux + (size_t)ch * 4 : nullptr;
         A.random_walk = c->dyn_random_walk;
         A.L = L;
-        HIP_TRY(c, hipMemsetAsync(A.acc, 0, GT * dcd::A_N * 8, s));
-        HIP_TRY(c, hipMemsetAsync(A.sc, 0, dcd::SC_N * 8, s));
-        hipLaunchKernelGGL(dcd::dyn_cells, dim3((L.T + 255) / 256), dim3(256), 6 * L.G * 8, s, A);
-        const int nb = (int)((c->n + 255) / 256);
-        hipLaunchKernelGGL(dcd::dyn_pass1, dim3(nb), dim3(256), 0, s, A);
-        hipLaunchKernelGGL(dcd::dyn_pass2, dim3(nb), dim3(256), 0, s, A);
-        hipLaunchKernelGGL(dcd::dyn_epilogue, dim3(1), dim3(dcd::EPI_THREADS),
-                           dcd::epi_lds_bytes(L.G, L.K), s, A);
+        // fixture passes: at most 1024 workgroups; pass 2 takes contiguous chunks
+        const long long nb_all = (c->n + dcd::FIX_BLOCK - 1) / dcd::FIX_BLOCK;
+        const int nb = (int)std::min<long long>(nb_all, 1024);
+        A.chunk = ((c->n + nb - 1) / nb + dcd::FIX_BLOCK - 1) / dcd::FIX_BLOCK * dcd::FIX_BLOCK;
+        const int nb2 = (int)((c->n + A.chunk - 1) / A.chunk);
+        const int cell_blocks = (L.T + dcd::CELL_BLOCK / 64 - 1) / (dcd::CELL_BLOCK / 64);
+        HIP_TRY(c, hipMemsetAsync(A.acc, 0, dcd::scratch_doubles(L.G, L.T, L.K) * 8, s));
+        hipLaunchKernelGGL(dcd::dyn_cells, dim3(cell_blocks), dim3(dcd::CELL_BLOCK), 0, s, A);
+        hipLaunchKernelGGL(dcd::dyn_pass1, dim3(nb), dim3(dcd::FIX_BLOCK), 0, s, A);
+        if (!c->lds_attr_set) {
+            HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(dcd::dyn_pass2),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           dcd::PASS2_LDS_CELLS * dcd::A_N * 8));
+            c->lds_attr_set = true;
+        }
+        hipLaunchKernelGGL(dcd::dyn_pass2, dim3(nb2), dim3(dcd::FIX_BLOCK),
+                           (size_t)dcd::PASS2_LDS_CELLS * dcd::A_N * 8, s, A);
+        hipLaunchKernelGGL(dcd::dyn_epi_cells, dim3(cell_blocks), dim3(dcd::CELL_BLOCK), 0, s, A);
+        hipLaunchKernelGGL(dcd::dyn_final, dim3(1), dim3(dcd::FINAL_BLOCK), 0, s, A);
         HIP_TRY(c, hipGetLastError());
     }
     return BPLHIP_OK;
@@ -651,8 +664,6 @@ int bplhip_set_fixtures_dynamic(bplhip_ctx* c, int64_t n, int32_t n_teams, int32
         return fail(c, BPLHIP_EINVAL, "set_fixtures_dynamic: covariates/k mismatch");
     if ((int64_t)n_teams * n_gameweeks > (int64_t)1 << 26)
         return fail(c, BPLHIP_EUNSUPPORTED, "set_fixtures_dynamic: too many (gameweek, team) cells");
-    if (dcd::epi_lds_bytes(n_gameweeks, k) > 64 * 1024)
-        return fail(c, BPLHIP_EUNSUPPORTED, "set_fixtures_dynamic: too many gameweeks");
     HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t s = static_cast<hipStream_t>(stream);
     std::vector<uint16_t> h(n), a(n), g(n);
@@ -671,6 +682,18 @@ int bplhip_set_fixtures_dynamic(bplhip_ctx* c, int64_t n, int32_t n_teams, int32
                         (long long)i);
         lgsum += std::lgamma((double)x[i] + 1.0) + std::lgamma((double)y[i] + 1.0);
     }
+    {   // stable sort by gameweek: a workgroup of dyn_pass2 then spans only a few gameweeks
+        std::vector<uint32_t> order(n);
+        for (int64_t i = 0; i < n; ++i) order[i] = (uint32_t)i;
+        if (n > (int64_t)0xFFFFFFFF) return fail(c, BPLHIP_EUNSUPPORTED, "set_fixtures_dynamic: n too large");
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t p, uint32_t q) { return g[p] < g[q]; });
+        auto permute = [&](auto& v) {
+            auto w = v;
+            for (int64_t i = 0; i < n; ++i) w[i] = v[order[i]];
+            v.swap(w);
+        };
+        permute(h); permute(a); permute(x); permute(y); permute(nv); permute(g);
+    }
     const size_t GT = (size_t)n_teams * n_gameweeks;
     HIP_TRY(c, c->d_h.ensure(n * 2));
     HIP_TRY(c, c->d_a.ensure(n * 2));
@@ -685,9 +708,7 @@ int bplhip_set_fixtures_dynamic(bplhip_ctx* c, int64_t n, int32_t n_teams, int32
     HIP_TRY(c, hipMemcpyAsync(c->dd_gw.p, g.data(), n * 2, hipMemcpyHostToDevice, s));
     HIP_TRY(c, hipMemcpyAsync(c->dd_nv.p, nv.data(), n, hipMemcpyHostToDevice, s));
     HIP_TRY(c, c->dd_cells.ensure(GT * dcd::P_N * 8));
-    HIP_TRY(c, c->dd_acc.ensure(GT * dcd::A_N * 8));
-    HIP_TRY(c, c->dd_lam.ensure((size_t)n * 2 * 8));
-    HIP_TRY(c, c->dd_sc.ensure(dcd::SC_N * 8));
+    HIP_TRY(c, c->dd_acc.ensure(dcd::scratch_doubles(n_gameweeks, n_teams, k) * 8));
     HIP_TRY(c, c->dd_hyp.ensure((size_t)6 * n_gameweeks * 8));
     c->h_xs.clear();
     if (k > 0) {

@@ -4,14 +4,20 @@
 // `.at[].set()` results are discarded) or, `random_walk = 0`,
 // the behaviour of the code as written (attack = defence = 0).
 //
-// First correct path for BASELINE config 4 (T = 100, G = 50, D = 35 502): float64
-// throughout, four small launches per evaluation, no fixture re-ordering:
-//   dyn_cells     per-(gameweek, team) constrained sites from z (walk = cumulative sum)
-//   dyn_pass1     per fixture: rates; global maxima for the rho bounds (atomicMax)
-//   dyn_pass2     per fixture: Poisson + tau value and adjoint, float64 atomics into the
-//                 six per-cell accumulators; arg-extremal fixtures (atomicMin of index)
-//   dyn_epilogue  bounds adjoint, reverse cumulative sum over gameweeks (adjoint of the
-//                 walk), priors + Jacobians, chain rule to z
+// BASELINE config 4 (T = 100, G = 50, D = 35 502).  float64 throughout; fixtures sorted by
+// gameweek; one memset + five launches per evaluation, every one parallel over its natural
+// axis (the 7 [G,T] latent tables make D large: the z-side work matters as much as the
+// fixtures):
+//   dyn_cells     one WAVE per team, lanes = gameweeks: the walk is a wave prefix sum
+//   dyn_pass1     fixtures (grid-stride): rates; maxima for the rho bounds, one atomicMax
+//                 per workgroup
+//   dyn_pass2     fixtures (contiguous chunk per workgroup): Poisson + tau value and adjoint
+//                 into the six per-cell accumulators -- LDS-private for the (few) gameweeks
+//                 the chunk spans, flushed with float64 atomics; arg-extremal fixtures
+//   dyn_epi_cells one wave per team: bounds adjoint, the walk's adjoint as a wave suffix
+//                 sum, priors + Jacobians and chain rule of the 7 cell tables, per-gameweek
+//                 sums by atomics
+//   dyn_final     per-gameweek hyper-parameters, covariate coefficients, scalars, potential
 // Roofline: HBM-bound stream of 9 B per fixture (u16,u16,u8,u8,u16,u8) + gathers from an
 // L2-resident cell table; at config-4 size (N = 2500) it is launch-latency bound.
 // Mathematics: SURVEY.md Appendix A.5 (+ Appendix A.1-A.3 for the shared pieces).
@@ -62,28 +68,38 @@ inline DynLayout make_dyn_layout(int G, int T, int K) {
     return L;
 }
 
-// scratch scalars (doubles / u64 words), zeroed by a memset before every evaluation
+// scratch, zeroed by ONE memset before every evaluation:
+//   acc [G*T][A_N] | sc [SC_N] (maxima / indices as u64 bits) | gsum [10][G] | red [4] | cov [2K]
 enum { SC_U = 0, SC_GRHO, SC_MAXP, SC_MAXH, SC_MAXA, SC_IDXP, SC_IDXQ, SC_IDXR, SC_N = 8 };
 // cell parameter record
 enum { P_AH = 0, P_AA, P_BH, P_BA, P_ATT, P_DEF, P_N = 6 };
 // cell accumulator record
 enum { A_ATT = 0, A_DEF, A_HATT, A_ADEF, A_AATT, A_HDEF, A_N = 6 };
+// red: 0 d/d mean_defence, 1 log-density of the cell sites
+enum { R_MD = 0, R_L = 1, R_N = 4 };
+
+inline size_t scratch_doubles(int G, int T, int K) {
+    return (size_t)G * T * A_N + SC_N + 10 * (size_t)G + R_N + 2 * (size_t)K;
+}
 
 struct DynArgs {
-    const uint16_t* h;
+    const uint16_t* h;   // fixtures sorted by gameweek
     const uint16_t* a;
     const uint8_t* x;
     const uint8_t* y;
     const uint16_t* gw;
     const uint8_t* nv;
     long long n;
-    const double* xs;   // [T,K] standardised covariates or nullptr
+    long long chunk;     // fixtures per workgroup of dyn_pass2
+    const double* xs;    // [T,K] standardised covariates or nullptr
     double lgsum;
-    double* cells;      // [G*T][P_N]
-    double* acc;        // [G*T][A_N]   (zeroed per evaluation)
-    double* lam;        // [2][n]
-    double* sc;         // [SC_N]       (zeroed per evaluation; maxima/indices as u64 bits)
-    double* hyp;        // [6][G] exp(std_*)  order: att, def, ha, aa, hd, ad
+    double* cells;       // [G*T][P_N]
+    double* acc;         // scratch (see above)
+    double* sc;
+    double* gsum;
+    double* red;
+    double* cov;
+    double* hyp;         // [6][G] exp(std_*)  order: att, def, ha, aa, hd, ad
     const double* z;
     double* potential;
     double* grad;
@@ -105,50 +121,90 @@ __device__ __forceinline__ void clipped_sig(double x, double* v, double* dv, dou
     else if (t > dc::SIG_HI) { *v = dc::SIG_HI; *dv = 0.0; }
     else { *v = t; *dv = t * (1.0 - t); }
 }
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const unsigned long long o = __shfl_xor(v, d, 64);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+// inclusive prefix sum over the 64 lanes (lane 0 first)
+__device__ __forceinline__ double wave_prefix(double v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const double o = __shfl_up(v, d, 64);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+// inclusive suffix sum over the 64 lanes (lane 63 first)
+__device__ __forceinline__ double wave_suffix(double v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const double o = __shfl_down(v, d, 64);
+        if (lane + d < 64) v += o;
+    }
+    return v;
+}
 
-// ---- per-(gameweek, team) constrained sites
-__global__ __launch_bounds__(256) void dyn_cells(DynArgs A) {
+constexpr int CELL_BLOCK = 256;   // 4 waves = 4 teams per workgroup
+constexpr int FIX_BLOCK = 256;
+
+// ---- per-(gameweek, team) constrained sites: one wave per team, lanes over gameweeks
+__global__ __launch_bounds__(CELL_BLOCK) void dyn_cells(DynArgs A) {
     const DynLayout& L = A.L;
     const int G = L.G, T = L.T, K = L.K;
     const double* z = A.z;
-    extern __shared__ double sh[];  // [6*G] exp(std)
-    for (int i = threadIdx.x; i < 6 * G; i += blockDim.x) {
-        const int j = i / G, g = i - j * G;
-        const int o = j == 0 ? L.o_s_att : j == 1 ? L.o_s_def : j == 2 ? L.o_s_ha
-                    : j == 3 ? L.o_s_aa : j == 4 ? L.o_s_hd : L.o_s_ad;
-        const double v = exp(z[o + g]);
-        sh[i] = v;
-        if (blockIdx.x == 0) A.hyp[i] = v;
-    }
-    __syncthreads();
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int t = blockIdx.x * (CELL_BLOCK / 64) + wave;
     if (t >= T) return;
-    double att = 0.0, def = z[L.o_md];
+    double att0 = 0.0, def0 = z[L.o_md];
     for (int k = 0; k < K; ++k) {
         const double xv = A.xs[(size_t)t * K + k];
-        att += xv * z[L.o_bA + k];
-        def += xv * z[L.o_bD + k];
+        att0 += xv * z[L.o_bA + k];
+        def0 += xv * z[L.o_bD + k];
     }
-    for (int g = 0; g < G; ++g) {
+    double carry_a = att0, carry_d = def0;
+    for (int g0 = 0; g0 < G; g0 += 64) {
+        const int g = g0 + lane;
+        const bool on = g < G;
         const int c = g * T + t;
+        double s[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const int o = j == 0 ? L.o_s_att : j == 1 ? L.o_s_def : j == 2 ? L.o_s_ha
+                        : j == 3 ? L.o_s_aa : j == 4 ? L.o_s_hd : L.o_s_ad;
+            s[j] = on ? exp(z[o + g]) : 0.0;
+            if (on && t == 0) A.hyp[j * G + g] = s[j];
+        }
         double a_ = 0.0, d_ = 0.0;
         if (A.random_walk) {
-            att += z[L.o_sat + c] * sh[g];
-            def += z[L.o_sdt + c] * sh[G + g];
-            a_ = att;
-            d_ = def;
+            const double ia = on ? z[L.o_sat + c] * s[0] : 0.0;
+            const double id = on ? z[L.o_sdt + c] * s[1] : 0.0;
+            a_ = carry_a + wave_prefix(ia, lane);
+            d_ = carry_d + wave_prefix(id, lane);
+            carry_a = __shfl(a_, 63, 64);
+            carry_d = __shfl(d_, 63, 64);
         }
-        const double hat = z[L.o_mha + g] + sh[2 * G + g] * z[L.o_hat + c];
-        const double aat = z[L.o_maa + g] + sh[3 * G + g] * z[L.o_aat + c];
-        const double hdf = z[L.o_mhd + g] + sh[4 * G + g] * z[L.o_hdf + c];
-        const double adf = z[L.o_mad + g] + sh[5 * G + g] * z[L.o_adf + c];
-        double* P = A.cells + (size_t)c * P_N;
-        P[P_AH] = a_ + hat;
-        P[P_AA] = a_ + aat;
-        P[P_BH] = d_ + hdf;
-        P[P_BA] = d_ + adf;
-        P[P_ATT] = a_;
-        P[P_DEF] = d_;
+        if (on) {
+            const double hat = z[L.o_mha + g] + s[2] * z[L.o_hat + c];
+            const double aat = z[L.o_maa + g] + s[3] * z[L.o_aat + c];
+            const double hdf = z[L.o_mhd + g] + s[4] * z[L.o_hdf + c];
+            const double adf = z[L.o_mad + g] + s[5] * z[L.o_adf + c];
+            double* P = A.cells + (size_t)c * P_N;
+            P[P_AH] = a_ + hat;
+            P[P_AA] = a_ + aat;
+            P[P_BH] = d_ + hdf;
+            P[P_BA] = d_ + adf;
+            P[P_ATT] = a_;
+            P[P_DEF] = d_;
+        }
     }
 }
 
@@ -170,49 +226,49 @@ __device__ __forceinline__ void fixture_etas(const DynArgs& A, long long i, int*
     }
 }
 
-__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        const unsigned long long o = __shfl_xor(v, d, 64);
-        v = o > v ? o : v;
-    }
-    return v;
-}
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-    return v;
-}
-
-// ---- pass 1: rates + maxima (positive doubles order like their bit patterns)
-__global__ __launch_bounds__(256) void dyn_pass1(DynArgs A) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+// ---- pass 1: maxima of the rates (positive doubles order like their bit patterns)
+__global__ __launch_bounds__(FIX_BLOCK) void dyn_pass1(DynArgs A) {
+    __shared__ unsigned long long shm[3 * (FIX_BLOCK / 64)];
     unsigned long long mP = 0, mH = 0, mA = 0;
-    if (i < A.n) {
+    for (long long i = (long long)blockIdx.x * FIX_BLOCK + threadIdx.x; i < A.n;
+         i += (long long)gridDim.x * FIX_BLOCK) {
         int ch, ca, nv;
         double eh, ea;
         fixture_etas(A, i, &ch, &ca, &nv, &eh, &ea);
         const double lh = exp(eh), la = exp(ea);
-        A.lam[i] = lh;
-        A.lam[A.n + i] = la;
-        mP = (unsigned long long)__double_as_longlong(lh * la);
-        mH = (unsigned long long)__double_as_longlong(lh);
-        mA = (unsigned long long)__double_as_longlong(la);
+        const unsigned long long p = (unsigned long long)__double_as_longlong(lh * la),
+                                 hh = (unsigned long long)__double_as_longlong(lh),
+                                 aa = (unsigned long long)__double_as_longlong(la);
+        mP = p > mP ? p : mP;
+        mH = hh > mH ? hh : mH;
+        mA = aa > mA ? aa : mA;
     }
     mP = wave_max_u64(mP);
     mH = wave_max_u64(mH);
     mA = wave_max_u64(mA);
-    if ((threadIdx.x & 63) == 0) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
+        shm[wave * 3 + 0] = mP; shm[wave * 3 + 1] = mH; shm[wave * 3 + 2] = mA;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        unsigned long long m = 0;
+        for (int w = 0; w < FIX_BLOCK / 64; ++w) m = shm[w * 3 + threadIdx.x] > m ? shm[w * 3 + threadIdx.x] : m;
         unsigned long long* sc = reinterpret_cast<unsigned long long*>(A.sc);
-        atomicMax(&sc[SC_MAXP], mP);
-        atomicMax(&sc[SC_MAXH], mH);
-        atomicMax(&sc[SC_MAXA], mA);
+        atomicMax(&sc[SC_MAXP + threadIdx.x], m);
     }
 }
 
-// ---- pass 2: value + adjoint per fixture
-__global__ __launch_bounds__(256) void dyn_pass2(DynArgs A) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+// ---- pass 2: value + adjoint per fixture; one contiguous chunk per workgroup
+// LDS: private accumulators for the gameweeks the chunk spans, when they fit
+constexpr int PASS2_LDS_CELLS = 1280;   // cells (x A_N doubles = 60 KB)
+__global__ __launch_bounds__(FIX_BLOCK) void dyn_pass2(DynArgs A) {
+    extern __shared__ double lacc[];     // [span*T][A_N]
+    __shared__ double shr[2 * (FIX_BLOCK / 64)];
+    const int T = A.L.T;
+    const long long i0 = (long long)blockIdx.x * A.chunk;
+    const long long i1 = i0 + A.chunk < A.n ? i0 + A.chunk : A.n;
+    if (i0 >= A.n) return;
     const unsigned long long* scu = reinterpret_cast<const unsigned long long*>(A.sc);
     const double M = __longlong_as_double((long long)scu[SC_MAXP]);
     const double Lh = __longlong_as_double((long long)scu[SC_MAXH]);
@@ -222,29 +278,38 @@ __global__ __launch_bounds__(256) void dyn_pass2(DynArgs A) {
     const double UB = M > 1.0 ? 1.0 / M : 1.0;
     const double LB = -1.0 / fmax(Lh, La);
     const double rho = LB + q * (UB - LB);
+    const int g_lo = A.gw[i0], g_hi = A.gw[i1 - 1];
+    const int ncell = (g_hi - g_lo + 1) * T;
+    const bool priv = ncell <= PASS2_LDS_CELLS;
+    const int cell0 = g_lo * T;
+    if (priv) {
+        for (int k = threadIdx.x; k < ncell * A_N; k += FIX_BLOCK) lacc[k] = 0.0;
+        __syncthreads();
+    }
     double Ui = 0.0, ui = 0.0;
-    if (i < A.n) {
+    for (long long i = i0 + threadIdx.x; i < i1; i += FIX_BLOCK) {
         int ch, ca, nv;
         double eh, ea;
         fixture_etas(A, i, &ch, &ca, &nv, &eh, &ea);
-        const double lh = A.lam[i], la = A.lam[A.n + i];
+        const double lh = exp(eh), la = exp(ea);
         const int x = A.x[i], y = A.y[i];
-        Ui = x * eh - lh + y * ea - la;
+        Ui += x * eh - lh + y * ea - la;
         double gh = x - lh, ga = y - la;
         if (x <= 1 && y <= 1) {
             const double c = x == 0 ? (y == 0 ? -lh * la : lh) : (y == 0 ? la : -1.0);
             const double arg = 1.0 + rho * c;
             if (arg > 0.0) {
                 Ui += log(arg);
-                ui = c / arg;
-                if (x == 0) gh += rho * ui;
-                if (y == 0) ga += rho * ui;
+                const double u = c / arg;
+                ui += u;
+                if (x == 0) gh += rho * u;
+                if (y == 0) ga += rho * u;
             } else {
                 Ui += log(0.0);  // -inf (tol = 0, bpl/_util.py:42)
             }
         }
-        double* Ah = A.acc + (size_t)ch * A_N;
-        double* Aa = A.acc + (size_t)ca * A_N;
+        double* Ah = priv ? lacc + (size_t)(ch - cell0) * A_N : A.acc + (size_t)ch * A_N;
+        double* Aa = priv ? lacc + (size_t)(ca - cell0) * A_N : A.acc + (size_t)ca * A_N;
         atomicAdd(&Ah[A_ATT], gh);
         atomicAdd(&Aa[A_DEF], -gh);
         atomicAdd(&Aa[A_ATT], ga);
@@ -264,129 +329,119 @@ __global__ __launch_bounds__(256) void dyn_pass2(DynArgs A) {
     }
     Ui = wave_sum(Ui);
     ui = wave_sum(ui);
-    if ((threadIdx.x & 63) == 0) {
-        atomicAdd(&A.sc[SC_U], Ui);
-        atomicAdd(&A.sc[SC_GRHO], ui);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
+        shr[wave * 2] = Ui;
+        shr[wave * 2 + 1] = ui;
+    }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        double v = 0.0;
+        for (int w = 0; w < FIX_BLOCK / 64; ++w) v += shr[w * 2 + threadIdx.x];
+        atomicAdd(&A.sc[threadIdx.x == 0 ? SC_U : SC_GRHO], v);
+    }
+    if (priv) {
+        for (int k = threadIdx.x; k < ncell * A_N; k += FIX_BLOCK) {
+            const double v = lacc[k];
+            if (v != 0.0) atomicAdd(&A.acc[(size_t)cell0 * A_N + k], v);
+        }
     }
 }
 
-// ---- epilogue: one workgroup
-constexpr int EPI_THREADS = 1024;
+// ---- adjoint of the rho bounds: up to three fixtures get an extra d/d eta
+struct Coupling {
+    int n;
+    int cell[12], which[12];
+    double val[12];
+};
+__device__ inline void coupling_add(const DynArgs& A, Coupling& C, long long idx1, bool home_rate,
+                                    double v) {
+    if (idx1 == 0) return;
+    const long long i = idx1 - 1;
+    const int T = A.L.T;
+    const int g = A.gw[i], h = A.h[i], a = A.a[i], nv = A.nv[i];
+    const int ch = g * T + h, ca = g * T + a;
+    auto put = [&](int cell, int which, double val) {
+        C.cell[C.n] = cell; C.which[C.n] = which; C.val[C.n] = val;
+        ++C.n;
+    };
+    if (home_rate) {  // d/d eta_h
+        put(ch, A_ATT, v); put(ca, A_DEF, -v);
+        if (!nv) { put(ch, A_HATT, v); put(ca, A_ADEF, -v); }
+    } else {
+        put(ca, A_ATT, v); put(ch, A_DEF, -v);
+        if (!nv) { put(ca, A_AATT, v); put(ch, A_HDEF, -v); }
+    }
+}
+struct Bounds {
+    double M, Lh, La, q, dq, sq, UB, LB, rho, G_rho;
+};
+__device__ inline Bounds load_bounds(const DynArgs& A) {
+    Bounds b;
+    const unsigned long long* scu = reinterpret_cast<const unsigned long long*>(A.sc);
+    b.M = __longlong_as_double((long long)scu[SC_MAXP]);
+    b.Lh = __longlong_as_double((long long)scu[SC_MAXH]);
+    b.La = __longlong_as_double((long long)scu[SC_MAXA]);
+    clipped_sig(A.z[A.L.o_corr], &b.q, &b.dq, &b.sq);
+    b.UB = b.M > 1.0 ? 1.0 / b.M : 1.0;
+    b.LB = -1.0 / fmax(b.Lh, b.La);
+    b.rho = b.LB + b.q * (b.UB - b.LB);
+    b.G_rho = A.sc[SC_GRHO];
+    return b;
+}
 
-__global__ __launch_bounds__(EPI_THREADS) void dyn_epilogue(DynArgs A) {
+// ---- per-cell chain rule: one wave per team, lanes over gameweeks (from the last one)
+__global__ __launch_bounds__(CELL_BLOCK) void dyn_epi_cells(DynArgs A) {
     const DynLayout& L = A.L;
     const int G = L.G, T = L.T, K = L.K;
-    const int tid = threadIdx.x;
     const double* z = A.z;
     double* grad = A.grad;
-    extern __shared__ double sh[];
-    double* hyp = sh;                  // [6*G] exp(std): att, def, ha, aa, hd, ad
-    double* gsum = hyp + 6 * G;        // [10*G] per-gameweek sums
-    double* red = gsum + 10 * G;       // [32] scalar accumulators
-    double* cpl = red + 32;            // [8*3] coupling entries {cell, which, value}
-    double* covA = cpl + 24;           // [2*K]
-    for (int i = tid; i < 6 * G; i += EPI_THREADS) hyp[i] = A.hyp[i];
-    for (int i = tid; i < 10 * G + 32 + 24 + 2 * K; i += EPI_THREADS) gsum[i] = 0.0;
-    __syncthreads();
-
-    const unsigned long long* scu = reinterpret_cast<const unsigned long long*>(A.sc);
-    const double M = __longlong_as_double((long long)scu[SC_MAXP]);
-    const double Lh = __longlong_as_double((long long)scu[SC_MAXH]);
-    const double La = __longlong_as_double((long long)scu[SC_MAXA]);
-    const double zc = z[L.o_corr];
-    double q, dq, sq;
-    clipped_sig(zc, &q, &dq, &sq);
-    const double UB = M > 1.0 ? 1.0 / M : 1.0;
-    const double LB = -1.0 / fmax(Lh, La);
-    const double rho = LB + q * (UB - LB);
-    const double G_rho = A.sc[SC_GRHO];
-
-    // ---- adjoint of the bounds: up to 3 fixtures get an extra d/d eta; recorded as
-    // {cell, accumulator, value} entries that the team loop adds while it reads acc
-    if (tid == 0) {
-        int ne = 0;
-        auto add = [&](long long idx1, bool home_rate, double v) {
-            if (idx1 == 0) return;
-            const long long i = idx1 - 1;
-            const int g = A.gw[i], h = A.h[i], a = A.a[i], nv = A.nv[i];
-            const int ch = g * T + h, ca = g * T + a;
-            auto put = [&](int cell, int which, double val) {
-                cpl[3 * ne] = (double)cell; cpl[3 * ne + 1] = (double)which; cpl[3 * ne + 2] = val;
-                ++ne;
-            };
-            if (home_rate) {  // d/d eta_h
-                put(ch, A_ATT, v); put(ca, A_DEF, -v);
-                if (!nv) { put(ch, A_HATT, v); put(ca, A_ADEF, -v); }
-            } else {
-                put(ca, A_ATT, v); put(ch, A_DEF, -v);
-                if (!nv) { put(ca, A_AATT, v); put(ch, A_HDEF, -v); }
-            }
-        };
-        // at most 2 + 1 fixtures x 4 entries; the table holds 8: P uses both rates (8
-        // entries) -> apply Q/R through a second small table region
-        if (M > 1.0) {
-            const double v = G_rho * q * (-UB);
-            const long long ip = scu[SC_IDXP] ? (long long)(~0ull - scu[SC_IDXP]) + 1 : 0;
-            add(ip, true, v);
-            add(ip, false, v);
-        }
-        red[20] = (double)ne;  // entries so far live in cpl[0 .. 3*ne)
-    }
-    __syncthreads();
-    // second coupling group (LB) kept in registers of every thread: one fixture, one rate
-    long long lbi = 0;
-    bool lb_home = false;
-    const double lbv = G_rho * (1.0 - q) * (-LB);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int t = blockIdx.x * (CELL_BLOCK / 64) + wave;
+    if (t >= T) return;
+    const Bounds b = load_bounds(A);
+    Coupling C;
+    C.n = 0;
     {
-        const unsigned long long w = Lh >= La ? scu[SC_IDXQ] : scu[SC_IDXR];
-        lbi = w ? (long long)(~0ull - w) + 1 : 0;
-        lb_home = Lh >= La;
+        const unsigned long long* scu = reinterpret_cast<const unsigned long long*>(A.sc);
+        if (b.M > 1.0) {
+            const double v = b.G_rho * b.q * (-b.UB);
+            const long long ip = scu[SC_IDXP] ? (long long)(~0ull - scu[SC_IDXP]) + 1 : 0;
+            coupling_add(A, C, ip, true, v);
+            coupling_add(A, C, ip, false, v);
+        }
+        const double lbv = b.G_rho * (1.0 - b.q) * (-b.LB);
+        const bool lb_home = b.Lh >= b.La;
+        const unsigned long long w = lb_home ? scu[SC_IDXQ] : scu[SC_IDXR];
+        coupling_add(A, C, w ? (long long)(~0ull - w) + 1 : 0, lb_home, lbv);
     }
-    int lb_ch = -1, lb_ca = -1, lb_nv = 0;
-    if (lbi > 0) {
-        const long long i = lbi - 1;
-        lb_ch = A.gw[i] * T + A.h[i];
-        lb_ca = A.gw[i] * T + A.a[i];
-        lb_nv = A.nv[i];
-    }
-    const int ne = (int)red[20];
     auto coupled = [&](int cell, int which, double base) {
         double v = base;
-        for (int e = 0; e < ne; ++e)
-            if ((int)cpl[3 * e] == cell && (int)cpl[3 * e + 1] == which) v += cpl[3 * e + 2];
-        if (lbi > 0) {
-            if (lb_home) {
-                if (cell == lb_ch && which == A_ATT) v += lbv;
-                if (cell == lb_ca && which == A_DEF) v -= lbv;
-                if (!lb_nv && cell == lb_ch && which == A_HATT) v += lbv;
-                if (!lb_nv && cell == lb_ca && which == A_ADEF) v -= lbv;
-            } else {
-                if (cell == lb_ca && which == A_ATT) v += lbv;
-                if (cell == lb_ch && which == A_DEF) v -= lbv;
-                if (!lb_nv && cell == lb_ca && which == A_AATT) v += lbv;
-                if (!lb_nv && cell == lb_ch && which == A_HDEF) v -= lbv;
-            }
-        }
+        for (int e = 0; e < C.n; ++e)
+            if (C.cell[e] == cell && C.which[e] == which) v += C.val[e];
         return v;
     };
-
-    // ---- per team: reverse cumulative sums over gameweeks, per-cell gradients
-    double Lloc = 0.0;
-    for (int t = tid; t < T; t += EPI_THREADS) {
-        double RA = 0.0, RD = 0.0;
-        for (int g = G - 1; g >= 0; --g) {
-            const int c = g * T + t;
-            const double* Ac = A.acc + (size_t)c * A_N;
-            const double ga_ = A.random_walk ? coupled(c, A_ATT, Ac[A_ATT]) : 0.0;
-            const double gd_ = A.random_walk ? coupled(c, A_DEF, Ac[A_DEF]) : 0.0;
+    double carry_a = 0.0, carry_d = 0.0, Lloc = 0.0;
+    const int nchunk = (G + 63) / 64;
+    for (int ck = nchunk - 1; ck >= 0; --ck) {
+        const int g = ck * 64 + lane;
+        const bool on = g < G;
+        const int c = on ? g * T + t : t;
+        const double* Ac = A.acc + (size_t)c * A_N;
+        const double ga_ = (on && A.random_walk) ? coupled(c, A_ATT, Ac[A_ATT]) : 0.0;
+        const double gd_ = (on && A.random_walk) ? coupled(c, A_DEF, Ac[A_DEF]) : 0.0;
+        // adjoint of the walk: gradient w.r.t. increment g = sum of cell gradients at g' >= g
+        const double RA = carry_a + wave_suffix(ga_, lane);
+        const double RD = carry_d + wave_suffix(gd_, lane);
+        carry_a = __shfl(RA, 0, 64);
+        carry_d = __shfl(RD, 0, 64);
+        if (on) {
             const double g_hat = coupled(c, A_HATT, Ac[A_HATT]);
             const double g_adf = coupled(c, A_ADEF, Ac[A_ADEF]);
             const double g_aat = coupled(c, A_AATT, Ac[A_AATT]);
             const double g_hdf = coupled(c, A_HDEF, Ac[A_HDEF]);
-            RA += ga_;
-            RD += gd_;
-            const double s_att = hyp[g], s_def = hyp[G + g], s_ha = hyp[2 * G + g],
-                         s_aa = hyp[3 * G + g], s_hd = hyp[4 * G + g], s_ad = hyp[5 * G + g];
+            const double s_att = A.hyp[g], s_def = A.hyp[G + g], s_ha = A.hyp[2 * G + g],
+                         s_aa = A.hyp[3 * G + g], s_hd = A.hyp[4 * G + g], s_ad = A.hyp[5 * G + g];
             const double sa = z[L.o_sat + c], sd = z[L.o_sdt + c];
             const double zu = z[L.o_u + c];
             double u, du, su;
@@ -404,35 +459,47 @@ __global__ __launch_bounds__(EPI_THREADS) void dyn_epilogue(DynArgs A) {
             grad[L.o_hdf + c] = -(s_hd * g_hdf - hdf);
             grad[L.o_adf + c] = -(s_ad * g_adf - adf);
             // per-gameweek sums: 0 sa*RA, 1 sd*RD, 2..5 sum G_x, 6..9 sum dec*G_x
-            atomicAdd(&gsum[0 * G + g], sa * RA);
-            atomicAdd(&gsum[1 * G + g], sd * RD);
-            atomicAdd(&gsum[2 * G + g], g_hat);
-            atomicAdd(&gsum[3 * G + g], g_aat);
-            atomicAdd(&gsum[4 * G + g], g_hdf);
-            atomicAdd(&gsum[5 * G + g], g_adf);
-            atomicAdd(&gsum[6 * G + g], hat * g_hat);
-            atomicAdd(&gsum[7 * G + g], aat * g_aat);
-            atomicAdd(&gsum[8 * G + g], hdf * g_hdf);
-            atomicAdd(&gsum[9 * G + g], adf * g_adf);
+            atomicAdd(&A.gsum[0 * G + g], sa * RA);
+            atomicAdd(&A.gsum[1 * G + g], sd * RD);
+            atomicAdd(&A.gsum[2 * G + g], g_hat);
+            atomicAdd(&A.gsum[3 * G + g], g_aat);
+            atomicAdd(&A.gsum[4 * G + g], g_hdf);
+            atomicAdd(&A.gsum[5 * G + g], g_adf);
+            atomicAdd(&A.gsum[6 * G + g], hat * g_hat);
+            atomicAdd(&A.gsum[7 * G + g], aat * g_aat);
+            atomicAdd(&A.gsum[8 * G + g], hdf * g_hdf);
+            atomicAdd(&A.gsum[9 * G + g], adf * g_adf);
             // priors of the cell sites
             Lloc += log(u) + 3.0 * log1p(-u) + 2.995732273553991 - softplus(zu) - softplus(-zu);
             Lloc += -0.5 * sa * sa - HALF_LOG_2PI - 0.5 * e * e / vv - 0.5 * log(vv) - HALF_LOG_2PI;
             Lloc += -0.5 * (hat * hat + aat * aat + hdf * hdf + adf * adf) - 4.0 * HALF_LOG_2PI;
         }
-        // RA, RD now hold the sums over all gameweeks: d/d(prior means of the walk)
-        atomicAdd(&red[0], RD);  // d/d mean_defence
-        for (int k = 0; k < K; ++k) {
-            atomicAdd(&covA[k], A.xs[(size_t)t * K + k] * RA);
-            atomicAdd(&covA[K + k], A.xs[(size_t)t * K + k] * RD);
-        }
     }
-    atomicAdd(&red[1], Lloc);
-    __syncthreads();
+    // carry_a, carry_d hold the sums over all gameweeks: d/d(prior means of the walk)
+    Lloc = wave_sum(Lloc);
+    if (lane == 0) {
+        atomicAdd(&A.red[R_MD], carry_d);
+        atomicAdd(&A.red[R_L], Lloc);
+    }
+    for (int j = lane; j < 2 * K; j += 64) {
+        const int k = j < K ? j : j - K;
+        atomicAdd(&A.cov[j], A.xs[(size_t)t * K + k] * (j < K ? carry_a : carry_d));
+    }
+}
 
-    // ---- per gameweek: hyper-parameter gradients and priors
+// ---- per-gameweek hyper-parameters, coefficients, scalars
+constexpr int FINAL_BLOCK = 256;
+__global__ __launch_bounds__(FINAL_BLOCK) void dyn_final(DynArgs A) {
+    __shared__ double shl[FINAL_BLOCK / 64];
+    const DynLayout& L = A.L;
+    const int G = L.G, K = L.K;
+    const int tid = threadIdx.x;
+    const double* z = A.z;
+    double* grad = A.grad;
+    const double* gsum = A.gsum;
     double Lg = 0.0;
-    for (int g = tid; g < G; g += EPI_THREADS) {
-        const double s_att = hyp[g], s_def = hyp[G + g];
+    for (int g = tid; g < G; g += FINAL_BLOCK) {
+        const double s_att = A.hyp[g], s_def = A.hyp[G + g];
         grad[L.o_s_att + g] = -(s_att * gsum[0 * G + g] + 1.0 - s_att * s_att);
         grad[L.o_s_def + g] = -(s_def * gsum[1 * G + g] + 1.0 - s_def * s_def);
         Lg += -0.5 * s_att * s_att - HALF_LOG_2PI + LN2 + z[L.o_s_att + g];
@@ -442,7 +509,7 @@ __global__ __launch_bounds__(EPI_THREADS) void dyn_epilogue(DynArgs A) {
         const double mu[4] = {0.1, -0.1, 0.1, -0.1};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const double s = hyp[(2 + j) * G + g], mean = z[o_mean[j] + g];
+            const double s = A.hyp[(2 + j) * G + g], mean = z[o_mean[j] + g];
             grad[o_mean[j] + g] = -(gsum[(2 + j) * G + g] - (mean - mu[j]) / 0.04);
             grad[o_std[j] + g] = -(s * gsum[(6 + j) * G + g] + 1.0 - s * s);
             const double r = (mean - mu[j]) / 0.2;
@@ -450,31 +517,32 @@ __global__ __launch_bounds__(EPI_THREADS) void dyn_epilogue(DynArgs A) {
             Lg += -0.5 * s * s - HALF_LOG_2PI + LN2 + z[o_std[j] + g];
         }
     }
-    atomicAdd(&red[1], Lg);
-    __syncthreads();
-    if (tid < 2 * K) {
-        const int o = tid < K ? L.o_bA + tid : L.o_bD + tid - K;
-        grad[o] = -(covA[tid] - z[o]);
-        atomicAdd(&red[1], -0.5 * z[o] * z[o] - HALF_LOG_2PI);
+    for (int k = tid; k < 2 * K; k += FINAL_BLOCK) {
+        const int o = k < K ? L.o_bA + k : L.o_bD + k - K;
+        grad[o] = -(A.cov[k] - z[o]);
+        Lg += -0.5 * z[o] * z[o] - HALF_LOG_2PI;
     }
+    Lg = wave_sum(Lg);
+    if ((tid & 63) == 0) shl[tid >> 6] = Lg;
     __syncthreads();
     if (tid == 0) {
-        const double m = z[L.o_md];
-        grad[L.o_md] = -(red[0] - m);
-        grad[L.o_corr] = -(G_rho * (UB - LB) * dq + (1.0 - 2.0 * sq));
-        double Ltot = red[1] + A.sc[SC_U] - A.lgsum;
+        double Lsum = 0.0;
+        for (int w = 0; w < FINAL_BLOCK / 64; ++w) Lsum += shl[w];
+        const Bounds b = load_bounds(A);
+        const double m = z[L.o_md], zc = z[L.o_corr];
+        grad[L.o_md] = -(A.red[R_MD] - m);
+        grad[L.o_corr] = -(b.G_rho * (b.UB - b.LB) * b.dq + (1.0 - 2.0 * b.sq));
+        double Ltot = Lsum + A.red[R_L] + A.sc[SC_U] - A.lgsum;
         Ltot += -0.5 * m * m - HALF_LOG_2PI;
         Ltot += -softplus(zc) - softplus(-zc);  // Uniform(0,1): log_prob 0 + sigmoid Jacobian
         A.potential[0] = -Ltot;
         if (A.aux) {
-            A.aux[0] = rho;
-            A.aux[1] = LB;
-            A.aux[2] = UB;
-            A.aux[3] = q;
+            A.aux[0] = b.rho;
+            A.aux[1] = b.LB;
+            A.aux[2] = b.UB;
+            A.aux[3] = b.q;
         }
     }
 }
-
-inline size_t epi_lds_bytes(int G, int K) { return (size_t)(16 * G + 32 + 24 + 2 * K) * 8; }
 
 }  // namespace dcd
