@@ -79,13 +79,17 @@ struct bplhip_ctx {
     int opt_device_nuts = 1;  // 1: tree builder on the device (nuts_dev.hip.h) when supported
     int opt_max_wg = 255;  // streaming workgroups (+1 prior workgroup = one per CU)
     int opt_vec_min_chains = 4;  // batched calls with at least this many chains use dc_vec (0: never)
-    int opt_vec_tpw = 2;         // minimum tiles per wave of the chain-vectorised partition
-    // chain-vectorised partition (dc_vec.hip.h): fewer, fatter workgroups, own sparse structure
+    int opt_vec_tpw = 0;         // > 0: force this many tiles per wave for every chain count
+    // chain-vectorised partitions (dc_vec.hip.h): fewer, fatter workgroups the more chains
+    // share a launch (the per-workgroup prologue builds 8 chains' tables); each has its
+    // own sparse-slab structure.  vps[0..2]: 1x / 2x / 4x the single-chain tiles per wave,
+    // used for <= 8 / <= 23 / more chains; vp = the one selected for the current launch.
     struct VecPart {
         bool ok = false, staged = true;
         int tpw = 1, n_wg = 1, total_c = 0, slab_chains = 0;
         DevBuf d_wg_off, d_wg_slots, d_col_off, d_wg_dst, d_hbuf;
-    } vp;
+    } vps[3];
+    VecPart* vp = &vps[0];
     bool lds_attr_set = false;
     // NUTS scratch (device): z, potential, grad, aux + pinned host mirror
     DevBuf d_nuts, d_ns;
@@ -289,10 +293,10 @@ int launch_eval(bplhip_ctx* c, int chains, const double* z, double* pot, double*
 
 // ---- chain-vectorised evaluation (dc_vec.hip.h): stream launch + tail launch
 int vec_hb_stride(const bplhip_ctx* c) {
-    return (zo_stride_of(c->L) + c->vp.n_wg * dc::N_SCAL + c->vp.total_c + 1) & ~1;
+    return (zo_stride_of(c->L) + c->vp->n_wg * dc::N_SCAL + c->vp->total_c + 1) & ~1;
 }
 size_t vec_tail_lds(const bplhip_ctx* c, bool staged) {
-    return dc::tail_lds_bytes(c->L.T, c->L.D, zo_stride_of(c->L), c->vp.n_wg, c->vp.total_c, staged);
+    return dc::tail_lds_bytes(c->L.T, c->L.D, zo_stride_of(c->L), c->vp->n_wg, c->vp->total_c, staged);
 }
 template <bool S, bool N>
 int launch_vec_tail(bplhip_ctx* c, const dc::EvalArgs& A, int chains, hipStream_t s) {
@@ -310,9 +314,9 @@ int launch_vec_n(bplhip_ctx* c, const dc::EvalArgs& A, int chains, hipStream_t s
     if (lds > 48 * 1024)
         HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(dc::dc_vec_stream<W, C, N>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((dc::dc_vec_stream<W, C, N>), dim3(dc::CB + c->vp.n_wg, groups),
+    hipLaunchKernelGGL((dc::dc_vec_stream<W, C, N>), dim3(dc::CB + c->vp->n_wg, groups),
                        dim3(dc::BLOCK), lds, s, A);
-    const int rc = c->vp.staged ? launch_vec_tail<true, N>(c, A, chains, s)
+    const int rc = c->vp->staged ? launch_vec_tail<true, N>(c, A, chains, s)
                                 : launch_vec_tail<false, N>(c, A, chains, s);
     if (rc != BPLHIP_OK) return rc;
     HIP_TRY(c, hipGetLastError());
@@ -328,9 +332,10 @@ int launch_vec_t(bplhip_ctx* c, const dc::EvalArgs& A, int chains, hipStream_t s
 int launch_eval_vec(bplhip_ctx* c, int chains, const double* z, double* pot, double* grad,
                     double* aux, hipStream_t s, double* nuts = nullptr, int nuts_stride = 0,
                     int nuts_depth = 0) {
-    if (chains > c->vp.slab_chains) {
-        HIP_TRY(c, c->vp.d_hbuf.ensure((size_t)chains * vec_hb_stride(c) * sizeof(double)));
-        c->vp.slab_chains = chains;
+    c->vp = &c->vps[chains <= 8 ? 0 : (chains <= 23 ? 1 : 2)];
+    if (chains > c->vp->slab_chains) {
+        HIP_TRY(c, c->vp->d_hbuf.ensure((size_t)chains * vec_hb_stride(c) * sizeof(double)));
+        c->vp->slab_chains = chains;
     }
     dc::EvalArgs A = eval_args(c, chains, z, pot, grad, aux);
     if (nuts) {
@@ -339,15 +344,15 @@ int launch_eval_vec(bplhip_ctx* c, int chains, const double* z, double* pot, dou
         A.nuts_max_depth = nuts_depth;
         A.z_stride = A.g_stride = A.p_stride = A.aux_stride = nuts_stride;
     }
-    A.tiles_per_wave = c->vp.tpw;
-    A.wg_off = c->vp.d_wg_off.as<const int>();
-    A.wg_slots = c->vp.d_wg_slots.as<const int>();
-    A.col_off = c->vp.d_col_off.as<const int>();
-    A.wg_dst = c->vp.d_wg_dst.as<const int>();
-    A.total_c = c->vp.total_c;
-    A.hbuf = c->vp.d_hbuf.as<double>();
+    A.tiles_per_wave = c->vp->tpw;
+    A.wg_off = c->vp->d_wg_off.as<const int>();
+    A.wg_slots = c->vp->d_wg_slots.as<const int>();
+    A.col_off = c->vp->d_col_off.as<const int>();
+    A.wg_dst = c->vp->d_wg_dst.as<const int>();
+    A.total_c = c->vp->total_c;
+    A.hbuf = c->vp->d_hbuf.as<double>();
     A.hb_stride = vec_hb_stride(c);
-    A.n_wg = c->vp.n_wg;
+    A.n_wg = c->vp->n_wg;
     A.tickets = nullptr;
     const bool clip = c->L.model == dc::MODEL_EXTENDED;
     if (c->weighted) return clip ? launch_vec_t<true, true>(c, A, chains, s)
@@ -356,8 +361,11 @@ int launch_eval_vec(bplhip_ctx* c, int chains, const double* z, double* pot, dou
                 : launch_vec_t<false, false>(c, A, chains, s);
 }
 
+bool vec_ok(const bplhip_ctx* c) {
+    return !c->dynamic && c->vps[0].ok && c->vps[1].ok && c->vps[2].ok;
+}
 bool use_vec(const bplhip_ctx* c, int chains) {
-    return !c->dynamic && c->vp.ok && c->opt_vec_min_chains > 0 && chains >= c->opt_vec_min_chains;
+    return vec_ok(c) && c->opt_vec_min_chains > 0 && chains >= c->opt_vec_min_chains;
 }
 
 // Static sparse-slab structure: which of the 3T per-team slots each streaming workgroup's
@@ -593,11 +601,12 @@ int bplhip_set_fixtures(bplhip_ctx* c, int model_kind, int64_t n, int32_t n_team
 
     // ---- chain-vectorised partition: fewer, fatter workgroups (the per-workgroup prologue
     // of 8 chains' tables is amortised over more tiles)
-    {
-        auto& vp = c->vp;
+    for (int pi = 0; pi < 3; ++pi) {
+        auto& vp = c->vps[pi];
+        c->vp = &vp;  // (the LDS helpers below read the current partition)
         vp.ok = false;
         vp.slab_chains = 0;
-        vp.tpw = std::max(tpw, c->opt_vec_tpw);
+        vp.tpw = c->opt_vec_tpw > 0 ? std::max(tpw, c->opt_vec_tpw) : tpw << pi;
         const int vwaves = (n_tiles + vp.tpw - 1) / vp.tpw;
         vp.n_wg = (vwaves + dc::WAVES - 1) / dc::WAVES;
         const SparseSlabs vs = build_sparse_slabs(hs, as, n, T, vp.tpw, vp.n_wg);
@@ -613,6 +622,7 @@ int bplhip_set_fixtures(bplhip_ctx* c, int model_kind, int64_t n, int32_t n_team
         vp.staged = vec_tail_lds(c, true) <= 96 * 1024;
         vp.ok = dc::vec_stream_lds_bytes(T) <= 64 * 1024 && vec_tail_lds(c, vp.staged) <= LDS_LIMIT;
     }
+    c->vp = &c->vps[0];
     c->bound = true;
     return BPLHIP_OK;
 }
@@ -629,8 +639,8 @@ int bplhip_set_option(bplhip_ctx* c, const char* name, int value) {
         c->opt_vec_min_chains = value;
         return BPLHIP_OK;
     }
-    if (n == "vec_tiles_per_wave") {  // takes effect at the next bplhip_set_fixtures
-        if (value < 1 || value > 4096) return fail(c, BPLHIP_EINVAL, "vec_tiles_per_wave out of range");
+    if (n == "vec_tiles_per_wave") {  // 0 = by chain count; takes effect at the next bplhip_set_fixtures
+        if (value < 0 || value > 4096) return fail(c, BPLHIP_EINVAL, "vec_tiles_per_wave out of range");
         c->opt_vec_tpw = value;
         return BPLHIP_OK;
     }
@@ -1268,7 +1278,8 @@ extern "C" int bplhip_nuts_run_chains(bplhip_ctx* c, const bplhip_nuts_cfg* cfg,
     if (cfg->num_warmup < 0 || cfg->num_samples < 1 || cfg->max_tree_depth < 1 ||
         cfg->max_tree_depth > 20 || cfg->thinning < 1 || !(cfg->step_size > 0))
         return fail(c, BPLHIP_EINVAL, "nuts_run_chains: bad configuration");
-    if (c->dynamic || !c->vp.ok || c->L.T > 64 || !c->vp.staged || c->L.D > 64 * nd::LEAF_NE)
+    if (!vec_ok(c) || c->L.T > 64 ||
+        !(c->vps[0].staged && c->vps[1].staged && c->vps[2].staged) || c->L.D > 64 * nd::LEAF_NE)
         return fail(c, BPLHIP_EUNSUPPORTED,
                     "nuts_run_chains: lock-step chains need the basic/extended model with <= 64 teams");
     HIP_TRY(c, hipSetDevice(c->device));

@@ -6,7 +6,7 @@ from bench import synthetic_league
 from bpl._ffi import HipContext, MODEL_BASIC
 h,a,x,y = synthetic_league(1_000_000, 20)
 c=HipContext(0)
-VEC=int(os.environ.get('VEC','1')); TPW=int(os.environ.get('VEC_TPW','2'))
+VEC=int(os.environ.get('VEC','1')); TPW=int(os.environ.get('VEC_TPW','0'))
 c.set_option('vec_tiles_per_wave',TPW); c.set_option('vec_min_chains', 1 if VEC else 0)
 c.set_fixtures(MODEL_BASIC,h,a,x,y,20)
 print(f"vec={VEC} vec_tiles_per_wave={TPW}")

@@ -8,7 +8,7 @@ from bpl._ffi import HipContext, MODEL_BASIC, default_nuts_cfg
 N = int(float(os.environ.get('N', '1e6')))
 h, a, x, y = synthetic_league(N, 20)
 c = HipContext(0)
-c.set_option('vec_tiles_per_wave', int(os.environ.get('VEC_TPW', '2')))
+c.set_option('vec_tiles_per_wave', int(os.environ.get('VEC_TPW', '0')))
 c.set_fixtures(MODEL_BASIC, h, a, x, y, 20)
 cfg = default_nuts_cfg(); cfg.num_warmup, cfg.num_samples = 300, 100
 for sd in (42, 43):
