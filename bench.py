@@ -188,6 +188,28 @@ def main():
         _, st = ctx.nuts_run(cfg, prng_key(42))
         extra["insitu_leapfrogs_per_s"] = st["total_leapfrogs"] / st["wall_seconds"]
         extra["insitu_leapfrogs"] = st["total_leapfrogs"]
+        # beside the headline (1 chain per GPU): 64 chains through the chain-vectorised
+        # kernel (bplhip_logp_grad_batched, numpyro chain_method="vectorized")
+        zc = torch.tensor(np.random.RandomState(7).uniform(-0.5, 0.5, (64, D)),
+                          dtype=torch.float64, device=dev)
+        Uc2 = torch.zeros(64, dtype=torch.float64, device=dev)
+        gc2 = torch.zeros_like(zc)
+        ac2 = torch.zeros((64, 4), dtype=torch.float64, device=dev)
+        for _ in range(20):
+            ctx.logp_grad(zc, Uc2, gc2, ac2)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(200):
+            ctx.logp_grad(zc, Uc2, gc2, ac2)
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / 200
+        extra["vectorised_64_chains"] = {
+            "evals_per_s": 64 / us * 1e6,
+            "algorithmic_GBps": 64 * n_fix * BYTES_PER_FIXTURE / us / 1e3,
+            "us_per_launch": us,
+        }
 
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")

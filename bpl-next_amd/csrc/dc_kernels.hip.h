@@ -683,7 +683,7 @@ __device__ void prior_body(const EvalArgs& A, int chain, char* smem) {
 template <bool NUTS>
 __device__ void tail_one_wave(const EvalArgs& A, int chain, const double* zoL, const double* cL,
                               const double* zL, const double* col, const double* xsL,
-                              double* gradL) {
+                              double* gradL, const nd::LeafState& leaf) {
     const Layout& L = A.L;
     const int T = L.T, K = L.K, D = L.D;
     const int t = threadIdx.x & 63;
@@ -808,7 +808,7 @@ __device__ void tail_one_wave(const EvalArgs& A, int chain, const double* zoL, c
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        nd::nuts_leaf(nuts_of(A, chain), D, A.nuts_max_depth, t, gradL);
+        nd::nuts_leaf(nuts_of(A, chain), D, A.nuts_max_depth, t, gradL, leaf);
     }
 }
 
@@ -835,6 +835,12 @@ __device__ void tail_body(const EvalArgs& A, int chain, char* smem) {
     int* coff = reinterpret_cast<int*>(gradL + D + 8);  // [3T+1]
     DC_STAMP(7);
 
+    // device-resident NUTS: wave 0 will book the leaf; its state (header, vectors, checkpoint)
+    // is requested now, so those round trips overlap with the hand-off loads below
+    nd::LeafState leaf{};
+    if (NUTS && wave == 0 && T <= 64)
+        leaf = nd::leaf_prefetch(nuts_of(A, chain), D, A.nuts_max_depth, lane);
+
     // ---- 1. ONE round of loads: every global value the tail needs is requested before
     // the first one is used (a rolled load -> LDS-store loop would serialise them)
     const double* hb = A.hbuf + (size_t)chain * A.hb_stride;
@@ -855,6 +861,8 @@ __device__ void tail_body(const EvalArgs& A, int chain, char* smem) {
             const int j = u * BLOCK + tid;
             v[u] = ld_sc1(&hb[j < nstage ? j : nstage - 1]);
         }
+        if (NUTS && wave == 0 && T <= 64)  // (header has landed by now or lands first)
+            nd::leaf_prefetch_ckpt(leaf, nuts_of(A, chain), D, A.nuts_max_depth, lane);
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int j = u * BLOCK + tid;
@@ -916,7 +924,7 @@ __device__ void tail_body(const EvalArgs& A, int chain, char* smem) {
     DC_STAMP(9);
     if (T <= 64) {  // the whole per-team epilogue fits one wave: no LDS traffic, no barriers
         if (wave == 0)
-            tail_one_wave<NUTS>(A, chain, zoL, cL, zL, col, xs_staged ? xsL : nullptr, gradL);
+            tail_one_wave<NUTS>(A, chain, zoL, cL, zL, col, xs_staged ? xsL : nullptr, gradL, leaf);
         DC_STAMP(10);
         return;
     }

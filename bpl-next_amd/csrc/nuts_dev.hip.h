@@ -146,46 +146,78 @@ __device__ __forceinline__ double hdr_word(double hv, int k) {  // k wave-unifor
     const int hi = __builtin_amdgcn_readlane((int)(x >> 32), k);
     return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
-__device__ inline void nuts_leaf(double* ns, int D, int max_depth, int lane, const double* gL) {
+// everything the leaf reads from the state buffer, requested before the gradient exists
+// (the tail issues this ahead of its own hand-off loads, so the round trips overlap)
+struct LeafState {
+    double hv;                      // header word `lane`
+    double invM[LEAF_NE], zn[LEAF_NE], r[LEAF_NE], rs[LEAF_NE];
+    double c_r[LEAF_NE], c_s[LEAF_NE];   // first checkpoint an odd leaf compares against
+    int num, idx_max, idx_min;
+};
+__device__ __forceinline__ LeafState leaf_prefetch(double* ns, int D, int max_depth, int lane) {
+    LeafState S;
     // ---- (A) one round of loads
-    const double hv = lane < H_N ? ns[lane] : 0.0;
-    double* p_invM = vec(ns, D, V_INVM);
-    double* p_zn = vec(ns, D, V_ZN);
-    double* p_rh = vec(ns, D, V_RH);
-    double* p_rsum = vec(ns, D, V_S_RSUM);
-    double invM[LEAF_NE], zn[LEAF_NE], r[LEAF_NE], rs[LEAF_NE], g[LEAF_NE];
+    S.hv = lane < H_N ? ns[lane] : 0.0;
+    const double* p_invM = vec(ns, D, V_INVM);
+    const double* p_zn = vec(ns, D, V_ZN);
+    const double* p_rh = vec(ns, D, V_RH);
+    const double* p_rsum = vec(ns, D, V_S_RSUM);
 #pragma unroll
     for (int e = 0; e < LEAF_NE; ++e) {
         const int i = lane + 64 * e;
         const bool ok = i < D;
-        invM[e] = ok ? p_invM[i] : 0.0;
-        zn[e] = ok ? p_zn[i] : 0.0;
-        r[e] = ok ? p_rh[i] : 0.0;
-        rs[e] = ok ? p_rsum[i] : 0.0;
-        g[e] = ok ? gL[i] : 0.0;
+        S.invM[e] = ok ? p_invM[i] : 0.0;
+        S.zn[e] = ok ? p_zn[i] : 0.0;
+        S.r[e] = ok ? p_rh[i] : 0.0;
+        S.rs[e] = ok ? p_rsum[i] : 0.0;
+    }
+    return S;
+}
+// second, dependent round (needs the header): issued after the caller has put its own loads
+// in flight, so waiting for the header does not delay them
+__device__ __forceinline__ void leaf_prefetch_ckpt(LeafState& S, double* ns, int D, int max_depth,
+                                                   int lane) {
+    S.num = (int)hdr_word(S.hv, H_S_NUM);  // leaves so far = index of this leaf
+    // checkpoint indices (numpyro _leaf_idx_to_ckpt_idxs)
+    int idx_max = 0, trail = 0;
+    for (int v = S.num >> 1; v > 0; v >>= 1) idx_max += v & 1;
+    for (int v = S.num; v & 1; v >>= 1) trail += 1;
+    S.idx_max = idx_max;
+    S.idx_min = idx_max - trail + 1;
+    // ---- (C) the second, dependent round: the first checkpoint an odd leaf compares against
+    const double* ck_r = vec(ns, D, V_CKPT);
+    const double* ck_s = ck_r + (size_t)max_depth * D;
+    const bool has_ck = S.idx_max >= S.idx_min;
+#pragma unroll
+    for (int e = 0; e < LEAF_NE; ++e) {
+        const int i = lane + 64 * e;
+        const bool ok = has_ck && i < D;
+        S.c_r[e] = ok ? ck_r[(size_t)idx_max * D + i] : 0.0;
+        S.c_s[e] = ok ? ck_s[(size_t)idx_max * D + i] : 0.0;
+    }
+}
+
+__device__ inline void nuts_leaf(double* ns, int D, int max_depth, int lane, const double* gL,
+                                 const LeafState& S) {
+    const double hv = S.hv;
+    double* p_zn = vec(ns, D, V_ZN);
+    double* p_rh = vec(ns, D, V_RH);
+    double* p_rsum = vec(ns, D, V_S_RSUM);
+    double invM[LEAF_NE], zn[LEAF_NE], r[LEAF_NE], rs[LEAF_NE], g[LEAF_NE], c_r[LEAF_NE], c_s[LEAF_NE];
+#pragma unroll
+    for (int e = 0; e < LEAF_NE; ++e) {
+        const int i = lane + 64 * e;
+        invM[e] = S.invM[e]; zn[e] = S.zn[e]; r[e] = S.r[e]; rs[e] = S.rs[e];
+        c_r[e] = S.c_r[e]; c_s[e] = S.c_s[e];
+        g[e] = i < D ? gL[i] : 0.0;
     }
     const double pe = gL[D];
     const double h_eps = hdr_word(hv, H_EPS), h_dir = hdr_word(hv, H_DIR);
     const double eps = h_eps * h_dir;
     const bool going_right = h_dir > 0.0;
-    const int num = (int)hdr_word(hv, H_S_NUM);  // leaves so far = index of this leaf
-    // checkpoint indices (numpyro _leaf_idx_to_ckpt_idxs)
-    int idx_max = 0, trail = 0;
-    for (int v = num >> 1; v > 0; v >>= 1) idx_max += v & 1;
-    for (int v = num; v & 1; v >>= 1) trail += 1;
-    const int idx_min = idx_max - trail + 1;
+    const int num = S.num, idx_max = S.idx_max, idx_min = S.idx_min;
     double* ck_r = vec(ns, D, V_CKPT);
     double* ck_s = ck_r + (size_t)max_depth * D;
-    // ---- (C, issued early) the first checkpoint an odd leaf compares against
-    double c_r[LEAF_NE], c_s[LEAF_NE];
-    const bool has_ck = idx_max >= idx_min;
-#pragma unroll
-    for (int e = 0; e < LEAF_NE; ++e) {
-        const int i = lane + 64 * e;
-        const bool ok = has_ck && i < D;
-        c_r[e] = ok ? ck_r[(size_t)idx_max * D + i] : 0.0;
-        c_s[e] = ok ? ck_s[(size_t)idx_max * D + i] : 0.0;
-    }
 
     // ---- (B) second half step, kinetic energy
     double kin = 0.0;
