@@ -181,7 +181,7 @@ def main():
     achieved = n_fix * BYTES_PER_FIXTURE / (per_eval_us * 1e-6) / 1e9
 
     extra = {}
-    if rank == 0 and not args.no_insitu:
+    if rank == 0 and not args.no_insitu and world == 1:
         # in situ: leapfrogs/s of a real NUTS chain on the same data (short, bounded)
         cfg = default_nuts_cfg()
         cfg.num_warmup, cfg.num_samples = 150, 100
@@ -251,7 +251,7 @@ def main():
             },
         }
         out.update(extra)
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # rank 0 at N = 1 only
             hh = bc["home_idx"].cpu().numpy().view(np.uint16)
             aa = bc["away_idx"].cpu().numpy().view(np.uint16)
             out["cpu_baseline"] = cpu_baseline(hh, aa, bc["home_goals"].cpu().numpy(),

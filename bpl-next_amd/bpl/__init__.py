@@ -7,5 +7,7 @@ __version__ = "0.2.0"
 
 from bpl.dixon_coles import DixonColesMatchPredictor
 from bpl.extended_dixon_coles import ExtendedDixonColesMatchPredictor
+from bpl.neutral_dixon_coles import NeutralDixonColesMatchPredictor
 
-__all__ = ["DixonColesMatchPredictor", "ExtendedDixonColesMatchPredictor"]
+__all__ = ["DixonColesMatchPredictor", "ExtendedDixonColesMatchPredictor",
+           "NeutralDixonColesMatchPredictor"]

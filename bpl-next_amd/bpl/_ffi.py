@@ -16,6 +16,7 @@ import numpy as np
 MODEL_BASIC = 0
 MODEL_EXTENDED = 1
 MODEL_DYNAMIC = 2
+MODEL_NEUTRAL = 3
 BPLHIP_EUNSUPPORTED = -5  # include/bplhip.h
 
 _LIB_NAME = os.environ.get("BPLHIP_LIB", "libbplhip.so")  # override: diagnostic builds only
@@ -29,6 +30,7 @@ ABI_SYMBOLS = (
     "bplhip_last_error",
     "bplhip_set_fixtures",
     "bplhip_set_fixtures_dynamic",
+    "bplhip_set_fixtures_neutral",
     "bplhip_constrain_dynamic",
     "bplhip_set_option",
     "bplhip_latent_dim",
@@ -114,6 +116,8 @@ def load_library():
     lib.bplhip_set_fixtures.restype = C.c_int
     lib.bplhip_set_fixtures_dynamic.argtypes = [vp, i64, i32, i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp]
     lib.bplhip_set_fixtures_dynamic.restype = C.c_int
+    lib.bplhip_set_fixtures_neutral.argtypes = [vp, i64, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp]
+    lib.bplhip_set_fixtures_neutral.restype = C.c_int
     lib.bplhip_constrain_dynamic.argtypes = [vp, vp, i64, vp, vp, vp, vp, vp, vp]
     lib.bplhip_constrain_dynamic.restype = C.c_int
     lib.bplhip_set_option.argtypes = [vp, C.c_char_p, C.c_int]
@@ -311,6 +315,38 @@ class HipContext:
                 self._stream()))
         self.dim = self._lib.bplhip_latent_dim(self._h)
         self.n_teams, self.n_gameweeks, self.model, self.n = n_teams, n_gameweeks, MODEL_DYNAMIC, n
+        return self
+
+    def set_fixtures_neutral(self, home_idx, away_idx, home_goals, away_goals, neutral_venue,
+                             n_teams: int, weights=None, covariates_std: Optional[np.ndarray] = None):
+        """Bind the neutral-venue model (bpl/neutral_dixon_coles.py).  `weights`: the final
+        per-fixture weights (time decay x game weights) or None."""
+        torch = self._torch
+
+        def dev(a, np_dtype):
+            arr = np.ascontiguousarray(np.asarray(a).astype(np_dtype))
+            return torch.from_numpy(arr.view(np.int16) if np_dtype == np.uint16 else arr).to(self.device)
+
+        h, a = dev(home_idx, np.uint16), dev(away_idx, np.uint16)
+        x, y, nv = dev(home_goals, np.uint8), dev(away_goals, np.uint8), dev(neutral_venue, np.uint8)
+        n = h.numel()
+        if not (a.numel() == x.numel() == y.numel() == nv.numel() == n):
+            raise ValueError("fixture arrays must have equal length")
+        w = None
+        if weights is not None:
+            w = dev(weights, np.float32)
+            if w.numel() != n:
+                raise ValueError("weights must have one entry per fixture")
+        cov, k = None, 0
+        if covariates_std is not None:
+            cov = np.ascontiguousarray(covariates_std, dtype=np.float64)
+            k = cov.shape[1]
+        with torch.cuda.device(self.device):
+            self._check(self._lib.bplhip_set_fixtures_neutral(
+                self._h, n, n_teams, h.data_ptr(), a.data_ptr(), x.data_ptr(), y.data_ptr(),
+                nv.data_ptr(), None if w is None else w.data_ptr(), _np_ptr(cov), k, self._stream()))
+        self.dim = self._lib.bplhip_latent_dim(self._h)
+        self.n_teams, self.model, self.n = n_teams, MODEL_NEUTRAL, n
         return self
 
     def constrain_dynamic(self, z_draws: np.ndarray):

@@ -1,0 +1,369 @@
+"""Neutral-venue Dixon-Coles model (host side), SURVEY.md §8 row f-4.
+
+Mirrors the reference's bpl/neutral_dixon_coles.py:30-902 (`NeutralDixonColesMatchPredictor`)
+method for method: same names, arguments, return shapes and error behaviour; arrays are
+numpy instead of jax.  `fit` drives libbplhip (bplhip_set_fixtures_neutral + bplhip_nuts_run);
+the predict methods are post-processing of posterior draws on the host.
+"""
+
+from __future__ import annotations
+
+import warnings
+from datetime import datetime
+from typing import Any, Dict, Iterable, Optional, Tuple, Union
+
+import numpy as np
+
+from bpl import _dist
+from bpl._util import (
+    dixon_coles_correlation_term,
+    map_choice,
+    parse_teams,
+    poisson_log_prob,
+    str_to_list,
+)
+from bpl.base import DTYPES, MAX_GOALS, _prng_key
+
+__all__ = ["NeutralDixonColesMatchPredictor"]
+
+_MCMC_KEYS = {"num_chains", "thinning", "progress_bar", "chain_method", "jit_model_args",
+              "postprocess_fn"}
+_RUN_KEYS = {"init_params", "extra_fields"}
+
+
+def latent_sites(T: int, K: int):
+    """(name, size) of every latent site in flat (sorted-name) order; D = 6T + 2K + 13."""
+    s = []
+    if K:
+        s.append(("attack_coefficients", K))
+    s += [("away_attack_decentered", T), ("away_defence_decentered", T), ("corr_coef_raw", 1)]
+    if K:
+        s.append(("defence_coefficients", K))
+    s += [("home_attack_decentered", T), ("home_defence_decentered", T),
+          ("mean_away_attack", 1), ("mean_away_defence", 1), ("mean_defence", 1),
+          ("mean_home_attack", 1), ("mean_home_defence", 1),
+          ("standardised_attack", T), ("standardised_defence", T),
+          ("std_attack", 1), ("std_away_attack", 1), ("std_away_defence", 1),
+          ("std_defence", 1), ("std_home_attack", 1), ("std_home_defence", 1), ("u", 1)]
+    return s
+
+
+def make_weights(n, time_diff, epsilon, game_weights, rescale_weights):
+    """bpl/neutral_dixon_coles.py:251-257 (parameter independent, so computed once)."""
+    w = np.ones(n)
+    if epsilon is not None:
+        w = w * np.exp(-epsilon * np.asarray(time_diff, dtype=np.float64))
+        if rescale_weights:
+            w = n * w / w.sum()
+    if game_weights is None:
+        # the reference multiplies by `game_weights` unconditionally (:256-257)
+        raise TypeError("unsupported operand type(s) for *: 'Array' and 'NoneType' "
+                        "(training_data['game_weights'] is required)")
+    return w * np.asarray(game_weights, dtype=np.float64)
+
+
+# pylint: disable=too-many-instance-attributes
+class NeutralDixonColesMatchPredictor:
+    """Dixon-Coles with rho-correlated attack/defence, optional covariates, separate home and
+    away attack/defence offsets per team that vanish at neutral venues, time decay and
+    per-game weights (see bpl/neutral_dixon_coles.py:30-52)."""
+
+    def __init__(self):
+        self.teams = None
+        self._teams_dict = None
+        for nm in ("attack", "defence", "home_attack", "away_attack", "home_defence", "away_defence",
+                   "time_diff", "epsilon", "rescale_weights", "game_weights", "corr_coef", "u", "rho",
+                   "attack_coefficients", "defence_coefficients", "mean_attack", "mean_defence",
+                   "std_attack", "std_defence", "mean_home_attack", "mean_away_attack",
+                   "mean_home_defence", "mean_away_defence", "std_home_attack", "std_away_attack",
+                   "std_home_defence", "std_away_defence", "standardised_attack",
+                   "standardised_defence", "_team_covariates_mean", "_team_covariates_std"):
+            setattr(self, nm, None)
+        self.mcmc_info_ = None
+
+    # pylint: disable=arguments-differ,too-many-arguments,too-many-statements,too-many-locals
+    def fit(
+        self,
+        training_data: Dict[str, Union[Iterable[str], Iterable[float]]],
+        epsilon: Optional[float] = None,
+        rescale_weights: Optional[bool] = False,
+        random_state: int = 42,
+        num_warmup: int = 500,
+        num_samples: int = 1000,
+        mcmc_kwargs: Optional[Dict[str, Any]] = None,
+        run_kwargs: Optional[Dict[str, Any]] = None,
+    ) -> "NeutralDixonColesMatchPredictor":
+        """Fit model to data (bpl/neutral_dixon_coles.py:286-384)."""
+        from bpl._ffi import HipContext, default_nuts_cfg, prng_key, threefry_split
+
+        self.teams, self._teams_dict, home_ind, away_ind = parse_teams(
+            training_data["home_team"], training_data["away_team"], DTYPES["teams"]
+        )
+        team_covariates = training_data.get("team_covariates")
+        self.epsilon = epsilon
+        self.rescale_weights = rescale_weights
+        self.time_diff = training_data.get("time_diff", None)
+        if epsilon is not None and self.time_diff is None:
+            raise ValueError(
+                """
+                    time_diff must be provided in training_data
+                    to include exponential time decay in model.
+                    """
+            )
+        self.game_weights = training_data.get("game_weights", None)
+        T = len(self.teams)
+        cov_std = None
+        if team_covariates:
+            if set(team_covariates.keys()) != set(self.teams):
+                raise ValueError("team_covariates must contain all the teams in the data.")
+            cov = np.array([team_covariates[t] for t in self.teams], dtype=np.float64)
+            self._team_covariates_mean = cov.mean(axis=0)
+            self._team_covariates_std = cov.std(axis=0)
+            cov_std = (cov - self._team_covariates_mean) / self._team_covariates_std
+        K = 0 if cov_std is None else cov_std.shape[1]
+
+        hg = np.asarray(training_data["home_goals"])
+        ag = np.asarray(training_data["away_goals"])
+        if hg.size and (hg.min() < 0 or ag.min() < 0 or hg.max() > 255 or ag.max() > 255):
+            raise ValueError("goals must be integers in [0, 255]")
+        nv = np.asarray(training_data["neutral_venue"]).astype(np.uint8)
+        weights = make_weights(len(hg), self.time_diff, epsilon, self.game_weights, rescale_weights)
+
+        mcmc_kwargs = dict(mcmc_kwargs or {})
+        run_kwargs = dict(run_kwargs or {})
+        bad = set(mcmc_kwargs) - _MCMC_KEYS
+        if bad:
+            raise TypeError(f"MCMC got unexpected keyword argument(s) {sorted(bad)}")
+        bad = set(run_kwargs) - _RUN_KEYS
+        if bad:
+            raise TypeError(f"MCMC.run got unexpected keyword argument(s) {sorted(bad)}")
+        num_chains = int(mcmc_kwargs.get("num_chains", 1))
+        thinning = int(mcmc_kwargs.get("thinning", 1))
+        rank, ws = _dist.world()
+        ctx = HipContext(_dist.local_device_index() if ws > 1 else 0)
+        try:
+            ctx.set_fixtures_neutral(home_ind, away_ind, hg, ag, nv, T, weights=weights,
+                                     covariates_std=cov_std)
+            D = ctx.dim
+            cfg = default_nuts_cfg()
+            cfg.num_warmup, cfg.num_samples, cfg.thinning = int(num_warmup), int(num_samples), thinning
+            key = prng_key(random_state)
+            keys = [key] if num_chains == 1 else threefry_split(key, num_chains)
+            z0 = run_kwargs.get("init_params")
+            if isinstance(z0, dict):
+                z0 = np.concatenate([np.asarray(z0[n], dtype=np.float64).reshape(-1)
+                                     for n, _ in latent_sites(T, K)])
+            mine = _dist.chains_of_rank(num_chains, rank, ws)
+            kept = cfg.num_samples // thinning
+            draws = np.empty((len(mine), kept, D))
+            corr = np.empty((len(mine), kept))
+            leap = np.zeros((len(mine), 3))
+            for j, c in enumerate(mine):
+                d, st = ctx.nuts_run(cfg, keys[c], None if z0 is None else np.asarray(z0, np.float64))
+                draws[j], corr[j] = d, st["corr_coef"]
+                leap[j] = (st["total_leapfrogs"], st["wall_seconds"], st["total_divergences"])
+            draws = _dist.gather_chains(draws, num_chains, device=ctx.device)
+            corr = _dist.gather_chains(corr, num_chains, device=ctx.device)
+            leap = _dist.gather_chains(leap, num_chains, device=ctx.device)
+        finally:
+            ctx.close()
+
+        # numpyro get_samples(): constrained latent sites + deterministic sites
+        z = draws.reshape(num_chains * kept, D)
+        o = 0
+        lat = {}
+        for name, size in latent_sites(T, K):
+            v = z[:, o:o + size]
+            o += size
+            if name.startswith("std_"):
+                v = np.exp(v)  # HalfNormal sites: ExpTransform
+            elif name in ("u", "corr_coef_raw"):
+                v = np.clip(1.0 / (1.0 + np.exp(-v)), np.finfo(np.float32).tiny,
+                            1.0 - np.finfo(np.float32).eps)  # Beta sites: SigmoidTransform
+            if size == 1 and not name.endswith("_coefficients"):
+                v = v[:, 0]
+            lat[name] = v
+        att_mean, def_mean = 0.0, lat["mean_defence"][:, None]
+        if K:
+            att_mean = lat["attack_coefficients"] @ cov_std.T
+            def_mean = def_mean + lat["defence_coefficients"] @ cov_std.T
+        self.attack = att_mean + lat["standardised_attack"] * lat["std_attack"][:, None]
+        self.defence = def_mean + lat["standardised_defence"] * lat["std_defence"][:, None]
+        for nm in ("home_attack", "away_attack", "home_defence", "away_defence"):
+            setattr(self, nm, lat["mean_" + nm][:, None]
+                    + lat["std_" + nm][:, None] * lat[nm + "_decentered"])
+        self.corr_coef = corr.reshape(-1)
+        self.u = lat["u"]
+        self.rho = 2.0 * lat["u"] - 1.0
+        self.attack_coefficients = lat.get("attack_coefficients", None)
+        self.defence_coefficients = lat.get("defence_coefficients", None)
+        for nm in ("mean_defence", "std_attack", "std_defence", "mean_home_attack",
+                   "mean_away_attack", "mean_home_defence", "mean_away_defence", "std_home_attack",
+                   "std_home_defence", "std_away_attack", "std_away_defence",
+                   "standardised_attack", "standardised_defence"):
+            setattr(self, nm, lat[nm])
+        self.mcmc_info_ = {"unconstrained": z, "num_chains": num_chains,
+                           "total_leapfrogs": int(leap[:, 0].sum()),
+                           "wall_seconds": float(leap[:, 1].max()),
+                           "divergences": int(leap[:, 2].sum())}
+        return self
+
+    def _parse_fixture_args(self, home_team, away_team, neutral_venue):
+        home_team, away_team = str_to_list(home_team, away_team)
+        neutral_venue = np.array(neutral_venue, DTYPES["venue"])
+        if isinstance(home_team[0], str):
+            home_team = np.array([self._teams_dict[t] for t in home_team], DTYPES["teams"])
+        if isinstance(away_team[0], str):
+            away_team = np.array([self._teams_dict[t] for t in away_team], DTYPES["teams"])
+        return np.asarray(home_team), np.asarray(away_team), neutral_venue
+
+    def _calculate_expected_goals(self, home_team, away_team, neutral_venue) -> Tuple[np.ndarray, np.ndarray]:
+        """Poisson rates of the home and away goals (bpl/neutral_dixon_coles.py:399-444)."""
+        home_team, away_team, neutral_venue = self._parse_fixture_args(home_team, away_team, neutral_venue)
+        on = 1 - neutral_venue.astype(np.float64)
+        home_rate = np.exp(self.attack[:, home_team] - self.defence[:, away_team]
+                           + on * self.home_attack[:, home_team] - on * self.away_defence[:, away_team])
+        away_rate = np.exp(self.attack[:, away_team] - self.defence[:, home_team]
+                           + on * self.away_attack[:, away_team] - on * self.home_defence[:, home_team])
+        return home_rate, away_rate
+
+    def predict_score_proba(self, home_team, away_team, home_goals, away_goals, neutral_venue) -> np.ndarray:
+        """Probability of a particular scoreline between two teams (mean over draws)."""
+        home_team, away_team, neutral_venue = self._parse_fixture_args(home_team, away_team, neutral_venue)
+        ehg, eag = self._calculate_expected_goals(home_team, away_team, neutral_venue)
+        corr_term = dixon_coles_correlation_term(home_goals, away_goals, ehg, eag, self.corr_coef)
+        home_probs = poisson_log_prob(ehg, home_goals)
+        away_probs = poisson_log_prob(eag, away_goals)
+        return np.exp(corr_term + home_probs + away_probs).mean(axis=0)
+
+    def add_new_team(self, team_name: str, team_covariates: Optional[np.ndarray] = None):
+        """Add another team with parameters drawn from the fitted priors
+        (bpl/neutral_dixon_coles.py:490-560)."""
+        if team_name in self.teams:
+            raise ValueError(f"Team {team_name} already known to model.")
+        if self.attack_coefficients is not None:
+            if team_covariates is None:
+                warnings.warn(
+                    f"You haven't provided features for {team_name}."
+                    " Assuming team_covariates are the average of known teams."
+                    " For better forecasts, provide team_covariates."
+                )
+                team_covariates = np.zeros(self.attack_coefficients.shape[1])
+            else:
+                team_covariates = (0.5 * (np.asarray(team_covariates) - self._team_covariates_mean)
+                                   / self._team_covariates_std)
+            mean_attack = np.dot(self.attack_coefficients, team_covariates.ravel())
+            mean_defence = self.mean_defence + np.dot(self.defence_coefficients, team_covariates.ravel())
+        else:
+            mean_attack = 0.0
+            mean_defence = self.mean_defence
+        log_a_tilde = np.random.normal(loc=0.0, scale=1.0, size=len(self.std_attack))
+        log_b_tilde = np.random.normal(loc=self.rho * log_a_tilde, scale=np.sqrt(1 - self.rho ** 2.0))
+        home_attack = np.random.normal(loc=self.mean_home_attack, scale=self.std_home_attack)
+        away_attack = np.random.normal(loc=self.mean_away_attack, scale=self.std_away_attack)
+        home_defence = np.random.normal(loc=self.mean_home_defence, scale=self.std_home_defence)
+        away_defence = np.random.normal(loc=self.mean_away_defence, scale=self.std_away_defence)
+        attack = mean_attack + log_a_tilde * self.std_attack
+        defence = mean_defence + log_b_tilde * self.std_defence
+        self.teams = np.append(self.teams, team_name)
+        self._teams_dict[team_name] = len(self._teams_dict)
+        self.attack = np.concatenate((self.attack, attack[:, None]), axis=1)
+        self.defence = np.concatenate((self.defence, defence[:, None]), axis=1)
+        self.home_attack = np.concatenate((self.home_attack, home_attack[:, None]), axis=1)
+        self.away_attack = np.concatenate((self.away_attack, away_attack[:, None]), axis=1)
+        self.home_defence = np.concatenate((self.home_defence, home_defence[:, None]), axis=1)
+        self.away_defence = np.concatenate((self.away_defence, away_defence[:, None]), axis=1)
+
+    def predict_score_grid_proba(self, home_team, away_team, neutral_venue,
+                                 max_goals: Optional[int] = MAX_GOALS) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+        """Scoreline probabilities on the (max_goals+1)^2 grid for every fixture."""
+        home_team, away_team, neutral_venue = self._parse_fixture_args(home_team, away_team, neutral_venue)
+        neutral_venue = np.broadcast_to(neutral_venue, (len(home_team),))
+        n_goals = np.arange(0, max_goals + 1)
+        home_goals, away_goals = np.meshgrid(n_goals, n_goals, indexing="ij")
+        k = (max_goals + 1) ** 2
+        probs = self.predict_score_proba(
+            np.repeat(home_team, k), np.repeat(away_team, k),
+            np.tile(home_goals.reshape(k), len(home_team)),
+            np.tile(away_goals.reshape(k), len(home_team)), np.repeat(neutral_venue, k),
+        ).reshape(len(home_team), max_goals + 1, max_goals + 1)
+        return probs, home_goals, away_goals
+
+    def predict_outcome_proba(self, home_team, away_team, neutral_venue, knockout: bool = False,
+                              max_goals: Optional[int] = MAX_GOALS) -> Dict[str, np.ndarray]:
+        """Home win, away win and draw probabilities; `knockout` renormalises over the wins."""
+        home_team, away_team, neutral_venue = self._parse_fixture_args(home_team, away_team, neutral_venue)
+        probs, home_goals, away_goals = self.predict_score_grid_proba(
+            home_team, away_team, neutral_venue, max_goals=max_goals)
+        home_win = probs[:, home_goals > away_goals].sum(axis=-1)
+        draw = probs[:, home_goals == away_goals].sum(axis=-1)
+        away_win = probs[:, home_goals < away_goals].sum(axis=-1)
+        if knockout:
+            norm = home_win + away_win
+            return {"home_win": home_win / norm, "away_win": away_win / norm}
+        return {"home_win": home_win, "draw": draw, "away_win": away_win}
+
+    def sample_score(self, home_team, away_team, neutral_venue, num_samples: int = 1,
+                     random_state: int = None, max_goals: Optional[int] = MAX_GOALS) -> Dict[str, np.ndarray]:
+        """Sample scorelines between two teams."""
+        home_team, away_team, neutral_venue = self._parse_fixture_args(home_team, away_team, neutral_venue)
+        if random_state is None:
+            random_state = int(datetime.now().timestamp() * 100)
+        probs, home_goals, away_goals = self.predict_score_grid_proba(
+            home_team, away_team, neutral_venue, max_goals=max_goals)
+        home_goals = np.array(home_goals.flatten(), DTYPES["goals"])
+        away_goals = np.array(away_goals.flatten(), DTYPES["goals"])
+        sample_idx = map_choice(_prng_key(random_state), np.arange(len(home_goals), dtype="uint32"),
+                                num_samples, probs.reshape((len(home_team), -1)))
+        return {"home_score": home_goals[sample_idx], "away_score": away_goals[sample_idx]}
+
+    def sample_outcome(self, home_team, away_team, neutral_venue, knockout: bool = False,
+                       num_samples: int = 1, random_state: int = None,
+                       max_goals: Optional[int] = MAX_GOALS) -> np.ndarray:
+        """Sample the winner ('Draw' unless `knockout`) of matches between two teams."""
+        home_team, away_team, neutral_venue = self._parse_fixture_args(home_team, away_team, neutral_venue)
+        if random_state is None:
+            random_state = int(datetime.now().timestamp() * 100)
+        probs = self.predict_outcome_proba(home_team, away_team, neutral_venue, knockout, max_goals=max_goals)
+        if knockout:
+            probs = np.array([probs["home_win"], probs["away_win"]]).T
+        else:
+            probs = np.array([probs["home_win"], probs["draw"], probs["away_win"]]).T
+        sample_idx = map_choice(_prng_key(random_state), np.arange(probs.shape[1], dtype="uint32"),
+                                num_samples, probs)
+        winner = np.empty((len(home_team), num_samples), dtype=DTYPES["teams"])
+        home_team_rep = home_team.repeat(num_samples).reshape((len(home_team), num_samples))
+        away_team_rep = away_team.repeat(num_samples).reshape((len(home_team), num_samples))
+        winner[sample_idx == 0] = home_team_rep[sample_idx == 0]
+        if knockout:
+            winner[sample_idx == 1] = away_team_rep[sample_idx == 1]
+        else:
+            winner[sample_idx == 2] = away_team_rep[sample_idx == 2]
+            winner[sample_idx == 1] = len(self.teams)  # temporary index for 'Draw'
+        return np.append(self.teams, "Draw")[winner]
+
+    def _n_proba(self, n, team, opponent, home, neutral_venue, max_goals, scored: bool):
+        n = [n] if isinstance(n, (int, np.integer)) else n
+        team, opponent, _ = self._parse_fixture_args(team, opponent, neutral_venue)
+        reps = (max_goals + 1) * len(n)
+        team_rep = np.repeat(team, reps)
+        opponent_rep = np.repeat(opponent, reps)
+        n_rep = np.resize(n, reps)
+        x_rep = np.repeat(np.arange(max_goals + 1), len(n))
+        nv_rep = np.repeat(neutral_venue, reps)
+        mine, theirs = (n_rep, x_rep) if scored else (x_rep, n_rep)
+        probs = (self.predict_score_proba(team_rep, opponent_rep, mine, theirs, nv_rep) if home
+                 else self.predict_score_proba(opponent_rep, team_rep, theirs, mine, nv_rep))
+        return probs.reshape(max_goals + 1, len(n)).sum(axis=0)
+
+    def predict_score_n_proba(self, n, team, opponent, home: Optional[bool] = True,
+                              neutral_venue: Optional[int] = 0,
+                              max_goals: Optional[int] = MAX_GOALS) -> np.ndarray:
+        """Probability that `team` scores n goals against `opponent`."""
+        return self._n_proba(n, team, opponent, home, neutral_venue, max_goals, scored=True)
+
+    def predict_concede_n_proba(self, n, team, opponent, home: Optional[bool] = True,
+                                neutral_venue: Optional[int] = 0,
+                                max_goals: Optional[int] = MAX_GOALS) -> np.ndarray:
+        """Probability that `team` concedes n goals against `opponent`."""
+        return self._n_proba(n, team, opponent, home, neutral_venue, max_goals, scored=False)

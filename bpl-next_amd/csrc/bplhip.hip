@@ -17,6 +17,7 @@
 #include "../../include/bplhip.h"
 #include "dc_dynamic.hip.h"
 #include "dc_kernels.hip.h"
+#include "dc_neutral.hip.h"
 #include "dc_predict.hip.h"
 #include "dc_vec.hip.h"
 #include "nuts.hpp"
@@ -105,6 +106,9 @@ struct bplhip_ctx {
     bool dynamic = false;
     dcd::DynLayout DL{};
     int dyn_random_walk = 1;
+    // neutral-venue model (dc_neutral.hip.h): the dynamic model's fixture passes + own z side
+    bool neutral = false;
+    dcn::NeuLayout NL{};
     DevBuf dd_gw, dd_nv, dd_cells, dd_acc, dd_hyp;
     std::map<GraphKey, hipGraphExec_t> graphs;
     hipStream_t cap_stream = nullptr;
@@ -236,6 +240,56 @@ int launch_eval_dynamic(bplhip_ctx* c, int chains, const double* z, double* pot,
     return BPLHIP_OK;
 }
 
+int launch_eval_neutral(bplhip_ctx* c, int chains, const double* z, double* pot, double* grad,
+                        double* aux, hipStream_t s) {
+    const dcn::NeuLayout& L = c->NL;
+    for (int ch = 0; ch < chains; ++ch) {  // chains run back to back
+        dcn::NeuArgs A{};
+        dcd::DynArgs& F = A.F;
+        F.h = c->d_h.as<const uint16_t>();
+        F.a = c->d_a.as<const uint16_t>();
+        F.x = c->d_x.as<const uint8_t>();
+        F.y = c->d_y.as<const uint8_t>();
+        F.gw = nullptr;
+        F.nv = c->dd_nv.as<const uint8_t>();
+        F.w = c->weighted ? c->d_w.as<const float>() : nullptr;
+        F.n = c->n;
+        F.xs = L.K ? c->d_xs.as<const double>() : nullptr;
+        F.lgsum = c->lgsum;
+        F.cells = c->dd_cells.as<double>();
+        F.acc = c->dd_acc.as<double>();
+        F.sc = F.acc + (size_t)L.T * dcd::A_N;
+        F.z = z + (size_t)ch * L.D;
+        F.potential = pot + ch;
+        F.grad = grad + (size_t)ch * L.D;
+        F.aux = aux ? aux + (size_t)ch * 4 : nullptr;
+        F.L.G = 1;
+        F.L.T = L.T;
+        F.L.K = L.K;
+        F.L.o_corr = L.o_corr;
+        A.L = L;
+        const long long nb_all = (c->n + dcd::FIX_BLOCK - 1) / dcd::FIX_BLOCK;
+        const int nb = (int)std::min<long long>(nb_all, 1024);
+        F.chunk = ((c->n + nb - 1) / nb + dcd::FIX_BLOCK - 1) / dcd::FIX_BLOCK * dcd::FIX_BLOCK;
+        const int nb2 = (int)((c->n + F.chunk - 1) / F.chunk);
+        HIP_TRY(c, hipMemsetAsync(F.acc, 0, ((size_t)L.T * dcd::A_N + dcd::SC_N) * 8, s));
+        hipLaunchKernelGGL(dcn::neu_cells, dim3((L.T + 255) / 256), dim3(256), 0, s, A);
+        if (!c->lds_attr_set) {
+            HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(dcd::dyn_pass2),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           dcd::PASS2_LDS_CELLS * dcd::A_N * 8));
+            c->lds_attr_set = true;
+        }
+        hipLaunchKernelGGL(dcd::dyn_pass1, dim3(nb), dim3(dcd::FIX_BLOCK), 0, s, F);
+        hipLaunchKernelGGL(dcd::dyn_pass2, dim3(nb2), dim3(dcd::FIX_BLOCK),
+                           (size_t)dcd::PASS2_LDS_CELLS * dcd::A_N * 8, s, F);
+        hipLaunchKernelGGL(dcn::neu_epilogue, dim3(1), dim3(dcn::NEU_EPI),
+                           (size_t)(dcn::NEU_SUMS + 2 * L.K) * 8, s, A);
+        HIP_TRY(c, hipGetLastError());
+    }
+    return BPLHIP_OK;
+}
+
 dc::EvalArgs eval_args(bplhip_ctx* c, int chains, const double* z, double* pot, double* grad,
                        double* aux) {
     dc::EvalArgs A{};
@@ -280,6 +334,7 @@ dc::EvalArgs eval_args(bplhip_ctx* c, int chains, const double* z, double* pot, 
 
 int launch_eval(bplhip_ctx* c, int chains, const double* z, double* pot, double* grad,
                 double* aux, hipStream_t s, double* nuts_state = nullptr, int nuts_depth = 0) {
+    if (c->neutral) return launch_eval_neutral(c, chains, z, pot, grad, aux, s);
     if (c->dynamic) return launch_eval_dynamic(c, chains, z, pot, grad, aux, s);
     dc::EvalArgs A = eval_args(c, chains, z, pot, grad, aux);
     A.nuts = nuts_state;
@@ -362,7 +417,7 @@ int launch_eval_vec(bplhip_ctx* c, int chains, const double* z, double* pot, dou
 }
 
 bool vec_ok(const bplhip_ctx* c) {
-    return !c->dynamic && c->vps[0].ok && c->vps[1].ok && c->vps[2].ok;
+    return !c->dynamic && !c->neutral && c->vps[0].ok && c->vps[1].ok && c->vps[2].ok;
 }
 bool use_vec(const bplhip_ctx* c, int chains) {
     return vec_ok(c) && c->opt_vec_min_chains > 0 && chains >= c->opt_vec_min_chains;
@@ -454,6 +509,7 @@ int bplhip_set_fixtures(bplhip_ctx* c, int model_kind, int64_t n, int32_t n_team
     if (!c) return BPLHIP_EINVAL;
     c->bound = false;
     c->dynamic = false;
+    c->neutral = false;
     if (model_kind != BPLHIP_MODEL_BASIC && model_kind != BPLHIP_MODEL_EXTENDED)
         return fail(c, BPLHIP_EINVAL, "set_fixtures: unknown model_kind %d", model_kind);
     if (n < 1 || n > (int64_t)1 << 40)
@@ -655,7 +711,79 @@ int bplhip_set_option(bplhip_ctx* c, const char* name, int value) {
 int bplhip_latent_dim(const bplhip_ctx* c) {
     if (!c) return BPLHIP_EINVAL;
     if (!c->bound) return BPLHIP_ESTATE;
-    return c->dynamic ? c->DL.D : c->L.D;
+    return c->neutral ? c->NL.D : (c->dynamic ? c->DL.D : c->L.D);
+}
+
+int bplhip_set_fixtures_neutral(bplhip_ctx* c, int64_t n, int32_t n_teams, const uint16_t* home_idx,
+                                const uint16_t* away_idx, const uint8_t* home_goals,
+                                const uint8_t* away_goals, const uint8_t* neutral_venue,
+                                const float* weights, const double* covariates, int32_t k,
+                                void* stream) {
+    if (!c) return BPLHIP_EINVAL;
+    c->bound = false;
+    if (n < 1 || n > (int64_t)0xFFFFFFFF || n_teams < 1 || n_teams > 65534)
+        return fail(c, BPLHIP_EINVAL, "set_fixtures_neutral: bad sizes");
+    if (!home_idx || !away_idx || !home_goals || !away_goals || !neutral_venue)
+        return fail(c, BPLHIP_EINVAL, "set_fixtures_neutral: null fixture array");
+    if (k < 0 || (k > 0 && !covariates) || (k == 0 && covariates))
+        return fail(c, BPLHIP_EINVAL, "set_fixtures_neutral: covariates/k mismatch");
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    std::vector<uint16_t> h(n), a(n);
+    std::vector<uint8_t> x(n), y(n), nv(n);
+    std::vector<float> w;
+    HIP_TRY(c, hipMemcpyAsync(h.data(), home_idx, n * 2, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(a.data(), away_idx, n * 2, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(x.data(), home_goals, n, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(y.data(), away_goals, n, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(nv.data(), neutral_venue, n, hipMemcpyDeviceToHost, s));
+    if (weights) {
+        w.resize(n);
+        HIP_TRY(c, hipMemcpyAsync(w.data(), weights, n * 4, hipMemcpyDeviceToHost, s));
+    }
+    HIP_TRY(c, hipStreamSynchronize(s));
+    double lgsum = 0.0;
+    for (int64_t i = 0; i < n; ++i) {
+        if (h[i] >= n_teams || a[i] >= n_teams || nv[i] > 1)
+            return fail(c, BPLHIP_EINVAL, "set_fixtures_neutral: value out of range at fixture %lld",
+                        (long long)i);
+        const double wi = weights ? (double)w[i] : 1.0;
+        lgsum += wi * (std::lgamma((double)x[i] + 1.0) + std::lgamma((double)y[i] + 1.0));
+    }
+    HIP_TRY(c, c->d_h.ensure(n * 2));
+    HIP_TRY(c, c->d_a.ensure(n * 2));
+    HIP_TRY(c, c->d_x.ensure(n));
+    HIP_TRY(c, c->d_y.ensure(n));
+    HIP_TRY(c, c->dd_nv.ensure(n));
+    HIP_TRY(c, hipMemcpyAsync(c->d_h.p, h.data(), n * 2, hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(c->d_a.p, a.data(), n * 2, hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(c->d_x.p, x.data(), n, hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(c->d_y.p, y.data(), n, hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(c->dd_nv.p, nv.data(), n, hipMemcpyHostToDevice, s));
+    if (weights) {
+        HIP_TRY(c, c->d_w.ensure(n * 4));
+        HIP_TRY(c, hipMemcpyAsync(c->d_w.p, w.data(), n * 4, hipMemcpyHostToDevice, s));
+    }
+    HIP_TRY(c, c->dd_cells.ensure((size_t)n_teams * dcd::P_N * 8));
+    HIP_TRY(c, c->dd_acc.ensure(((size_t)n_teams * dcd::A_N + dcd::SC_N) * 8));
+    c->h_xs.clear();
+    if (k > 0) {
+        c->h_xs.assign(covariates, covariates + (size_t)n_teams * k);
+        HIP_TRY(c, c->d_xs.ensure((size_t)n_teams * k * 8));
+        HIP_TRY(c, hipMemcpyAsync(c->d_xs.p, c->h_xs.data(), (size_t)n_teams * k * 8,
+                                  hipMemcpyHostToDevice, s));
+    }
+    HIP_TRY(c, hipStreamSynchronize(s));
+    drop_graphs(c);
+    c->NL = dcn::make_neu_layout(n_teams, k);
+    c->n = n;
+    c->lgsum = lgsum;
+    c->weighted = weights != nullptr;
+    c->lds_attr_set = false;
+    c->dynamic = false;
+    c->neutral = true;
+    c->bound = true;
+    return BPLHIP_OK;
 }
 
 int bplhip_set_fixtures_dynamic(bplhip_ctx* c, int64_t n, int32_t n_teams, int32_t n_gameweeks,
@@ -666,6 +794,7 @@ int bplhip_set_fixtures_dynamic(bplhip_ctx* c, int64_t n, int32_t n_teams, int32
                                 void* stream) {
     if (!c) return BPLHIP_EINVAL;
     c->bound = false;
+    c->neutral = false;
     if (n < 1 || n_teams < 1 || n_teams > 65534 || n_gameweeks < 1 || n_gameweeks > 65535)
         return fail(c, BPLHIP_EINVAL, "set_fixtures_dynamic: bad sizes");
     if (!home_idx || !away_idx || !home_goals || !away_goals || !gameweek || !neutral_venue)
@@ -748,7 +877,7 @@ int bplhip_logp_grad_batched(bplhip_ctx* c, int32_t n_chains, const double* z,
     HIP_TRY(c, hipSetDevice(c->device));
     if (use_vec(c, n_chains))
         return launch_eval_vec(c, n_chains, z, potential, grad, aux, static_cast<hipStream_t>(stream));
-    if (!c->dynamic) {
+    if (!c->dynamic && !c->neutral) {
         int rc = ensure_slabs(c, n_chains);
         if (rc != BPLHIP_OK) return rc;
     }
@@ -771,7 +900,7 @@ int bplhip_logp_grad_graph(bplhip_ctx* c, int32_t count, int32_t n_z, const doub
     auto it = c->graphs.find(key);
     if (it == c->graphs.end()) {
         if (!c->cap_stream) HIP_TRY(c, hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking));
-        const int D = c->dynamic ? c->DL.D : c->L.D;
+        const int D = bplhip_latent_dim(c);
         HIP_TRY(c, hipStreamBeginCapture(c->cap_stream, hipStreamCaptureModeThreadLocal));
         int rc = BPLHIP_OK;
         for (int i = 0; i < count && rc == BPLHIP_OK; ++i) {
@@ -1140,7 +1269,20 @@ nuts::Config make_nuts_config(const bplhip_ctx* c, const bplhip_nuts_cfg* cfg) {
     nc.init_radius = cfg->init_radius;
     nc.max_delta_energy = cfg->max_delta_energy;
 
-    if (c->dynamic) {  // bpl/dynamic_dixon_coles.py:74-241, model execution order
+    if (c->neutral) {  // bpl/neutral_dixon_coles.py:138-261, model execution order
+        const dcn::NeuLayout& L = c->NL;
+        const int T = L.T;
+        nc.sites = {{L.o_md, 1}, {L.o_s_att, 1}, {L.o_s_def, 1}, {L.o_mha, 1}, {L.o_maa, 1},
+                    {L.o_mhd, 1}, {L.o_mad, 1}, {L.o_s_ha, 1}, {L.o_s_aa, 1}, {L.o_s_hd, 1},
+                    {L.o_s_ad, 1}};
+        if (L.K) {
+            nc.sites.push_back({L.o_bA, L.K});
+            nc.sites.push_back({L.o_bD, L.K});
+        }
+        nc.sites.push_back({L.o_u, 1});
+        for (int o : {L.o_sat, L.o_sdt, L.o_hat, L.o_aat, L.o_hdf, L.o_adf}) nc.sites.push_back({o, T});
+        nc.sites.push_back({L.o_corr, 1});
+    } else if (c->dynamic) {  // bpl/dynamic_dixon_coles.py:74-241, model execution order
         const dcd::DynLayout& L = c->DL;
         const int G = L.G, GT = L.G * L.T;
         nc.sites = {{L.o_mha, G}, {L.o_maa, G}, {L.o_mhd, G}, {L.o_mad, G}, {L.o_s_ha, G},
@@ -1211,7 +1353,7 @@ extern "C" int bplhip_nuts_run(bplhip_ctx* c, const bplhip_nuts_cfg* cfg, const 
         cfg->max_tree_depth > 20 || cfg->thinning < 1 || !(cfg->step_size > 0))
         return fail(c, BPLHIP_EINVAL, "nuts_run: bad configuration");
     HIP_TRY(c, hipSetDevice(c->device));
-    const int D = c->dynamic ? c->DL.D : c->L.D;
+    const int D = bplhip_latent_dim(c);
     const size_t nd = (size_t)2 * D + 1 + 4;
     HIP_TRY(c, c->d_nuts.ensure(nd * 8));
     if (c->h_pinned_bytes < nd * 8) {
@@ -1233,7 +1375,7 @@ extern "C" int bplhip_nuts_run(bplhip_ctx* c, const bplhip_nuts_cfg* cfg, const 
     const auto t0 = std::chrono::steady_clock::now();
     int st;
     int dev_rc = BPLHIP_OK;
-    const bool device_tree = c->opt_device_nuts && !c->dynamic && c->L.T <= 64 && c->staged &&
+    const bool device_tree = c->opt_device_nuts && !c->dynamic && !c->neutral && c->L.T <= 64 && c->staged &&
                              c->L.D <= 64 * nd::LEAF_NE;
     if (device_tree) {
         const size_t nsd = nd::ns_doubles(D, nc.max_tree_depth);
@@ -1339,6 +1481,7 @@ extern "C" int bplhip_constrain(bplhip_ctx* c, const double* z_draws, int64_t s,
     if (!c) return BPLHIP_EINVAL;
     if (!c->bound) return fail(c, BPLHIP_ESTATE, "constrain: no fixtures bound");
     if (c->dynamic) return fail(c, BPLHIP_ESTATE, "constrain: use bplhip_constrain_dynamic");
+    if (c->neutral) return fail(c, BPLHIP_ESTATE, "constrain: the neutral model's sites are mapped by the caller");
     if (!z_draws || s < 0) return fail(c, BPLHIP_EINVAL, "constrain: bad argument");
     const dc::Layout& L = c->L;
     const int T = L.T;

@@ -87,8 +87,9 @@ struct DynArgs {
     const uint16_t* a;
     const uint8_t* x;
     const uint8_t* y;
-    const uint16_t* gw;
+    const uint16_t* gw;  // nullptr: one gameweek (the neutral-venue model, dc_neutral.hip.h)
     const uint8_t* nv;
+    const float* w;      // per-fixture weights or nullptr
     long long n;
     long long chunk;     // fixtures per workgroup of dyn_pass2
     const double* xs;    // [T,K] standardised covariates or nullptr
@@ -211,7 +212,7 @@ __global__ __launch_bounds__(CELL_BLOCK) void dyn_cells(DynArgs A) {
 __device__ __forceinline__ void fixture_etas(const DynArgs& A, long long i, int* ch, int* ca,
                                              int* neutral, double* eh, double* ea) {
     const int T = A.L.T;
-    const int g = A.gw[i], h = A.h[i], a = A.a[i];
+    const int g = A.gw ? A.gw[i] : 0, h = A.h[i], a = A.a[i];
     *ch = g * T + h;
     *ca = g * T + a;
     *neutral = A.nv[i];
@@ -278,7 +279,7 @@ __global__ __launch_bounds__(FIX_BLOCK) void dyn_pass2(DynArgs A) {
     const double UB = M > 1.0 ? 1.0 / M : 1.0;
     const double LB = -1.0 / fmax(Lh, La);
     const double rho = LB + q * (UB - LB);
-    const int g_lo = A.gw[i0], g_hi = A.gw[i1 - 1];
+    const int g_lo = A.gw ? A.gw[i0] : 0, g_hi = A.gw ? A.gw[i1 - 1] : 0;
     const int ncell = (g_hi - g_lo + 1) * T;
     const bool priv = ncell <= PASS2_LDS_CELLS;
     const int cell0 = g_lo * T;
@@ -293,21 +294,25 @@ __global__ __launch_bounds__(FIX_BLOCK) void dyn_pass2(DynArgs A) {
         fixture_etas(A, i, &ch, &ca, &nv, &eh, &ea);
         const double lh = exp(eh), la = exp(ea);
         const int x = A.x[i], y = A.y[i];
-        Ui += x * eh - lh + y * ea - la;
+        const double wi = A.w ? (double)A.w[i] : 1.0;
+        double Uf = x * eh - lh + y * ea - la;
         double gh = x - lh, ga = y - la;
         if (x <= 1 && y <= 1) {
             const double c = x == 0 ? (y == 0 ? -lh * la : lh) : (y == 0 ? la : -1.0);
             const double arg = 1.0 + rho * c;
             if (arg > 0.0) {
-                Ui += log(arg);
+                Uf += log(arg);
                 const double u = c / arg;
-                ui += u;
+                ui += wi * u;
                 if (x == 0) gh += rho * u;
                 if (y == 0) ga += rho * u;
             } else {
-                Ui += log(0.0);  // -inf (tol = 0, bpl/_util.py:42)
+                Uf += log(0.0);  // -inf (tol = 0, bpl/_util.py:42)
             }
         }
+        Ui += wi * Uf;
+        gh *= wi;
+        ga *= wi;
         double* Ah = priv ? lacc + (size_t)(ch - cell0) * A_N : A.acc + (size_t)ch * A_N;
         double* Aa = priv ? lacc + (size_t)(ca - cell0) * A_N : A.acc + (size_t)ca * A_N;
         atomicAdd(&Ah[A_ATT], gh);
@@ -359,7 +364,7 @@ __device__ inline void coupling_add(const DynArgs& A, Coupling& C, long long idx
     if (idx1 == 0) return;
     const long long i = idx1 - 1;
     const int T = A.L.T;
-    const int g = A.gw[i], h = A.h[i], a = A.a[i], nv = A.nv[i];
+    const int g = A.gw ? A.gw[i] : 0, h = A.h[i], a = A.a[i], nv = A.nv[i];
     const int ch = g * T + h, ca = g * T + a;
     auto put = [&](int cell, int which, double val) {
         C.cell[C.n] = cell; C.which[C.n] = which; C.val[C.n] = val;

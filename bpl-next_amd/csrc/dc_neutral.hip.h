@@ -1,0 +1,230 @@
+// dc_neutral.hip.h -- gfx950 kernels for the neutral-venue Dixon-Coles model
+// (bpl/neutral_dixon_coles.py:102-283): the extended model's
+// rho-correlated attack/defence plus four per-team non-centred offsets (home_attack,
+// away_attack, home_defence, away_defence) that are switched off at neutral venues, an
+// always-weighted likelihood, no rate clip.
+//
+// First correct path: float64, the fixture passes are the dynamic model's with ONE
+// "gameweek" (dc_dynamic.hip.h: dyn_pass1 = rates + maxima, dyn_pass2 = value + adjoint
+// into LDS-private per-team accumulators, now with per-fixture weights); only the z-side
+// is model specific:
+//   neu_cells     per team: constrained sites -> the six-entry cell record of dyn_pass*
+//   neu_epilogue  bounds adjoint, priors + Jacobians, chain rule to z (one workgroup; the
+//                 z side is O(T))
+// Roofline: HBM-bound stream of 11 B per fixture (u16,u16,u8,u8,u8 neutral, f32 weight).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "dc_dynamic.hip.h"
+
+namespace dcn {
+
+using dc::HALF_LOG_2PI;
+using dc::LN2;
+
+// flat latent layout: sorted site names (numpyro), D = 6T + 2K + 13
+struct NeuLayout {
+    int T, K, D;
+    int o_bA, o_aat, o_adf, o_corr, o_bD, o_hat, o_hdf, o_maa, o_mad, o_md, o_mha, o_mhd, o_sat,
+        o_sdt, o_s_att, o_s_aa, o_s_ad, o_s_def, o_s_ha, o_s_hd, o_u;
+};
+inline NeuLayout make_neu_layout(int T, int K) {
+    NeuLayout L{};
+    L.T = T; L.K = K;
+    int o = 0;
+    L.o_bA = o; o += K;        // attack_coefficients
+    L.o_aat = o; o += T;       // away_attack_decentered
+    L.o_adf = o; o += T;       // away_defence_decentered
+    L.o_corr = o; o += 1;      // corr_coef_raw
+    L.o_bD = o; o += K;        // defence_coefficients
+    L.o_hat = o; o += T;       // home_attack_decentered
+    L.o_hdf = o; o += T;       // home_defence_decentered
+    L.o_maa = o; o += 1;       // mean_away_attack
+    L.o_mad = o; o += 1;       // mean_away_defence
+    L.o_md = o; o += 1;        // mean_defence
+    L.o_mha = o; o += 1;       // mean_home_attack
+    L.o_mhd = o; o += 1;       // mean_home_defence
+    L.o_sat = o; o += T;       // standardised_attack
+    L.o_sdt = o; o += T;       // standardised_defence
+    L.o_s_att = o; o += 1;     // std_attack
+    L.o_s_aa = o; o += 1;      // std_away_attack
+    L.o_s_ad = o; o += 1;      // std_away_defence
+    L.o_s_def = o; o += 1;     // std_defence
+    L.o_s_ha = o; o += 1;      // std_home_attack
+    L.o_s_hd = o; o += 1;      // std_home_defence
+    L.o_u = o; o += 1;         // u
+    L.D = o;
+    return L;
+}
+
+struct NeuArgs {
+    dcd::DynArgs F;   // fixtures, cells, scratch (acc | sc), z / potential / grad / aux
+    NeuLayout L;
+};
+
+// ---- per team: constrained sites -> cell record (dcd::P_*)
+__global__ __launch_bounds__(256) void neu_cells(NeuArgs A) {
+    const NeuLayout& L = A.L;
+    const double* z = A.F.z;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= L.T) return;
+    double att = 0.0, def = z[L.o_md];
+    for (int k = 0; k < L.K; ++k) {
+        const double xv = A.F.xs[(size_t)t * L.K + k];
+        att += xv * z[L.o_bA + k];
+        def += xv * z[L.o_bD + k];
+    }
+    att += z[L.o_sat + t] * exp(z[L.o_s_att]);
+    def += z[L.o_sdt + t] * exp(z[L.o_s_def]);
+    const double hat = z[L.o_mha] + exp(z[L.o_s_ha]) * z[L.o_hat + t];
+    const double aat = z[L.o_maa] + exp(z[L.o_s_aa]) * z[L.o_aat + t];
+    const double hdf = z[L.o_mhd] + exp(z[L.o_s_hd]) * z[L.o_hdf + t];
+    const double adf = z[L.o_mad] + exp(z[L.o_s_ad]) * z[L.o_adf + t];
+    double* P = A.F.cells + (size_t)t * dcd::P_N;
+    P[dcd::P_AH] = att + hat;
+    P[dcd::P_AA] = att + aat;
+    P[dcd::P_BH] = def + hdf;
+    P[dcd::P_BA] = def + adf;
+    P[dcd::P_ATT] = att;
+    P[dcd::P_DEF] = def;
+}
+
+// ---- epilogue: one workgroup
+constexpr int NEU_EPI = 256;
+// sums: 0 dL/d rho_p | 1 sum sa G_att | 2 sum sd G_def | 3 sum G_def | 4..7 sum G_x
+// (hat, aat, hdf, adf) | 8..11 sum dec_x G_x | 12 log-density of the team sites | 13.. cov
+constexpr int NEU_SUMS = 13;
+
+__global__ __launch_bounds__(NEU_EPI) void neu_epilogue(NeuArgs A) {
+    extern __shared__ double sums[];  // [NEU_SUMS + 2K]
+    const NeuLayout& L = A.L;
+    const int T = L.T, K = L.K;
+    const int tid = threadIdx.x;
+    const double* z = A.F.z;
+    double* grad = A.F.grad;
+    for (int i = tid; i < NEU_SUMS + 2 * K; i += NEU_EPI) sums[i] = 0.0;
+    __syncthreads();
+
+    const dcd::Bounds b = dcd::load_bounds(A.F);
+    dcd::Coupling C;
+    C.n = 0;
+    {
+        const unsigned long long* scu = reinterpret_cast<const unsigned long long*>(A.F.sc);
+        if (b.M > 1.0) {
+            const double v = b.G_rho * b.q * (-b.UB);
+            const long long ip = scu[dcd::SC_IDXP] ? (long long)(~0ull - scu[dcd::SC_IDXP]) + 1 : 0;
+            dcd::coupling_add(A.F, C, ip, true, v);
+            dcd::coupling_add(A.F, C, ip, false, v);
+        }
+        const double lbv = b.G_rho * (1.0 - b.q) * (-b.LB);
+        const bool lb_home = b.Lh >= b.La;
+        const unsigned long long w = lb_home ? scu[dcd::SC_IDXQ] : scu[dcd::SC_IDXR];
+        dcd::coupling_add(A.F, C, w ? (long long)(~0ull - w) + 1 : 0, lb_home, lbv);
+    }
+    auto coupled = [&](int cell, int which, double base) {
+        double v = base;
+        for (int e = 0; e < C.n; ++e)
+            if (C.cell[e] == cell && C.which[e] == which) v += C.val[e];
+        return v;
+    };
+    const double s_att = exp(z[L.o_s_att]), s_def = exp(z[L.o_s_def]), s_ha = exp(z[L.o_s_ha]),
+                 s_aa = exp(z[L.o_s_aa]), s_hd = exp(z[L.o_s_hd]), s_ad = exp(z[L.o_s_ad]);
+    const double zu = z[L.o_u];
+    double u, du, su;
+    dcd::clipped_sig(zu, &u, &du, &su);
+    const double rp = 2.0 * u - 1.0, vv = 1.0 - rp * rp, log_vv = log(vv);
+
+    double loc[NEU_SUMS];
+#pragma unroll
+    for (int i = 0; i < NEU_SUMS; ++i) loc[i] = 0.0;
+    for (int t = tid; t < T; t += NEU_EPI) {
+        const double* Ac = A.F.acc + (size_t)t * dcd::A_N;
+        const double G_att = coupled(t, dcd::A_ATT, Ac[dcd::A_ATT]);
+        const double G_def = coupled(t, dcd::A_DEF, Ac[dcd::A_DEF]);
+        const double G_hat = coupled(t, dcd::A_HATT, Ac[dcd::A_HATT]);
+        const double G_adf = coupled(t, dcd::A_ADEF, Ac[dcd::A_ADEF]);
+        const double G_aat = coupled(t, dcd::A_AATT, Ac[dcd::A_AATT]);
+        const double G_hdf = coupled(t, dcd::A_HDEF, Ac[dcd::A_HDEF]);
+        const double sa = z[L.o_sat + t], sd = z[L.o_sdt + t];
+        const double e = sd - rp * sa;
+        grad[L.o_sat + t] = -(s_att * G_att - sa + rp * e / vv);
+        grad[L.o_sdt + t] = -(s_def * G_def - e / vv);
+        const double hat = z[L.o_hat + t], aat = z[L.o_aat + t], hdf = z[L.o_hdf + t],
+                     adf = z[L.o_adf + t];
+        grad[L.o_hat + t] = -(s_ha * G_hat - hat);
+        grad[L.o_aat + t] = -(s_aa * G_aat - aat);
+        grad[L.o_hdf + t] = -(s_hd * G_hdf - hdf);
+        grad[L.o_adf + t] = -(s_ad * G_adf - adf);
+        loc[0] += e * sa / vv - rp * e * e / (vv * vv) + rp / vv;
+        loc[1] += sa * G_att;
+        loc[2] += sd * G_def;
+        loc[3] += G_def;
+        loc[4] += G_hat; loc[5] += G_aat; loc[6] += G_hdf; loc[7] += G_adf;
+        loc[8] += hat * G_hat; loc[9] += aat * G_aat; loc[10] += hdf * G_hdf; loc[11] += adf * G_adf;
+        loc[12] += -0.5 * sa * sa - HALF_LOG_2PI - 0.5 * e * e / vv - 0.5 * log_vv - HALF_LOG_2PI
+                   - 0.5 * (hat * hat + aat * aat + hdf * hdf + adf * adf) - 4.0 * HALF_LOG_2PI;
+        for (int k = 0; k < K; ++k) {
+            const double xv = A.F.xs[(size_t)t * K + k];
+            atomicAdd(&sums[NEU_SUMS + k], xv * G_att);
+            atomicAdd(&sums[NEU_SUMS + K + k], xv * G_def);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NEU_SUMS; ++i) {
+        const double v = dcd::wave_sum(loc[i]);
+        if ((tid & 63) == 0) atomicAdd(&sums[i], v);
+    }
+    __syncthreads();
+
+    for (int k = tid; k < 2 * K; k += NEU_EPI) {  // covariate coefficients ~ N(0,1)
+        const int o = k < K ? L.o_bA + k : L.o_bD + k - K;
+        grad[o] = -(sums[NEU_SUMS + k] - z[o]);
+    }
+    if (tid == 0) {
+        double Ltot = sums[12] + A.F.sc[dcd::SC_U] - A.F.lgsum;
+        for (int k = 0; k < 2 * K; ++k) {
+            const int o = k < K ? L.o_bA + k : L.o_bD + k - K;
+            Ltot += -0.5 * z[o] * z[o] - HALF_LOG_2PI;
+        }
+        const double m = z[L.o_md];
+        Ltot += -0.5 * m * m - HALF_LOG_2PI;
+        grad[L.o_md] = -(sums[3] - m);
+        // HalfNormal(scale) sites in log space: std_attack / std_defence scale 0.5, others 1
+        const int o_std[6] = {L.o_s_att, L.o_s_def, L.o_s_ha, L.o_s_aa, L.o_s_hd, L.o_s_ad};
+        const double sv[6] = {s_att, s_def, s_ha, s_aa, s_hd, s_ad};
+        const double scale[6] = {0.5, 0.5, 1.0, 1.0, 1.0, 1.0};
+        const double dotG[6] = {sums[1], sums[2], sums[8], sums[9], sums[10], sums[11]};
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const double r = sv[j] / scale[j];
+            Ltot += LN2 - log(scale[j]) - HALF_LOG_2PI - 0.5 * r * r + z[o_std[j]];
+            grad[o_std[j]] = -(sv[j] * dotG[j] - r * r + 1.0);
+        }
+        const int o_mean[4] = {L.o_mha, L.o_maa, L.o_mhd, L.o_mad};
+        const double mu[4] = {0.1, -0.1, 0.1, -0.1};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const double mean = z[o_mean[j]];
+            const double r = (mean - mu[j]) / 0.2;
+            Ltot += -0.5 * r * r + 1.6094379124341003 - HALF_LOG_2PI;
+            grad[o_mean[j]] = -(sums[4 + j] - (mean - mu[j]) / 0.04);
+        }
+        // u ~ Beta(2,4) through the sigmoid; corr_coef_raw ~ Beta(2,2)
+        Ltot += log(u) + 3.0 * log1p(-u) + 2.995732273553991 - dcd::softplus(zu) - dcd::softplus(-zu);
+        grad[L.o_u] = -((1.0 / u - 3.0 / (1.0 - u)) * du + 2.0 * sums[0] * du + (1.0 - 2.0 * su));
+        const double zc = z[L.o_corr];
+        Ltot += log(b.q) + log1p(-b.q) + 1.791759469228055 - dcd::softplus(zc) - dcd::softplus(-zc);
+        grad[L.o_corr] = -((1.0 / b.q - 1.0 / (1.0 - b.q)) * b.dq + (1.0 - 2.0 * b.sq) +
+                           b.G_rho * (b.UB - b.LB) * b.dq);
+        A.F.potential[0] = -Ltot;
+        if (A.F.aux) {
+            A.F.aux[0] = b.rho;
+            A.F.aux[1] = b.LB;
+            A.F.aux[2] = b.UB;
+            A.F.aux[3] = b.q;
+        }
+    }
+}
+
+}  // namespace dcn

@@ -55,8 +55,10 @@ enum {
 enum {
     BPLHIP_MODEL_BASIC = 0,    /* bpl/dixon_coles.py:39-84           */
     BPLHIP_MODEL_EXTENDED = 1, /* bpl/extended_dixon_coles.py:78-248 */
-    BPLHIP_MODEL_DYNAMIC = 2   /* bpl/dynamic_dixon_coles.py:63-247 (bound through
+    BPLHIP_MODEL_DYNAMIC = 2,  /* bpl/dynamic_dixon_coles.py:63-247 (bound through
                                   bplhip_set_fixtures_dynamic)       */
+    BPLHIP_MODEL_NEUTRAL = 3   /* bpl/neutral_dixon_coles.py:102-283 (bound through
+                                  bplhip_set_fixtures_neutral)       */
 };
 
 typedef struct bplhip_ctx bplhip_ctx;
@@ -123,6 +125,22 @@ int bplhip_constrain_dynamic(bplhip_ctx* ctx, const double* z_draws, int64_t s,
                              double* attack, double* defence, double* home_attack,
                              double* away_attack, double* home_defence,
                              double* away_defence);
+
+/* Bind the arguments of the neutral-venue model, bpl/neutral_dixon_coles.py:102-283 as run
+ * at :342-356: `neutral_venue` device u8[n] (0/1), `weights` device f32[n] = the final
+ * per-fixture weights (time decay x game weights, :251-257; NULL = all ones), covariates as
+ * for the extended model.  Latent layout (sorted site names, D = 6T + 2K + 13):
+ * attack_coefficients[K], away_attack_decentered[T], away_defence_decentered[T],
+ * corr_coef_raw, defence_coefficients[K], home_attack_decentered[T],
+ * home_defence_decentered[T], mean_away_attack, mean_away_defence, mean_defence,
+ * mean_home_attack, mean_home_defence, standardised_attack[T], standardised_defence[T],
+ * std_attack, std_away_attack, std_away_defence, std_defence, std_home_attack,
+ * std_home_defence, u.  After this call logp_grad / nuts_run work on the neutral model. */
+int bplhip_set_fixtures_neutral(bplhip_ctx* ctx, int64_t n, int32_t n_teams,
+                                const uint16_t* home_idx, const uint16_t* away_idx,
+                                const uint8_t* home_goals, const uint8_t* away_goals,
+                                const uint8_t* neutral_venue, const float* weights,
+                                const double* covariates, int32_t k, void* stream);
 
 /* Tuning knobs (no reference counterpart; defaults are the measured best):
  *   "device_nuts" 1 (default) = NUTS tree builder on the device: leaf bookkeeping in the

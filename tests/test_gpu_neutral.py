@@ -1,0 +1,140 @@
+"""GPU: the neutral-venue model (row f-4) through the C-ABI vs its float64 oracle, and the
+reference's own property tests (tests/test_neutral_dixon_coles.py) on a fitted model.
+
+Tolerances (float64 path end to end; the only float32 data are the weights, which the oracle
+receives rounded to float32 as well):  |dU| <= 1e-11 |U|,  |dgrad|_inf <= 1e-10 |grad|_inf.
+"""
+import numpy as np
+import pytest
+
+import dc_neutral_oracle as NO
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-02
+MAX_GOALS = 15
+
+
+def _bind(ctx, fx):
+    cov = None if fx.covariates is None else NO.standardise_covariates(fx.covariates)
+    ctx.set_fixtures_neutral(fx.home_idx, fx.away_idx, fx.home_goals, fx.away_goals, fx.neutral,
+                             fx.n_teams, weights=fx.weights.astype(np.float32), covariates_std=cov)
+    assert ctx.dim == NO.latent_dim(fx.n_teams, fx.k)
+
+
+def _cases():
+    dd = NO.neutral_dummy_recipe()
+    yield "dummy", NO.fixtures_from_data(dd)
+    yield "dummy_eps", NO.fixtures_from_data(dd, epsilon=0.3, rescale_weights=True)
+    yield "dummy_cov", NO.fixtures_from_data(dd, epsilon=0.1,
+                                             covariates=np.random.RandomState(0).normal(size=(20, 3)))
+    yield "synthetic_3e4", NO.synthetic_neutral(30_000, 30, k=2)
+    yield "synthetic_1e6", NO.synthetic_neutral(1_000_000, 20)
+
+
+@pytest.mark.parametrize("name,fx", list(_cases()))
+def test_logp_grad_matches_oracle(hip_ctx, name, fx):
+    import torch
+
+    fx.weights = fx.weights.astype(np.float32).astype(np.float64)  # what the device holds
+    _bind(hip_ctx, fx)
+    D = hip_ctx.dim
+    for seed, scale in ((1, 0.2), (2, 0.5), (3, 1.0)):
+        z = np.random.RandomState(seed).uniform(-scale, scale, D)
+        Uo, go, auxo = NO.potential_and_grad(fx, z)
+        U, g, aux = hip_ctx.logp_grad(torch.tensor(z, dtype=torch.float64, device=hip_ctx.device))
+        U, g, aux = float(U.cpu()[0]), g.cpu().numpy(), aux.cpu().numpy()[0]
+        print(f"{name:14s} N={fx.n:8d} U={Uo:.6f} dU={U - Uo:+.2e} dg={np.abs(g - go).max():.2e} "
+              f"|g|={np.abs(go).max():.2e}")
+        assert abs(U - Uo) <= 1e-11 * abs(Uo)
+        assert np.abs(g - go).max() <= 1e-10 * np.abs(go).max()
+        assert abs(aux[0] - auxo["rho"]) <= 1e-12
+        assert abs(aux[1] - auxo["LB"]) <= 1e-12 and abs(aux[2] - auxo["UB"]) <= 1e-12
+
+
+@pytest.fixture(scope="module")
+def model():
+    from bpl import NeutralDixonColesMatchPredictor
+
+    dd = NO.neutral_dummy_recipe()
+    m = NeutralDixonColesMatchPredictor().fit(dd, num_warmup=300, num_samples=300)
+    return m, dd
+
+
+def test_fit(model):
+    m, _ = model
+    for nm in ("attack", "defence", "home_attack", "home_defence", "away_attack", "away_defence",
+               "teams", "corr_coef"):
+        assert getattr(m, nm) is not None
+    assert m.attack.shape == (300, 20) and m.corr_coef.shape == (300,)
+    assert m.mcmc_info_["divergences"] <= 3
+    # the data were drawn with a home mean of 2.1 against 1.7 away, 1.9 / 1.9 on neutral ground
+    assert m.mean_home_attack.mean() - m.mean_away_attack.mean() > 0.0
+    # deterministic corr_coef site obeys its bounds at every draw
+    h = np.array([m._teams_dict[t] for t in _["home_team"]])
+    a = np.array([m._teams_dict[t] for t in _["away_team"]])
+    lh, la = m._calculate_expected_goals(h, a, _["neutral_venue"])
+    UB = np.minimum(1.0 / (lh * la).max(axis=1), 1.0)
+    LB = -1.0 / np.maximum(lh.max(axis=1), la.max(axis=1))
+    assert np.all(m.corr_coef <= UB + 1e-9) and np.all(m.corr_coef >= LB - 1e-9)
+
+
+def test_predict_score_proba(model):
+    m, dd = model
+    probs = m.predict_score_proba(dd["home_team"], dd["away_team"], dd["home_goals"],
+                                  dd["away_goals"], dd["neutral_venue"])
+    assert np.all((probs >= 0) & (probs <= 1))
+    assert 0 <= m.predict_score_proba("0", "1", 1, 0, 0)[0] <= 1
+
+
+def test_predict_outcome_proba(model):
+    m, dd = model
+    probs = m.predict_outcome_proba(dd["home_team"], dd["away_team"], dd["neutral_venue"])
+    assert np.allclose(probs["home_win"] + probs["away_win"] + probs["draw"], 1.0, atol=TOL)
+    single = m.predict_outcome_proba("0", "1", 0)
+    assert single["home_win"] + single["away_win"] + single["draw"] == pytest.approx(1.0, abs=TOL)
+    ko = m.predict_outcome_proba("0", "1", 1, knockout=True)
+    assert set(ko) == {"home_win", "away_win"} and ko["home_win"] + ko["away_win"] == pytest.approx(1.0)
+
+
+def test_predict_n_proba(model):
+    m, _ = model
+    n = np.arange(MAX_GOALS + 1)
+    ph = m.predict_score_n_proba(n, "0", "1")
+    pa = m.predict_score_n_proba(n, "0", "1", home=False)
+    assert len(ph) == len(n) and np.all((ph >= 0) & (ph <= 1)) and sum(ph) == pytest.approx(1.0, abs=TOL)
+    assert sum(pa) == pytest.approx(1.0, abs=TOL)
+    assert sum(ph * n) > sum(pa * n)  # score more at home
+    ch = m.predict_concede_n_proba(n, "0", "1")
+    ca = m.predict_concede_n_proba(n, "0", "1", home=False)
+    assert sum(ch) == pytest.approx(1.0, abs=TOL) and sum(ch * n) < sum(ca * n)  # concede more away
+    # scoring at home == the opponent conceding away
+    assert np.allclose(ph, m.predict_concede_n_proba(n, "1", "0", home=False), atol=1e-12)
+    assert len(m.predict_score_n_proba(1, "0", "1")) == 1
+
+
+def test_sampling_and_new_team(model):
+    m, _ = model
+    s = m.sample_score(["0", "2"], ["1", "3"], [0, 1], num_samples=50, random_state=1)
+    assert s["home_score"].shape == (2, 50) and s["away_score"].shape == (2, 50)
+    w = m.sample_outcome(["0", "2"], ["1", "3"], [0, 1], num_samples=50, random_state=1)
+    assert w.shape == (2, 50) and set(np.unique(w[0])) <= {"0", "1", "Draw"}
+    wk = m.sample_outcome(["0"], ["1"], [1], knockout=True, num_samples=50, random_state=1)
+    assert set(np.unique(wk)) <= {"0", "1"}
+    with pytest.raises(ValueError):
+        m.add_new_team("0")
+    np.random.seed(0)
+    m.add_new_team("new")
+    assert m.attack.shape[1] == 21 and "new" in m.teams
+    assert 0 <= m.predict_score_proba("new", "1", 1, 0, 0)[0] <= 1
+
+
+def test_errors():
+    from bpl import NeutralDixonColesMatchPredictor
+
+    dd = NO.neutral_dummy_recipe()
+    bad = {k: v for k, v in dd.items() if k != "time_diff"}
+    with pytest.raises(ValueError):
+        NeutralDixonColesMatchPredictor().fit(bad, epsilon=1.0, num_warmup=5, num_samples=5)
+    bad = {k: v for k, v in dd.items() if k != "game_weights"}
+    with pytest.raises(TypeError):
+        NeutralDixonColesMatchPredictor().fit(bad, num_warmup=5, num_samples=5)
