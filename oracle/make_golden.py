@@ -66,6 +66,33 @@ def main():
             UB=np.array(ubs),
         )
         print(f"wrote m{model}_{name}.npz  ({len(pts)} points, N={fx.n})")
+    neutral_golden()
+
+
+def neutral_golden():
+    """Neutral-venue model (row f-4): the reference's `neutral_dummy_data` recipe
+    (tests/conftest.py:66-117) with time decay + rescaling and 3 covariates."""
+    import dc_neutral_oracle as NO
+
+    dd = NO.neutral_dummy_recipe()
+    cov = np.random.RandomState(0).normal(size=(20, 3))
+    for name, fx in (("dummy", NO.fixtures_from_data(dd)),
+                     ("dummy_eps_cov", NO.fixtures_from_data(dd, epsilon=0.3, rescale_weights=True,
+                                                             covariates=cov))):
+        fx.weights = fx.weights.astype(np.float32).astype(np.float64)  # as the device holds them
+        D = NO.latent_dim(fx.n_teams, fx.k)
+        zs = [np.random.RandomState(s).uniform(-sc, sc, D) for s, sc in ((1, 0.2), (2, 0.5), (3, 1.0))]
+        res = [NO.potential_and_grad(fx, z) for z in zs]
+        np.savez_compressed(
+            os.path.join(OUT, f"m3_{name}.npz"), model=3,
+            home_idx=fx.home_idx.astype(np.uint16), away_idx=fx.away_idx.astype(np.uint16),
+            home_goals=fx.home_goals.astype(np.uint8), away_goals=fx.away_goals.astype(np.uint8),
+            neutral=fx.neutral.astype(np.uint8), weights=fx.weights, n_teams=fx.n_teams,
+            covariates=np.zeros((0, 0)) if fx.covariates is None else fx.covariates,
+            z=np.stack(zs), U=np.array([r[0] for r in res]), grad=np.stack([r[1] for r in res]),
+            rho=np.array([r[2]["rho"] for r in res]), LB=np.array([r[2]["LB"] for r in res]),
+            UB=np.array([r[2]["UB"] for r in res]))
+        print(f"wrote m3_{name}.npz  (3 points, N={fx.n})")
 
 
 if __name__ == "__main__":

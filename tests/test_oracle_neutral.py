@@ -49,3 +49,22 @@ def test_layout_and_weights():
     w = NO.make_weights(4, [0.0, 1.0, 2.0, 3.0], 0.5, [1.0, 2.0, 1.0, 0.5], rescale_weights=True)
     base = np.exp(-0.5 * np.arange(4.0))
     assert np.allclose(w, 4 * base / base.sum() * np.array([1.0, 2.0, 1.0, 0.5]))
+
+
+@pytest.mark.parametrize("name", ["dummy", "dummy_eps_cov"])
+def test_golden_vectors(name):
+    """tests/golden/m3_*.npz (oracle/make_golden.py): the committed vectors are reproduced by
+    both restatements -- a regression pin for the oracle itself and the data of the GPU test."""
+    import os
+
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", f"m3_{name}.npz"))
+    cov = g["covariates"] if g["covariates"].size else None
+    fx = NO.NeutralFixtures(g["home_idx"], g["away_idx"], g["home_goals"], g["away_goals"],
+                            g["neutral"], g["weights"], int(g["n_teams"]), covariates=cov)
+    for i in range(g["z"].shape[0]):
+        U, gr, aux = NO.potential_and_grad(fx, g["z"][i])
+        assert abs(U - g["U"][i]) <= 1e-12 * abs(U) and np.abs(gr - g["grad"][i]).max() <= 1e-9
+        Ut, gt, _ = NO.torch_potential_and_grad(fx, g["z"][i])
+        assert abs(Ut - g["U"][i]) <= 1e-11 * abs(U)
+        assert np.abs(gt - g["grad"][i]).max() <= 1e-10 * np.abs(gt).max()
+        assert abs(aux["rho"] - g["rho"][i]) < 1e-13
