@@ -8,6 +8,7 @@ __version__ = "0.2.0"
 from bpl.dixon_coles import DixonColesMatchPredictor
 from bpl.extended_dixon_coles import ExtendedDixonColesMatchPredictor
 from bpl.neutral_dixon_coles import NeutralDixonColesMatchPredictor
+from bpl.neutral_dixon_coles_WC import NeutralDixonColesMatchPredictorWC
 
 __all__ = ["DixonColesMatchPredictor", "ExtendedDixonColesMatchPredictor",
-           "NeutralDixonColesMatchPredictor"]
+           "NeutralDixonColesMatchPredictor", "NeutralDixonColesMatchPredictorWC"]

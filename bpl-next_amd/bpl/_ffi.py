@@ -116,7 +116,7 @@ def load_library():
     lib.bplhip_set_fixtures.restype = C.c_int
     lib.bplhip_set_fixtures_dynamic.argtypes = [vp, i64, i32, i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp]
     lib.bplhip_set_fixtures_dynamic.restype = C.c_int
-    lib.bplhip_set_fixtures_neutral.argtypes = [vp, i64, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp]
+    lib.bplhip_set_fixtures_neutral.argtypes = [vp, i64, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, i32, vp]
     lib.bplhip_set_fixtures_neutral.restype = C.c_int
     lib.bplhip_constrain_dynamic.argtypes = [vp, vp, i64, vp, vp, vp, vp, vp, vp]
     lib.bplhip_constrain_dynamic.restype = C.c_int
@@ -318,9 +318,11 @@ class HipContext:
         return self
 
     def set_fixtures_neutral(self, home_idx, away_idx, home_goals, away_goals, neutral_venue,
-                             n_teams: int, weights=None, covariates_std: Optional[np.ndarray] = None):
+                             n_teams: int, weights=None, covariates_std: Optional[np.ndarray] = None,
+                             home_conf=None, away_conf=None, n_conf: int = 0):
         """Bind the neutral-venue model (bpl/neutral_dixon_coles.py).  `weights`: the final
-        per-fixture weights (time decay x game weights) or None."""
+        per-fixture weights (time decay x game weights) or None.  `home_conf`, `away_conf`,
+        `n_conf`: confederation indices of the World-Cup variant."""
         torch = self._torch
 
         def dev(a, np_dtype):
@@ -341,10 +343,17 @@ class HipContext:
         if covariates_std is not None:
             cov = np.ascontiguousarray(covariates_std, dtype=np.float64)
             k = cov.shape[1]
+        hc = ac = None
+        if n_conf:
+            hc, ac = dev(home_conf, np.uint8), dev(away_conf, np.uint8)
+            if hc.numel() != n or ac.numel() != n:
+                raise ValueError("confederation arrays must have one entry per fixture")
         with torch.cuda.device(self.device):
             self._check(self._lib.bplhip_set_fixtures_neutral(
                 self._h, n, n_teams, h.data_ptr(), a.data_ptr(), x.data_ptr(), y.data_ptr(),
-                nv.data_ptr(), None if w is None else w.data_ptr(), _np_ptr(cov), k, self._stream()))
+                nv.data_ptr(), None if hc is None else hc.data_ptr(),
+                None if ac is None else ac.data_ptr(), int(n_conf),
+                None if w is None else w.data_ptr(), _np_ptr(cov), k, self._stream()))
         self.dim = self._lib.bplhip_latent_dim(self._h)
         self.n_teams, self.model, self.n = n_teams, MODEL_NEUTRAL, n
         return self

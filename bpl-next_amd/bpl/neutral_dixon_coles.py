@@ -31,12 +31,16 @@ _MCMC_KEYS = {"num_chains", "thinning", "progress_bar", "chain_method", "jit_mod
 _RUN_KEYS = {"init_params", "extra_fields"}
 
 
-def latent_sites(T: int, K: int):
-    """(name, size) of every latent site in flat (sorted-name) order; D = 6T + 2K + 13."""
+def latent_sites(T: int, K: int, C: int = 0):
+    """(name, size) of every latent site in flat (sorted-name) order; D = 6T + 2K + C + 13
+    (C confederations: World-Cup variant)."""
     s = []
     if K:
         s.append(("attack_coefficients", K))
-    s += [("away_attack_decentered", T), ("away_defence_decentered", T), ("corr_coef_raw", 1)]
+    s += [("away_attack_decentered", T), ("away_defence_decentered", T)]
+    if C:
+        s.append(("confederation_strength_decentered", C))
+    s.append(("corr_coef_raw", 1))
     if K:
         s.append(("defence_coefficients", K))
     s += [("home_attack_decentered", T), ("home_defence_decentered", T),
@@ -77,7 +81,8 @@ class NeutralDixonColesMatchPredictor:
                    "std_attack", "std_defence", "mean_home_attack", "mean_away_attack",
                    "mean_home_defence", "mean_away_defence", "std_home_attack", "std_away_attack",
                    "std_home_defence", "std_away_defence", "standardised_attack",
-                   "standardised_defence", "_team_covariates_mean", "_team_covariates_std"):
+                   "standardised_defence", "_team_covariates_mean", "_team_covariates_std",
+                   "confederation_strength"):
             setattr(self, nm, None)
         self.mcmc_info_ = None
 
@@ -94,12 +99,6 @@ class NeutralDixonColesMatchPredictor:
         run_kwargs: Optional[Dict[str, Any]] = None,
     ) -> "NeutralDixonColesMatchPredictor":
         """Fit model to data (bpl/neutral_dixon_coles.py:286-384)."""
-        from bpl._ffi import HipContext, default_nuts_cfg, prng_key, threefry_split
-
-        self.teams, self._teams_dict, home_ind, away_ind = parse_teams(
-            training_data["home_team"], training_data["away_team"], DTYPES["teams"]
-        )
-        team_covariates = training_data.get("team_covariates")
         self.epsilon = epsilon
         self.rescale_weights = rescale_weights
         self.time_diff = training_data.get("time_diff", None)
@@ -111,6 +110,21 @@ class NeutralDixonColesMatchPredictor:
                     """
             )
         self.game_weights = training_data.get("game_weights", None)
+        n = len(list(training_data["home_goals"]))
+        weights = make_weights(n, self.time_diff, epsilon, self.game_weights, rescale_weights)
+        return self._fit(training_data, weights, None, random_state, num_warmup, num_samples,
+                         mcmc_kwargs, run_kwargs)
+
+    def _fit(self, training_data, weights, conf, random_state, num_warmup, num_samples,
+             mcmc_kwargs, run_kwargs):
+        """Shared by the neutral and the World-Cup model.  `conf`: None or
+        (home_conf_idx, away_conf_idx, n_conf)."""
+        from bpl._ffi import HipContext, default_nuts_cfg, prng_key, threefry_split
+
+        self.teams, self._teams_dict, home_ind, away_ind = parse_teams(
+            training_data["home_team"], training_data["away_team"], DTYPES["teams"]
+        )
+        team_covariates = training_data.get("team_covariates")
         T = len(self.teams)
         cov_std = None
         if team_covariates:
@@ -121,13 +135,13 @@ class NeutralDixonColesMatchPredictor:
             self._team_covariates_std = cov.std(axis=0)
             cov_std = (cov - self._team_covariates_mean) / self._team_covariates_std
         K = 0 if cov_std is None else cov_std.shape[1]
+        C = 0 if conf is None else int(conf[2])
 
         hg = np.asarray(training_data["home_goals"])
         ag = np.asarray(training_data["away_goals"])
         if hg.size and (hg.min() < 0 or ag.min() < 0 or hg.max() > 255 or ag.max() > 255):
             raise ValueError("goals must be integers in [0, 255]")
         nv = np.asarray(training_data["neutral_venue"]).astype(np.uint8)
-        weights = make_weights(len(hg), self.time_diff, epsilon, self.game_weights, rescale_weights)
 
         mcmc_kwargs = dict(mcmc_kwargs or {})
         run_kwargs = dict(run_kwargs or {})
@@ -143,7 +157,9 @@ class NeutralDixonColesMatchPredictor:
         ctx = HipContext(_dist.local_device_index() if ws > 1 else 0)
         try:
             ctx.set_fixtures_neutral(home_ind, away_ind, hg, ag, nv, T, weights=weights,
-                                     covariates_std=cov_std)
+                                     covariates_std=cov_std,
+                                     home_conf=None if conf is None else conf[0],
+                                     away_conf=None if conf is None else conf[1], n_conf=C)
             D = ctx.dim
             cfg = default_nuts_cfg()
             cfg.num_warmup, cfg.num_samples, cfg.thinning = int(num_warmup), int(num_samples), thinning
@@ -152,7 +168,7 @@ class NeutralDixonColesMatchPredictor:
             z0 = run_kwargs.get("init_params")
             if isinstance(z0, dict):
                 z0 = np.concatenate([np.asarray(z0[n], dtype=np.float64).reshape(-1)
-                                     for n, _ in latent_sites(T, K)])
+                                     for n, _ in latent_sites(T, K, C)])
             mine = _dist.chains_of_rank(num_chains, rank, ws)
             kept = cfg.num_samples // thinning
             draws = np.empty((len(mine), kept, D))
@@ -172,7 +188,7 @@ class NeutralDixonColesMatchPredictor:
         z = draws.reshape(num_chains * kept, D)
         o = 0
         lat = {}
-        for name, size in latent_sites(T, K):
+        for name, size in latent_sites(T, K, C):
             v = z[:, o:o + size]
             o += size
             if name.startswith("std_"):
@@ -180,7 +196,7 @@ class NeutralDixonColesMatchPredictor:
             elif name in ("u", "corr_coef_raw"):
                 v = np.clip(1.0 / (1.0 + np.exp(-v)), np.finfo(np.float32).tiny,
                             1.0 - np.finfo(np.float32).eps)  # Beta sites: SigmoidTransform
-            if size == 1 and not name.endswith("_coefficients"):
+            if size == 1 and name.startswith(("mean_", "std_", "u", "corr_coef_raw")):
                 v = v[:, 0]
             lat[name] = v
         att_mean, def_mean = 0.0, lat["mean_defence"][:, None]
@@ -192,6 +208,8 @@ class NeutralDixonColesMatchPredictor:
         for nm in ("home_attack", "away_attack", "home_defence", "away_defence"):
             setattr(self, nm, lat["mean_" + nm][:, None]
                     + lat["std_" + nm][:, None] * lat[nm + "_decentered"])
+        if C:  # LocScaleReparam(centered=0) of Normal(0, 1): the value is the decentered site
+            self.confederation_strength = lat["confederation_strength_decentered"]
         self.corr_coef = corr.reshape(-1)
         self.u = lat["u"]
         self.rho = 2.0 * lat["u"] - 1.0
@@ -217,27 +235,101 @@ class NeutralDixonColesMatchPredictor:
             away_team = np.array([self._teams_dict[t] for t in away_team], DTYPES["teams"])
         return np.asarray(home_team), np.asarray(away_team), neutral_venue
 
-    def _calculate_expected_goals(self, home_team, away_team, neutral_venue) -> Tuple[np.ndarray, np.ndarray]:
-        """Poisson rates of the home and away goals (bpl/neutral_dixon_coles.py:399-444)."""
-        home_team, away_team, neutral_venue = self._parse_fixture_args(home_team, away_team, neutral_venue)
-        on = 1 - neutral_venue.astype(np.float64)
-        home_rate = np.exp(self.attack[:, home_team] - self.defence[:, away_team]
-                           + on * self.home_attack[:, home_team] - on * self.away_defence[:, away_team])
-        away_rate = np.exp(self.attack[:, away_team] - self.defence[:, home_team]
-                           + on * self.away_attack[:, away_team] - on * self.home_defence[:, home_team])
-        return home_rate, away_rate
+    # ---- internals on index arrays; `conf` = None or (home_conf_idx, away_conf_idx)
+    def _rates(self, home_team, away_team, neutral_venue, conf=None):
+        on = 1 - np.asarray(neutral_venue).astype(np.float64)
+        eh = (self.attack[:, home_team] - self.defence[:, away_team]
+              + on * self.home_attack[:, home_team] - on * self.away_defence[:, away_team])
+        ea = (self.attack[:, away_team] - self.defence[:, home_team]
+              + on * self.away_attack[:, away_team] - on * self.home_defence[:, home_team])
+        if conf is not None:
+            d = self.confederation_strength[:, conf[0]] - self.confederation_strength[:, conf[1]]
+            eh, ea = eh + d, ea - d
+        return np.exp(eh), np.exp(ea)
 
-    def predict_score_proba(self, home_team, away_team, home_goals, away_goals, neutral_venue) -> np.ndarray:
-        """Probability of a particular scoreline between two teams (mean over draws)."""
-        home_team, away_team, neutral_venue = self._parse_fixture_args(home_team, away_team, neutral_venue)
-        ehg, eag = self._calculate_expected_goals(home_team, away_team, neutral_venue)
+    def _score_proba(self, home_team, away_team, home_goals, away_goals, neutral_venue, conf=None):
+        ehg, eag = self._rates(home_team, away_team, neutral_venue, conf)
         corr_term = dixon_coles_correlation_term(home_goals, away_goals, ehg, eag, self.corr_coef)
         home_probs = poisson_log_prob(ehg, home_goals)
         away_probs = poisson_log_prob(eag, away_goals)
         return np.exp(corr_term + home_probs + away_probs).mean(axis=0)
 
-    def add_new_team(self, team_name: str, team_covariates: Optional[np.ndarray] = None):
-        """Add another team with parameters drawn from the fitted priors
+    def _grid(self, home_team, away_team, neutral_venue, conf, max_goals):
+        m = len(home_team)
+        neutral_venue = np.broadcast_to(neutral_venue, (m,))
+        n_goals = np.arange(0, max_goals + 1)
+        home_goals, away_goals = np.meshgrid(n_goals, n_goals, indexing="ij")
+        k = (max_goals + 1) ** 2
+        conf_rep = None if conf is None else (np.repeat(conf[0], k), np.repeat(conf[1], k))
+        probs = self._score_proba(
+            np.repeat(home_team, k), np.repeat(away_team, k), np.tile(home_goals.reshape(k), m),
+            np.tile(away_goals.reshape(k), m), np.repeat(neutral_venue, k), conf_rep,
+        ).reshape(m, max_goals + 1, max_goals + 1)
+        return probs, home_goals, away_goals
+
+    def _outcome(self, home_team, away_team, neutral_venue, conf, knockout, max_goals):
+        probs, home_goals, away_goals = self._grid(home_team, away_team, neutral_venue, conf, max_goals)
+        home_win = probs[:, home_goals > away_goals].sum(axis=-1)
+        draw = probs[:, home_goals == away_goals].sum(axis=-1)
+        away_win = probs[:, home_goals < away_goals].sum(axis=-1)
+        if knockout:
+            # don't consider draws (renormalise with home win and away win only)
+            norm = home_win + away_win
+            return {"home_win": home_win / norm, "away_win": away_win / norm}
+        return {"home_win": home_win, "draw": draw, "away_win": away_win}
+
+    def _sample_score(self, home_team, away_team, neutral_venue, conf, num_samples, random_state,
+                      max_goals):
+        if random_state is None:
+            random_state = int(datetime.now().timestamp() * 100)
+        probs, home_goals, away_goals = self._grid(home_team, away_team, neutral_venue, conf, max_goals)
+        home_goals = np.array(home_goals.flatten(), DTYPES["goals"])
+        away_goals = np.array(away_goals.flatten(), DTYPES["goals"])
+        sample_idx = map_choice(_prng_key(random_state), np.arange(len(home_goals), dtype="uint32"),
+                                num_samples, probs.reshape((len(home_team), -1)))
+        return {"home_score": home_goals[sample_idx], "away_score": away_goals[sample_idx]}
+
+    def _sample_outcome(self, home_team, away_team, neutral_venue, conf, knockout, num_samples,
+                        random_state, max_goals):
+        if random_state is None:
+            random_state = int(datetime.now().timestamp() * 100)
+        probs = self._outcome(home_team, away_team, neutral_venue, conf, knockout, max_goals)
+        if knockout:
+            probs = np.array([probs["home_win"], probs["away_win"]]).T
+        else:
+            probs = np.array([probs["home_win"], probs["draw"], probs["away_win"]]).T
+        sample_idx = map_choice(_prng_key(random_state), np.arange(probs.shape[1], dtype="uint32"),
+                                num_samples, probs)
+        winner = np.empty((len(home_team), num_samples), dtype=DTYPES["teams"])
+        home_team_rep = home_team.repeat(num_samples).reshape((len(home_team), num_samples))
+        away_team_rep = away_team.repeat(num_samples).reshape((len(home_team), num_samples))
+        winner[sample_idx == 0] = home_team_rep[sample_idx == 0]
+        if knockout:
+            winner[sample_idx == 1] = away_team_rep[sample_idx == 1]
+        else:
+            winner[sample_idx == 2] = away_team_rep[sample_idx == 2]
+            winner[sample_idx == 1] = len(self.teams)  # temporary index for 'Draw'
+        return np.append(self.teams, "Draw")[winner]
+
+    def _n_proba(self, n, team, opponent, conf, home, neutral_venue, max_goals, scored: bool):
+        n = [n] if isinstance(n, (int, np.integer)) else n
+        reps = (max_goals + 1) * len(n)
+        team_rep = np.repeat(team, reps)
+        opponent_rep = np.repeat(opponent, reps)
+        n_rep = np.resize(n, reps)
+        x_rep = np.repeat(np.arange(max_goals + 1), len(n))
+        nv_rep = np.repeat(neutral_venue, reps)
+        mine, theirs = (n_rep, x_rep) if scored else (x_rep, n_rep)
+        if home:
+            c = None if conf is None else (np.repeat(conf[0], reps), np.repeat(conf[1], reps))
+            probs = self._score_proba(team_rep, opponent_rep, mine, theirs, nv_rep, c)
+        else:
+            c = None if conf is None else (np.repeat(conf[1], reps), np.repeat(conf[0], reps))
+            probs = self._score_proba(opponent_rep, team_rep, theirs, mine, nv_rep, c)
+        return probs.reshape(max_goals + 1, len(n)).sum(axis=0)
+
+    def _new_team_draws(self, team_name: str, team_covariates):
+        """Parameters of a new team drawn from the fitted priors
         (bpl/neutral_dixon_coles.py:490-560)."""
         if team_name in self.teams:
             raise ValueError(f"Team {team_name} already known to model.")
@@ -274,96 +366,55 @@ class NeutralDixonColesMatchPredictor:
         self.home_defence = np.concatenate((self.home_defence, home_defence[:, None]), axis=1)
         self.away_defence = np.concatenate((self.away_defence, away_defence[:, None]), axis=1)
 
+    # ---- public API (bpl/neutral_dixon_coles.py:399-902)
+    def _calculate_expected_goals(self, home_team, away_team, neutral_venue) -> Tuple[np.ndarray, np.ndarray]:
+        """Poisson rates of the home and away goals."""
+        return self._rates(*self._parse_fixture_args(home_team, away_team, neutral_venue))
+
+    def predict_score_proba(self, home_team, away_team, home_goals, away_goals, neutral_venue) -> np.ndarray:
+        """Probability of a particular scoreline between two teams (mean over draws)."""
+        h, a, nv = self._parse_fixture_args(home_team, away_team, neutral_venue)
+        return self._score_proba(h, a, home_goals, away_goals, nv)
+
+    def add_new_team(self, team_name: str, team_covariates: Optional[np.ndarray] = None):
+        """Add another team with parameters drawn from the fitted priors."""
+        self._new_team_draws(team_name, team_covariates)
+
     def predict_score_grid_proba(self, home_team, away_team, neutral_venue,
                                  max_goals: Optional[int] = MAX_GOALS) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
         """Scoreline probabilities on the (max_goals+1)^2 grid for every fixture."""
-        home_team, away_team, neutral_venue = self._parse_fixture_args(home_team, away_team, neutral_venue)
-        neutral_venue = np.broadcast_to(neutral_venue, (len(home_team),))
-        n_goals = np.arange(0, max_goals + 1)
-        home_goals, away_goals = np.meshgrid(n_goals, n_goals, indexing="ij")
-        k = (max_goals + 1) ** 2
-        probs = self.predict_score_proba(
-            np.repeat(home_team, k), np.repeat(away_team, k),
-            np.tile(home_goals.reshape(k), len(home_team)),
-            np.tile(away_goals.reshape(k), len(home_team)), np.repeat(neutral_venue, k),
-        ).reshape(len(home_team), max_goals + 1, max_goals + 1)
-        return probs, home_goals, away_goals
+        h, a, nv = self._parse_fixture_args(home_team, away_team, neutral_venue)
+        return self._grid(h, a, nv, None, max_goals)
 
     def predict_outcome_proba(self, home_team, away_team, neutral_venue, knockout: bool = False,
                               max_goals: Optional[int] = MAX_GOALS) -> Dict[str, np.ndarray]:
         """Home win, away win and draw probabilities; `knockout` renormalises over the wins."""
-        home_team, away_team, neutral_venue = self._parse_fixture_args(home_team, away_team, neutral_venue)
-        probs, home_goals, away_goals = self.predict_score_grid_proba(
-            home_team, away_team, neutral_venue, max_goals=max_goals)
-        home_win = probs[:, home_goals > away_goals].sum(axis=-1)
-        draw = probs[:, home_goals == away_goals].sum(axis=-1)
-        away_win = probs[:, home_goals < away_goals].sum(axis=-1)
-        if knockout:
-            norm = home_win + away_win
-            return {"home_win": home_win / norm, "away_win": away_win / norm}
-        return {"home_win": home_win, "draw": draw, "away_win": away_win}
+        h, a, nv = self._parse_fixture_args(home_team, away_team, neutral_venue)
+        return self._outcome(h, a, nv, None, knockout, max_goals)
 
     def sample_score(self, home_team, away_team, neutral_venue, num_samples: int = 1,
                      random_state: int = None, max_goals: Optional[int] = MAX_GOALS) -> Dict[str, np.ndarray]:
         """Sample scorelines between two teams."""
-        home_team, away_team, neutral_venue = self._parse_fixture_args(home_team, away_team, neutral_venue)
-        if random_state is None:
-            random_state = int(datetime.now().timestamp() * 100)
-        probs, home_goals, away_goals = self.predict_score_grid_proba(
-            home_team, away_team, neutral_venue, max_goals=max_goals)
-        home_goals = np.array(home_goals.flatten(), DTYPES["goals"])
-        away_goals = np.array(away_goals.flatten(), DTYPES["goals"])
-        sample_idx = map_choice(_prng_key(random_state), np.arange(len(home_goals), dtype="uint32"),
-                                num_samples, probs.reshape((len(home_team), -1)))
-        return {"home_score": home_goals[sample_idx], "away_score": away_goals[sample_idx]}
+        h, a, nv = self._parse_fixture_args(home_team, away_team, neutral_venue)
+        return self._sample_score(h, a, nv, None, num_samples, random_state, max_goals)
 
     def sample_outcome(self, home_team, away_team, neutral_venue, knockout: bool = False,
                        num_samples: int = 1, random_state: int = None,
                        max_goals: Optional[int] = MAX_GOALS) -> np.ndarray:
         """Sample the winner ('Draw' unless `knockout`) of matches between two teams."""
-        home_team, away_team, neutral_venue = self._parse_fixture_args(home_team, away_team, neutral_venue)
-        if random_state is None:
-            random_state = int(datetime.now().timestamp() * 100)
-        probs = self.predict_outcome_proba(home_team, away_team, neutral_venue, knockout, max_goals=max_goals)
-        if knockout:
-            probs = np.array([probs["home_win"], probs["away_win"]]).T
-        else:
-            probs = np.array([probs["home_win"], probs["draw"], probs["away_win"]]).T
-        sample_idx = map_choice(_prng_key(random_state), np.arange(probs.shape[1], dtype="uint32"),
-                                num_samples, probs)
-        winner = np.empty((len(home_team), num_samples), dtype=DTYPES["teams"])
-        home_team_rep = home_team.repeat(num_samples).reshape((len(home_team), num_samples))
-        away_team_rep = away_team.repeat(num_samples).reshape((len(home_team), num_samples))
-        winner[sample_idx == 0] = home_team_rep[sample_idx == 0]
-        if knockout:
-            winner[sample_idx == 1] = away_team_rep[sample_idx == 1]
-        else:
-            winner[sample_idx == 2] = away_team_rep[sample_idx == 2]
-            winner[sample_idx == 1] = len(self.teams)  # temporary index for 'Draw'
-        return np.append(self.teams, "Draw")[winner]
-
-    def _n_proba(self, n, team, opponent, home, neutral_venue, max_goals, scored: bool):
-        n = [n] if isinstance(n, (int, np.integer)) else n
-        team, opponent, _ = self._parse_fixture_args(team, opponent, neutral_venue)
-        reps = (max_goals + 1) * len(n)
-        team_rep = np.repeat(team, reps)
-        opponent_rep = np.repeat(opponent, reps)
-        n_rep = np.resize(n, reps)
-        x_rep = np.repeat(np.arange(max_goals + 1), len(n))
-        nv_rep = np.repeat(neutral_venue, reps)
-        mine, theirs = (n_rep, x_rep) if scored else (x_rep, n_rep)
-        probs = (self.predict_score_proba(team_rep, opponent_rep, mine, theirs, nv_rep) if home
-                 else self.predict_score_proba(opponent_rep, team_rep, theirs, mine, nv_rep))
-        return probs.reshape(max_goals + 1, len(n)).sum(axis=0)
+        h, a, nv = self._parse_fixture_args(home_team, away_team, neutral_venue)
+        return self._sample_outcome(h, a, nv, None, knockout, num_samples, random_state, max_goals)
 
     def predict_score_n_proba(self, n, team, opponent, home: Optional[bool] = True,
                               neutral_venue: Optional[int] = 0,
                               max_goals: Optional[int] = MAX_GOALS) -> np.ndarray:
         """Probability that `team` scores n goals against `opponent`."""
-        return self._n_proba(n, team, opponent, home, neutral_venue, max_goals, scored=True)
+        t, o, _ = self._parse_fixture_args(team, opponent, neutral_venue)
+        return self._n_proba(n, t, o, None, home, neutral_venue, max_goals, scored=True)
 
     def predict_concede_n_proba(self, n, team, opponent, home: Optional[bool] = True,
                                 neutral_venue: Optional[int] = 0,
                                 max_goals: Optional[int] = MAX_GOALS) -> np.ndarray:
         """Probability that `team` concedes n goals against `opponent`."""
-        return self._n_proba(n, team, opponent, home, neutral_venue, max_goals, scored=False)
+        t, o, _ = self._parse_fixture_args(team, opponent, neutral_venue)
+        return self._n_proba(n, t, o, None, home, neutral_venue, max_goals, scored=False)

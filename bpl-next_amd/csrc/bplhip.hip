@@ -109,7 +109,7 @@ struct bplhip_ctx {
     // neutral-venue model (dc_neutral.hip.h): the dynamic model's fixture passes + own z side
     bool neutral = false;
     dcn::NeuLayout NL{};
-    DevBuf dd_gw, dd_nv, dd_cells, dd_acc, dd_hyp;
+    DevBuf dd_gw, dd_nv, dd_cells, dd_acc, dd_hyp, dd_hc, dd_ac;
     std::map<GraphKey, hipGraphExec_t> graphs;
     hipStream_t cap_stream = nullptr;
 
@@ -259,6 +259,11 @@ int launch_eval_neutral(bplhip_ctx* c, int chains, const double* z, double* pot,
         F.cells = c->dd_cells.as<double>();
         F.acc = c->dd_acc.as<double>();
         F.sc = F.acc + (size_t)L.T * dcd::A_N;
+        F.cacc = F.sc + dcd::SC_N;
+        F.n_conf = L.C;
+        F.hc = L.C ? c->dd_hc.as<const uint8_t>() : nullptr;
+        F.ac = L.C ? c->dd_ac.as<const uint8_t>() : nullptr;
+        F.cs = z + (size_t)ch * L.D + L.o_conf;
         F.z = z + (size_t)ch * L.D;
         F.potential = pot + ch;
         F.grad = grad + (size_t)ch * L.D;
@@ -272,7 +277,7 @@ int launch_eval_neutral(bplhip_ctx* c, int chains, const double* z, double* pot,
         const int nb = (int)std::min<long long>(nb_all, 1024);
         F.chunk = ((c->n + nb - 1) / nb + dcd::FIX_BLOCK - 1) / dcd::FIX_BLOCK * dcd::FIX_BLOCK;
         const int nb2 = (int)((c->n + F.chunk - 1) / F.chunk);
-        HIP_TRY(c, hipMemsetAsync(F.acc, 0, ((size_t)L.T * dcd::A_N + dcd::SC_N) * 8, s));
+        HIP_TRY(c, hipMemsetAsync(F.acc, 0, ((size_t)L.T * dcd::A_N + dcd::SC_N + L.C) * 8, s));
         hipLaunchKernelGGL(dcn::neu_cells, dim3((L.T + 255) / 256), dim3(256), 0, s, A);
         if (!c->lds_attr_set) {
             HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(dcd::dyn_pass2),
@@ -717,12 +722,16 @@ int bplhip_latent_dim(const bplhip_ctx* c) {
 int bplhip_set_fixtures_neutral(bplhip_ctx* c, int64_t n, int32_t n_teams, const uint16_t* home_idx,
                                 const uint16_t* away_idx, const uint8_t* home_goals,
                                 const uint8_t* away_goals, const uint8_t* neutral_venue,
+                                const uint8_t* home_conf, const uint8_t* away_conf, int32_t n_conf,
                                 const float* weights, const double* covariates, int32_t k,
                                 void* stream) {
     if (!c) return BPLHIP_EINVAL;
     c->bound = false;
     if (n < 1 || n > (int64_t)0xFFFFFFFF || n_teams < 1 || n_teams > 65534)
         return fail(c, BPLHIP_EINVAL, "set_fixtures_neutral: bad sizes");
+    if (n_conf < 0 || n_conf > 255 || (n_conf > 0 && (!home_conf || !away_conf)) ||
+        (n_conf == 0 && (home_conf || away_conf)))
+        return fail(c, BPLHIP_EINVAL, "set_fixtures_neutral: confederation arrays / n_conf mismatch");
     if (!home_idx || !away_idx || !home_goals || !away_goals || !neutral_venue)
         return fail(c, BPLHIP_EINVAL, "set_fixtures_neutral: null fixture array");
     if (k < 0 || (k > 0 && !covariates) || (k == 0 && covariates))
@@ -764,8 +773,21 @@ int bplhip_set_fixtures_neutral(bplhip_ctx* c, int64_t n, int32_t n_teams, const
         HIP_TRY(c, c->d_w.ensure(n * 4));
         HIP_TRY(c, hipMemcpyAsync(c->d_w.p, w.data(), n * 4, hipMemcpyHostToDevice, s));
     }
+    if (n_conf > 0) {  // (device -> device: the library keeps its own copy)
+        std::vector<uint8_t> hcv(n), acv(n);
+        HIP_TRY(c, hipMemcpy(hcv.data(), home_conf, n, hipMemcpyDeviceToHost));
+        HIP_TRY(c, hipMemcpy(acv.data(), away_conf, n, hipMemcpyDeviceToHost));
+        for (int64_t i = 0; i < n; ++i)
+            if (hcv[i] >= n_conf || acv[i] >= n_conf)
+                return fail(c, BPLHIP_EINVAL, "set_fixtures_neutral: confederation out of range at fixture %lld",
+                            (long long)i);
+        HIP_TRY(c, c->dd_hc.ensure(n));
+        HIP_TRY(c, c->dd_ac.ensure(n));
+        HIP_TRY(c, hipMemcpy(c->dd_hc.p, hcv.data(), n, hipMemcpyHostToDevice));
+        HIP_TRY(c, hipMemcpy(c->dd_ac.p, acv.data(), n, hipMemcpyHostToDevice));
+    }
     HIP_TRY(c, c->dd_cells.ensure((size_t)n_teams * dcd::P_N * 8));
-    HIP_TRY(c, c->dd_acc.ensure(((size_t)n_teams * dcd::A_N + dcd::SC_N) * 8));
+    HIP_TRY(c, c->dd_acc.ensure(((size_t)n_teams * dcd::A_N + dcd::SC_N + n_conf) * 8));
     c->h_xs.clear();
     if (k > 0) {
         c->h_xs.assign(covariates, covariates + (size_t)n_teams * k);
@@ -775,7 +797,7 @@ int bplhip_set_fixtures_neutral(bplhip_ctx* c, int64_t n, int32_t n_teams, const
     }
     HIP_TRY(c, hipStreamSynchronize(s));
     drop_graphs(c);
-    c->NL = dcn::make_neu_layout(n_teams, k);
+    c->NL = dcn::make_neu_layout(n_teams, k, n_conf);
     c->n = n;
     c->lgsum = lgsum;
     c->weighted = weights != nullptr;
@@ -1275,12 +1297,14 @@ nuts::Config make_nuts_config(const bplhip_ctx* c, const bplhip_nuts_cfg* cfg) {
         nc.sites = {{L.o_md, 1}, {L.o_s_att, 1}, {L.o_s_def, 1}, {L.o_mha, 1}, {L.o_maa, 1},
                     {L.o_mhd, 1}, {L.o_mad, 1}, {L.o_s_ha, 1}, {L.o_s_aa, 1}, {L.o_s_hd, 1},
                     {L.o_s_ad, 1}};
+        if (L.C) nc.sites.push_back({L.o_u, 1});  // bpl/neutral_dixon_coles_WC.py:116 (u first)
         if (L.K) {
             nc.sites.push_back({L.o_bA, L.K});
             nc.sites.push_back({L.o_bD, L.K});
         }
-        nc.sites.push_back({L.o_u, 1});
+        if (!L.C) nc.sites.push_back({L.o_u, 1});
         for (int o : {L.o_sat, L.o_sdt, L.o_hat, L.o_aat, L.o_hdf, L.o_adf}) nc.sites.push_back({o, T});
+        if (L.C) nc.sites.push_back({L.o_conf, L.C});
         nc.sites.push_back({L.o_corr, 1});
     } else if (c->dynamic) {  // bpl/dynamic_dixon_coles.py:74-241, model execution order
         const dcd::DynLayout& L = c->DL;

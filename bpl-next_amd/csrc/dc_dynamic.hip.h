@@ -90,6 +90,12 @@ struct DynArgs {
     const uint16_t* gw;  // nullptr: one gameweek (the neutral-venue model, dc_neutral.hip.h)
     const uint8_t* nv;
     const float* w;      // per-fixture weights or nullptr
+    // World-Cup variant of the neutral model: confederation of each side, strengths, adjoint
+    const uint8_t* hc;   // nullptr: no confederation term
+    const uint8_t* ac;
+    const double* cs;    // [n_conf] strengths (latent values)
+    double* cacc;        // [n_conf] accumulators (scratch, zeroed per evaluation)
+    int n_conf;
     long long n;
     long long chunk;     // fixtures per workgroup of dyn_pass2
     const double* xs;    // [T,K] standardised covariates or nullptr
@@ -225,6 +231,11 @@ __device__ __forceinline__ void fixture_etas(const DynArgs& A, long long i, int*
         *eh = Ph[P_AH] - Pa[P_BA];
         *ea = Pa[P_AA] - Ph[P_BH];
     }
+    if (A.hc) {  // bpl/neutral_dixon_coles_WC.py:188-203
+        const double d = A.cs[A.hc[i]] - A.cs[A.ac[i]];
+        *eh += d;
+        *ea -= d;
+    }
 }
 
 // ---- pass 1: maxima of the rates (positive doubles order like their bit patterns)
@@ -281,10 +292,11 @@ __global__ __launch_bounds__(FIX_BLOCK) void dyn_pass2(DynArgs A) {
     const double rho = LB + q * (UB - LB);
     const int g_lo = A.gw ? A.gw[i0] : 0, g_hi = A.gw ? A.gw[i1 - 1] : 0;
     const int ncell = (g_hi - g_lo + 1) * T;
-    const bool priv = ncell <= PASS2_LDS_CELLS;
+    const bool priv = ncell + (A.n_conf + A_N - 1) / A_N <= PASS2_LDS_CELLS;
     const int cell0 = g_lo * T;
+    double* lconf = lacc + (size_t)ncell * A_N;  // [n_conf] (private path)
     if (priv) {
-        for (int k = threadIdx.x; k < ncell * A_N; k += FIX_BLOCK) lacc[k] = 0.0;
+        for (int k = threadIdx.x; k < ncell * A_N + A.n_conf; k += FIX_BLOCK) lacc[k] = 0.0;
         __syncthreads();
     }
     double Ui = 0.0, ui = 0.0;
@@ -325,6 +337,11 @@ __global__ __launch_bounds__(FIX_BLOCK) void dyn_pass2(DynArgs A) {
             atomicAdd(&Aa[A_AATT], ga);
             atomicAdd(&Ah[A_HDEF], -ga);
         }
+        if (A.hc) {
+            double* cacc = priv ? lconf : A.cacc;
+            atomicAdd(&cacc[A.hc[i]], gh - ga);
+            atomicAdd(&cacc[A.ac[i]], ga - gh);
+        }
         unsigned long long* sc = reinterpret_cast<unsigned long long*>(A.sc);
         // arg-extremal fixtures: smallest index among those attaining the maximum
         // (stored as ~0 - i under atomicMax, so the zeroed word means "none")
@@ -350,14 +367,18 @@ __global__ __launch_bounds__(FIX_BLOCK) void dyn_pass2(DynArgs A) {
             const double v = lacc[k];
             if (v != 0.0) atomicAdd(&A.acc[(size_t)cell0 * A_N + k], v);
         }
+        for (int k = threadIdx.x; k < A.n_conf; k += FIX_BLOCK) {
+            const double v = lconf[k];
+            if (v != 0.0) atomicAdd(&A.cacc[k], v);
+        }
     }
 }
 
 // ---- adjoint of the rho bounds: up to three fixtures get an extra d/d eta
-struct Coupling {
-    int n;
-    int cell[12], which[12];
-    double val[12];
+struct Coupling {  // entries {cell, accumulator, value}; accumulator A_N = confederation `cell`
+    int n;                      // <= 3 rates x (2 + 2 + 2) entries
+    int cell[18], which[18];
+    double val[18];
 };
 __device__ inline void coupling_add(const DynArgs& A, Coupling& C, long long idx1, bool home_rate,
                                     double v) {
@@ -373,9 +394,11 @@ __device__ inline void coupling_add(const DynArgs& A, Coupling& C, long long idx
     if (home_rate) {  // d/d eta_h
         put(ch, A_ATT, v); put(ca, A_DEF, -v);
         if (!nv) { put(ch, A_HATT, v); put(ca, A_ADEF, -v); }
+        if (A.hc) { put(A.hc[i], A_N, v); put(A.ac[i], A_N, -v); }
     } else {
         put(ca, A_ATT, v); put(ch, A_DEF, -v);
         if (!nv) { put(ca, A_AATT, v); put(ch, A_HDEF, -v); }
+        if (A.hc) { put(A.ac[i], A_N, v); put(A.hc[i], A_N, -v); }
     }
 }
 struct Bounds {

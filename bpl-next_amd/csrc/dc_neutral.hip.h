@@ -23,19 +23,22 @@ namespace dcn {
 using dc::HALF_LOG_2PI;
 using dc::LN2;
 
-// flat latent layout: sorted site names (numpyro), D = 6T + 2K + 13
+// flat latent layout: sorted site names (numpyro), D = 6T + 2K + C + 13 (C confederations,
+// World-Cup variant bpl/neutral_dixon_coles_WC.py; C = 0 for the plain neutral model)
 struct NeuLayout {
-    int T, K, D;
+    int T, K, C, D;
+    int o_conf;
     int o_bA, o_aat, o_adf, o_corr, o_bD, o_hat, o_hdf, o_maa, o_mad, o_md, o_mha, o_mhd, o_sat,
         o_sdt, o_s_att, o_s_aa, o_s_ad, o_s_def, o_s_ha, o_s_hd, o_u;
 };
-inline NeuLayout make_neu_layout(int T, int K) {
+inline NeuLayout make_neu_layout(int T, int K, int C = 0) {
     NeuLayout L{};
-    L.T = T; L.K = K;
+    L.T = T; L.K = K; L.C = C;
     int o = 0;
     L.o_bA = o; o += K;        // attack_coefficients
     L.o_aat = o; o += T;       // away_attack_decentered
     L.o_adf = o; o += T;       // away_defence_decentered
+    L.o_conf = o; o += C;      // confederation_strength_decentered
     L.o_corr = o; o += 1;      // corr_coef_raw
     L.o_bD = o; o += K;        // defence_coefficients
     L.o_hat = o; o += T;       // home_attack_decentered
@@ -181,11 +184,19 @@ __global__ __launch_bounds__(NEU_EPI) void neu_epilogue(NeuArgs A) {
         const int o = k < K ? L.o_bA + k : L.o_bD + k - K;
         grad[o] = -(sums[NEU_SUMS + k] - z[o]);
     }
+    for (int cf = tid; cf < L.C; cf += NEU_EPI) {  // confederation strengths ~ N(0,1) (loc 0, scale 1)
+        const double G = coupled(cf, dcd::A_N, A.F.cacc[cf]);
+        grad[L.o_conf + cf] = -(G - z[L.o_conf + cf]);
+    }
     if (tid == 0) {
         double Ltot = sums[12] + A.F.sc[dcd::SC_U] - A.F.lgsum;
         for (int k = 0; k < 2 * K; ++k) {
             const int o = k < K ? L.o_bA + k : L.o_bD + k - K;
             Ltot += -0.5 * z[o] * z[o] - HALF_LOG_2PI;
+        }
+        for (int cf = 0; cf < L.C; ++cf) {
+            const double v = z[L.o_conf + cf];
+            Ltot += -0.5 * v * v - HALF_LOG_2PI;
         }
         const double m = z[L.o_md];
         Ltot += -0.5 * m * m - HALF_LOG_2PI;

@@ -135,11 +135,16 @@ int bplhip_constrain_dynamic(bplhip_ctx* ctx, const double* z_draws, int64_t s,
  * home_defence_decentered[T], mean_away_attack, mean_away_defence, mean_defence,
  * mean_home_attack, mean_home_defence, standardised_attack[T], standardised_defence[T],
  * std_attack, std_away_attack, std_away_defence, std_defence, std_home_attack,
- * std_home_defence, u.  After this call logp_grad / nuts_run work on the neutral model. */
+ * std_home_defence, u.  World-Cup variant (bpl/neutral_dixon_coles_WC.py:83-232): `home_conf`,
+ * `away_conf` device u8[n] confederation indices and n_conf > 0 add the site
+ * confederation_strength_decentered[n_conf] (after away_defence_decentered, D += n_conf);
+ * NULL, NULL, 0 for the plain neutral model.  After this call logp_grad / nuts_run work on
+ * the neutral model. */
 int bplhip_set_fixtures_neutral(bplhip_ctx* ctx, int64_t n, int32_t n_teams,
                                 const uint16_t* home_idx, const uint16_t* away_idx,
                                 const uint8_t* home_goals, const uint8_t* away_goals,
-                                const uint8_t* neutral_venue, const float* weights,
+                                const uint8_t* neutral_venue, const uint8_t* home_conf,
+                                const uint8_t* away_conf, int32_t n_conf, const float* weights,
                                 const double* covariates, int32_t k, void* stream);
 
 /* Tuning knobs (no reference counterpart; defaults are the measured best):

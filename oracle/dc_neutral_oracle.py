@@ -19,9 +19,14 @@ attack/defence, optional covariates) with
   * HalfNormal(0.5) on std_attack / std_defence (:140-141), no rate clip,
   * an always-weighted likelihood: w = [exp(-eps*dt) (rescaled)] * game_weights (:251-257).
 
-Latent layout (flat, sorted site names), T teams, K covariates; D = 6T + 2K + 13:
+The World-Cup variant (bpl/neutral_dixon_coles_WC.py:83-232) adds a per-confederation
+strength ~ N(0,1): eta_h += cs[home_conf] - cs[away_conf], eta_a += cs[away_conf] - cs[home_conf]
+(:188-203), and always time-weights (:206-208).
+
+Latent layout (flat, sorted site names), T teams, K covariates, C confederations (0 for the
+plain neutral model); D = 6T + 2K + C + 13:
   attack_coefficients[K], away_attack_decentered[T], away_defence_decentered[T],
-  corr_coef_raw, defence_coefficients[K], home_attack_decentered[T],
+  confederation_strength_decentered[C], corr_coef_raw, defence_coefficients[K], home_attack_decentered[T],
   home_defence_decentered[T], mean_away_attack, mean_away_defence, mean_defence,
   mean_home_attack, mean_home_defence, standardised_attack[T], standardised_defence[T],
   std_attack, std_away_attack, std_away_defence, std_defence, std_home_attack,
@@ -53,6 +58,10 @@ class NeutralFixtures:
     weights: np.ndarray  # final per-fixture weights (time decay x game weights)
     n_teams: int
     covariates: Optional[np.ndarray] = None  # RAW [T,K]
+    # World-Cup variant (bpl/neutral_dixon_coles_WC.py): confederation of each side
+    home_conf: Optional[np.ndarray] = None
+    away_conf: Optional[np.ndarray] = None
+    n_conf: int = 0
 
     def __post_init__(self):
         for f in ("home_idx", "away_idx", "home_goals", "away_goals", "neutral"):
@@ -60,6 +69,9 @@ class NeutralFixtures:
         self.weights = np.asarray(self.weights, dtype=np.float64)
         if self.covariates is not None:
             self.covariates = np.asarray(self.covariates, dtype=np.float64)
+        if self.n_conf:
+            self.home_conf = np.asarray(self.home_conf).astype(np.int64)
+            self.away_conf = np.asarray(self.away_conf).astype(np.int64)
 
     @property
     def n(self):
@@ -80,11 +92,14 @@ def make_weights(n, time_diff=None, epsilon=None, game_weights=None, rescale_wei
     return w * np.asarray(game_weights, dtype=np.float64)
 
 
-def site_list(T: int, K: int = 0):
+def site_list(T: int, K: int = 0, C: int = 0):
     s = []
     if K:
         s.append(("attack_coefficients", K))
-    s += [("away_attack_decentered", T), ("away_defence_decentered", T), ("corr_coef_raw", 1)]
+    s += [("away_attack_decentered", T), ("away_defence_decentered", T)]
+    if C:
+        s.append(("confederation_strength_decentered", C))
+    s.append(("corr_coef_raw", 1))
     if K:
         s.append(("defence_coefficients", K))
     s += [("home_attack_decentered", T), ("home_defence_decentered", T),
@@ -96,13 +111,13 @@ def site_list(T: int, K: int = 0):
     return s
 
 
-def latent_dim(T, K=0):
-    return sum(n for _, n in site_list(T, K))
+def latent_dim(T, K=0, C=0):
+    return sum(n for _, n in site_list(T, K, C))
 
 
-def site_slices(T, K=0) -> Dict[str, slice]:
+def site_slices(T, K=0, C=0) -> Dict[str, slice]:
     out, o = {}, 0
-    for name, n in site_list(T, K):
+    for name, n in site_list(T, K, C):
         out[name] = slice(o, o + n)
         o += n
     return out
@@ -127,8 +142,8 @@ def _clip_sig(zr):
 
 def potential_and_grad(fx: NeutralFixtures, z: np.ndarray):
     """U(z) = -log p(z, data) and its gradient; aux: rho (corr_coef), LB, UB and sites."""
-    T, K, N = fx.n_teams, fx.k, fx.n
-    sl = site_slices(T, K)
+    T, K, N, C = fx.n_teams, fx.k, fx.n, fx.n_conf
+    sl = site_slices(T, K, C)
     z = np.asarray(z, dtype=np.float64)
     g = np.zeros_like(z)
     L = 0.0
@@ -204,6 +219,12 @@ def potential_and_grad(fx: NeutralFixtures, z: np.ndarray):
     # ---- likelihood
     eh = attack[h] - defence[a] + on * (hat[h] - adf[a])
     ea = attack[a] - defence[h] + on * (aat[a] - hdf[h])
+    if C:  # confederation_strength ~ N(0,1), non-centred with loc 0 / scale 1 (WC :178-203)
+        cs = z[sl["confederation_strength_decentered"]]
+        L += (-0.5 * cs ** 2 - HALF_LOG_2PI).sum()
+        g[sl["confederation_strength_decentered"]] += -cs
+        eh = eh + cs[fx.home_conf] - cs[fx.away_conf]
+        ea = ea + cs[fx.away_conf] - cs[fx.home_conf]
     lh, la = np.exp(eh), np.exp(ea)
     L += (w * (x * eh - lh - gammaln(x + 1.0))).sum() + (w * (y * ea - la - gammaln(y + 1.0))).sum()
     gh = w * (x - lh)  # dL/d eta_h
@@ -263,6 +284,9 @@ def potential_and_grad(fx: NeutralFixtures, z: np.ndarray):
         g[sl[nm + "_decentered"]] += s * Gt
         g[sl["mean_" + nm]] += Gt.sum()
         g[sl["std_" + nm]] += s * (dec[nm] * Gt).sum()
+    if C:
+        g[sl["confederation_strength_decentered"]] += (
+            np.bincount(fx.home_conf, gh - ga, C) + np.bincount(fx.away_conf, ga - gh, C))
     g[sl["u"]] += g_u
     g[sl["corr_coef_raw"]] += g_c
     aux = {"rho": rho, "LB": LB, "UB": UB, "q": q, "attack": attack, "defence": defence,
@@ -276,8 +300,8 @@ def torch_potential_and_grad(fx: NeutralFixtures, z: np.ndarray):
     differentiated by autograd (float64)."""
     import torch
 
-    T, K = fx.n_teams, fx.k
-    sl = site_slices(T, K)
+    T, K, C = fx.n_teams, fx.k, fx.n_conf
+    sl = site_slices(T, K, C)
     zt = torch.tensor(np.asarray(z, dtype=np.float64), requires_grad=True)
     N01 = lambda v, loc=0.0, sc=1.0: -0.5 * ((v - loc) / sc) ** 2 - math.log(sc) - HALF_LOG_2PI
     logp = torch.zeros((), dtype=torch.float64)
@@ -353,8 +377,15 @@ def torch_potential_and_grad(fx: NeutralFixtures, z: np.ndarray):
     x = torch.tensor(fx.home_goals, dtype=torch.float64)
     y = torch.tensor(fx.away_goals, dtype=torch.float64)
     w = torch.tensor(fx.weights)
-    lam_h = torch.exp(attack[h] - defence[a] + (1 - nv) * home_attack[h] - (1 - nv) * away_defence[a])
-    lam_a = torch.exp(attack[a] - defence[h] + (1 - nv) * away_attack[a] - (1 - nv) * home_defence[h])
+    conf_h = conf_a = 0.0
+    if C:
+        confederation_strength = noncentred("confederation_strength", 0.0, 1.0)
+        conf_h = confederation_strength[torch.tensor(fx.home_conf)]
+        conf_a = confederation_strength[torch.tensor(fx.away_conf)]
+    lam_h = torch.exp(attack[h] - defence[a] + conf_h - conf_a
+                      + (1 - nv) * home_attack[h] - (1 - nv) * away_defence[a])
+    lam_a = torch.exp(attack[a] - defence[h] + conf_a - conf_h
+                      + (1 - nv) * away_attack[a] - (1 - nv) * home_defence[h])
     pois = lambda k, lam: k * torch.log(lam) - torch.lgamma(k + 1.0) - lam
     logp = logp + (w * pois(x, lam_h)).sum() + (w * pois(y, lam_a)).sum()
 
@@ -397,9 +428,12 @@ def neutral_dummy_recipe(epsilon=None, rescale_weights=False):
     for p, q in itertools.combinations(teams, 2):
         home_team.append(p)
         away_team.append(q)
+    # deterministic assignment of teams to conferences (tests/conftest.py:103-105)
     return {"home_team": home_team, "away_team": away_team, "home_goals": home_goals,
             "away_goals": away_goals, "neutral_venue": neutral_venue, "time_diff": time_diff,
-            "game_weights": game_weights}
+            "game_weights": game_weights,
+            "home_conf": [str(int(t) // 4) for t in home_team],
+            "away_conf": [str(int(t) // 4) for t in away_team]}
 
 
 def fixtures_from_data(dd, epsilon=None, rescale_weights=False, covariates=None):
@@ -412,11 +446,35 @@ def fixtures_from_data(dd, epsilon=None, rescale_weights=False, covariates=None)
                            len(teams), covariates=covariates)
 
 
-def synthetic_neutral(n, n_teams=20, seed=11, k=0):
+def make_weights_wc(n, time_diff, epsilon, game_weights, rescale_weights=False):
+    """bpl/neutral_dixon_coles_WC.py:206-208 (always time-weighted; rescaled AFTER the game weights)."""
+    w = np.exp(-epsilon * np.asarray(time_diff, dtype=np.float64)) * np.asarray(game_weights, np.float64)
+    if rescale_weights:
+        w = n * w / w.sum()
+    return w
+
+
+def fixtures_from_data_wc(dd, epsilon=0.0, rescale_weights=False, covariates=None):
+    """World-Cup variant: confederations from dd['home_conf'] / dd['away_conf'] (string sorted)."""
+    fx = fixtures_from_data(dd, covariates=covariates)
+    confs = sorted(set(dd["home_conf"]) | set(dd["away_conf"]))
+    cidx = {c: i for i, c in enumerate(confs)}
+    fx.home_conf = np.array([cidx[c] for c in dd["home_conf"]])
+    fx.away_conf = np.array([cidx[c] for c in dd["away_conf"]])
+    fx.n_conf = len(confs)
+    fx.weights = make_weights_wc(fx.n, dd["time_diff"], epsilon, dd["game_weights"], rescale_weights)
+    return fx
+
+
+def synthetic_neutral(n, n_teams=20, seed=11, k=0, n_conf=0):
     rs = np.random.RandomState(seed)
     h = rs.randint(0, n_teams, n)
     a = (h + 1 + rs.randint(0, n_teams - 1, n)) % n_teams
     nv = rs.randint(0, 2, n)
     w = rs.uniform(0.2, 3.0, n)
     cov = rs.normal(size=(n_teams, k)) if k else None
-    return NeutralFixtures(h, a, rs.poisson(1.4, n), rs.poisson(1.1, n), nv, w, n_teams, covariates=cov)
+    x, y = rs.poisson(1.4, n), rs.poisson(1.1, n)
+    conf_of = rs.randint(0, max(n_conf, 1), n_teams)
+    return NeutralFixtures(h, a, x, y, nv, w, n_teams, covariates=cov,
+                           home_conf=conf_of[h] if n_conf else None,
+                           away_conf=conf_of[a] if n_conf else None, n_conf=n_conf)

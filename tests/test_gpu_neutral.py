@@ -17,8 +17,9 @@ MAX_GOALS = 15
 def _bind(ctx, fx):
     cov = None if fx.covariates is None else NO.standardise_covariates(fx.covariates)
     ctx.set_fixtures_neutral(fx.home_idx, fx.away_idx, fx.home_goals, fx.away_goals, fx.neutral,
-                             fx.n_teams, weights=fx.weights.astype(np.float32), covariates_std=cov)
-    assert ctx.dim == NO.latent_dim(fx.n_teams, fx.k)
+                             fx.n_teams, weights=fx.weights.astype(np.float32), covariates_std=cov,
+                             home_conf=fx.home_conf, away_conf=fx.away_conf, n_conf=fx.n_conf)
+    assert ctx.dim == NO.latent_dim(fx.n_teams, fx.k, fx.n_conf)
 
 
 def _cases():
@@ -29,6 +30,10 @@ def _cases():
                                              covariates=np.random.RandomState(0).normal(size=(20, 3)))
     yield "synthetic_3e4", NO.synthetic_neutral(30_000, 30, k=2)
     yield "synthetic_1e6", NO.synthetic_neutral(1_000_000, 20)
+    # World-Cup variant: confederation strengths
+    yield "wc_dummy", NO.fixtures_from_data_wc(dd, epsilon=0.2, rescale_weights=True)
+    yield "wc_synthetic_3e4", NO.synthetic_neutral(30_000, 30, k=2, n_conf=5)
+    yield "wc_synthetic_1e6", NO.synthetic_neutral(1_000_000, 40, n_conf=6)
 
 
 @pytest.mark.parametrize("name,fx", list(_cases()))
@@ -138,3 +143,36 @@ def test_errors():
     bad = {k: v for k, v in dd.items() if k != "game_weights"}
     with pytest.raises(TypeError):
         NeutralDixonColesMatchPredictor().fit(bad, num_warmup=5, num_samples=5)
+
+
+# ---- World-Cup variant: the reference's tests/test_neutral_dixon_coles_WC.py on a fitted model
+@pytest.fixture(scope="module")
+def model_wc():
+    from bpl import NeutralDixonColesMatchPredictorWC
+
+    dd = NO.neutral_dummy_recipe()
+    return NeutralDixonColesMatchPredictorWC().fit(dd, num_warmup=300, num_samples=300), dd
+
+
+def test_wc_fit_and_predict(model_wc):
+    m, dd = model_wc
+    for nm in ("confederation_strength", "attack", "defence", "home_attack", "home_defence",
+               "away_attack", "away_defence", "teams", "conferences", "corr_coef"):
+        assert getattr(m, nm) is not None
+    assert m.confederation_strength.shape == (300, 5) and list(m.conferences) == ["0", "1", "2", "3", "4"]
+    probs = m.predict_score_proba(dd["home_team"], dd["away_team"], dd["home_conf"], dd["away_conf"],
+                                  dd["home_goals"], dd["away_goals"], dd["neutral_venue"])
+    assert np.all((probs >= 0) & (probs <= 1))
+    assert 0 <= m.predict_score_proba("0", "1", "0", "1", 1, 0, 0)[0] <= 1
+    out = m.predict_outcome_proba(dd["home_team"], dd["away_team"], dd["home_conf"], dd["away_conf"],
+                                  dd["neutral_venue"])
+    assert np.allclose(out["home_win"] + out["away_win"] + out["draw"], 1.0, atol=5e-2)
+    n = np.arange(MAX_GOALS + 1)
+    ph = m.predict_score_n_proba(n, "0", "1", "0", "0")
+    pa = m.predict_score_n_proba(n, "0", "1", "0", "0", home=False)
+    assert sum(ph) == pytest.approx(1.0, abs=5e-2) and sum(ph * n) > sum(pa * n)
+    assert np.allclose(ph, m.predict_concede_n_proba(n, "1", "0", "0", "0", home=False), atol=1e-12)
+    s = m.sample_score(["0"], ["5"], ["0"], ["1"], [1], num_samples=20, random_state=3)
+    assert s["home_score"].shape == (1, 20)
+    w = m.sample_outcome(["0"], ["5"], ["0"], ["1"], [1], knockout=True, num_samples=20, random_state=3)
+    assert set(np.unique(w)) <= {"0", "5"}

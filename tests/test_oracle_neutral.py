@@ -13,11 +13,13 @@ def _cases():
     cov = np.random.RandomState(0).normal(size=(20, 3))
     yield "dummy_cov", NO.fixtures_from_data(dd, epsilon=0.1, covariates=cov)
     yield "synthetic", NO.synthetic_neutral(3000, 7, k=2)
+    yield "wc_dummy", NO.fixtures_from_data_wc(dd, epsilon=0.2, rescale_weights=True)
+    yield "wc_synthetic", NO.synthetic_neutral(3000, 9, k=1, n_conf=3)
 
 
 @pytest.mark.parametrize("name,fx", list(_cases()))
 def test_numpy_matches_torch_autograd(name, fx):
-    D = NO.latent_dim(fx.n_teams, fx.k)
+    D = NO.latent_dim(fx.n_teams, fx.k, fx.n_conf)
     for seed, scale in ((0, 0.1), (1, 0.3), (2, 0.6), (3, 1.0)):  # (z = 0 ties every rate: the max adjoint is a convention there)
         z = np.random.RandomState(seed).uniform(-scale, scale, D)
         U, g, aux = NO.potential_and_grad(fx, z)
@@ -29,8 +31,8 @@ def test_numpy_matches_torch_autograd(name, fx):
 
 
 def test_finite_differences():
-    fx = NO.synthetic_neutral(500, 6, k=1)
-    D = NO.latent_dim(6, 1)
+    fx = NO.synthetic_neutral(500, 6, k=1, n_conf=2)
+    D = NO.latent_dim(6, 1, 2)
     z = np.random.RandomState(5).uniform(-0.4, 0.4, D)
     U, g, _ = NO.potential_and_grad(fx, z)
     hstep = 1e-6
