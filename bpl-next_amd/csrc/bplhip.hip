@@ -222,7 +222,7 @@ int launch_eval_dynamic(bplhip_ctx* c, int chains, const double* z, double* pot,
         A.chunk = ((c->n + nb - 1) / nb + dcd::FIX_BLOCK - 1) / dcd::FIX_BLOCK * dcd::FIX_BLOCK;
         const int nb2 = (int)((c->n + A.chunk - 1) / A.chunk);
         const int cell_blocks = (L.T + dcd::CELL_BLOCK / 64 - 1) / (dcd::CELL_BLOCK / 64);
-        HIP_TRY(c, hipMemsetAsync(A.acc, 0, dcd::scratch_doubles(L.G, L.T, L.K) * 8, s));
+        A.scratch_n = dcd::scratch_doubles(L.G, L.T, L.K);
         hipLaunchKernelGGL(dcd::dyn_cells, dim3(cell_blocks), dim3(dcd::CELL_BLOCK), 0, s, A);
         hipLaunchKernelGGL(dcd::dyn_pass1, dim3(nb), dim3(dcd::FIX_BLOCK), 0, s, A);
         if (!c->lds_attr_set) {

@@ -98,6 +98,7 @@ struct DynArgs {
     int n_conf;
     long long n;
     long long chunk;     // fixtures per workgroup of dyn_pass2
+    size_t scratch_n;    // doubles of scratch cleared by dyn_cells
     const double* xs;    // [T,K] standardised covariates or nullptr
     double lgsum;
     double* cells;       // [G*T][P_N]
@@ -170,6 +171,10 @@ __global__ __launch_bounds__(CELL_BLOCK) void dyn_cells(DynArgs A) {
     const double* z = A.z;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int t = blockIdx.x * (CELL_BLOCK / 64) + wave;
+    // this launch also clears the evaluation's scratch (saves a separate fill launch)
+    for (size_t i = (size_t)blockIdx.x * CELL_BLOCK + threadIdx.x; i < A.scratch_n;
+         i += (size_t)gridDim.x * CELL_BLOCK)
+        A.acc[i] = 0.0;
     if (t >= T) return;
     double att0 = 0.0, def0 = z[L.o_md];
     for (int k = 0; k < K; ++k) {
@@ -426,11 +431,12 @@ __global__ __launch_bounds__(CELL_BLOCK) void dyn_epi_cells(DynArgs A) {
     double* grad = A.grad;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int t = blockIdx.x * (CELL_BLOCK / 64) + wave;
-    if (t >= T) return;
     const Bounds b = load_bounds(A);
-    Coupling C;
-    C.n = 0;
-    {
+    // adjoint of the bounds: built once per workgroup in LDS (a per-thread table would live in
+    // scratch memory), read by every lane
+    __shared__ Coupling C;
+    if (threadIdx.x == 0) {
+        C.n = 0;
         const unsigned long long* scu = reinterpret_cast<const unsigned long long*>(A.sc);
         if (b.M > 1.0) {
             const double v = b.G_rho * b.q * (-b.UB);
@@ -443,12 +449,15 @@ __global__ __launch_bounds__(CELL_BLOCK) void dyn_epi_cells(DynArgs A) {
         const unsigned long long w = lb_home ? scu[SC_IDXQ] : scu[SC_IDXR];
         coupling_add(A, C, w ? (long long)(~0ull - w) + 1 : 0, lb_home, lbv);
     }
+    __syncthreads();
+    const int cn = C.n;
     auto coupled = [&](int cell, int which, double base) {
         double v = base;
-        for (int e = 0; e < C.n; ++e)
+        for (int e = 0; e < cn; ++e)
             if (C.cell[e] == cell && C.which[e] == which) v += C.val[e];
         return v;
     };
+    if (t >= T) return;  // (after the barrier)
     double carry_a = 0.0, carry_d = 0.0, Lloc = 0.0;
     const int nchunk = (G + 63) / 64;
     for (int ck = nchunk - 1; ck >= 0; --ck) {
@@ -456,28 +465,47 @@ __global__ __launch_bounds__(CELL_BLOCK) void dyn_epi_cells(DynArgs A) {
         const bool on = g < G;
         const int c = on ? g * T + t : t;
         const double* Ac = A.acc + (size_t)c * A_N;
-        const double ga_ = (on && A.random_walk) ? coupled(c, A_ATT, Ac[A_ATT]) : 0.0;
-        const double gd_ = (on && A.random_walk) ? coupled(c, A_DEF, Ac[A_DEF]) : 0.0;
+        double G6[A_N];
+#pragma unroll
+        for (int j = 0; j < A_N; ++j) G6[j] = on ? Ac[j] : 0.0;
+        bool hit = false;  // (at most three fixtures' cells carry a bounds adjoint)
+        for (int e = 0; e < cn; ++e) hit = hit || C.cell[e] == c;
+        if (hit && on) {
+#pragma unroll
+            for (int j = 0; j < A_N; ++j) G6[j] = coupled(c, j, G6[j]);
+        }
+        const double ga_ = A.random_walk ? G6[A_ATT] : 0.0;
+        const double gd_ = A.random_walk ? G6[A_DEF] : 0.0;
         // adjoint of the walk: gradient w.r.t. increment g = sum of cell gradients at g' >= g
         const double RA = carry_a + wave_suffix(ga_, lane);
         const double RD = carry_d + wave_suffix(gd_, lane);
         carry_a = __shfl(RA, 0, 64);
         carry_d = __shfl(RD, 0, 64);
         if (on) {
-            const double g_hat = coupled(c, A_HATT, Ac[A_HATT]);
-            const double g_adf = coupled(c, A_ADEF, Ac[A_ADEF]);
-            const double g_aat = coupled(c, A_AATT, Ac[A_AATT]);
-            const double g_hdf = coupled(c, A_HDEF, Ac[A_HDEF]);
+            const double g_hat = G6[A_HATT], g_adf = G6[A_ADEF], g_aat = G6[A_AATT], g_hdf = G6[A_HDEF];
             const double s_att = A.hyp[g], s_def = A.hyp[G + g], s_ha = A.hyp[2 * G + g],
                          s_aa = A.hyp[3 * G + g], s_hd = A.hyp[4 * G + g], s_ad = A.hyp[5 * G + g];
             const double sa = z[L.o_sat + c], sd = z[L.o_sdt + c];
             const double zu = z[L.o_u + c];
-            double u, du, su;
-            clipped_sig(zu, &u, &du, &su);
-            const double rp = 2.0 * u - 1.0, vv = 1.0 - rp * rp, e = sd - rp * sa;
-            grad[L.o_sat + c] = -(s_att * RA - sa + rp * e / vv);
-            grad[L.o_sdt + c] = -(s_def * RD - e / vv);
-            const double dL_drp = e * sa / vv - rp * e * e / (vv * vv) + rp / vv;
+            // u = sigmoid(zu) ~ Beta(2,4): one exp + one log1p serve the value, its derivative,
+            // log u = -sp(-zu), log(1-u) = -sp(zu) and the Jacobian -sp(zu) - sp(-zu)
+            const double az = fabs(zu), ez = exp(-az), l1 = log1p(ez);
+            const double sp_pos = az + l1;                      // softplus(|zu|)
+            const double sp_z = zu >= 0 ? sp_pos : l1;          // softplus(zu)
+            const double sp_mz = zu >= 0 ? l1 : sp_pos;         // softplus(-zu)
+            const double s_abs = 1.0 / (1.0 + ez);
+            const double su = zu >= 0 ? s_abs : 1.0 - s_abs;
+            double u = su, du = su * (1.0 - su), log_u = -sp_mz, log_1mu = -sp_z;
+            if (su < dc::SIG_LO || su > dc::SIG_HI) {           // clipped (|zu| > ~87)
+                u = su < dc::SIG_LO ? dc::SIG_LO : dc::SIG_HI;
+                du = 0.0;
+                log_u = log(u);
+                log_1mu = log1p(-u);
+            }
+            const double rp = 2.0 * u - 1.0, vv = 1.0 - rp * rp, iv = 1.0 / vv, e = sd - rp * sa;
+            grad[L.o_sat + c] = -(s_att * RA - sa + rp * e * iv);
+            grad[L.o_sdt + c] = -(s_def * RD - e * iv);
+            const double dL_drp = e * sa * iv - rp * e * e * iv * iv + rp * iv;
             grad[L.o_u + c] = -((1.0 / u - 3.0 / (1.0 - u)) * du + 2.0 * dL_drp * du +
                                 (1.0 - 2.0 * su));
             const double hat = z[L.o_hat + c], aat = z[L.o_aat + c], hdf = z[L.o_hdf + c],
@@ -498,8 +526,8 @@ __global__ __launch_bounds__(CELL_BLOCK) void dyn_epi_cells(DynArgs A) {
             atomicAdd(&A.gsum[8 * G + g], hdf * g_hdf);
             atomicAdd(&A.gsum[9 * G + g], adf * g_adf);
             // priors of the cell sites
-            Lloc += log(u) + 3.0 * log1p(-u) + 2.995732273553991 - softplus(zu) - softplus(-zu);
-            Lloc += -0.5 * sa * sa - HALF_LOG_2PI - 0.5 * e * e / vv - 0.5 * log(vv) - HALF_LOG_2PI;
+            Lloc += log_u + 3.0 * log_1mu + 2.995732273553991 - sp_z - sp_mz;
+            Lloc += -0.5 * sa * sa - HALF_LOG_2PI - 0.5 * e * e * iv - 0.5 * log(vv) - HALF_LOG_2PI;
             Lloc += -0.5 * (hat * hat + aat * aat + hdf * hdf + adf * adf) - 4.0 * HALF_LOG_2PI;
         }
     }
