@@ -79,6 +79,7 @@ struct bplhip_ctx {
     // tuning options (bplhip_set_option)
     int opt_device_nuts = 1;  // 1: tree builder on the device (nuts_dev.hip.h) when supported
     int opt_max_wg = 255;  // streaming workgroups (+1 prior workgroup = one per CU)
+    int opt_persistent_nuts = 1;  // bplhip_nuts_run_chains: whole chains on the device (0: lock step)
     int opt_vec_min_chains = 4;  // batched calls with at least this many chains use dc_vec (0: never)
     int opt_vec_tpw = 0;         // > 0: force this many tiles per wave for every chain count
     // chain-vectorised partitions (dc_vec.hip.h): fewer, fatter workgroups the more chains
@@ -338,12 +339,14 @@ dc::EvalArgs eval_args(bplhip_ctx* c, int chains, const double* z, double* pot, 
 }
 
 int launch_eval(bplhip_ctx* c, int chains, const double* z, double* pot, double* grad,
-                double* aux, hipStream_t s, double* nuts_state = nullptr, int nuts_depth = 0) {
+                double* aux, hipStream_t s, double* nuts_state = nullptr, int nuts_depth = 0,
+                const nd::Persist* persist = nullptr) {
     if (c->neutral) return launch_eval_neutral(c, chains, z, pot, grad, aux, s);
     if (c->dynamic) return launch_eval_dynamic(c, chains, z, pot, grad, aux, s);
     dc::EvalArgs A = eval_args(c, chains, z, pot, grad, aux);
     A.nuts = nuts_state;
     A.nuts_max_depth = nuts_depth;
+    A.persist = persist;
     const bool clip = c->L.model == dc::MODEL_EXTENDED;
     if (c->weighted) return clip ? launch_eval_t<true, true>(c, A, chains, s)
                                  : launch_eval_t<true, false>(c, A, chains, s);
@@ -391,7 +394,7 @@ int launch_vec_t(bplhip_ctx* c, const dc::EvalArgs& A, int chains, hipStream_t s
 // z / pot / grad / aux point into chain 0's state (strides = nuts_stride)
 int launch_eval_vec(bplhip_ctx* c, int chains, const double* z, double* pot, double* grad,
                     double* aux, hipStream_t s, double* nuts = nullptr, int nuts_stride = 0,
-                    int nuts_depth = 0) {
+                    int nuts_depth = 0, const nd::Persist* persist = nullptr) {
     c->vp = &c->vps[chains <= 8 ? 0 : (chains <= 23 ? 1 : 2)];
     if (chains > c->vp->slab_chains) {
         HIP_TRY(c, c->vp->d_hbuf.ensure((size_t)chains * vec_hb_stride(c) * sizeof(double)));
@@ -402,6 +405,7 @@ int launch_eval_vec(bplhip_ctx* c, int chains, const double* z, double* pot, dou
         A.nuts = nuts;
         A.nuts_stride = nuts_stride;
         A.nuts_max_depth = nuts_depth;
+        A.persist = persist;
         A.z_stride = A.g_stride = A.p_stride = A.aux_stride = nuts_stride;
     }
     A.tiles_per_wave = c->vp->tpw;
@@ -693,6 +697,10 @@ int bplhip_set_option(bplhip_ctx* c, const char* name, int value) {
     const std::string n(name);
     if (n == "device_nuts") {
         c->opt_device_nuts = value != 0;
+        return BPLHIP_OK;
+    }
+    if (n == "persistent_nuts") {
+        c->opt_persistent_nuts = value != 0;
         return BPLHIP_OK;
     }
     if (n == "vec_min_chains") {  // batched calls with >= value chains use the vectorised kernel
@@ -1277,6 +1285,175 @@ struct VecDeviceEngine {
     }
 };
 
+// Persistent chains (nuts_dev.hip.h): the host finds the initial states, generates every
+// chain's random inputs (they are data independent), uploads them, and from then on only
+// enqueues evaluations -- C == 1: the single-chain kernel, else the chain-vectorised one --
+// checking the chains' "all done" flags once per chunk of launches.
+int run_chains_persistent(bplhip_ctx* c, hipStream_t s, const nuts::Config& nc, int C, const double* z0,
+                          const tf::Key* keys, double* draws_out, std::vector<nuts::Result>* res) {
+    const int D = c->L.D, md = nc.max_tree_depth;
+    const int n_iter = nc.num_warmup + nc.num_samples;
+    const int kept = nc.num_samples / nc.thinning;
+    const size_t nsd = (nd::ns_doubles(D, md) + 1) & ~(size_t)1;
+    const size_t stride = (nsd + nd::pd_doubles(D) + 1) & ~(size_t)1;
+    const std::vector<nuts::Window> sched = nuts::build_adaptation_schedule(nc.num_warmup);
+    std::vector<int> win_end;
+    for (const auto& w : sched) win_end.push_back(w.end);
+    if (win_end.empty()) win_end.push_back(-1);
+
+    DevBuf d_ns, d_norm, d_par, d_win, d_draws, d_stats, d_desc;
+    HIP_TRY(c, d_ns.ensure((size_t)C * stride * 8));
+    HIP_TRY(c, hipMemsetAsync(d_ns.p, 0, (size_t)C * stride * 8, s));
+    HIP_TRY(c, d_norm.ensure((size_t)C * n_iter * D * 8));
+    HIP_TRY(c, d_par.ensure((size_t)C * n_iter * md * 5 * 8));
+    HIP_TRY(c, d_win.ensure(win_end.size() * 4));
+    HIP_TRY(c, d_draws.ensure((size_t)C * kept * D * 8));
+    HIP_TRY(c, d_stats.ensure((size_t)C * kept * 6 * 8));
+    HIP_TRY(c, d_desc.ensure(sizeof(nd::Persist)));
+    double* ns = d_ns.as<double>();
+
+    // ---- initial states (ChainDriver::init: key plumbing + init_to_uniform with retries)
+    res->assign(C, nuts::Result{});
+    std::vector<nuts::ChainDriver> cds;
+    cds.reserve(C);
+    for (int ch = 0; ch < C; ++ch) cds.emplace_back(nc, D, draws_out + (size_t)ch * kept * D, &(*res)[ch]);
+    std::vector<double> stage(std::max<size_t>((size_t)D + nd::H_N, 64));
+    int rc = BPLHIP_OK;
+    for (int ch = 0; ch < C; ++ch) {
+        double* nsc = ns + (size_t)ch * stride;
+        auto set_state = [&](const double* zz, double* pe, bool* fin) {
+            double* zn = nd::vec(nsc, D, nd::V_ZN);
+            double* gr = nd::vec(nsc, D, nd::V_GRAD);
+            if (hipMemcpyAsync(zn, zz, (size_t)D * 8, hipMemcpyHostToDevice, s) != hipSuccess) return false;
+            rc = launch_eval(c, 1, zn, nsc + nd::H_LEAF_PE, gr, nsc + nd::H_LEAF_AUX0, s);
+            if (rc != BPLHIP_OK) return false;
+            (void)hipMemcpyAsync(nd::vec(nsc, D, nd::V_Z), zn, (size_t)D * 8, hipMemcpyDeviceToDevice, s);
+            (void)hipMemcpyAsync(nd::vec(nsc, D, nd::V_G), gr, (size_t)D * 8, hipMemcpyDeviceToDevice, s);
+            (void)hipMemcpyAsync(nsc + nd::H_CUR_PE, nsc + nd::H_LEAF_PE, 8, hipMemcpyDeviceToDevice, s);
+            (void)hipMemcpyAsync(nsc + nd::H_T_AUX0, nsc + nd::H_LEAF_AUX0, 32, hipMemcpyDeviceToDevice, s);
+            (void)hipMemcpyAsync(stage.data(), nsc + nd::H_LEAF_PE, 8, hipMemcpyDeviceToHost, s);
+            (void)hipMemcpyAsync(stage.data() + 1, gr, (size_t)D * 8, hipMemcpyDeviceToHost, s);
+            if (hipStreamSynchronize(s) != hipSuccess) return false;
+            bool ok = std::isfinite(stage[0]);
+            for (int i = 0; i < D && ok; ++i) ok = std::isfinite(stage[1 + i]);
+            *fin = ok;
+            *pe = stage[0];
+            return true;
+        };
+        const int st = cds[ch].init(set_state, z0 ? z0 + (size_t)ch * D : nullptr, keys[ch]);
+        if (st == nuts::ST_EVAL_FAILED) return rc != BPLHIP_OK ? rc : fail(c, BPLHIP_EHIP, "persistent nuts: init failed");
+        if (st == nuts::ST_NO_FINITE_INIT) return BPLHIP_ENUMERIC;
+    }
+
+    // ---- all random inputs of every chain (sample_kernel / build_tree / _double_tree splits)
+    {
+        std::vector<double> nrm((size_t)C * n_iter * D), par((size_t)C * n_iter * md * 5);
+        for (int ch = 0; ch < C; ++ch) {
+            tf::Key key_hmc = cds[ch].key_hmc;
+            for (int it = 0; it < n_iter; ++it) {
+                tf::Key k_mom, k_tr;
+                tf::split3(key_hmc, &key_hmc, &k_mom, &k_tr);
+                tf::normal(k_mom, D, nrm.data() + ((size_t)ch * n_iter + it) * D);
+                tf::Key key = k_tr;
+                for (int j = 0; j < md; ++j) {
+                    tf::Key k_next, k_dir, k_dbl, k_sub, k_t2;
+                    tf::split3(key, &k_next, &k_dir, &k_dbl);
+                    key = k_next;
+                    tf::split2(k_dbl, &k_sub, &k_t2);
+                    double* q = par.data() + (((size_t)ch * n_iter + it) * md + j) * 5;
+                    q[0] = tf::bernoulli(k_dir, 0.5) ? 1.0 : 0.0;
+                    q[1] = (double)k_sub.hi; q[2] = (double)k_sub.lo;
+                    q[3] = (double)k_t2.hi;  q[4] = (double)k_t2.lo;
+                }
+            }
+        }
+        HIP_TRY(c, hipMemcpy(d_norm.p, nrm.data(), nrm.size() * 8, hipMemcpyHostToDevice));
+        HIP_TRY(c, hipMemcpy(d_par.p, par.data(), par.size() * 8, hipMemcpyHostToDevice));
+        HIP_TRY(c, hipMemcpy(d_win.p, win_end.data(), win_end.size() * 4, hipMemcpyHostToDevice));
+    }
+    nd::Persist P{};
+    P.normals = d_norm.as<const double>();
+    P.par = d_par.as<const double>();
+    P.win_end = d_win.as<const int>();
+    P.draws = d_draws.as<double>();
+    P.stats = d_stats.as<double>();
+    P.n_iter = n_iter; P.kept = kept; P.max_depth = md; P.n_win = (int)win_end.size(); P.D = D;
+    P.pd_off = nsd;
+    HIP_TRY(c, hipMemcpy(d_desc.p, &P, sizeof P, hipMemcpyHostToDevice));
+    {   // PD blocks + identity mass matrices
+        std::vector<double> pd(nd::pd_doubles(D), 0.0), ones(D, 1.0);
+        pd[nd::P_WARM] = nc.num_warmup; pd[nd::P_TOTAL] = n_iter; pd[nd::P_STEP] = nc.step_size;
+        pd[nd::P_DA_PROX] = std::log(10.0 * nc.step_size);
+        pd[nd::P_NWIN] = (double)sched.size();
+        pd[nd::P_ADAPT_SS] = nc.adapt_step_size; pd[nd::P_ADAPT_MM] = nc.adapt_mass_matrix;
+        pd[nd::P_TARGET] = nc.target_accept_prob; pd[nd::P_THIN] = nc.thinning;
+        pd[nd::P_START_IDX] = nc.num_warmup + nc.num_samples % nc.thinning;
+        pd[nd::P_MAXDE] = nc.max_delta_energy;
+        for (int i = 0; i < D; ++i) pd[nd::P_N + 2 * (size_t)D + i] = 1.0;  // mass_sqrt
+        for (int ch = 0; ch < C; ++ch) {
+            double* nsc = ns + (size_t)ch * stride;
+            HIP_TRY(c, hipMemcpy(nsc + nsd, pd.data(), pd.size() * 8, hipMemcpyHostToDevice));
+            HIP_TRY(c, hipMemcpy(nd::vec(nsc, D, nd::V_INVM), ones.data(), (size_t)D * 8, hipMemcpyHostToDevice));
+        }
+    }
+    std::vector<double> evals0(C);
+    HIP_TRY(c, hipMemcpy2D(evals0.data(), 8, ns + nd::H_EVALS, stride * 8, 8, C, hipMemcpyDeviceToHost));
+
+    // ---- run: first transitions, then blind chunks of evaluations
+    hipLaunchKernelGGL(nd::kp_start, dim3(C), dim3(64), 0, s, ns, stride, P);
+    const nd::Persist* dP = d_desc.as<const nd::Persist>();
+    std::vector<double> flags(C);
+    const int chunk = 256;
+    bool all_done = false;
+    // every launch advances every unfinished chain by one leapfrog: an upper bound exists
+    const double max_steps = (double)n_iter * (double)((1u << md) - 1) + 2.0 * chunk;
+    double steps_done = 0.0;
+    while (!all_done) {
+        if (steps_done > max_steps)
+            return fail(c, BPLHIP_EHIP, "persistent nuts: chains did not finish within the leapfrog bound");
+        steps_done += chunk;
+        for (int k = 0; k < chunk; ++k) {
+            rc = C == 1 ? launch_eval(c, 1, nd::vec(ns, D, nd::V_ZN), ns + nd::H_LEAF_PE, nd::vec(ns, D, nd::V_GRAD),
+                                      ns + nd::H_LEAF_AUX0, s, ns, md, dP)
+                        : launch_eval_vec(c, C, nd::vec(ns, D, nd::V_ZN), ns + nd::H_LEAF_PE,
+                                          nd::vec(ns, D, nd::V_GRAD), ns + nd::H_LEAF_AUX0, s, ns, (int)stride,
+                                          md, dP);
+            if (rc != BPLHIP_OK) return rc;
+        }
+        HIP_TRY(c, hipMemcpy2DAsync(flags.data(), 8, ns + nsd + nd::P_ALLDONE, stride * 8, 8, C,
+                                    hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipStreamSynchronize(s));
+        all_done = true;
+        for (int ch = 0; ch < C; ++ch) all_done = all_done && flags[ch] != 0.0;
+    }
+
+    // ---- results
+    std::vector<double> stats((size_t)C * kept * 6), pd(nd::pd_doubles(D)), hdr(nd::H_N);
+    HIP_TRY(c, hipMemcpy(draws_out, d_draws.p, (size_t)C * kept * D * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(stats.data(), d_stats.p, stats.size() * 8, hipMemcpyDeviceToHost));
+    for (int ch = 0; ch < C; ++ch) {
+        nuts::Result& r = (*res)[ch];
+        const double* nsc = ns + (size_t)ch * stride;
+        HIP_TRY(c, hipMemcpy(pd.data(), nsc + nsd, pd.size() * 8, hipMemcpyDeviceToHost));
+        HIP_TRY(c, hipMemcpy(hdr.data(), nsc, (size_t)nd::H_N * 8, hipMemcpyDeviceToHost));
+        r.potential_energy.resize(kept); r.accept_prob.resize(kept); r.step_size.resize(kept);
+        r.aux0.resize(kept); r.num_steps.resize(kept); r.diverging.resize(kept);
+        for (int i = 0; i < kept; ++i) {
+            const double* st = stats.data() + ((size_t)ch * kept + i) * 6;
+            r.potential_energy[i] = st[0]; r.accept_prob[i] = st[1]; r.step_size[i] = st[2];
+            r.num_steps[i] = (int)st[3]; r.diverging[i] = (int)st[4]; r.aux0[i] = st[5];
+        }
+        r.final_step_size = pd[nd::P_STEP];
+        r.mean_accept_prob = pd[nd::P_MEAN_ACC];
+        r.total_divergences = (int64_t)pd[nd::P_NDIV];
+        r.total_leapfrogs = (int64_t)(hdr[nd::H_EVALS] - evals0[ch]);
+        r.inverse_mass_matrix.resize(D);
+        HIP_TRY(c, hipMemcpy(r.inverse_mass_matrix.data(), nd::vec(const_cast<double*>(nsc), D, nd::V_INVM),
+                             (size_t)D * 8, hipMemcpyDeviceToHost));
+    }
+    return BPLHIP_OK;
+}
+
 // numpyro's configuration + the latent sites in model execution order (init key order)
 nuts::Config make_nuts_config(const bplhip_ctx* c, const bplhip_nuts_cfg* cfg) {
     nuts::Config nc;
@@ -1401,7 +1578,20 @@ extern "C" int bplhip_nuts_run(bplhip_ctx* c, const bplhip_nuts_cfg* cfg, const 
     int dev_rc = BPLHIP_OK;
     const bool device_tree = c->opt_device_nuts && !c->dynamic && !c->neutral && c->L.T <= 64 && c->staged &&
                              c->L.D <= 64 * nd::LEAF_NE;
-    if (device_tree) {
+    if (device_tree && c->opt_persistent_nuts) {
+        // the whole chain on the device (nuts_dev.hip.h, persistent chains)
+        int rc1 = ensure_slabs(c, 1);
+        if (rc1 != BPLHIP_OK) return rc1;
+        const tf::Key k1{seed_hi, seed_lo};
+        std::vector<nuts::Result> pres;
+        const int prc = run_chains_persistent(c, static_cast<hipStream_t>(stream), nc, 1, z0, &k1,
+                                              draws_out, &pres);
+        if (prc == BPLHIP_ENUMERIC)
+            return fail(c, BPLHIP_ENUMERIC, "nuts_run: no finite initial point after 100 tries");
+        if (prc != BPLHIP_OK) return prc;
+        res = pres[0];
+        st = nuts::ST_OK;
+    } else if (device_tree) {
         const size_t nsd = nd::ns_doubles(D, nc.max_tree_depth);
         HIP_TRY(c, c->d_ns.ensure(nsd * 8));
         HIP_TRY(c, hipMemsetAsync(c->d_ns.p, 0, nsd * 8, static_cast<hipStream_t>(stream)));
@@ -1452,6 +1642,23 @@ extern "C" int bplhip_nuts_run_chains(bplhip_ctx* c, const bplhip_nuts_cfg* cfg,
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int D = c->L.D, C = n_chains;
     const nuts::Config nc = make_nuts_config(c, cfg);
+    if (c->opt_persistent_nuts) {
+        int rc0 = ensure_slabs(c, 1);
+        if (rc0 != BPLHIP_OK) return rc0;
+        std::vector<tf::Key> pkeys(C);
+        for (int ch = 0; ch < C; ++ch) pkeys[ch] = tf::Key{seeds[2 * ch], seeds[2 * ch + 1]};
+        std::vector<nuts::Result> pres;
+        const auto pt0 = std::chrono::steady_clock::now();
+        const int prc = run_chains_persistent(c, s, nc, C, z0, pkeys.data(), draws_out, &pres);
+        const double pwall =
+            std::chrono::duration<double>(std::chrono::steady_clock::now() - pt0).count();
+        if (prc == BPLHIP_ENUMERIC)
+            return fail(c, BPLHIP_ENUMERIC, "nuts_run_chains: no finite initial point after 100 tries");
+        if (prc != BPLHIP_OK) return prc;
+        if (stats)
+            for (int ch = 0; ch < C; ++ch) fill_stats(&stats[ch], pres[ch], pwall, D);
+        return BPLHIP_OK;
+    }
     const size_t stride = (nd::ns_doubles(D, nc.max_tree_depth) + 1) & ~(size_t)1;
     const int par_stride = nd::par_doubles(nc.max_tree_depth);
     DevBuf d_ns, d_par;

@@ -113,6 +113,7 @@ struct EvalArgs {
     double* nuts;           // chain c at nuts + c*nuts_stride
     int nuts_stride;
     int nuts_max_depth;
+    const nd::Persist* persist;  // persistent chains: doubling / transition advance in the tail
     Layout L;
 };
 __device__ __forceinline__ const double* z_of(const EvalArgs& A, int c) { return A.z + (size_t)c * A.z_stride; }
@@ -808,7 +809,8 @@ __device__ void tail_one_wave(const EvalArgs& A, int chain, const double* zoL, c
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        nd::nuts_leaf(nuts_of(A, chain), D, A.nuts_max_depth, t, gradL, leaf);
+        const bool sub_done = nd::nuts_leaf(nuts_of(A, chain), D, A.nuts_max_depth, t, gradL, leaf);
+        if (A.persist != nullptr && sub_done) nd::persist_advance(nuts_of(A, chain), *A.persist, chain, t);
     }
 }
 

@@ -197,7 +197,7 @@ __device__ __forceinline__ void leaf_prefetch_ckpt(LeafState& S, double* ns, int
     }
 }
 
-__device__ inline void nuts_leaf(double* ns, int D, int max_depth, int lane, const double* gL,
+__device__ inline bool nuts_leaf(double* ns, int D, int max_depth, int lane, const double* gL,
                                  const LeafState& S) {
     const double hv = S.hv;
     double* p_zn = vec(ns, D, V_ZN);
@@ -320,6 +320,7 @@ __device__ inline void nuts_leaf(double* ns, int D, int max_depth, int lane, con
             ns[H_S_AUX2] = gL[D + 3]; ns[H_S_AUX3] = gL[D + 4];
         }
     }
+    return done;  // (wave uniform) the subtree of this doubling is complete
 }
 
 // ---------------------------------------------------------------- small kernels (1 wave)
@@ -477,6 +478,175 @@ __global__ __launch_bounds__(64) void kv_end(double* ns, size_t stride, int D, i
 }
 __global__ __launch_bounds__(64) void kv_finish(double* ns, size_t stride, int D) {
     finish_body(ns + blockIdx.x * stride, D, threadIdx.x);
+}
+
+// ---------------------------------------------------------------- persistent chains
+// The whole chain on the device: when a doubling ends, the wave that booked the last leaf
+// also combines the trees, and when the transition ends it adapts (dual averaging, Welford
+// mass matrix, numpyro's windowed schedule), stores the draw and starts the next transition
+// -- all random inputs of a chain are data independent (momentum normals, doubling
+// directions and keys), so the host generates them up front.  The host only enqueues
+// evaluations and looks at the "all done" flags once per chunk: no per-transition round trip
+// and no lock step between chains (every chain always has a useful leapfrog to do).
+//
+// Per-chain "PD" block after the NS region: scalars, then W_MEAN | W_M2 | MSQRT (D each).
+enum {
+    P_ITER = 0, P_WARM, P_TOTAL, P_ALLDONE, P_STEP, P_DA_T, P_DA_XT, P_DA_XAVG, P_DA_GAVG,
+    P_DA_PROX, P_WIN, P_NWIN, P_ADAPT_SS, P_ADAPT_MM, P_TARGET, P_W_N, P_MEAN_ACC, P_NDIV,
+    P_THIN, P_START_IDX, P_MAXDE, P_N = 24
+};
+__host__ __device__ inline size_t pd_doubles(int D) { return (size_t)P_N + 3 * (size_t)D; }
+
+struct Persist {             // device-resident descriptor, shared by all chains
+    const double* normals;   // [C][n_iter][D]   momentum draws (unit normal)
+    const double* par;       // [C][n_iter][max_depth][5]  going_right, sub_hi, sub_lo, tr_hi, tr_lo
+    const int* win_end;      // [n_win] last iteration of each adaptation window
+    double* draws;           // [C][kept][D]
+    double* stats;           // [C][kept][6]  pe, accept_prob, step_size, num_steps, diverging, aux0
+    int n_iter, kept, max_depth, n_win, D;
+    size_t pd_off;           // doubles from a chain's NS base to its PD block
+};
+
+__device__ __forceinline__ void wave_mem_sync() {  // stores of this wave visible to its loads
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+
+// momentum of iteration `it` (r = mass_sqrt * unit normal), tree := current state, doubling 0
+__device__ inline void persist_start_transition(double* ns, const Persist& P, int chain, int it,
+                                                int lane) {
+    const int D = P.D;
+    double* pd = ns + P.pd_off;
+    const double* msq = pd + P_N + 2 * (size_t)D;
+    const double* nrm = P.normals + ((size_t)chain * P.n_iter + it) * D;
+    double* r = vec(ns, D, V_TL_R);
+    for (int i = lane; i < D; i += 64) r[i] = msq[i] * nrm[i];
+    wave_mem_sync();
+    init_body(ns, D, pd[P_STEP], pd[P_MAXDE], lane);
+    wave_mem_sync();
+    const double* q = P.par + ((size_t)chain * P.n_iter + it) * P.max_depth * 5;
+    begin_body(ns, D, 0, q[0] != 0.0, (uint32_t)q[1], (uint32_t)q[2], lane);
+}
+
+// called by the leaf's wave when the subtree of the current doubling is complete
+__device__ inline void persist_advance(double* ns, const Persist& P, int chain, int lane) {
+    const int D = P.D, md = P.max_depth;
+    double* pd = ns + P.pd_off;
+    wave_mem_sync();
+    if (pd[P_ALLDONE] != 0.0) return;
+    const int it = (int)pd[P_ITER];
+    {   // end of the doubling: _combine_tree(tree, subtree, biased_transition=True)
+        const int j = (int)ns[H_T_DEPTH];
+        const double* q = P.par + (((size_t)chain * P.n_iter + it) * md + j) * 5;
+        end_body(ns, D, md, (uint32_t)q[3], (uint32_t)q[4], lane);
+        wave_mem_sync();
+    }
+    if (ns[H_STOP] == 0.0) {  // next doubling of the same transition
+        const int j = (int)ns[H_T_DEPTH];
+        const double* q = P.par + (((size_t)chain * P.n_iter + it) * md + j) * 5;
+        begin_body(ns, D, j, q[0] != 0.0, (uint32_t)q[1], (uint32_t)q[2], lane);
+        return;
+    }
+    // ---- the transition is complete: proposal -> state, statistics, adaptation, next one
+    const double num = ns[H_T_NUM];
+    const double accept_prob = num > 0 ? ns[H_T_SUMACC] / num : 0.0;
+    const bool diverging = ns[H_T_DIV] != 0.0;
+    const double used_step = ns[H_EPS], t_pe = ns[H_T_PE], t_aux0 = ns[H_T_AUX0];
+    finish_body(ns, D, lane);
+    wave_mem_sync();
+    const double* zc = vec(ns, D, V_Z);
+    double* w_mean = pd + P_N;
+    double* w_m2 = w_mean + D;
+    double* msq = w_m2 + D;
+    double* invM = vec(ns, D, V_INVM);
+    const int warm = (int)pd[P_WARM], total = (int)pd[P_TOTAL];
+    double step = pd[P_STEP];
+    if (it < warm) {  // numpyro warmup_adapter.update_fn
+        const bool adapt_ss = pd[P_ADAPT_SS] != 0.0, adapt_mm = pd[P_ADAPT_MM] != 0.0;
+        double da_t = pd[P_DA_T], x_t = pd[P_DA_XT], x_avg = pd[P_DA_XAVG], g_avg = pd[P_DA_GAVG];
+        if (adapt_ss) {  // dual_averaging(t0 = 10, kappa = 0.75, gamma = 0.05)
+            const double g = pd[P_TARGET] - accept_prob;
+            da_t += 1.0;
+            g_avg = (1.0 - 1.0 / (da_t + 10.0)) * g_avg + g / (da_t + 10.0);
+            x_t = pd[P_DA_PROX] - sqrt(da_t) / 0.05 * g_avg;
+            const double weight_t = pow(da_t, -0.75);
+            x_avg = (1.0 - weight_t) * x_avg + weight_t * x_t;
+            const double sx = it == warm - 1 ? exp(x_avg) : exp(x_t);
+            step = sx < 1.1754943508222875e-38 ? 1.1754943508222875e-38 : sx;
+        }
+        int win = (int)pd[P_WIN];
+        const int nwin = (int)pd[P_NWIN];
+        const bool is_middle = 0 < win && win < nwin - 1;
+        double w_n = pd[P_W_N];
+        if (adapt_mm && is_middle) {  // welford_covariance(diagonal=True)
+            w_n += 1.0;
+            for (int i = lane; i < D; i += 64) {
+                const double d_pre = zc[i] - w_mean[i];
+                const double mnew = w_mean[i] + d_pre / w_n;
+                w_mean[i] = mnew;
+                w_m2[i] += d_pre * (zc[i] - mnew);
+            }
+        }
+        const bool at_end = it == P.win_end[win];
+        if (at_end) win += 1;
+        double prox = pd[P_DA_PROX];
+        if (at_end && is_middle) {
+            if (adapt_mm) {
+                for (int i = lane; i < D; i += 64) {
+                    double c = w_m2[i] / (w_n - 1.0);
+                    c = (w_n / (w_n + 5.0)) * c + 1e-3 * (5.0 / (w_n + 5.0));
+                    invM[i] = c;
+                    msq[i] = 1.0 / sqrt(c);
+                    w_mean[i] = 0.0;
+                    w_m2[i] = 0.0;
+                }
+                w_n = 0.0;
+            }
+            if (adapt_ss) {
+                da_t = 0.0; x_t = 0.0; x_avg = 0.0; g_avg = 0.0;
+                prox = log(10.0 * step);
+            }
+        }
+        if (lane == 0) {
+            pd[P_DA_T] = da_t; pd[P_DA_XT] = x_t; pd[P_DA_XAVG] = x_avg; pd[P_DA_GAVG] = g_avg;
+            pd[P_DA_PROX] = prox; pd[P_WIN] = (double)win; pd[P_W_N] = w_n; pd[P_STEP] = step;
+        }
+    } else {
+        const int n = it - warm + 1;
+        const int thin = (int)pd[P_THIN], start_idx = (int)pd[P_START_IDX];
+        if (it >= start_idx && (it - start_idx) % thin == thin - 1) {
+            const int idx = (it - start_idx) / thin;
+            double* dr = P.draws + ((size_t)chain * P.kept + idx) * D;
+            for (int i = lane; i < D; i += 64) dr[i] = zc[i];
+            if (lane == 0) {
+                double* st = P.stats + ((size_t)chain * P.kept + idx) * 6;
+                st[0] = t_pe; st[1] = accept_prob; st[2] = used_step; st[3] = num;
+                st[4] = diverging ? 1.0 : 0.0; st[5] = t_aux0;
+            }
+        }
+        if (lane == 0) {
+            pd[P_MEAN_ACC] += (accept_prob - pd[P_MEAN_ACC]) / n;
+            if (diverging) pd[P_NDIV] += 1.0;
+        }
+    }
+    if (it + 1 >= total) {  // chain finished: every later launch is a no-op for it
+        if (lane == 0) {
+            pd[P_ITER] = (double)(it + 1);
+            pd[P_ALLDONE] = 1.0;
+            ns[H_S_DONE] = 1.0;
+            ns[H_S_ACTIVE] = 0.0;
+        }
+        return;
+    }
+    if (lane == 0) pd[P_ITER] = (double)(it + 1);
+    wave_mem_sync();
+    persist_start_transition(ns, P, chain, it + 1, lane);
+}
+
+// first transition of every chain (after the host has set the initial state)
+__global__ __launch_bounds__(64) void kp_start(double* ns, size_t stride, Persist P) {
+    persist_start_transition(ns + blockIdx.x * stride, P, blockIdx.x, 0, threadIdx.x);
 }
 
 }  // namespace nd

@@ -190,37 +190,53 @@ def test_device_tree_matches_host_tree(hip_ctx):
         z0 = np.random.RandomState(2).uniform(-0.2, 0.2, hip_ctx.dim)
         cfg = default_nuts_cfg()
         cfg.num_warmup, cfg.num_samples, cfg.step_size = 0, 8, 0.02
-        out = {}
-        for mode in (1, 0):
-            hip_ctx.set_option("device_nuts", mode)
-            out[mode] = hip_ctx.nuts_run(cfg, (0, 11), z0)
-        (d1, s1), (d0, s0) = out[1], out[0]
-        assert s1["total_leapfrogs"] == s0["total_leapfrogs"] > 100
-        assert s1["num_steps"].tolist() == s0["num_steps"].tolist()
-        # rounding-level differences grow ~30x per transition (trajectories of 100+ steps)
-        assert np.abs(d1[:4] - d0[:4]).max() < 1e-10 and np.abs(d1 - d0).max() < 1e-4
-        assert np.abs(s1["potential_energy"][:4] - s0["potential_energy"][:4]).max() < 1e-8
-        assert np.abs(s1["accept_prob"][:4] - s0["accept_prob"][:4]).max() < 1e-9
-        assert np.allclose(s1["corr_coef"][:4], s0["corr_coef"][:4], atol=1e-12)
-        # adaptation on: same tree sizes early on, healthy statistics in both
+        # three engines: whole chain on the device (persistent), device tree with host-side
+        # adaptation, host tree
+        engines = {"persistent": (1, 1), "device": (1, 0), "host": (0, 0)}
+
+        def run(name, key, z_init=None):
+            dn, pn = engines[name]
+            hip_ctx.set_option("device_nuts", dn)
+            hip_ctx.set_option("persistent_nuts", pn)
+            try:
+                return hip_ctx.nuts_run(cfg, key, z_init)
+            finally:
+                hip_ctx.set_option("device_nuts", 1)
+                hip_ctx.set_option("persistent_nuts", 1)
+
+        d0, s0 = run("host", (0, 11), z0)
+        for name in ("persistent", "device"):
+            d1, s1 = run(name, (0, 11), z0)
+            assert s1["total_leapfrogs"] == s0["total_leapfrogs"] > 100
+            assert s1["num_steps"].tolist() == s0["num_steps"].tolist()
+            # rounding-level differences grow ~30x per transition (trajectories of 100+ steps)
+            assert np.abs(d1[:4] - d0[:4]).max() < 1e-10 and np.abs(d1 - d0).max() < 1e-4
+            assert np.abs(s1["potential_energy"][:4] - s0["potential_energy"][:4]).max() < 1e-8
+            assert np.abs(s1["accept_prob"][:4] - s0["accept_prob"][:4]).max() < 1e-9
+            assert np.allclose(s1["corr_coef"][:4], s0["corr_coef"][:4], atol=1e-12)
+            assert np.allclose(s1["step_size"], 0.02)
+        # adaptation on: healthy statistics in all three
         cfg.num_warmup, cfg.num_samples, cfg.step_size = 60, 40, 1.0
-        for mode in (1, 0):
-            hip_ctx.set_option("device_nuts", mode)
-            d, st = hip_ctx.nuts_run(cfg, (0, 5))
+        for name in engines:
+            d, st = run(name, (0, 5))
             assert np.isfinite(d).all() and st["total_divergences"] == 0
             assert 0.55 < st["mean_accept_prob"] <= 1.0
-        hip_ctx.set_option("device_nuts", 1)
+            assert st["inverse_mass_matrix"].shape == (hip_ctx.dim,) and (st["inverse_mass_matrix"] > 0).all()
 
 
-def test_lockstep_chains_match_single_chains(hip_ctx):
-    """Lock-step chains (bplhip_nuts_run_chains: one chain-vectorised evaluation per leapfrog
-    of all chains, numpyro chain_method="vectorized") follow the same key sequences and the
+@pytest.mark.parametrize("persistent", [1, 0])
+def test_lockstep_chains_match_single_chains(hip_ctx, persistent):
+    """Several chains on one GPU (bplhip_nuts_run_chains, numpyro chain_method="vectorized"):
+    `persistent` 1 = whole chains on the device (adaptation, draw collection and the next
+    transition's start in the kernel tail; the host only enqueues evaluations), 0 = lock-step
+    trees with host-side adaptation.  Both follow the same key sequences and the
     same algorithm as bplhip_nuts_run chain by chain.  The vectorised kernel groups its
     float32 partial sums differently (1e-10 relative in U), so with a fixed step size the
     trees coincide and the first draws agree closely; the difference then grows with the
     chaotic trajectories, as between the host and device tree builders."""
     from bpl._ffi import MODEL_BASIC, MODEL_EXTENDED, default_nuts_cfg
 
+    hip_ctx.set_option("persistent_nuts", persistent)
     for model, name, nch in ((MODEL_BASIC, "dummy", 5), (MODEL_EXTENDED, "dummy_cov", 9)):
         fx = cases.fixtures(name)
         cov = None if fx.covariates is None or model == MODEL_BASIC else O.standardise_covariates(fx.covariates)
@@ -248,6 +264,10 @@ def test_lockstep_chains_match_single_chains(hip_ctx):
             assert 0.55 < st["mean_accept_prob"] <= 1.0
         # distinct keys -> distinct chains
         assert np.abs(multi[0][0] - multi[1][0]).max() > 1e-3
+        # one chain through the same entry point (persistent: the single-chain kernel)
+        one = hip_ctx.nuts_run_chains(cfg, keys[:1])
+        assert np.isfinite(one[0][0]).all() and 0.55 < one[0][1]["mean_accept_prob"] <= 1.0
+    hip_ctx.set_option("persistent_nuts", 1)
 
 
 def test_fit_num_chains_lockstep_vs_sequential(dummy_data):
