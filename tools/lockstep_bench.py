@@ -20,7 +20,7 @@ for C in [int(v) for v in os.environ.get('CHAINS', '2,4,8,16,32,64').split(',')]
     res = c.nuts_run_chains(cfg, [(0, 42 + i) for i in range(C)])
     leap = sum(r[1]['total_leapfrogs'] for r in res); wall = res[0][1]['wall_seconds']
     acc = np.mean([r[1]['mean_accept_prob'] for r in res])
-    print(f"lock-step chains={C:3d}: {leap / wall:10.0f} leapfrogs/s aggregate ({leap} in {wall:.3f} s, "
+    print(f"chains on one GPU={C:3d}: {leap / wall:10.0f} leapfrogs/s aggregate ({leap} in {wall:.3f} s, "
           f"mean accept {acc:.3f}, steps/transition {leap / (C * 400):.1f})", flush=True)
     if C <= 4:
         print("    per chain:", [(r[1]['total_leapfrogs'], float('%.2e' % r[1]['final_step_size'])) for r in res], flush=True)
