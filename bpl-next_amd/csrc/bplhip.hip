@@ -217,22 +217,24 @@ int launch_eval_dynamic(bplhip_ctx* c, int chains, const double* z, double* pot,
         A.aux = aux ? aux + (size_t)ch * 4 : nullptr;
         A.random_walk = c->dyn_random_walk;
         A.L = L;
-        // fixture passes: at most 1024 workgroups; pass 2 takes contiguous chunks
-        const long long nb_all = (c->n + dcd::FIX_BLOCK - 1) / dcd::FIX_BLOCK;
+        // fixture passes: at most 1024 workgroups of 16 waves (every workgroup ends with same-address
+        // global atomics: maxima, U, its private accumulators); pass 2 takes contiguous chunks
+        const int fb = c->n >= (1 << 18) ? dcd::FIX_BLOCK : 256;  // threads per workgroup
+        const long long nb_all = (c->n + fb - 1) / fb;
         const int nb = (int)std::min<long long>(nb_all, 1024);
-        A.chunk = ((c->n + nb - 1) / nb + dcd::FIX_BLOCK - 1) / dcd::FIX_BLOCK * dcd::FIX_BLOCK;
+        A.chunk = ((c->n + nb - 1) / nb + fb - 1) / fb * fb;
         const int nb2 = (int)((c->n + A.chunk - 1) / A.chunk);
         const int cell_blocks = (L.T + dcd::CELL_BLOCK / 64 - 1) / (dcd::CELL_BLOCK / 64);
         A.scratch_n = dcd::scratch_doubles(L.G, L.T, L.K);
         hipLaunchKernelGGL(dcd::dyn_cells, dim3(cell_blocks), dim3(dcd::CELL_BLOCK), 0, s, A);
-        hipLaunchKernelGGL(dcd::dyn_pass1, dim3(nb), dim3(dcd::FIX_BLOCK), 0, s, A);
+        hipLaunchKernelGGL(dcd::dyn_pass1, dim3(nb), dim3(fb), 0, s, A);
         if (!c->lds_attr_set) {
             HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(dcd::dyn_pass2),
                                            hipFuncAttributeMaxDynamicSharedMemorySize,
                                            dcd::PASS2_LDS_CELLS * dcd::A_N * 8));
             c->lds_attr_set = true;
         }
-        hipLaunchKernelGGL(dcd::dyn_pass2, dim3(nb2), dim3(dcd::FIX_BLOCK),
+        hipLaunchKernelGGL(dcd::dyn_pass2, dim3(nb2), dim3(fb),
                            (size_t)dcd::PASS2_LDS_CELLS * dcd::A_N * 8, s, A);
         hipLaunchKernelGGL(dcd::dyn_epi_cells, dim3(cell_blocks), dim3(dcd::CELL_BLOCK), 0, s, A);
         hipLaunchKernelGGL(dcd::dyn_final, dim3(1), dim3(dcd::FINAL_BLOCK), 0, s, A);
@@ -274,11 +276,12 @@ int launch_eval_neutral(bplhip_ctx* c, int chains, const double* z, double* pot,
         F.L.K = L.K;
         F.L.o_corr = L.o_corr;
         A.L = L;
-        const long long nb_all = (c->n + dcd::FIX_BLOCK - 1) / dcd::FIX_BLOCK;
+        const int fb = c->n >= (1 << 18) ? dcd::FIX_BLOCK : 256;  // threads per workgroup
+        const long long nb_all = (c->n + fb - 1) / fb;
         const int nb = (int)std::min<long long>(nb_all, 1024);
-        F.chunk = ((c->n + nb - 1) / nb + dcd::FIX_BLOCK - 1) / dcd::FIX_BLOCK * dcd::FIX_BLOCK;
+        F.chunk = ((c->n + nb - 1) / nb + fb - 1) / fb * fb;
         const int nb2 = (int)((c->n + F.chunk - 1) / F.chunk);
-        HIP_TRY(c, hipMemsetAsync(F.acc, 0, ((size_t)L.T * dcd::A_N + dcd::SC_N + L.C) * 8, s));
+        F.scratch_n = (size_t)L.T * dcd::A_N + dcd::SC_N + L.C;
         hipLaunchKernelGGL(dcn::neu_cells, dim3((L.T + 255) / 256), dim3(256), 0, s, A);
         if (!c->lds_attr_set) {
             HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(dcd::dyn_pass2),
@@ -286,8 +289,8 @@ int launch_eval_neutral(bplhip_ctx* c, int chains, const double* z, double* pot,
                                            dcd::PASS2_LDS_CELLS * dcd::A_N * 8));
             c->lds_attr_set = true;
         }
-        hipLaunchKernelGGL(dcd::dyn_pass1, dim3(nb), dim3(dcd::FIX_BLOCK), 0, s, F);
-        hipLaunchKernelGGL(dcd::dyn_pass2, dim3(nb2), dim3(dcd::FIX_BLOCK),
+        hipLaunchKernelGGL(dcd::dyn_pass1, dim3(nb), dim3(fb), 0, s, F);
+        hipLaunchKernelGGL(dcd::dyn_pass2, dim3(nb2), dim3(fb),
                            (size_t)dcd::PASS2_LDS_CELLS * dcd::A_N * 8, s, F);
         hipLaunchKernelGGL(dcn::neu_epilogue, dim3(1), dim3(dcn::NEU_EPI),
                            (size_t)(dcn::NEU_SUMS + 2 * L.K) * 8, s, A);
@@ -767,6 +770,24 @@ int bplhip_set_fixtures_neutral(bplhip_ctx* c, int64_t n, int32_t n_teams, const
         const double wi = weights ? (double)w[i] : 1.0;
         lgsum += wi * (std::lgamma((double)x[i] + 1.0) + std::lgamma((double)y[i] + 1.0));
     }
+    // sort by (venue, home, away): a wave of dyn_pass2 then usually sits on one pair and adds
+    // its 64 contributions with one set of atomics.  (Confederations follow the teams.)
+    std::vector<uint32_t> order(n);
+    {
+        for (int64_t i = 0; i < n; ++i) order[i] = (uint32_t)i;
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t p, uint32_t q) {
+            const uint64_t kp = ((uint64_t)nv[p] << 32) | ((uint64_t)h[p] << 16) | a[p];
+            const uint64_t kq = ((uint64_t)nv[q] << 32) | ((uint64_t)h[q] << 16) | a[q];
+            return kp < kq;
+        });
+        auto permute = [&](auto& v) {
+            auto t = v;
+            for (int64_t i = 0; i < n; ++i) t[i] = v[order[i]];
+            v.swap(t);
+        };
+        permute(h); permute(a); permute(x); permute(y); permute(nv);
+        if (weights) permute(w);
+    }
     HIP_TRY(c, c->d_h.ensure(n * 2));
     HIP_TRY(c, c->d_a.ensure(n * 2));
     HIP_TRY(c, c->d_x.ensure(n));
@@ -789,6 +810,11 @@ int bplhip_set_fixtures_neutral(bplhip_ctx* c, int64_t n, int32_t n_teams, const
             if (hcv[i] >= n_conf || acv[i] >= n_conf)
                 return fail(c, BPLHIP_EINVAL, "set_fixtures_neutral: confederation out of range at fixture %lld",
                             (long long)i);
+        {   // same order as the fixtures
+            auto t1 = hcv, t2 = acv;
+            for (int64_t i = 0; i < n; ++i) { t1[i] = hcv[order[i]]; t2[i] = acv[order[i]]; }
+            hcv.swap(t1); acv.swap(t2);
+        }
         HIP_TRY(c, c->dd_hc.ensure(n));
         HIP_TRY(c, c->dd_ac.ensure(n));
         HIP_TRY(c, hipMemcpy(c->dd_hc.p, hcv.data(), n, hipMemcpyHostToDevice));
@@ -1291,7 +1317,8 @@ struct VecDeviceEngine {
 // checking the chains' "all done" flags once per chunk of launches.
 int run_chains_persistent(bplhip_ctx* c, hipStream_t s, const nuts::Config& nc, int C, const double* z0,
                           const tf::Key* keys, double* draws_out, std::vector<nuts::Result>* res) {
-    const int D = c->L.D, md = nc.max_tree_depth;
+    const int D = bplhip_latent_dim(c), md = nc.max_tree_depth;
+    const bool generic = c->neutral || c->dynamic;  // evaluation != dc_eval: leaf as its own launch
     const int n_iter = nc.num_warmup + nc.num_samples;
     const int kept = nc.num_samples / nc.thinning;
     const size_t nsd = (nd::ns_doubles(D, md) + 1) & ~(size_t)1;
@@ -1413,6 +1440,16 @@ int run_chains_persistent(bplhip_ctx* c, hipStream_t s, const nuts::Config& nc, 
             return fail(c, BPLHIP_EHIP, "persistent nuts: chains did not finish within the leapfrog bound");
         steps_done += chunk;
         for (int k = 0; k < chunk; ++k) {
+            if (generic) {
+                for (int ch = 0; ch < C && rc == BPLHIP_OK; ++ch) {
+                    double* nsc = ns + (size_t)ch * stride;
+                    rc = launch_eval(c, 1, nd::vec(nsc, D, nd::V_ZN), nsc + nd::H_LEAF_PE,
+                                     nd::vec(nsc, D, nd::V_GRAD), nsc + nd::H_LEAF_AUX0, s);
+                }
+                if (rc != BPLHIP_OK) return rc;
+                hipLaunchKernelGGL(nd::kp_leaf, dim3(C), dim3(64), (size_t)(D + 8) * 8, s, ns, stride, D, md, P);
+                continue;
+            }
             rc = C == 1 ? launch_eval(c, 1, nd::vec(ns, D, nd::V_ZN), ns + nd::H_LEAF_PE, nd::vec(ns, D, nd::V_GRAD),
                                       ns + nd::H_LEAF_AUX0, s, ns, md, dP)
                         : launch_eval_vec(c, C, nd::vec(ns, D, nd::V_ZN), ns + nd::H_LEAF_PE,
@@ -1578,10 +1615,14 @@ extern "C" int bplhip_nuts_run(bplhip_ctx* c, const bplhip_nuts_cfg* cfg, const 
     int dev_rc = BPLHIP_OK;
     const bool device_tree = c->opt_device_nuts && !c->dynamic && !c->neutral && c->L.T <= 64 && c->staged &&
                              c->L.D <= 64 * nd::LEAF_NE;
-    if (device_tree && c->opt_persistent_nuts) {
+    const bool generic_persist = c->opt_device_nuts && c->opt_persistent_nuts && c->neutral &&
+                                 D <= 64 * nd::LEAF_NE;
+    if ((device_tree || generic_persist) && c->opt_persistent_nuts) {
         // the whole chain on the device (nuts_dev.hip.h, persistent chains)
-        int rc1 = ensure_slabs(c, 1);
-        if (rc1 != BPLHIP_OK) return rc1;
+        if (!generic_persist) {
+            int rc1 = ensure_slabs(c, 1);
+            if (rc1 != BPLHIP_OK) return rc1;
+        }
         const tf::Key k1{seed_hi, seed_lo};
         std::vector<nuts::Result> pres;
         const int prc = run_chains_persistent(c, static_cast<hipStream_t>(stream), nc, 1, z0, &k1,
@@ -1634,17 +1675,22 @@ extern "C" int bplhip_nuts_run_chains(bplhip_ctx* c, const bplhip_nuts_cfg* cfg,
     if (cfg->num_warmup < 0 || cfg->num_samples < 1 || cfg->max_tree_depth < 1 ||
         cfg->max_tree_depth > 20 || cfg->thinning < 1 || !(cfg->step_size > 0))
         return fail(c, BPLHIP_EINVAL, "nuts_run_chains: bad configuration");
-    if (!vec_ok(c) || c->L.T > 64 ||
-        !(c->vps[0].staged && c->vps[1].staged && c->vps[2].staged) || c->L.D > 64 * nd::LEAF_NE)
+    // neutral-venue family: persistent chains with the leaf as its own launch (kp_leaf)
+    const bool generic_ok = c->neutral && c->opt_persistent_nuts && bplhip_latent_dim(c) <= 64 * nd::LEAF_NE;
+    if (!generic_ok &&
+        (!vec_ok(c) || c->L.T > 64 ||
+         !(c->vps[0].staged && c->vps[1].staged && c->vps[2].staged) || c->L.D > 64 * nd::LEAF_NE))
         return fail(c, BPLHIP_EUNSUPPORTED,
-                    "nuts_run_chains: lock-step chains need the basic/extended model with <= 64 teams");
+                    "nuts_run_chains: chains on the device need <= 64 teams (basic / extended / neutral models)");
     HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const int D = c->L.D, C = n_chains;
+    const int D = bplhip_latent_dim(c), C = n_chains;
     const nuts::Config nc = make_nuts_config(c, cfg);
     if (c->opt_persistent_nuts) {
-        int rc0 = ensure_slabs(c, 1);
-        if (rc0 != BPLHIP_OK) return rc0;
+        if (!generic_ok) {
+            int rc0 = ensure_slabs(c, 1);
+            if (rc0 != BPLHIP_OK) return rc0;
+        }
         std::vector<tf::Key> pkeys(C);
         for (int ch = 0; ch < C; ++ch) pkeys[ch] = tf::Key{seeds[2 * ch], seeds[2 * ch + 1]};
         std::vector<nuts::Result> pres;

@@ -26,6 +26,7 @@
 #include <stdint.h>
 
 #include "dc_layout.h"
+#include "dc_kernels.hip.h"  // DPP wave reductions
 
 namespace dcd {
 
@@ -162,7 +163,7 @@ __device__ __forceinline__ double wave_suffix(double v, int lane) {
 }
 
 constexpr int CELL_BLOCK = 256;   // 4 waves = 4 teams per workgroup
-constexpr int FIX_BLOCK = 256;
+constexpr int FIX_BLOCK = 1024;       // largest workgroup of the fixture passes (launches use 256 or 1024)
 
 // ---- per-(gameweek, team) constrained sites: one wave per team, lanes over gameweeks
 __global__ __launch_bounds__(CELL_BLOCK) void dyn_cells(DynArgs A) {
@@ -247,8 +248,8 @@ __device__ __forceinline__ void fixture_etas(const DynArgs& A, long long i, int*
 __global__ __launch_bounds__(FIX_BLOCK) void dyn_pass1(DynArgs A) {
     __shared__ unsigned long long shm[3 * (FIX_BLOCK / 64)];
     unsigned long long mP = 0, mH = 0, mA = 0;
-    for (long long i = (long long)blockIdx.x * FIX_BLOCK + threadIdx.x; i < A.n;
-         i += (long long)gridDim.x * FIX_BLOCK) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < A.n;
+         i += (long long)gridDim.x * blockDim.x) {
         int ch, ca, nv;
         double eh, ea;
         fixture_etas(A, i, &ch, &ca, &nv, &eh, &ea);
@@ -270,7 +271,7 @@ __global__ __launch_bounds__(FIX_BLOCK) void dyn_pass1(DynArgs A) {
     __syncthreads();
     if (threadIdx.x < 3) {
         unsigned long long m = 0;
-        for (int w = 0; w < FIX_BLOCK / 64; ++w) m = shm[w * 3 + threadIdx.x] > m ? shm[w * 3 + threadIdx.x] : m;
+        for (int w = 0; w < (int)blockDim.x / 64; ++w) m = shm[w * 3 + threadIdx.x] > m ? shm[w * 3 + threadIdx.x] : m;
         unsigned long long* sc = reinterpret_cast<unsigned long long*>(A.sc);
         atomicMax(&sc[SC_MAXP + threadIdx.x], m);
     }
@@ -301,58 +302,83 @@ __global__ __launch_bounds__(FIX_BLOCK) void dyn_pass2(DynArgs A) {
     const int cell0 = g_lo * T;
     double* lconf = lacc + (size_t)ncell * A_N;  // [n_conf] (private path)
     if (priv) {
-        for (int k = threadIdx.x; k < ncell * A_N + A.n_conf; k += FIX_BLOCK) lacc[k] = 0.0;
+        for (int k = threadIdx.x; k < ncell * A_N + A.n_conf; k += blockDim.x) lacc[k] = 0.0;
         __syncthreads();
     }
     double Ui = 0.0, ui = 0.0;
-    for (long long i = i0 + threadIdx.x; i < i1; i += FIX_BLOCK) {
-        int ch, ca, nv;
-        double eh, ea;
-        fixture_etas(A, i, &ch, &ca, &nv, &eh, &ea);
-        const double lh = exp(eh), la = exp(ea);
-        const int x = A.x[i], y = A.y[i];
-        const double wi = A.w ? (double)A.w[i] : 1.0;
-        double Uf = x * eh - lh + y * ea - la;
-        double gh = x - lh, ga = y - la;
-        if (x <= 1 && y <= 1) {
-            const double c = x == 0 ? (y == 0 ? -lh * la : lh) : (y == 0 ? la : -1.0);
-            const double arg = 1.0 + rho * c;
-            if (arg > 0.0) {
-                Uf += log(arg);
-                const double u = c / arg;
-                ui += wi * u;
-                if (x == 0) gh += rho * u;
-                if (y == 0) ga += rho * u;
-            } else {
-                Uf += log(0.0);  // -inf (tol = 0, bpl/_util.py:42)
+    const int lane_ = threadIdx.x & 63;
+    for (long long base = i0; base < i1; base += blockDim.x) {  // (wave-uniform trip count)
+        const long long i = base + threadIdx.x;
+        const bool active = i < i1;
+        int ch = 0, ca = 0, nv = 0, hcv = 0, acv = 0;
+        double gh = 0.0, ga = 0.0;
+        if (active) {
+            double eh, ea;
+            fixture_etas(A, i, &ch, &ca, &nv, &eh, &ea);
+            if (A.hc) { hcv = A.hc[i]; acv = A.ac[i]; }
+            const double lh = exp(eh), la = exp(ea);
+            const int x = A.x[i], y = A.y[i];
+            const double wi = A.w ? (double)A.w[i] : 1.0;
+            double Uf = x * eh - lh + y * ea - la;
+            gh = x - lh;
+            ga = y - la;
+            if (x <= 1 && y <= 1) {
+                const double c = x == 0 ? (y == 0 ? -lh * la : lh) : (y == 0 ? la : -1.0);
+                const double arg = 1.0 + rho * c;
+                if (arg > 0.0) {
+                    Uf += log(arg);
+                    const double u = c / arg;
+                    ui += wi * u;
+                    if (x == 0) gh += rho * u;
+                    if (y == 0) ga += rho * u;
+                } else {
+                    Uf += log(0.0);  // -inf (tol = 0, bpl/_util.py:42)
+                }
+            }
+            Ui += wi * Uf;
+            gh *= wi;
+            ga *= wi;
+            unsigned long long* sc = reinterpret_cast<unsigned long long*>(A.sc);
+            // arg-extremal fixtures: smallest index among those attaining the maximum
+            // (stored as ~0 - i under atomicMax, so the zeroed word means "none")
+            if (lh * la == M) atomicMax(&sc[SC_IDXP], ~0ull - (unsigned long long)i);
+            if (lh == Lh) atomicMax(&sc[SC_IDXQ], ~0ull - (unsigned long long)i);
+            if (la == La) atomicMax(&sc[SC_IDXR], ~0ull - (unsigned long long)i);
+        }
+        // accumulate: when the whole wave sits on one (home cell, away cell, venue,
+        // confederations) -- the usual case for fixtures sorted by pair -- reduce by DPP and
+        // add once; 64 same-address atomics would serialise
+        const unsigned long long am = __ballot(active);
+        if (am == 0ull) continue;
+        const int first = __ffsll((long long)am) - 1;
+        const int k_ch = __shfl(ch, first, 64), k_ca = __shfl(ca, first, 64), k_nv = __shfl(nv, first, 64),
+                  k_hc = __shfl(hcv, first, 64), k_ac = __shfl(acv, first, 64);
+        const bool same = !active || (ch == k_ch && ca == k_ca && nv == k_nv && hcv == k_hc && acv == k_ac);
+        const bool uniform = __all(same);
+        if (uniform) {
+            gh = dc::wave_sum_f64(gh);
+            ga = dc::wave_sum_f64(ga);
+            ch = k_ch; ca = k_ca; nv = k_nv; hcv = k_hc; acv = k_ac;
+        }
+        if (uniform ? lane_ == first : active) {
+            double* Ah = priv ? lacc + (size_t)(ch - cell0) * A_N : A.acc + (size_t)ch * A_N;
+            double* Aa = priv ? lacc + (size_t)(ca - cell0) * A_N : A.acc + (size_t)ca * A_N;
+            atomicAdd(&Ah[A_ATT], gh);
+            atomicAdd(&Aa[A_DEF], -gh);
+            atomicAdd(&Aa[A_ATT], ga);
+            atomicAdd(&Ah[A_DEF], -ga);
+            if (!nv) {
+                atomicAdd(&Ah[A_HATT], gh);
+                atomicAdd(&Aa[A_ADEF], -gh);
+                atomicAdd(&Aa[A_AATT], ga);
+                atomicAdd(&Ah[A_HDEF], -ga);
+            }
+            if (A.hc) {
+                double* cacc = priv ? lconf : A.cacc;
+                atomicAdd(&cacc[hcv], gh - ga);
+                atomicAdd(&cacc[acv], ga - gh);
             }
         }
-        Ui += wi * Uf;
-        gh *= wi;
-        ga *= wi;
-        double* Ah = priv ? lacc + (size_t)(ch - cell0) * A_N : A.acc + (size_t)ch * A_N;
-        double* Aa = priv ? lacc + (size_t)(ca - cell0) * A_N : A.acc + (size_t)ca * A_N;
-        atomicAdd(&Ah[A_ATT], gh);
-        atomicAdd(&Aa[A_DEF], -gh);
-        atomicAdd(&Aa[A_ATT], ga);
-        atomicAdd(&Ah[A_DEF], -ga);
-        if (!nv) {
-            atomicAdd(&Ah[A_HATT], gh);
-            atomicAdd(&Aa[A_ADEF], -gh);
-            atomicAdd(&Aa[A_AATT], ga);
-            atomicAdd(&Ah[A_HDEF], -ga);
-        }
-        if (A.hc) {
-            double* cacc = priv ? lconf : A.cacc;
-            atomicAdd(&cacc[A.hc[i]], gh - ga);
-            atomicAdd(&cacc[A.ac[i]], ga - gh);
-        }
-        unsigned long long* sc = reinterpret_cast<unsigned long long*>(A.sc);
-        // arg-extremal fixtures: smallest index among those attaining the maximum
-        // (stored as ~0 - i under atomicMax, so the zeroed word means "none")
-        if (lh * la == M) atomicMax(&sc[SC_IDXP], ~0ull - (unsigned long long)i);
-        if (lh == Lh) atomicMax(&sc[SC_IDXQ], ~0ull - (unsigned long long)i);
-        if (la == La) atomicMax(&sc[SC_IDXR], ~0ull - (unsigned long long)i);
     }
     Ui = wave_sum(Ui);
     ui = wave_sum(ui);
@@ -364,15 +390,15 @@ __global__ __launch_bounds__(FIX_BLOCK) void dyn_pass2(DynArgs A) {
     __syncthreads();
     if (threadIdx.x < 2) {
         double v = 0.0;
-        for (int w = 0; w < FIX_BLOCK / 64; ++w) v += shr[w * 2 + threadIdx.x];
+        for (int w = 0; w < (int)blockDim.x / 64; ++w) v += shr[w * 2 + threadIdx.x];
         atomicAdd(&A.sc[threadIdx.x == 0 ? SC_U : SC_GRHO], v);
     }
     if (priv) {
-        for (int k = threadIdx.x; k < ncell * A_N; k += FIX_BLOCK) {
+        for (int k = threadIdx.x; k < ncell * A_N; k += blockDim.x) {
             const double v = lacc[k];
             if (v != 0.0) atomicAdd(&A.acc[(size_t)cell0 * A_N + k], v);
         }
-        for (int k = threadIdx.x; k < A.n_conf; k += FIX_BLOCK) {
+        for (int k = threadIdx.x; k < A.n_conf; k += blockDim.x) {
             const double v = lconf[k];
             if (v != 0.0) atomicAdd(&A.cacc[k], v);
         }
@@ -385,30 +411,46 @@ struct Coupling {  // entries {cell, accumulator, value}; accumulator A_N = conf
     int cell[18], which[18];
     double val[18];
 };
-__device__ inline void coupling_add(const DynArgs& A, Coupling& C, long long idx1, bool home_rate,
-                                    double v) {
-    if (idx1 == 0) return;
-    const long long i = idx1 - 1;
-    const int T = A.L.T;
-    const int g = A.gw ? A.gw[i] : 0, h = A.h[i], a = A.a[i], nv = A.nv[i];
-    const int ch = g * T + h, ca = g * T + a;
-    auto put = [&](int cell, int which, double val) {
-        C.cell[C.n] = cell; C.which[C.n] = which; C.val[C.n] = val;
-        ++C.n;
-    };
-    if (home_rate) {  // d/d eta_h
-        put(ch, A_ATT, v); put(ca, A_DEF, -v);
-        if (!nv) { put(ch, A_HATT, v); put(ca, A_ADEF, -v); }
-        if (A.hc) { put(A.hc[i], A_N, v); put(A.ac[i], A_N, -v); }
-    } else {
-        put(ca, A_ATT, v); put(ch, A_DEF, -v);
-        if (!nv) { put(ca, A_AATT, v); put(ch, A_HDEF, -v); }
-        if (A.hc) { put(A.ac[i], A_N, v); put(A.hc[i], A_N, -v); }
-    }
-}
 struct Bounds {
     double M, Lh, La, q, dq, sq, UB, LB, rho, G_rho;
 };
+// a sigmoid-transformed site from ONE exp and ONE log1p: value (clipped), derivative, log v,
+// log(1-v), unclipped sigmoid and softplus(z) + softplus(-z) (the Jacobian term)
+struct SigSite {
+    double v, dv, log_v, log_1mv, sig, sp_sum;
+};
+__device__ inline SigSite sig_site(double zr) {
+    const double az = fabs(zr), ez = exp(-az), l1 = log1p(ez);
+    const double sp_pos = az + l1;                 // softplus(|z|)
+    const double s_abs = 1.0 / (1.0 + ez);
+    SigSite r;
+    r.sig = zr >= 0 ? s_abs : 1.0 - s_abs;
+    r.sp_sum = sp_pos + l1;
+    r.v = r.sig;
+    r.dv = r.sig * (1.0 - r.sig);
+    r.log_v = zr >= 0 ? -l1 : -sp_pos;             // log sigmoid(z)   = -softplus(-z)
+    r.log_1mv = zr >= 0 ? -sp_pos : -l1;           // log(1-sigmoid(z)) = -softplus(z)
+    if (r.sig < dc::SIG_LO || r.sig > dc::SIG_HI) {
+        r.v = r.sig < dc::SIG_LO ? dc::SIG_LO : dc::SIG_HI;
+        r.dv = 0.0;
+        r.log_v = log(r.v);
+        r.log_1mv = log1p(-r.v);
+    }
+    return r;
+}
+__device__ inline Bounds bounds_from(const DynArgs& A, double q, double dq, double sq) {
+    Bounds b;
+    const unsigned long long* scu = reinterpret_cast<const unsigned long long*>(A.sc);
+    b.M = __longlong_as_double((long long)scu[SC_MAXP]);
+    b.Lh = __longlong_as_double((long long)scu[SC_MAXH]);
+    b.La = __longlong_as_double((long long)scu[SC_MAXA]);
+    b.q = q; b.dq = dq; b.sq = sq;
+    b.UB = b.M > 1.0 ? 1.0 / b.M : 1.0;
+    b.LB = -1.0 / fmax(b.Lh, b.La);
+    b.rho = b.LB + b.q * (b.UB - b.LB);
+    b.G_rho = A.sc[SC_GRHO];
+    return b;
+}
 __device__ inline Bounds load_bounds(const DynArgs& A) {
     Bounds b;
     const unsigned long long* scu = reinterpret_cast<const unsigned long long*>(A.sc);
@@ -423,6 +465,60 @@ __device__ inline Bounds load_bounds(const DynArgs& A) {
     return b;
 }
 
+// Build the workgroup's coupling table in LDS.  The (at most two) arg-extremal fixtures are
+// fetched by two threads at once: their indices come out of the scratch words, so a single
+// thread would pay one dependent global round trip per fixture.
+struct CouplingFix {
+    int g, h, a, nv, hc, ac, have;
+};
+__device__ inline void build_coupling(const DynArgs& A, const Bounds& b, Coupling* C, CouplingFix* F,
+                                      int tid) {
+    const unsigned long long* scu = reinterpret_cast<const unsigned long long*>(A.sc);
+    const bool lb_home = b.Lh >= b.La;
+    if (tid < 2) {
+        const unsigned long long w = tid == 0 ? scu[SC_IDXP] : (lb_home ? scu[SC_IDXQ] : scu[SC_IDXR]);
+        CouplingFix f{};
+        f.have = w != 0 && (tid == 1 || b.M > 1.0);
+        if (f.have) {
+            const long long i = (long long)(~0ull - w);
+            f.g = A.gw ? A.gw[i] : 0;
+            f.h = A.h[i];
+            f.a = A.a[i];
+            f.nv = A.nv[i];
+            f.hc = A.hc ? A.hc[i] : 0;
+            f.ac = A.hc ? A.ac[i] : 0;
+        }
+        F[tid] = f;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        C->n = 0;
+        const int T = A.L.T;
+        auto add = [&](const CouplingFix& f, bool home_rate, double v) {
+            if (!f.have) return;
+            const int ch = f.g * T + f.h, ca = f.g * T + f.a;
+            auto put = [&](int cell, int which, double val) {
+                C->cell[C->n] = cell; C->which[C->n] = which; C->val[C->n] = val;
+                ++C->n;
+            };
+            if (home_rate) {  // d/d eta_h
+                put(ch, A_ATT, v); put(ca, A_DEF, -v);
+                if (!f.nv) { put(ch, A_HATT, v); put(ca, A_ADEF, -v); }
+                if (A.hc) { put(f.hc, A_N, v); put(f.ac, A_N, -v); }
+            } else {
+                put(ca, A_ATT, v); put(ch, A_DEF, -v);
+                if (!f.nv) { put(ca, A_AATT, v); put(ch, A_HDEF, -v); }
+                if (A.hc) { put(f.ac, A_N, v); put(f.hc, A_N, -v); }
+            }
+        };
+        const double vP = b.G_rho * b.q * (-b.UB);
+        add(F[0], true, vP);
+        add(F[0], false, vP);
+        add(F[1], lb_home, b.G_rho * (1.0 - b.q) * (-b.LB));
+    }
+    __syncthreads();
+}
+
 // ---- per-cell chain rule: one wave per team, lanes over gameweeks (from the last one)
 __global__ __launch_bounds__(CELL_BLOCK) void dyn_epi_cells(DynArgs A) {
     const DynLayout& L = A.L;
@@ -435,21 +531,8 @@ __global__ __launch_bounds__(CELL_BLOCK) void dyn_epi_cells(DynArgs A) {
     // adjoint of the bounds: built once per workgroup in LDS (a per-thread table would live in
     // scratch memory), read by every lane
     __shared__ Coupling C;
-    if (threadIdx.x == 0) {
-        C.n = 0;
-        const unsigned long long* scu = reinterpret_cast<const unsigned long long*>(A.sc);
-        if (b.M > 1.0) {
-            const double v = b.G_rho * b.q * (-b.UB);
-            const long long ip = scu[SC_IDXP] ? (long long)(~0ull - scu[SC_IDXP]) + 1 : 0;
-            coupling_add(A, C, ip, true, v);
-            coupling_add(A, C, ip, false, v);
-        }
-        const double lbv = b.G_rho * (1.0 - b.q) * (-b.LB);
-        const bool lb_home = b.Lh >= b.La;
-        const unsigned long long w = lb_home ? scu[SC_IDXQ] : scu[SC_IDXR];
-        coupling_add(A, C, w ? (long long)(~0ull - w) + 1 : 0, lb_home, lbv);
-    }
-    __syncthreads();
+    __shared__ CouplingFix CF[2];
+    build_coupling(A, b, &C, CF, threadIdx.x);
     const int cn = C.n;
     auto coupled = [&](int cell, int which, double base) {
         double v = base;

@@ -17,6 +17,7 @@
 #include <stdint.h>
 
 #include "dc_dynamic.hip.h"
+#include "dc_kernels.hip.h"  // DPP wave reductions
 
 namespace dcn {
 
@@ -71,6 +72,8 @@ __global__ __launch_bounds__(256) void neu_cells(NeuArgs A) {
     const NeuLayout& L = A.L;
     const double* z = A.F.z;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    // this launch also clears the evaluation's scratch (acc | sc | cacc)
+    for (size_t i = t; i < A.F.scratch_n; i += (size_t)gridDim.x * blockDim.x) A.F.acc[i] = 0.0;
     if (t >= L.T) return;
     double att = 0.0, def = z[L.o_md];
     for (int k = 0; k < L.K; ++k) {
@@ -106,36 +109,49 @@ __global__ __launch_bounds__(NEU_EPI) void neu_epilogue(NeuArgs A) {
     const int tid = threadIdx.x;
     const double* z = A.F.z;
     double* grad = A.F.grad;
-    for (int i = tid; i < NEU_SUMS + 2 * K; i += NEU_EPI) sums[i] = 0.0;
-    __syncthreads();
-
-    const dcd::Bounds b = dcd::load_bounds(A.F);
-    dcd::Coupling C;
-    C.n = 0;
+    // this thread's first team: requested before anything else, so the global round trips
+    // overlap with the scalar sites and the coupling fetch below
+    double pG[dcd::A_N], pz[6];
     {
-        const unsigned long long* scu = reinterpret_cast<const unsigned long long*>(A.F.sc);
-        if (b.M > 1.0) {
-            const double v = b.G_rho * b.q * (-b.UB);
-            const long long ip = scu[dcd::SC_IDXP] ? (long long)(~0ull - scu[dcd::SC_IDXP]) + 1 : 0;
-            dcd::coupling_add(A.F, C, ip, true, v);
-            dcd::coupling_add(A.F, C, ip, false, v);
-        }
-        const double lbv = b.G_rho * (1.0 - b.q) * (-b.LB);
-        const bool lb_home = b.Lh >= b.La;
-        const unsigned long long w = lb_home ? scu[dcd::SC_IDXQ] : scu[dcd::SC_IDXR];
-        dcd::coupling_add(A.F, C, w ? (long long)(~0ull - w) + 1 : 0, lb_home, lbv);
+        const int t0 = tid < T ? tid : 0;
+        const double* Ac = A.F.acc + (size_t)t0 * dcd::A_N;
+#pragma unroll
+        for (int j = 0; j < dcd::A_N; ++j) pG[j] = Ac[j];
+        pz[0] = z[L.o_sat + t0]; pz[1] = z[L.o_sdt + t0]; pz[2] = z[L.o_hat + t0];
+        pz[3] = z[L.o_aat + t0]; pz[4] = z[L.o_hdf + t0]; pz[5] = z[L.o_adf + t0];
     }
+    for (int i = tid; i < NEU_SUMS + 2 * K; i += NEU_EPI) sums[i] = 0.0;
+    // scalar sites first, in parallel lanes of one wave (a float64 libm call costs ~1 us of
+    // dependent instructions: they must not run one after another on one lane):
+    //   lanes 0..5 exp(std sites) | lanes 6, 7 sigmoid sites u, corr_coef_raw
+    __shared__ double scal[6 + 2 * 6];
+    if (tid < 6) {
+        const int o = tid == 0 ? L.o_s_att : tid == 1 ? L.o_s_def : tid == 2 ? L.o_s_ha
+                    : tid == 3 ? L.o_s_aa : tid == 4 ? L.o_s_hd : L.o_s_ad;
+        scal[tid] = exp(z[o]);
+    } else if (tid < 8) {
+        const dcd::SigSite ss = dcd::sig_site(z[tid == 6 ? L.o_u : L.o_corr]);
+        double* q = scal + 6 + (tid - 6) * 6;
+        q[0] = ss.v; q[1] = ss.dv; q[2] = ss.log_v; q[3] = ss.log_1mv; q[4] = ss.sig; q[5] = ss.sp_sum;
+    }
+    __syncthreads();
+    const double* su_ = scal + 6;       // u site
+    const double* sc_ = scal + 12;      // corr_coef_raw site
+    const dcd::Bounds b = dcd::bounds_from(A.F, sc_[0], sc_[1], sc_[4]);
+    // adjoint of the bounds: one table per workgroup in LDS
+    __shared__ dcd::Coupling C;
+    __shared__ dcd::CouplingFix CF[2];
+    dcd::build_coupling(A.F, b, &C, CF, tid);
+    const int cn = C.n;
     auto coupled = [&](int cell, int which, double base) {
         double v = base;
-        for (int e = 0; e < C.n; ++e)
+        for (int e = 0; e < cn; ++e)
             if (C.cell[e] == cell && C.which[e] == which) v += C.val[e];
         return v;
     };
-    const double s_att = exp(z[L.o_s_att]), s_def = exp(z[L.o_s_def]), s_ha = exp(z[L.o_s_ha]),
-                 s_aa = exp(z[L.o_s_aa]), s_hd = exp(z[L.o_s_hd]), s_ad = exp(z[L.o_s_ad]);
-    const double zu = z[L.o_u];
-    double u, du, su;
-    dcd::clipped_sig(zu, &u, &du, &su);
+    const double s_att = scal[0], s_def = scal[1], s_ha = scal[2], s_aa = scal[3], s_hd = scal[4],
+                 s_ad = scal[5];
+    const double u = su_[0], du = su_[1], su = su_[4];
     const double rp = 2.0 * u - 1.0, vv = 1.0 - rp * rp, log_vv = log(vv);
 
     double loc[NEU_SUMS];
@@ -143,18 +159,24 @@ __global__ __launch_bounds__(NEU_EPI) void neu_epilogue(NeuArgs A) {
     for (int i = 0; i < NEU_SUMS; ++i) loc[i] = 0.0;
     for (int t = tid; t < T; t += NEU_EPI) {
         const double* Ac = A.F.acc + (size_t)t * dcd::A_N;
-        const double G_att = coupled(t, dcd::A_ATT, Ac[dcd::A_ATT]);
-        const double G_def = coupled(t, dcd::A_DEF, Ac[dcd::A_DEF]);
-        const double G_hat = coupled(t, dcd::A_HATT, Ac[dcd::A_HATT]);
-        const double G_adf = coupled(t, dcd::A_ADEF, Ac[dcd::A_ADEF]);
-        const double G_aat = coupled(t, dcd::A_AATT, Ac[dcd::A_AATT]);
-        const double G_hdf = coupled(t, dcd::A_HDEF, Ac[dcd::A_HDEF]);
-        const double sa = z[L.o_sat + t], sd = z[L.o_sdt + t];
+        double G6[dcd::A_N];
+#pragma unroll
+        for (int j = 0; j < dcd::A_N; ++j) G6[j] = t == tid ? pG[j] : Ac[j];
+        bool hit = false;  // (at most three fixtures' teams carry a bounds adjoint)
+        for (int e = 0; e < cn; ++e) hit = hit || (C.cell[e] == t && C.which[e] < dcd::A_N);
+        if (hit) {
+#pragma unroll
+            for (int j = 0; j < dcd::A_N; ++j) G6[j] = coupled(t, j, G6[j]);
+        }
+        const double G_att = G6[dcd::A_ATT], G_def = G6[dcd::A_DEF], G_hat = G6[dcd::A_HATT],
+                     G_adf = G6[dcd::A_ADEF], G_aat = G6[dcd::A_AATT], G_hdf = G6[dcd::A_HDEF];
+        const bool first = t == tid;
+        const double sa = first ? pz[0] : z[L.o_sat + t], sd = first ? pz[1] : z[L.o_sdt + t];
         const double e = sd - rp * sa;
         grad[L.o_sat + t] = -(s_att * G_att - sa + rp * e / vv);
         grad[L.o_sdt + t] = -(s_def * G_def - e / vv);
-        const double hat = z[L.o_hat + t], aat = z[L.o_aat + t], hdf = z[L.o_hdf + t],
-                     adf = z[L.o_adf + t];
+        const double hat = first ? pz[2] : z[L.o_hat + t], aat = first ? pz[3] : z[L.o_aat + t],
+                     hdf = first ? pz[4] : z[L.o_hdf + t], adf = first ? pz[5] : z[L.o_adf + t];
         grad[L.o_hat + t] = -(s_ha * G_hat - hat);
         grad[L.o_aat + t] = -(s_aa * G_aat - aat);
         grad[L.o_hdf + t] = -(s_hd * G_hdf - hdf);
@@ -173,10 +195,14 @@ __global__ __launch_bounds__(NEU_EPI) void neu_epilogue(NeuArgs A) {
             atomicAdd(&sums[NEU_SUMS + K + k], xv * G_def);
         }
     }
+    // wave sums by DPP (same-address LDS atomics from many lanes serialise badly), then one
+    // LDS atomic per wave and value
+    if ((tid & ~63) < T) {
 #pragma unroll
-    for (int i = 0; i < NEU_SUMS; ++i) {
-        const double v = dcd::wave_sum(loc[i]);
-        if ((tid & 63) == 0) atomicAdd(&sums[i], v);
+        for (int i = 0; i < NEU_SUMS; ++i) {
+            const double v = dc::wave_sum_f64(loc[i]);
+            if ((tid & 63) == 0) atomicAdd(&sums[i], v);
+        }
     }
     __syncthreads();
 
@@ -188,52 +214,56 @@ __global__ __launch_bounds__(NEU_EPI) void neu_epilogue(NeuArgs A) {
         const double G = coupled(cf, dcd::A_N, A.F.cacc[cf]);
         grad[L.o_conf + cf] = -(G - z[L.o_conf + cf]);
     }
-    if (tid == 0) {
-        double Ltot = sums[12] + A.F.sc[dcd::SC_U] - A.F.lgsum;
-        for (int k = 0; k < 2 * K; ++k) {
+    // scalar sites, one per lane of wave 0: 0..5 HalfNormal stds | 6..9 Normal means | 10 u | 11 corr
+    if (tid < 64) {
+        double Lp = 0.0;
+        if (tid < 6) {  // HalfNormal(scale) in log space: std_attack / std_defence scale 0.5, others 1
+            const int o = tid == 0 ? L.o_s_att : tid == 1 ? L.o_s_def : tid == 2 ? L.o_s_ha
+                        : tid == 3 ? L.o_s_aa : tid == 4 ? L.o_s_hd : L.o_s_ad;
+            const double sv = tid == 0 ? s_att : tid == 1 ? s_def : tid == 2 ? s_ha
+                            : tid == 3 ? s_aa : tid == 4 ? s_hd : s_ad;
+            const double scale = tid < 2 ? 0.5 : 1.0;
+            const double dotG = tid == 0 ? sums[1] : tid == 1 ? sums[2] : sums[6 + tid];
+            const double r = sv / scale;
+            Lp = LN2 - (tid < 2 ? -LN2 : 0.0) - HALF_LOG_2PI - 0.5 * r * r + z[o];  // log(0.5) = -ln 2
+            grad[o] = -(sv * dotG - r * r + 1.0);
+        } else if (tid < 10) {
+            const int j = tid - 6;
+            const int o = j == 0 ? L.o_mha : j == 1 ? L.o_maa : j == 2 ? L.o_mhd : L.o_mad;
+            const double mu = (j & 1) ? -0.1 : 0.1;
+            const double mean = z[o], r = (mean - mu) / 0.2;
+            Lp = -0.5 * r * r + 1.6094379124341003 - HALF_LOG_2PI;
+            grad[o] = -(sums[4 + j] - (mean - mu) / 0.04);
+        } else if (tid == 10) {  // u ~ Beta(2,4) through the sigmoid
+            Lp = su_[2] + 3.0 * su_[3] + 2.995732273553991 - su_[5];
+            grad[L.o_u] = -((1.0 / u - 3.0 / (1.0 - u)) * du + 2.0 * sums[0] * du + (1.0 - 2.0 * su));
+        } else if (tid == 11) {  // corr_coef_raw ~ Beta(2,2)
+            Lp = sc_[2] + sc_[3] + 1.791759469228055 - sc_[5];
+            grad[L.o_corr] = -((1.0 / b.q - 1.0 / (1.0 - b.q)) * b.dq + (1.0 - 2.0 * b.sq) +
+                               b.G_rho * (b.UB - b.LB) * b.dq);
+        } else if (tid == 12) {
+            const double m = z[L.o_md];
+            Lp = -0.5 * m * m - HALF_LOG_2PI;
+            grad[L.o_md] = -(sums[3] - m);
+        }
+        for (int k = tid; k < 2 * K; k += 64) {
             const int o = k < K ? L.o_bA + k : L.o_bD + k - K;
-            Ltot += -0.5 * z[o] * z[o] - HALF_LOG_2PI;
+            Lp += -0.5 * z[o] * z[o] - HALF_LOG_2PI;
         }
-        for (int cf = 0; cf < L.C; ++cf) {
+        for (int cf = tid; cf < L.C; cf += 64) {
             const double v = z[L.o_conf + cf];
-            Ltot += -0.5 * v * v - HALF_LOG_2PI;
+            Lp += -0.5 * v * v - HALF_LOG_2PI;
         }
-        const double m = z[L.o_md];
-        Ltot += -0.5 * m * m - HALF_LOG_2PI;
-        grad[L.o_md] = -(sums[3] - m);
-        // HalfNormal(scale) sites in log space: std_attack / std_defence scale 0.5, others 1
-        const int o_std[6] = {L.o_s_att, L.o_s_def, L.o_s_ha, L.o_s_aa, L.o_s_hd, L.o_s_ad};
-        const double sv[6] = {s_att, s_def, s_ha, s_aa, s_hd, s_ad};
-        const double scale[6] = {0.5, 0.5, 1.0, 1.0, 1.0, 1.0};
-        const double dotG[6] = {sums[1], sums[2], sums[8], sums[9], sums[10], sums[11]};
-#pragma unroll
-        for (int j = 0; j < 6; ++j) {
-            const double r = sv[j] / scale[j];
-            Ltot += LN2 - log(scale[j]) - HALF_LOG_2PI - 0.5 * r * r + z[o_std[j]];
-            grad[o_std[j]] = -(sv[j] * dotG[j] - r * r + 1.0);
-        }
-        const int o_mean[4] = {L.o_mha, L.o_maa, L.o_mhd, L.o_mad};
-        const double mu[4] = {0.1, -0.1, 0.1, -0.1};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const double mean = z[o_mean[j]];
-            const double r = (mean - mu[j]) / 0.2;
-            Ltot += -0.5 * r * r + 1.6094379124341003 - HALF_LOG_2PI;
-            grad[o_mean[j]] = -(sums[4 + j] - (mean - mu[j]) / 0.04);
-        }
-        // u ~ Beta(2,4) through the sigmoid; corr_coef_raw ~ Beta(2,2)
-        Ltot += log(u) + 3.0 * log1p(-u) + 2.995732273553991 - dcd::softplus(zu) - dcd::softplus(-zu);
-        grad[L.o_u] = -((1.0 / u - 3.0 / (1.0 - u)) * du + 2.0 * sums[0] * du + (1.0 - 2.0 * su));
-        const double zc = z[L.o_corr];
-        Ltot += log(b.q) + log1p(-b.q) + 1.791759469228055 - dcd::softplus(zc) - dcd::softplus(-zc);
-        grad[L.o_corr] = -((1.0 / b.q - 1.0 / (1.0 - b.q)) * b.dq + (1.0 - 2.0 * b.sq) +
-                           b.G_rho * (b.UB - b.LB) * b.dq);
-        A.F.potential[0] = -Ltot;
-        if (A.F.aux) {
-            A.F.aux[0] = b.rho;
-            A.F.aux[1] = b.LB;
-            A.F.aux[2] = b.UB;
-            A.F.aux[3] = b.q;
+        Lp = dcd::wave_sum(Lp);
+        if (tid == 0) {
+            const double Ltot = sums[12] + A.F.sc[dcd::SC_U] - A.F.lgsum + Lp;
+            A.F.potential[0] = -Ltot;
+            if (A.F.aux) {
+                A.F.aux[0] = b.rho;
+                A.F.aux[1] = b.LB;
+                A.F.aux[2] = b.UB;
+                A.F.aux[3] = b.q;
+            }
         }
     }
 }

@@ -644,6 +644,29 @@ __device__ inline void persist_advance(double* ns, const Persist& P, int chain, 
     persist_start_transition(ns, P, chain, it + 1, lane);
 }
 
+// Leaf bookkeeping as its own launch, for models whose evaluation is not dc_eval (the float64
+// family: neutral-venue / World-Cup): the evaluation wrote potential, aux and gradient into
+// the chain's state; one wave per chain books the leaf and advances the chain.
+__global__ __launch_bounds__(64) void kp_leaf(double* ns_all, size_t stride, int D, int max_depth,
+                                              Persist P) {
+    extern __shared__ double gL[];  // grad[D] | potential | aux[4]
+    double* ns = ns_all + blockIdx.x * stride;
+    const int lane = threadIdx.x;
+    if (ns[H_S_DONE] != 0.0) return;  // chain finished
+    LeafState leaf = leaf_prefetch(ns, D, max_depth, lane);
+    const double* gr = vec(ns, D, V_GRAD);
+    for (int i = lane; i < D; i += 64) gL[i] = gr[i];
+    if (lane == 0) {
+        gL[D] = ns[H_LEAF_PE];
+        gL[D + 1] = ns[H_LEAF_AUX0]; gL[D + 2] = ns[H_LEAF_AUX1];
+        gL[D + 3] = ns[H_LEAF_AUX2]; gL[D + 4] = ns[H_LEAF_AUX3];
+    }
+    leaf_prefetch_ckpt(leaf, ns, D, max_depth, lane);
+    __syncthreads();
+    const bool sub_done = nuts_leaf(ns, D, max_depth, lane, gL, leaf);
+    if (sub_done) persist_advance(ns, P, blockIdx.x, lane);
+}
+
 // first transition of every chain (after the host has set the initial state)
 __global__ __launch_bounds__(64) void kp_start(double* ns, size_t stride, Persist P) {
     persist_start_transition(ns + blockIdx.x * stride, P, blockIdx.x, 0, threadIdx.x);

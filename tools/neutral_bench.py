@@ -21,4 +21,4 @@ for N, T in ((570, 20), (1_000_000, 20)):
     cfg = default_nuts_cfg(); cfg.num_warmup, cfg.num_samples = 100, 50
     d, st = c.nuts_run(cfg, (0, 42))
     print(f"neutral N={N:8d} D={D}: {t:8.2f} us/eval {1e6 / t:10.1f} evals/s  algorithmic GB/s={N * 11 / t / 1e3:8.2f}"
-          f"  in-situ (host tree) {st['total_leapfrogs'] / st['wall_seconds']:8.0f} leapfrogs/s", flush=True)
+          f"  in-situ (persistent chain) {st['total_leapfrogs'] / st['wall_seconds']:8.0f} leapfrogs/s", flush=True)
