@@ -174,8 +174,18 @@ class NeutralDixonColesMatchPredictor:
             draws = np.empty((len(mine), kept, D))
             corr = np.empty((len(mine), kept))
             leap = np.zeros((len(mine), 3))
+            z0a = None if z0 is None else np.asarray(z0, np.float64)
+            results = None
+            if len(mine) > 1 and mcmc_kwargs.get("chain_method", "parallel") != "sequential":
+                from bpl._ffi import BPLHIP_EUNSUPPORTED, BplHipError
+
+                try:  # chains of this rank run concurrently on the device
+                    results = ctx.nuts_run_chains(cfg, [keys[c] for c in mine], z0a)
+                except BplHipError as e:
+                    if e.code != BPLHIP_EUNSUPPORTED:
+                        raise
             for j, c in enumerate(mine):
-                d, st = ctx.nuts_run(cfg, keys[c], None if z0 is None else np.asarray(z0, np.float64))
+                d, st = results[j] if results is not None else ctx.nuts_run(cfg, keys[c], z0a)
                 draws[j], corr[j] = d, st["corr_coef"]
                 leap[j] = (st["total_leapfrogs"], st["wall_seconds"], st["total_divergences"])
             draws = _dist.gather_chains(draws, num_chains, device=ctx.device)

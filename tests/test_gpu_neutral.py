@@ -133,6 +133,17 @@ def test_sampling_and_new_team(model):
     assert 0 <= m.predict_score_proba("new", "1", 1, 0, 0)[0] <= 1
 
 
+def test_fit_two_chains():
+    from bpl import NeutralDixonColesMatchPredictor
+
+    dd = NO.neutral_dummy_recipe()
+    m = NeutralDixonColesMatchPredictor().fit(dd, num_warmup=150, num_samples=100,
+                                              mcmc_kwargs={"num_chains": 2})
+    assert m.attack.shape == (200, 20) and np.isfinite(m.attack).all()
+    assert np.abs(m.attack[:100].mean(0) - m.attack[100:].mean(0)).max() > 1e-6  # distinct chains
+    assert np.abs(m.attack[:100].mean(0) - m.attack[100:].mean(0)).max() < 0.6   # same posterior
+
+
 def test_errors():
     from bpl import NeutralDixonColesMatchPredictor
 
