@@ -153,8 +153,8 @@ int hb_stride_of(const bplhip_ctx* c) {
 int ensure_slabs(bplhip_ctx* c, int chains) {
     if (chains <= c->slab_chains) return BPLHIP_OK;
     HIP_TRY(c, c->d_hbuf.ensure((size_t)chains * hb_stride_of(c) * sizeof(double)));
-    HIP_TRY(c, c->d_tickets.ensure((size_t)chains * sizeof(unsigned int)));
-    HIP_TRY(c, hipMemset(c->d_tickets.p, 0, (size_t)chains * sizeof(unsigned int)));
+    HIP_TRY(c, c->d_tickets.ensure((size_t)chains * dc::TK_WORDS * sizeof(unsigned int)));
+    HIP_TRY(c, hipMemset(c->d_tickets.p, 0, (size_t)chains * dc::TK_WORDS * sizeof(unsigned int)));
     c->slab_chains = chains;
     return BPLHIP_OK;
 }
@@ -568,25 +568,42 @@ int bplhip_set_fixtures(bplhip_ctx* c, int model_kind, int64_t n, int32_t n_team
     std::sort(order.begin(), order.end());
 
     const int T = n_teams;
-    const int n_tiles = (int)((n + dc::TILE - 1) / dc::TILE);
-    const int64_t n_pad = (int64_t)n_tiles * dc::TILE;
-    std::vector<uint16_t> hs(n_pad, (uint16_t)T), as(n_pad, (uint16_t)T);
-    std::vector<uint8_t> xs8(n_pad, 2), ys8(n_pad, 2);
+    // Every pair's run is padded to a multiple of LANE_FIX with NULL fixtures (same pair,
+    // goals (255, 255), weight 0): a lane never straddles a pair boundary.  Then the whole
+    // array is padded to the tile size with the sentinel team T (zero table entries).
+    std::vector<uint16_t> hs, as;
+    std::vector<uint8_t> xs8, ys8;
     std::vector<float> ws;
-    if (weights) ws.assign(n_pad, 0.0f);
+    hs.reserve(n + n / 8 + dc::TILE); as.reserve(hs.capacity());
+    xs8.reserve(hs.capacity()); ys8.reserve(hs.capacity());
+    if (weights) ws.reserve(hs.capacity());
     std::vector<uint32_t> pairs;
     std::vector<double> cA(T, 0.0), cD(T, 0.0), cH(T, 0.0);
     double lgsum = 0.0;
+    auto pad_run = [&]() {
+        while (hs.size() % dc::LANE_FIX) {
+            hs.push_back(hs.back());
+            as.push_back(as.back());
+            xs8.push_back(255);
+            ys8.push_back(255);
+            if (weights) ws.push_back(0.0f);
+        }
+    };
     for (int64_t r = 0; r < n; ++r) {
         const uint32_t i = (uint32_t)order[r];
-        hs[r] = h[i];
-        as[r] = a[i];
-        xs8[r] = x[i];
-        ys8[r] = y[i];
-        const double wi = weights ? (double)w[i] : 1.0;
-        if (weights) ws[r] = w[i];
+        if (x[i] == 255 && y[i] == 255)
+            return fail(c, BPLHIP_EINVAL, "set_fixtures: the scoreline 255-255 is reserved (fixture %u)", i);
         const uint32_t pk = (uint32_t)h[i] | ((uint32_t)a[i] << 16);
-        if (pairs.empty() || pairs.back() != pk) pairs.push_back(pk);
+        if (pairs.empty() || pairs.back() != pk) {
+            if (!pairs.empty()) pad_run();
+            pairs.push_back(pk);
+        }
+        hs.push_back(h[i]);
+        as.push_back(a[i]);
+        xs8.push_back(x[i]);
+        ys8.push_back(y[i]);
+        const double wi = weights ? (double)w[i] : 1.0;
+        if (weights) ws.push_back(w[i]);
         cA[h[i]] += wi * x[i];
         cA[a[i]] += wi * y[i];
         cD[a[i]] += wi * x[i];
@@ -594,6 +611,15 @@ int bplhip_set_fixtures(bplhip_ctx* c, int model_kind, int64_t n, int32_t n_team
         cH[h[i]] += wi * x[i];
         lgsum += wi * (std::lgamma((double)x[i] + 1.0) + std::lgamma((double)y[i] + 1.0));
     }
+    pad_run();
+    const int64_t n_lanefix = (int64_t)hs.size();  // real + null fixtures
+    const int n_tiles = (int)((n_lanefix + dc::TILE - 1) / dc::TILE);
+    const int64_t n_pad = (int64_t)n_tiles * dc::TILE;
+    hs.resize(n_pad, (uint16_t)T);
+    as.resize(n_pad, (uint16_t)T);
+    xs8.resize(n_pad, 2);
+    ys8.resize(n_pad, 2);
+    if (weights) ws.resize(n_pad, 0.0f);
 
     // ---- launch geometry: 8 waves per workgroup, contiguous tiles per wave
     const int max_wg = c->opt_max_wg;  // one workgroup per CU by default
@@ -602,7 +628,7 @@ int bplhip_set_fixtures(bplhip_ctx* c, int model_kind, int64_t n, int32_t n_team
     const int waves = (n_tiles + tpw - 1) / tpw;
     const int n_wg = (waves + dc::WAVES - 1) / dc::WAVES;
 
-    SparseSlabs sp = build_sparse_slabs(hs, as, n, T, tpw, n_wg);
+    SparseSlabs sp = build_sparse_slabs(hs, as, n_lanefix, T, tpw, n_wg);
     std::vector<int>&wg_off = sp.wg_off, &wg_slots = sp.wg_slots, &col_off = sp.col_off,
     &wg_dst = sp.wg_dst;
 
@@ -677,7 +703,7 @@ int bplhip_set_fixtures(bplhip_ctx* c, int model_kind, int64_t n, int32_t n_team
         vp.tpw = c->opt_vec_tpw > 0 ? std::max(tpw, c->opt_vec_tpw) : tpw << pi;
         const int vwaves = (n_tiles + vp.tpw - 1) / vp.tpw;
         vp.n_wg = (vwaves + dc::WAVES - 1) / dc::WAVES;
-        const SparseSlabs vs = build_sparse_slabs(hs, as, n, T, vp.tpw, vp.n_wg);
+        const SparseSlabs vs = build_sparse_slabs(hs, as, n_lanefix, T, vp.tpw, vp.n_wg);
         vp.total_c = vs.wg_off[vp.n_wg];
         HIP_TRY(c, vp.d_wg_off.ensure(vs.wg_off.size() * 4));
         HIP_TRY(c, vp.d_wg_slots.ensure(vs.wg_slots.size() * 4));

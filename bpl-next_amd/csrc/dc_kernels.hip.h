@@ -15,7 +15,8 @@
 //         from z in float32 (v_exp_f32), rho from three DPP max reductions over the
 //         unique-pair table;
 //       - fixtures: 8 per lane from 16-B / 8-B vector loads (6 or 10 B per fixture);
-//         per fixture: 2 LDS gathers, 2 products, tau term (1 v_log_f32 + 1 v_rcp_f32);
+//         per lane: 2 LDS gathers, 2 products, 4 tau terms (v_log_f32 + v_rcp_f32 each);
+//         per fixture: SWAR score-class test only (pair runs are lane aligned);
 //         per-(home,away) run sums: in lane -> across the wave by DPP -> float64 LDS
 //         per-team accumulators; one slab of partial sums per workgroup, stored
 //         write-through (sc1).
@@ -47,6 +48,9 @@ constexpr int WAVES = BLOCK / 64;
 constexpr int N_SCAL = 4;                // SLAM, SLOG2, SU, CLIPC
 constexpr int MAX_RG = 32;               // row groups of the slab reduction
 constexpr int RUN_LOOP_MAX = 4;          // runs per wave-tile handled by masked DPP sums
+constexpr int TK_GROUPS = 16;            // two-level arrival tickets: group counters ...
+constexpr int TK_STRIDE = 32;            // ... one per 128-byte line
+constexpr int TK_WORDS = (1 + TK_GROUPS) * TK_STRIDE;  // u32 words per chain
 
 // z-only record written by the prior workgroup (doubles), per chain:
 //   [0..ZO_HDR)         scalars, see enum
@@ -97,7 +101,7 @@ struct EvalArgs {
     int hb_stride;
     int n_wg;               // streaming workgroups (grid.x = n_wg + 1)
     int zo_stride;
-    unsigned int* tickets;  // [chains] arrival counters
+    unsigned int* tickets;  // [chains][TK_WORDS] arrival counters (top + TK_GROUPS groups)
     int chains;             // number of chains of this launch (dc_vec.hip.h)
     // in / out: chain c at z + c*z_stride, potential + c*p_stride, grad + c*g_stride,
     // aux + c*aux_stride (plain batches: D, 1, D, 4; device NUTS: all inside the state buffer)
@@ -605,8 +609,10 @@ __device__ void prior_body(const EvalArgs& A, int chain, char* smem) {
         const int o = (tid >= K ? L.o_bD + tid - K : L.o_bA + tid);
         st_sc1(&gz[o], z[o]);
     }
+    // The two serial pieces of the record run on different waves at the same time (a single lane
+    // executing ~300 dependent float64 instructions is the longest pole of this workgroup).
     if (tid == 0) {
-        // combine the waves' arg-maxima (strict >: the lowest wave wins ties)
+        // ---- bounds: combine the waves' arg-maxima (strict >: the lowest wave wins ties)
         double M = 0.0, Lh = 0.0, La = 0.0;
         uint32_t pP = 0, pQ = 0, pR = 0;
         for (int wv = 0; wv < WAVES; ++wv) {
@@ -625,8 +631,22 @@ __device__ void prior_body(const EvalArgs& A, int chain, char* smem) {
         const double UB = M > 1.0 ? 1.0 / M : 1.0;
         const double LB = -1.0 / fmax(Lh, La);
         const double rho = LB + q * (UB - LB);
-
-        // scalar priors + Jacobians (L = log density)
+        st_sc1(&zo[ZO_Q], q);
+        st_sc1(&zo[ZO_DQ], dq);
+        st_sc1(&zo[ZO_UB], UB);
+        st_sc1(&zo[ZO_LB], LB);
+        st_sc1(&zo[ZO_RHO], rho);
+        st_sc1(&zo[ZO_DRHO], rho - (double)rho_f);
+        st_sc1(&zo[ZO_M], M);
+        st_sc1(&zo[ZO_LH], Lh);
+        st_sc1(&zo[ZO_LA], La);
+        st_sc1(&zo[ZO_PP], (double)pP);
+        st_sc1(&zo[ZO_PQ], (double)pQ);
+        st_sc1(&zo[ZO_PR], (double)pR);
+        st_sc1(&zo[ZO_FLAGS], (double)flags);
+    }
+    if (tid == 64) {
+        // ---- scalar priors + Jacobians (L = log density) and their gradient
         const double zsa = z[L.o_sa], zsd = z[L.o_sd];
         double Lz = sc[5] + sc[6] + 1.791759469228055 /*log 6*/ + sc[7];  // Beta(2,2) + Jac
         Lz += -0.5 * s_a * s_a - HALF_LOG_2PI + LN2 + zsa;  // HalfNormal(1) + Exp Jacobian
@@ -660,19 +680,6 @@ __device__ void prior_body(const EvalArgs& A, int chain, char* smem) {
         st_sc1(&zo[ZO_SA], s_a);
         st_sc1(&zo[ZO_SD], s_d);
         st_sc1(&zo[ZO_SH], s_h);
-        st_sc1(&zo[ZO_Q], q);
-        st_sc1(&zo[ZO_DQ], dq);
-        st_sc1(&zo[ZO_UB], UB);
-        st_sc1(&zo[ZO_LB], LB);
-        st_sc1(&zo[ZO_RHO], rho);
-        st_sc1(&zo[ZO_DRHO], rho - (double)rho_f);
-        st_sc1(&zo[ZO_M], M);
-        st_sc1(&zo[ZO_LH], Lh);
-        st_sc1(&zo[ZO_LA], La);
-        st_sc1(&zo[ZO_PP], (double)pP);
-        st_sc1(&zo[ZO_PQ], (double)pQ);
-        st_sc1(&zo[ZO_PR], (double)pR);
-        st_sc1(&zo[ZO_FLAGS], (double)flags);
     }
 }
 
@@ -1125,7 +1132,9 @@ __device__ __forceinline__ void class_terms(float rho, float c, float* l2, float
     *u = t > 0.0f ? c * __builtin_amdgcn_rcpf(t) : 0.0f;
 }
 
-// All 8 fixtures of the lane are the pair (h, a).
+// All fixtures of a lane are one pair (h, a): the library pads every pair's run to a multiple
+// of LANE_FIX with NULL fixtures -- same pair, goals (255, 255), weight 0 -- so a lane never
+// straddles a pair boundary and the rates and tau terms are computed once per lane.
 template <bool WEIGHTED, bool CLIP>
 __device__ __forceinline__ LaneOut lane_uniform(const LaneData& Ld, float rho,
                                                 const float2* tabH, const float2* tabA) {
@@ -1150,7 +1159,7 @@ __device__ __forceinline__ LaneOut lane_uniform(const LaneData& Ld, float rho,
     float n00, n10, n01, n11, nall, sx, sy;  // (weighted) class counts, total, goal sums
     if (!WEIGHTED) {
         const uint32_t one = 0x01010101u;
-        int c00 = 0, c10 = 0, c01 = 0, c11 = 0;
+        int c00 = 0, c10 = 0, c01 = 0, c11 = 0, nz = 0;
         uint32_t ax = 0, ay = 0;
 #pragma unroll
         for (int q = 0; q < XWORDS; ++q) {
@@ -1159,13 +1168,14 @@ __device__ __forceinline__ LaneOut lane_uniform(const LaneData& Ld, float rho,
             c10 += __popc(zero_bytes((x ^ one) | y));
             c01 += __popc(zero_bytes(x | (y ^ one)));
             c11 += __popc(zero_bytes((x ^ one) | (y ^ one)));
+            nz += __popc(zero_bytes(~(x & y)));  // null fixtures: goals (255, 255)
             ax = __builtin_amdgcn_sad_u8(x, 0u, ax);
             ay = __builtin_amdgcn_sad_u8(y, 0u, ay);
         }
         n00 = (float)c00; n10 = (float)c10; n01 = (float)c01; n11 = (float)c11;
-        nall = (float)LANE_FIX;
-        sx = (float)ax;
-        sy = (float)ay;
+        nall = (float)(LANE_FIX - nz);
+        sx = (float)((int)ax - 255 * nz);
+        sy = (float)((int)ay - 255 * nz);
     } else {
         n00 = n10 = n01 = n11 = nall = sx = sy = 0.f;
 #pragma unroll
@@ -1208,81 +1218,6 @@ __device__ __forceinline__ LaneOut lane_uniform(const LaneData& Ld, float rho,
             o.sclip += sy * (__logf(la_raw) - (float)LOG_RATE_CLIP);
         }
     }
-    return o;
-}
-
-// The lane's 8 fixtures span more than one pair: per-fixture arithmetic; finished runs go
-// to the LDS accumulators, the last one stays pending like a uniform lane's.
-template <bool WEIGHTED, bool CLIP>
-__device__ __forceinline__ LaneOut lane_mixed(const LaneData& Ld, float rho, const float2* tabH,
-                                              const float2* tabA, double* acc, int T1) {
-    const uint32_t* hw = Ld.hw;
-    const uint32_t* aw = Ld.aw;
-    const uint32_t* xw = Ld.xw;
-    const uint32_t* yw = Ld.yw;
-    const float* wj = Ld.wj;
-    LaneOut o;
-    o.slam = o.slog = o.su = o.sclip = 0.f;
-    o.rsh = o.rsa = 0.f;
-    uint32_t kj = 0, cur = (hw[0] & 0xFFFFu) | ((aw[0] & 0xFFFFu) << 16);
-#pragma unroll
-    for (int j = 0; j < LANE_FIX; ++j) {
-        const uint32_t hj = (hw[j >> 1] >> (16 * (j & 1))) & 0xFFFFu;
-        const uint32_t aj = (aw[j >> 1] >> (16 * (j & 1))) & 0xFFFFu;
-        const uint32_t xj = (xw[j >> 2] >> (8 * (j & 3))) & 0xFFu;
-        const uint32_t yj = (yw[j >> 2] >> (8 * (j & 3))) & 0xFFu;
-        kj = hj | (aj << 16);
-        const float2 th = tabH[hj], ta = tabA[aj];
-        float lh = th.x * ta.y, la = ta.x * th.y;
-        bool ch = false, ca = false;
-        const float lh_raw = lh, la_raw = la;
-        if (CLIP) {
-            ch = lh > (float)RATE_CLIP;
-            ca = la > (float)RATE_CLIP;
-            lh = ch ? (float)RATE_CLIP : lh;
-            la = ca ? (float)RATE_CLIP : la;
-        }
-        const bool x0 = xj == 0, y0 = yj == 0;
-        const bool low = (xj <= 1) & (yj <= 1);
-        float c = x0 ? (y0 ? -lh * la : lh) : (y0 ? la : -1.0f);
-        c = low ? c : 0.0f;
-        float l2, u;
-        class_terms(rho, c, &l2, &u);
-        const float ru = rho * u;
-        float sh = lh - (x0 ? ru : 0.0f);
-        float sa = la - (y0 ? ru : 0.0f);
-        float wv = 1.0f;
-        if (WEIGHTED) wv = wj[j];
-        if (CLIP) {
-            if (ch) {
-                sh = (float)xj;
-                o.sclip += wv * (float)xj * (__logf(lh_raw) - (float)LOG_RATE_CLIP);
-            }
-            if (ca) {
-                sa = (float)yj;
-                o.sclip += wv * (float)yj * (__logf(la_raw) - (float)LOG_RATE_CLIP);
-            }
-        }
-        if (WEIGHTED) {
-            sh *= wv;
-            sa *= wv;
-            o.slam += wv * (lh + la);
-            o.slog += wv * l2;
-            o.su += wv * u;
-        } else {
-            o.slam += lh + la;
-            o.slog += l2;
-            o.su += u;
-        }
-        if (kj != cur) {  // pair boundary inside the lane: flush the finished run
-            flush_run(acc, T1, cur, o.rsh, o.rsa);
-            o.rsh = o.rsa = 0.f;
-            cur = kj;
-        }
-        o.rsh += sh;
-        o.rsa += sa;
-    }
-    o.key = cur;  // the lane's last run stays pending and merges with its neighbours
     return o;
 }
 
@@ -1357,26 +1292,14 @@ __global__ DC_LAUNCH_BOUNDS void dc_eval(EvalArgs A) {
             LaneData nxt = cur;
             if (tile + 1 < tile_end)  // prefetch the next tile
                 nxt = load_lane<WEIGHTED>(A, (size_t)(tile + 1) * 64 + lane);
-            // One lane = LANE_FIX consecutive fixtures.  Sorted by pair, they almost always share
-            // ONE (home, away): then the two rates and the four score-class tau terms are
-            // computed once for the lane and each fixture is only classified; a lane that
-            // straddles a pair boundary takes the per-fixture path.
-            LaneOut lo;
-            {
-                const uint32_t hrep = (cur.hw[0] & 0xFFFFu) * 0x00010001u;
-                const uint32_t arep = (cur.aw[0] & 0xFFFFu) * 0x00010001u;
-                uint32_t mixed = 0;
-#pragma unroll
-                for (int q = 0; q < HWORDS; ++q) mixed |= (cur.hw[q] ^ hrep) | (cur.aw[q] ^ arep);
+            // One lane = LANE_FIX consecutive fixtures of ONE (home, away) pair (runs are padded
+            // with null fixtures): the two rates and the four score-class tau terms are computed
+            // once for the lane and each fixture is only classified.
 #ifdef DC_STAMPS
-                if (mixed == 0xFFFFFFFFu) rho_dbg += 1.0f;  // forces the loads to have landed
-                DC_STAMP(12);
+            if (cur.hw[0] == 0xFFFFFFFFu) rho_dbg += 1.0f;  // forces the loads to have landed
+            DC_STAMP(12);
 #endif
-                if (mixed == 0)
-                    lo = lane_uniform<WEIGHTED, CLIP>(cur, rho, tabH, tabA);
-                else
-                    lo = lane_mixed<WEIGHTED, CLIP>(cur, rho, tabH, tabA, acc, T1);
-            }
+            const LaneOut lo = lane_uniform<WEIGHTED, CLIP>(cur, rho, tabH, tabA);
             // scalars: float32 over the lane's 8 fixtures only, float64 from there on
             // (a float32 sum over the whole wave-tile would cost ~1e-4 absolute in U)
             dSLAM += (double)lo.slam;
@@ -1453,15 +1376,30 @@ __global__ DC_LAUNCH_BOUNDS void dc_eval(EvalArgs A) {
     // ---- 5. the last-arriving workgroup runs the tail.  Payloads were stored
     // write-through (sc1); every storing wave drains, the workgroup barriers, one lane
     // takes a ticket (relaxed, agent scope); the last arriver reads with sc1 loads.
+    // Tickets are two-level: ~250 same-address atomics arriving within a microsecond queue
+    // up at ~12 ns each (the last one returned 2.6 us after the burst began); with TK_GROUPS
+    // group counters on separate cache lines and one top counter the queues are 16 deep.
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     DC_STAMP(5);
     if (tid == 0) {
-        const unsigned int tk = __hip_atomic_fetch_add(&A.tickets[chain], 1u, __ATOMIC_RELAXED,
-                                                       __HIP_MEMORY_SCOPE_AGENT);
-        const int last = tk == (unsigned int)A.n_wg;  // n_wg + 1 arrivals
-        if (last)  // re-arm for the next launch (stream ordered)
-            __hip_atomic_store(&A.tickets[chain], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned int* tk = A.tickets + (size_t)chain * TK_WORDS;
+        const unsigned int g = blockIdx.x % TK_GROUPS;
+        const unsigned int members = (gridDim.x - g + TK_GROUPS - 1) / TK_GROUPS;  // blocks of group g
+        const unsigned int groups = gridDim.x < TK_GROUPS ? gridDim.x : TK_GROUPS; // non-empty groups
+        int last = 0;
+        unsigned int* tg = tk + (1 + g) * TK_STRIDE;
+        const unsigned int t1 =
+            __hip_atomic_fetch_add(tg, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t1 == members - 1) {  // last of its group: re-arm it (stream ordered), go up
+            __hip_atomic_store(tg, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned int t2 =
+                __hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (t2 == groups - 1) {
+                __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                last = 1;
+            }
+        }
         *shflag = last;
     }
     __syncthreads();

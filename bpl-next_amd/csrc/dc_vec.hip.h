@@ -58,7 +58,7 @@ __device__ __forceinline__ LaneClass classify(const LaneData& Ld, uint32_t& rem,
         mixed |= (Ld.hw[q] ^ (h0 * 0x00010001u)) | (Ld.aw[q] ^ (a0 * 0x00010001u));
     if (!WEIGHTED && rem == ALL && mixed == 0) {  // the common case: one pair, SWAR counts
         const uint32_t one = 0x01010101u;
-        int c00 = 0, c10 = 0, c01 = 0, c11 = 0;
+        int c00 = 0, c10 = 0, c01 = 0, c11 = 0, nz = 0;
         uint32_t ax = 0, ay = 0;
 #pragma unroll
         for (int q = 0; q < XWORDS; ++q) {
@@ -67,14 +67,15 @@ __device__ __forceinline__ LaneClass classify(const LaneData& Ld, uint32_t& rem,
             c10 += __popc(zero_bytes((x ^ one) | y));
             c01 += __popc(zero_bytes(x | (y ^ one)));
             c11 += __popc(zero_bytes((x ^ one) | (y ^ one)));
+            nz += __popc(zero_bytes(~(x & y)));  // null fixtures: goals (255, 255)
             ax = __builtin_amdgcn_sad_u8(x, 0u, ax);
             ay = __builtin_amdgcn_sad_u8(y, 0u, ay);
         }
         c.key = h0 | (a0 << 16);
         c.n00 = (float)c00; c.n10 = (float)c10; c.n01 = (float)c01; c.n11 = (float)c11;
-        c.nall = (float)LANE_FIX;
-        c.sx = (float)ax;
-        c.sy = (float)ay;
+        c.nall = (float)(LANE_FIX - nz);
+        c.sx = (float)((int)ax - 255 * nz);
+        c.sy = (float)((int)ay - 255 * nz);
         rem = 0;
         return c;
     }
@@ -96,7 +97,8 @@ __device__ __forceinline__ LaneClass classify(const LaneData& Ld, uint32_t& rem,
         }
         const bool m = r && kj == key;
         members |= m ? (1u << j) : 0u;
-        const float wv = m ? (WEIGHTED ? Ld.wj[j] : 1.0f) : 0.0f;
+        const bool null_fx = (xj & yj) == 255u;  // padding of a pair's run (weight 0 when weighted)
+        const float wv = (m && !null_fx) ? (WEIGHTED ? Ld.wj[j] : 1.0f) : 0.0f;
         c.n00 += (xj | yj) == 0 ? wv : 0.f;
         c.n10 += (xj == 1 && yj == 0) ? wv : 0.f;
         c.n01 += (xj == 0 && yj == 1) ? wv : 0.f;
