@@ -685,16 +685,20 @@ __device__ void prior_body(const EvalArgs& A, int chain, char* smem) {
 
 // ------------------------------------------------------------------------ tail
 
-// Per-team epilogue for T <= 64, executed by ONE wave: lane t owns team t, the adjoint of
-// the bounds is a lane-local add, sums are DPP wave reductions.  Same arithmetic and the
-// same summation order on every run (deterministic).
+// Per-team epilogue for T <= 64: lane t owns team t, sums are DPP wave reductions, adds and
+// FMAs only.  A single wave issues a dependent instruction every ~5 cycles, so the work is
+// split by OUTPUT GROUP over four waves that never need each other's results:
+//   wave 0  attack sites      (+ attack coefficients)       wave 2  home-advantage sites, corr, u
+//   wave 1  defence sites     (+ defence coefficients)      wave 3  the potential (value corrections)
+// Same arithmetic and the same summation order on every run (deterministic).  With NUTS the
+// workgroup then barriers and wave 0 books the leaf.
 template <bool NUTS>
-__device__ void tail_one_wave(const EvalArgs& A, int chain, const double* zoL, const double* cL,
-                              const double* zL, const double* col, const double* xsL,
-                              double* gradL, const nd::LeafState& leaf) {
+__device__ void tail_waves(const EvalArgs& A, int chain, const double* zoL, const double* cL,
+                           const double* zL, const double* col, const double* xsL,
+                           double* gradL, const nd::LeafState& leaf) {
     const Layout& L = A.L;
     const int T = L.T, K = L.K, D = L.D;
-    const int t = threadIdx.x & 63;
+    const int t = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool on = t < T;
     double* grad = grad_of(A, chain);
     constexpr bool nuts = NUTS;
@@ -705,19 +709,13 @@ __device__ void tail_one_wave(const EvalArgs& A, int chain, const double* zoL, c
     const double* gz = zoL + ZO_HDR;
     const double* eps = gz + D;
     const int ncol = 3 * T;
-    const double s_a = zoL[ZO_SA], s_d = zoL[ZO_SD], s_h = zoL[ZO_SH];
-    const double q = zoL[ZO_Q], dq = zoL[ZO_DQ], UB = zoL[ZO_UB], LB = zoL[ZO_LB];
-    const double M = zoL[ZO_M], Lh = zoL[ZO_LH], La = zoL[ZO_LA];
-    const double SLAM = col[ncol + 0], SLOG = col[ncol + 1], SU = col[ncol + 2],
-                 CLIPC = col[ncol + 3];
-    const double G_rho = SU;
-    const double ra = on ? col[t] : 0.0, rd = on ? col[T + t] : 0.0, rh = on ? col[2 * T + t] : 0.0;
-    // first-order value correction for the float32 rounding of the tables
-    double corr = on ? -(rh * eps[t] + (ra - rh) * eps[T + t] + rd * eps[2 * T + t]) : 0.0;
-    double ga = on ? cL[t] - ra : 0.0;
-    double gd = on ? -(cL[T + t] - rd) : 0.0;
-    double gh = on ? cL[2 * T + t] - rh : 0.0;
-    if (A.P > 0) {  // adjoint of the bounds (Appendix A.3)
+    const double q = zoL[ZO_Q], UB = zoL[ZO_UB], LB = zoL[ZO_LB];
+    const double G_rho = col[ncol + 2];  // SU
+    // adjoint of the bounds (Appendix A.3): what the arg-extremal pairs add to team t's
+    // d/d attack (ja), d/d defence (jd), d/d home advantage (jh)
+    double ja = 0.0, jd = 0.0, jh = 0.0;
+    if (A.P > 0 && wave < 3) {
+        const double M = zoL[ZO_M], Lh = zoL[ZO_LH], La = zoL[ZO_LA];
         const uint32_t pP = (uint32_t)zoL[ZO_PP], pQ = (uint32_t)zoL[ZO_PQ],
                        pR = (uint32_t)zoL[ZO_PR];
         const unsigned int flags = (unsigned int)zoL[ZO_FLAGS];
@@ -725,99 +723,110 @@ __device__ void tail_one_wave(const EvalArgs& A, int chain, const double* zoL, c
             const double v = G_rho * q * (-UB);
             const int h = pP & 0xFFFFu, a = pP >> 16;
             if (!(flags & 1u)) {
-                if (t == h) { ga += v; gh += v; }
-                if (t == a) gd -= v;
+                if (t == h) { ja += v; jh += v; }
+                if (t == a) jd -= v;
             }
             if (!(flags & 2u)) {
-                if (t == a) ga += v;
-                if (t == h) gd -= v;
+                if (t == a) ja += v;
+                if (t == h) jd -= v;
             }
         }
         const double v = G_rho * (1.0 - q) * (-LB);
         if (Lh >= La) {
             const int h = pQ & 0xFFFFu, a = pQ >> 16;
             if (!(flags & 4u)) {
-                if (t == h) { ga += v; gh += v; }
-                if (t == a) gd -= v;
+                if (t == h) { ja += v; jh += v; }
+                if (t == a) jd -= v;
             }
         } else {
             const int h = pR & 0xFFFFu, a = pR >> 16;
             if (!(flags & 8u)) {
-                if (t == a) ga += v;
-                if (t == h) gd -= v;
+                if (t == a) ja += v;
+                if (t == h) jd -= v;
             }
         }
     }
-    const double sum_gd = wave_sum_f64(gd), sum_gh = wave_sum_f64(gh);
-    corr = wave_sum_f64(corr);
-    const double Lz = zoL[ZO_LZ], drho = zoL[ZO_DRHO];
-    const double Ltot = Lz + corr + G_rho * drho - SLAM - A.lgsum + LN2 * SLOG - CLIPC;
-    DC_STAMP(11);
-    if (L.model == MODEL_BASIC) {
-        const double ad = on ? zL[L.o_adec + t] : 0.0, dd = on ? zL[L.o_ddec + t] : 0.0;
-        if (on) {
-            put(L.o_adec + t, gz[L.o_adec + t] - s_a * ga);
-            put(L.o_ddec + t, gz[L.o_ddec + t] - s_d * gd);
-        }
-        const double dot_a = wave_sum_f64(ad * ga), dot_d = wave_sum_f64(dd * gd);
-        if (t == 0) {
-            put(L.o_ha, gz[L.o_ha] - sum_gh);
-            put(L.o_md, gz[L.o_md] - sum_gd);
-            put(L.o_sa, gz[L.o_sa] - s_a * dot_a);
-            put(L.o_sd, gz[L.o_sd] - s_d * dot_d);
-            put(L.o_corr, gz[L.o_corr] - G_rho * (UB - LB) * dq);
-            *pot_of(A, chain) = -Ltot;
-        }
-    } else {
-        const double sa = on ? zL[L.o_sat + t] : 0.0, sd = on ? zL[L.o_sdt + t] : 0.0,
-                     hd = on ? zL[L.o_hadec + t] : 0.0;
-        if (on) {
-            put(L.o_sat + t, gz[L.o_sat + t] - s_a * ga);
-            put(L.o_sdt + t, gz[L.o_sdt + t] - s_d * gd);
-            put(L.o_hadec + t, gz[L.o_hadec + t] - s_h * gh);
-        }
-        const double dot_a = wave_sum_f64(sa * ga), dot_d = wave_sum_f64(sd * gd),
-                     dot_h = wave_sum_f64(hd * gh);
+    const bool basic = L.model == MODEL_BASIC;
+    if (wave == 0) {  // ---- attack
+        const double s_a = zoL[ZO_SA];
+        const double ga = on ? cL[t] - col[t] + ja : 0.0;
+        const int o = basic ? L.o_adec : L.o_sat;
+        const double dec = on ? zL[o + t] : 0.0;
+        if (on) put(o + t, gz[o + t] - s_a * ga);
+        const double dot_a = wave_sum_f64(dec * ga);
+        if (t == 0) put(L.o_sa, gz[L.o_sa] - s_a * dot_a);
         for (int k = 0; k < K; ++k) {  // d/d beta_k: sum_t Xs[t,k] g_t
             const double xv = on ? (xsL ? xsL[(size_t)t * K + k] : A.xs[(size_t)t * K + k]) : 0.0;
-            const double sA = wave_sum_f64(xv * ga), sD = wave_sum_f64(xv * gd);
+            const double sA = wave_sum_f64(xv * ga);
+            if (t == 0) put(L.o_bA + k, gz[L.o_bA + k] - sA);
+        }
+    } else if (wave == 1) {  // ---- defence
+        const double s_d = zoL[ZO_SD];
+        const double gd = on ? -(cL[T + t] - col[T + t]) + jd : 0.0;
+        const int o = basic ? L.o_ddec : L.o_sdt;
+        const double dec = on ? zL[o + t] : 0.0;
+        if (on) put(o + t, gz[o + t] - s_d * gd);
+        double sum_gd = gd, dot_d = dec * gd;
+        sum_gd = wave_sum_f64(sum_gd);
+        dot_d = wave_sum_f64(dot_d);
+        if (t == 0) {
+            put(L.o_md, gz[L.o_md] - sum_gd);
+            put(L.o_sd, gz[L.o_sd] - s_d * dot_d);
+        }
+        for (int k = 0; k < K; ++k) {
+            const double xv = on ? (xsL ? xsL[(size_t)t * K + k] : A.xs[(size_t)t * K + k]) : 0.0;
+            const double sD = wave_sum_f64(xv * gd);
+            if (t == 0) put(L.o_bD + k, gz[L.o_bD + k] - sD);
+        }
+    } else if (wave == 2) {  // ---- home advantage, corr_coef_raw, u
+        const double gh = on ? cL[2 * T + t] - col[2 * T + t] + jh : 0.0;
+        const double sum_gh = wave_sum_f64(gh);
+        if (basic) {
+            if (t == 0) put(L.o_ha, gz[L.o_ha] - sum_gh);
+        } else {
+            const double s_h = zoL[ZO_SH];
+            const double hd = on ? zL[L.o_hadec + t] : 0.0;
+            if (on) put(L.o_hadec + t, gz[L.o_hadec + t] - s_h * gh);
+            const double dot_h = wave_sum_f64(hd * gh);
             if (t == 0) {
-                put(L.o_bA + k, gz[L.o_bA + k] - sA);
-                put(L.o_bD + k, gz[L.o_bD + k] - sD);
+                put(L.o_mha, gz[L.o_mha] - sum_gh);
+                put(L.o_sh, gz[L.o_sh] - s_h * dot_h);
+                put(L.o_u, gz[L.o_u]);
             }
         }
+        if (t == 0) put(L.o_corr, gz[L.o_corr] - G_rho * (UB - LB) * zoL[ZO_DQ]);
+    } else if (wave == 3) {  // ---- value: first-order corrections for the float32 table rounding
+        const double ra = on ? col[t] : 0.0, rd = on ? col[T + t] : 0.0, rh = on ? col[2 * T + t] : 0.0;
+        double corr = on ? -(rh * eps[t] + (ra - rh) * eps[T + t] + rd * eps[2 * T + t]) : 0.0;
+        corr = wave_sum_f64(corr);
+        const double Ltot = zoL[ZO_LZ] + corr + G_rho * zoL[ZO_DRHO] - col[ncol + 0] - A.lgsum +
+                            LN2 * col[ncol + 1] - col[ncol + 3];
         if (t == 0) {
-            put(L.o_mha, gz[L.o_mha] - sum_gh);
-            put(L.o_sh, gz[L.o_sh] - s_h * dot_h);
-            put(L.o_md, gz[L.o_md] - sum_gd);
-            put(L.o_sa, gz[L.o_sa] - s_a * dot_a);
-            put(L.o_sd, gz[L.o_sd] - s_d * dot_d);
-            put(L.o_corr, gz[L.o_corr] - G_rho * (UB - LB) * dq);
-            put(L.o_u, gz[L.o_u]);
             *pot_of(A, chain) = -Ltot;
+            if (A.aux != nullptr) {
+                double* aux = aux_of(A, chain);
+                aux[0] = zoL[ZO_RHO];
+                aux[1] = LB;
+                aux[2] = UB;
+                aux[3] = q;
+            }
+            if (nuts) {
+                gradL[D] = -Ltot;
+                gradL[D + 1] = zoL[ZO_RHO];
+                gradL[D + 2] = LB;
+                gradL[D + 3] = UB;
+                gradL[D + 4] = q;
+            }
         }
     }
     DC_STAMP(14);
-    if (t == 0 && A.aux != nullptr) {
-        double* aux = aux_of(A, chain);
-        aux[0] = zoL[ZO_RHO];
-        aux[1] = LB;
-        aux[2] = UB;
-        aux[3] = q;
-    }
-    if (nuts) {  // device-resident NUTS: this wave finishes the leapfrog and books the leaf
-        if (t == 0) {
-            gradL[D] = -Ltot;
-            gradL[D + 1] = zoL[ZO_RHO];
-            gradL[D + 2] = LB;
-            gradL[D + 3] = UB;
-            gradL[D + 4] = q;
+    if (nuts) {  // device-resident NUTS: wave 0 finishes the leapfrog and books the leaf
+        __syncthreads();
+        if (wave == 0) {
+            const bool sub_done = nd::nuts_leaf(nuts_of(A, chain), D, A.nuts_max_depth, t, gradL, leaf);
+            if (A.persist != nullptr && sub_done)
+                nd::persist_advance(nuts_of(A, chain), *A.persist, chain, t);
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const bool sub_done = nd::nuts_leaf(nuts_of(A, chain), D, A.nuts_max_depth, t, gradL, leaf);
-        if (A.persist != nullptr && sub_done) nd::persist_advance(nuts_of(A, chain), *A.persist, chain, t);
     }
 }
 
@@ -931,9 +940,8 @@ __device__ void tail_body(const EvalArgs& A, int chain, char* smem) {
     }
     __syncthreads();
     DC_STAMP(9);
-    if (T <= 64) {  // the whole per-team epilogue fits one wave: no LDS traffic, no barriers
-        if (wave == 0)
-            tail_one_wave<NUTS>(A, chain, zoL, cL, zL, col, xs_staged ? xsL : nullptr, gradL, leaf);
+    if (T <= 64) {  // lane = team: four waves, one output group each, no LDS traffic
+        tail_waves<NUTS>(A, chain, zoL, cL, zL, col, xs_staged ? xsL : nullptr, gradL, leaf);
         DC_STAMP(10);
         return;
     }
