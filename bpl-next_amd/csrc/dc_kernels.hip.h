@@ -217,6 +217,8 @@ __device__ __forceinline__ double wave_max_f64(double v) {  // v >= 0
 }
 
 // Workgroup sum of NV doubles (all threads get the totals).  scratch: WAVES*NV doubles.
+// (The unrolled serial combine is one round of independent LDS reads; a lane-parallel read +
+// second DPP reduction measured slower.)
 template <int NV>
 __device__ __forceinline__ void block_sum(double (&v)[NV], double* scratch, int tid) {
     const int lane = tid & 63, wave = tid >> 6;
@@ -496,6 +498,41 @@ __device__ void prior_body(const EvalArgs& A, int chain, char* smem) {
     const double q = sc[3], dq = sc[4];
     const double m = z[L.o_md];
 
+    // ---- scalar priors + Jacobians (L = log density) and their gradient: one lane of wave 1,
+    // while wave 0 builds the cells below (only the team sums v[] are still missing at the end)
+    double Lz = 0.0;
+    if (tid == 64) {
+        const double zsa = z[L.o_sa], zsd = z[L.o_sd];
+        Lz = sc[5] + sc[6] + 1.791759469228055 /*log 6*/ + sc[7];  // Beta(2,2) + Jac
+        Lz += -0.5 * s_a * s_a - HALF_LOG_2PI + LN2 + zsa;  // HalfNormal(1) + Exp Jacobian
+        Lz += -0.5 * s_d * s_d - HALF_LOG_2PI + LN2 + zsd;
+        Lz += -0.5 * m * m - HALF_LOG_2PI;
+        st_sc1(&gz[L.o_corr], -((1.0 / q - 1.0 / (1.0 - q)) * dq + (1.0 - 2.0 * sc[8])));
+        st_sc1(&gz[L.o_md], m);
+        st_sc1(&gz[L.o_sa], s_a * s_a - 1.0);
+        st_sc1(&gz[L.o_sd], s_d * s_d - 1.0);
+        if (L.model == MODEL_BASIC) {
+            const double gam = z[L.o_ha], r = (gam - 0.1) / 0.2;
+            Lz += -0.5 * r * r + 1.6094379124341003 /*-log 0.2*/ - HALF_LOG_2PI;
+            st_sc1(&gz[L.o_ha], (gam - 0.1) / 0.04);
+        } else {
+            const double mha = z[L.o_mha], zsh = z[L.o_sh];
+            const double r = (mha - 0.1) / 0.2;
+            Lz += -0.5 * r * r + 1.6094379124341003 - HALF_LOG_2PI;
+            Lz += -0.5 * s_h * s_h - HALF_LOG_2PI + LN2 + zsh;
+            Lz += sc[11] + 3.0 * sc[12] + 2.995732273553991 /*log 20*/ + sc[13];
+            for (int k = 0; k < K; ++k) {
+                const double ba = z[L.o_bA + k], bd = z[L.o_bD + k];
+                Lz += -0.5 * ba * ba - 0.5 * bd * bd - 2.0 * HALF_LOG_2PI;
+            }
+            st_sc1(&gz[L.o_mha], (mha - 0.1) / 0.04);
+            st_sc1(&gz[L.o_sh], s_h * s_h - 1.0);
+        }
+        st_sc1(&zo[ZO_SA], s_a);
+        st_sc1(&zo[ZO_SD], s_d);
+        st_sc1(&zo[ZO_SH], s_h);
+    }
+
     // ---- per team: constrained sites, true (float64) tables, rounding errors eps
     for (int i = tid; i < 3 * T; i += BLOCK) {
         const int j = i / T, t = i - j * T;  // j: 0 EAg, 1 EA, 2 EDn
@@ -533,21 +570,29 @@ __device__ void prior_body(const EvalArgs& A, int chain, char* smem) {
     __syncthreads();
     DC_STAMP(2);
 
-    // ---- bounds: float32 maxima (-> rho_f32 of the streaming workgroups) and the true
-    // float64 maxima with their arg-pairs (ties -> smallest pair index)
-    float* redm = reinterpret_cast<float*>(scratch);
-    float mPf, mQf, mRf;
-    pair_maxima_f32<CLIP>(A, tabH, tabA, pr0, redm, tid, &mPf, &mQf, &mRf);
-    const float rho_f = rho_f32(mPf, mQf, mRf, fs.q);
-    __syncthreads();
-
-    // (ties: the pair with the smallest index wins; a thread sees its pairs in ascending
-    // order and keeps the first, lanes and waves are in ascending pair order too)
+    // ---- bounds: float32 maxima (-> rho_f32 of the streaming workgroups, same expressions as
+    // pair_maxima_f32) and the true float64 maxima with their arg-pairs, in ONE pass over the
+    // pairs and ONE barrier.  (Ties: the pair with the smallest index wins; a thread sees
+    // its pairs in ascending order and keeps the first, lanes and waves are in ascending
+    // pair order too.)
+    float* redm = reinterpret_cast<float*>(sc + 16);  // [WAVES*4] (sc[16..32) is free; scratch is reused by block_sum)
+    float mPf = 0.f, mQf = 0.f, mRf = 0.f;
     double mP = 0.0, mQ = 0.0, mR = 0.0;
     uint32_t aP = 0, aQ = 0, aR = 0;  // arg-pairs (home | away << 16)
     for (int p = tid; p < A.P; p += BLOCK) {
         const uint32_t pr = p == tid ? pr0 : A.pairs[p];
         const int h = pr & 0xFFFFu, a = pr >> 16;
+        {
+            const float2 th = tabH[h], ta = tabA[a];
+            float lhf = th.x * ta.y, laf = ta.x * th.y;
+            if (CLIP) {
+                lhf = fminf(lhf, (float)RATE_CLIP);
+                laf = fminf(laf, (float)RATE_CLIP);
+            }
+            mPf = fmaxf(mPf, lhf * laf);
+            mQf = fmaxf(mQf, lhf);
+            mRf = fmaxf(mRf, laf);
+        }
         double lh = tru[h] * tru[2 * T + a], la = tru[T + a] * tru[2 * T + h];
         if (CLIP) {
             lh = fmin(lh, RATE_CLIP);
@@ -556,6 +601,14 @@ __device__ void prior_body(const EvalArgs& A, int chain, char* smem) {
         if (lh * la > mP) { mP = lh * la; aP = pr; }
         if (lh > mQ) { mQ = lh; aQ = pr; }
         if (la > mR) { mR = la; aR = pr; }
+    }
+    mPf = wave_max_f32(mPf);
+    mQf = wave_max_f32(mQf);
+    mRf = wave_max_f32(mRf);
+    if (lane == 0) {
+        redm[wave * 4 + 0] = mPf;
+        redm[wave * 4 + 1] = mQf;
+        redm[wave * 4 + 2] = mRf;
     }
     {
         const double wP = wave_max_f64(mP), wQ = wave_max_f64(mQ), wR = wave_max_f64(mR);
@@ -611,16 +664,26 @@ __device__ void prior_body(const EvalArgs& A, int chain, char* smem) {
     }
     // The two serial pieces of the record run on different waves at the same time (a single lane
     // executing ~300 dependent float64 instructions is the longest pole of this workgroup).
+    // ---- bounds: combine the waves' arg-maxima on lanes 0..WAVES-1 of wave 0 (a serial loop
+    // of 48 dependent LDS reads cost 1.1 us here); ties: the lowest wave wins
+    double M = 0.0, Lh = 0.0, La = 0.0;
+    uint32_t pP = 0, pQ = 0, pR = 0;
+    if (wave == 0) {
+        const bool src = lane < WAVES;
+        const double a0 = src ? amx[lane * 8 + 0] : 0.0, a1 = src ? amx[lane * 8 + 1] : 0.0,
+                     a2 = src ? amx[lane * 8 + 2] : 0.0;
+        const uint32_t q0 = src ? (uint32_t)amx[lane * 8 + 3] : 0u, q1 = src ? (uint32_t)amx[lane * 8 + 4] : 0u,
+                       q2 = src ? (uint32_t)amx[lane * 8 + 5] : 0u;
+        M = wave_max_f64(a0);
+        Lh = wave_max_f64(a1);
+        La = wave_max_f64(a2);
+        const unsigned long long bP = __ballot(src && a0 == M), bQ = __ballot(src && a1 == Lh),
+                                 bR = __ballot(src && a2 == La);
+        pP = (uint32_t)__builtin_amdgcn_readlane((int)q0, bP ? __ffsll((long long)bP) - 1 : 0);
+        pQ = (uint32_t)__builtin_amdgcn_readlane((int)q1, bQ ? __ffsll((long long)bQ) - 1 : 0);
+        pR = (uint32_t)__builtin_amdgcn_readlane((int)q2, bR ? __ffsll((long long)bR) - 1 : 0);
+    }
     if (tid == 0) {
-        // ---- bounds: combine the waves' arg-maxima (strict >: the lowest wave wins ties)
-        double M = 0.0, Lh = 0.0, La = 0.0;
-        uint32_t pP = 0, pQ = 0, pR = 0;
-        for (int wv = 0; wv < WAVES; ++wv) {
-            const double a0 = amx[wv * 8 + 0], a1 = amx[wv * 8 + 1], a2 = amx[wv * 8 + 2];
-            if (a0 > M) { M = a0; pP = (uint32_t)amx[wv * 8 + 3]; }
-            if (a1 > Lh) { Lh = a1; pQ = (uint32_t)amx[wv * 8 + 4]; }
-            if (a2 > La) { La = a2; pR = (uint32_t)amx[wv * 8 + 5]; }
-        }
         unsigned int flags = 0;
         if (CLIP) {
             if (tru[pP & 0xFFFFu] * tru[2 * T + (pP >> 16)] > RATE_CLIP) flags |= 1u;
@@ -628,9 +691,20 @@ __device__ void prior_body(const EvalArgs& A, int chain, char* smem) {
             if (tru[pQ & 0xFFFFu] * tru[2 * T + (pQ >> 16)] > RATE_CLIP) flags |= 4u;
             if (tru[T + (pR >> 16)] * tru[2 * T + (pR & 0xFFFFu)] > RATE_CLIP) flags |= 8u;
         }
+        DC_STAMP(13);
         const double UB = M > 1.0 ? 1.0 / M : 1.0;
         const double LB = -1.0 / fmax(Lh, La);
         const double rho = LB + q * (UB - LB);
+        // the float32 rho every streaming workgroup computed (bit for bit)
+        float fP = 0.f, fQ = 0.f, fR = 0.f;
+#pragma unroll
+        for (int wv = 0; wv < WAVES; ++wv) {
+            fP = fmaxf(fP, redm[wv * 4 + 0]);
+            fQ = fmaxf(fQ, redm[wv * 4 + 1]);
+            fR = fmaxf(fR, redm[wv * 4 + 2]);
+        }
+        const float rho_f = rho_f32(fP, fQ, fR, fs.q);
+        DC_STAMP(15);
         st_sc1(&zo[ZO_Q], q);
         st_sc1(&zo[ZO_DQ], dq);
         st_sc1(&zo[ZO_UB], UB);
@@ -645,45 +719,15 @@ __device__ void prior_body(const EvalArgs& A, int chain, char* smem) {
         st_sc1(&zo[ZO_PR], (double)pR);
         st_sc1(&zo[ZO_FLAGS], (double)flags);
     }
-    if (tid == 64) {
-        // ---- scalar priors + Jacobians (L = log density) and their gradient
-        const double zsa = z[L.o_sa], zsd = z[L.o_sd];
-        double Lz = sc[5] + sc[6] + 1.791759469228055 /*log 6*/ + sc[7];  // Beta(2,2) + Jac
-        Lz += -0.5 * s_a * s_a - HALF_LOG_2PI + LN2 + zsa;  // HalfNormal(1) + Exp Jacobian
-        Lz += -0.5 * s_d * s_d - HALF_LOG_2PI + LN2 + zsd;
-        Lz += -0.5 * m * m - HALF_LOG_2PI;
-        st_sc1(&gz[L.o_corr], -((1.0 / q - 1.0 / (1.0 - q)) * dq + (1.0 - 2.0 * sc[8])));
-        st_sc1(&gz[L.o_md], m);
-        st_sc1(&gz[L.o_sa], s_a * s_a - 1.0);
-        st_sc1(&gz[L.o_sd], s_d * s_d - 1.0);
-        if (L.model == MODEL_BASIC) {
-            const double gam = z[L.o_ha], r = (gam - 0.1) / 0.2;
-            Lz += -0.5 * r * r + 1.6094379124341003 /*-log 0.2*/ - HALF_LOG_2PI;
-            st_sc1(&gz[L.o_ha], (gam - 0.1) / 0.04);
-        } else {
-            const double mha = z[L.o_mha], zsh = z[L.o_sh];
-            const double r = (mha - 0.1) / 0.2;
-            Lz += -0.5 * r * r + 1.6094379124341003 - HALF_LOG_2PI;
-            Lz += -0.5 * s_h * s_h - HALF_LOG_2PI + LN2 + zsh;
+    if (tid == 64) {  // what was waiting for the team sums
+        if (L.model == MODEL_EXTENDED) {
             const double u = sc[9], du = sc[10];
-            Lz += sc[11] + 3.0 * sc[12] + 2.995732273553991 /*log 20*/ + sc[13];
-            for (int k = 0; k < K; ++k) {
-                const double ba = z[L.o_bA + k], bd = z[L.o_bD + k];
-                Lz += -0.5 * ba * ba - 0.5 * bd * bd - 2.0 * HALF_LOG_2PI;
-            }
-            st_sc1(&gz[L.o_mha], (mha - 0.1) / 0.04);
-            st_sc1(&gz[L.o_sh], s_h * s_h - 1.0);
             st_sc1(&gz[L.o_u], -(2.0 * v[1] * du + (1.0 / u - 3.0 / (1.0 - u)) * du +
                                  (1.0 - 2.0 * sc[14])));
         }
         st_sc1(&zo[ZO_LZ], Lz + v[0]);
-        st_sc1(&zo[ZO_SA], s_a);
-        st_sc1(&zo[ZO_SD], s_d);
-        st_sc1(&zo[ZO_SH], s_h);
     }
 }
-
-// ------------------------------------------------------------------------ tail
 
 // Per-team epilogue for T <= 64: lane t owns team t, sums are DPP wave reductions, adds and
 // FMAs only.  A single wave issues a dependent instruction every ~5 cycles, so the work is
