@@ -629,6 +629,17 @@ int bplhip_set_fixtures(bplhip_ctx* c, int model_kind, int64_t n, int32_t n_team
     const int n_wg = (waves + dc::WAVES - 1) / dc::WAVES;
 
     SparseSlabs sp = build_sparse_slabs(hs, as, n_lanefix, T, tpw, n_wg);
+    // device copy of the home indices: halfword 1 of every lane carries the lane's number of
+    // real fixtures (all fixtures of a lane share one pair, only halfword 0 is read as index)
+    std::vector<uint16_t> hs_dev(hs);
+    for (int64_t l = 0; l < n_pad / dc::LANE_FIX; ++l) {
+        int cnt = 0;
+        for (int j = 0; j < dc::LANE_FIX; ++j) {
+            const int64_t r = l * dc::LANE_FIX + j;
+            cnt += r < n_lanefix && !(xs8[r] == 255 && ys8[r] == 255);
+        }
+        hs_dev[l * dc::LANE_FIX + 1] = (uint16_t)cnt;
+    }
     std::vector<int>&wg_off = sp.wg_off, &wg_slots = sp.wg_slots, &col_off = sp.col_off,
     &wg_dst = sp.wg_dst;
 
@@ -645,7 +656,7 @@ int bplhip_set_fixtures(bplhip_ctx* c, int model_kind, int64_t n, int32_t n_team
     HIP_TRY(c, c->d_a.ensure(n_pad * 2));
     HIP_TRY(c, c->d_x.ensure(n_pad));
     HIP_TRY(c, c->d_y.ensure(n_pad));
-    HIP_TRY(c, hipMemcpyAsync(c->d_h.p, hs.data(), n_pad * 2, hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(c->d_h.p, hs_dev.data(), n_pad * 2, hipMemcpyHostToDevice, s));
     HIP_TRY(c, hipMemcpyAsync(c->d_a.p, as.data(), n_pad * 2, hipMemcpyHostToDevice, s));
     HIP_TRY(c, hipMemcpyAsync(c->d_x.p, xs8.data(), n_pad, hipMemcpyHostToDevice, s));
     HIP_TRY(c, hipMemcpyAsync(c->d_y.p, ys8.data(), n_pad, hipMemcpyHostToDevice, s));

@@ -1220,10 +1220,13 @@ __device__ __forceinline__ LaneOut lane_uniform(const LaneData& Ld, float rho,
             c10 += __popc(zero_bytes((x ^ one) | y));
             c01 += __popc(zero_bytes(x | (y ^ one)));
             c11 += __popc(zero_bytes((x ^ one) | (y ^ one)));
-            nz += __popc(zero_bytes(~(x & y)));  // null fixtures: goals (255, 255)
             ax = __builtin_amdgcn_sad_u8(x, 0u, ax);
             ay = __builtin_amdgcn_sad_u8(y, 0u, ay);
         }
+        // null fixtures (goals (255, 255), never a low score) pad the end of a pair's run; the
+        // lane's number of REAL fixtures rides in the second home-index halfword, which nothing
+        // else reads (all fixtures of a lane share one pair)
+        nz = LANE_FIX - (int)(Ld.hw[0] >> 16);
         n00 = (float)c00; n10 = (float)c10; n01 = (float)c01; n11 = (float)c11;
         nall = (float)(LANE_FIX - nz);
         sx = (float)((int)ax - 255 * nz);
@@ -1388,6 +1391,10 @@ __global__ DC_LAUNCH_BOUNDS void dc_eval(EvalArgs A) {
                 flush_run(acc, T1, key, rsh, rsa);
             }
 
+            // The prefetched words must not be touched before this point: without the opaque
+            // redefinition the compiler hoists the next tile's first use (index masking) up to
+            // the loads, which turns the prefetch into a stall (measured: +20 % at N = 1e8).
+            asm volatile("" : "+v"(nxt.hw[0]), "+v"(nxt.aw[0]), "+v"(nxt.xw[0]), "+v"(nxt.yw[0]));
             cur = nxt;
             ++tile;
         }

@@ -54,8 +54,9 @@ __device__ __forceinline__ LaneClass classify(const LaneData& Ld, uint32_t& rem,
     const uint32_t h0 = Ld.hw[0] & 0xFFFFu, a0 = Ld.aw[0] & 0xFFFFu;
     uint32_t mixed = 0;
 #pragma unroll
-    for (int q = 0; q < HWORDS; ++q)
-        mixed |= (Ld.hw[q] ^ (h0 * 0x00010001u)) | (Ld.aw[q] ^ (a0 * 0x00010001u));
+    for (int q = 0; q < HWORDS; ++q)  // (halfword 1 of the home indices carries the lane's count)
+        mixed |= (q == 0 ? (Ld.hw[0] ^ h0) & 0xFFFFu : Ld.hw[q] ^ (h0 * 0x00010001u)) |
+                 (Ld.aw[q] ^ (a0 * 0x00010001u));
     if (!WEIGHTED && rem == ALL && mixed == 0) {  // the common case: one pair, SWAR counts
         const uint32_t one = 0x01010101u;
         int c00 = 0, c10 = 0, c01 = 0, c11 = 0, nz = 0;
@@ -67,10 +68,13 @@ __device__ __forceinline__ LaneClass classify(const LaneData& Ld, uint32_t& rem,
             c10 += __popc(zero_bytes((x ^ one) | y));
             c01 += __popc(zero_bytes(x | (y ^ one)));
             c11 += __popc(zero_bytes((x ^ one) | (y ^ one)));
-            nz += __popc(zero_bytes(~(x & y)));  // null fixtures: goals (255, 255)
             ax = __builtin_amdgcn_sad_u8(x, 0u, ax);
             ay = __builtin_amdgcn_sad_u8(y, 0u, ay);
         }
+        // null fixtures (goals (255, 255), never a low score) pad the end of a pair's run; the
+        // lane's number of REAL fixtures rides in the second home-index halfword, which nothing
+        // else reads (all fixtures of a lane share one pair)
+        nz = LANE_FIX - (int)(Ld.hw[0] >> 16);
         c.key = h0 | (a0 << 16);
         c.n00 = (float)c00; c.n10 = (float)c10; c.n01 = (float)c01; c.n11 = (float)c11;
         c.nall = (float)(LANE_FIX - nz);
@@ -85,7 +89,7 @@ __device__ __forceinline__ LaneClass classify(const LaneData& Ld, uint32_t& rem,
     c.n00 = c.n10 = c.n01 = c.n11 = c.nall = c.sx = c.sy = 0.f;
 #pragma unroll
     for (int j = 0; j < LANE_FIX; ++j) {
-        const uint32_t hj = (Ld.hw[j >> 1] >> (16 * (j & 1))) & 0xFFFFu;
+        const uint32_t hj = j == 1 ? h0 : (Ld.hw[j >> 1] >> (16 * (j & 1))) & 0xFFFFu;  // (1: the count)
         const uint32_t aj = (Ld.aw[j >> 1] >> (16 * (j & 1))) & 0xFFFFu;
         const uint32_t xj = (Ld.xw[j >> 2] >> (8 * (j & 3))) & 0xFFu;
         const uint32_t yj = (Ld.yw[j >> 2] >> (8 * (j & 3))) & 0xFFu;
@@ -308,6 +312,8 @@ __global__ __launch_bounds__(BLOCK) void dc_vec_stream(EvalArgs A) {
             for (int b = 0; b < CB; ++b)
                 flush_run(acc + (size_t)b * accn, T1, pkey, prs[b], pra[b]);
         }
+        // (see dc_eval: keeps the compiler from consuming the prefetched words at issue time)
+        asm volatile("" : "+v"(nxt.hw[0]), "+v"(nxt.aw[0]), "+v"(nxt.xw[0]), "+v"(nxt.yw[0]));
         cur = nxt;
         ++tile;
     }
