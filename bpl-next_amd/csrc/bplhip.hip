@@ -629,16 +629,18 @@ int bplhip_set_fixtures(bplhip_ctx* c, int model_kind, int64_t n, int32_t n_team
     const int n_wg = (waves + dc::WAVES - 1) / dc::WAVES;
 
     SparseSlabs sp = build_sparse_slabs(hs, as, n_lanefix, T, tpw, n_wg);
-    // device copy of the home indices: halfword 1 of every lane carries the lane's number of
-    // real fixtures (all fixtures of a lane share one pair, only halfword 0 is read as index)
-    std::vector<uint16_t> hs_dev(hs);
-    for (int64_t l = 0; l < n_pad / dc::LANE_FIX; ++l) {
-        int cnt = 0;
+    // device copies of the indices, run-length encoded: ONE word per lane (all fixtures of a
+    // lane share one pair): home | (number of real fixtures of the lane) << 16, and away
+    const int64_t n_lanes = n_pad / dc::LANE_FIX;
+    std::vector<uint32_t> h_lane(n_lanes), a_lane(n_lanes);
+    for (int64_t l = 0; l < n_lanes; ++l) {
+        uint32_t cnt = 0;
         for (int j = 0; j < dc::LANE_FIX; ++j) {
             const int64_t r = l * dc::LANE_FIX + j;
             cnt += r < n_lanefix && !(xs8[r] == 255 && ys8[r] == 255);
         }
-        hs_dev[l * dc::LANE_FIX + 1] = (uint16_t)cnt;
+        h_lane[l] = (uint32_t)hs[l * dc::LANE_FIX] | (cnt << 16);
+        a_lane[l] = (uint32_t)as[l * dc::LANE_FIX];
     }
     std::vector<int>&wg_off = sp.wg_off, &wg_slots = sp.wg_slots, &col_off = sp.col_off,
     &wg_dst = sp.wg_dst;
@@ -652,12 +654,12 @@ int bplhip_set_fixtures(bplhip_ctx* c, int model_kind, int64_t n, int32_t n_team
     HIP_TRY(c, hipMemcpyAsync(c->d_wg_slots.p, wg_slots.data(), wg_slots.size() * 4, hipMemcpyHostToDevice, s));
     HIP_TRY(c, hipMemcpyAsync(c->d_col_off.p, col_off.data(), col_off.size() * 4, hipMemcpyHostToDevice, s));
     HIP_TRY(c, hipMemcpyAsync(c->d_wg_dst.p, wg_dst.data(), wg_dst.size() * 4, hipMemcpyHostToDevice, s));
-    HIP_TRY(c, c->d_h.ensure(n_pad * 2));
-    HIP_TRY(c, c->d_a.ensure(n_pad * 2));
+    HIP_TRY(c, c->d_h.ensure(n_lanes * 4));
+    HIP_TRY(c, c->d_a.ensure(n_lanes * 4));
     HIP_TRY(c, c->d_x.ensure(n_pad));
     HIP_TRY(c, c->d_y.ensure(n_pad));
-    HIP_TRY(c, hipMemcpyAsync(c->d_h.p, hs_dev.data(), n_pad * 2, hipMemcpyHostToDevice, s));
-    HIP_TRY(c, hipMemcpyAsync(c->d_a.p, as.data(), n_pad * 2, hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(c->d_h.p, h_lane.data(), n_lanes * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(c->d_a.p, a_lane.data(), n_lanes * 4, hipMemcpyHostToDevice, s));
     HIP_TRY(c, hipMemcpyAsync(c->d_x.p, xs8.data(), n_pad, hipMemcpyHostToDevice, s));
     HIP_TRY(c, hipMemcpyAsync(c->d_y.p, ys8.data(), n_pad, hipMemcpyHostToDevice, s));
     if (weights) {

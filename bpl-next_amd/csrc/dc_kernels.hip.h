@@ -71,8 +71,8 @@ enum {
 
 struct EvalArgs {
     // fixtures (library-owned, sorted by (home,away), padded to TILE with team T)
-    const uint32_t* h;  // [n_tiles*64*HWORDS]  LANE_FIX x u16 home index per lane
-    const uint32_t* a;  // [n_tiles*64*HWORDS]  LANE_FIX x u16 away index
+    const uint32_t* h;  // [n_tiles*64]  per lane: home index | real fixtures of the lane << 16
+    const uint32_t* a;  // [n_tiles*64]  per lane: away index
     const uint32_t* x;  // [n_tiles*64*XWORDS]  LANE_FIX x u8 home goals
     const uint32_t* y;  // [n_tiles*64*XWORDS]  LANE_FIX x u8 away goals
     const float* w;     // [n_tiles*64*LANE_FIX] f32 weights, or nullptr
@@ -1127,9 +1127,11 @@ __device__ void tail_body(const EvalArgs& A, int chain, char* smem) {
 
 // ------------------------------------------------------------ per-lane fixture math
 
-// the lane's LANE_FIX consecutive fixtures, still packed as loaded (16-B / 8-B / 4-B loads)
+// the lane's LANE_FIX consecutive fixtures, still packed as loaded.  All of them share one
+// (home, away) pair, so the indices are stored once per lane (run-length encoded):
+//   hw[0] = home | (number of real fixtures of the lane) << 16,   aw[0] = away
 struct LaneData {
-    uint32_t hw[HWORDS], aw[HWORDS], xw[XWORDS], yw[XWORDS];
+    uint32_t hw[1], aw[1], xw[XWORDS], yw[XWORDS];
     float wj[LANE_FIX];
 };
 template <int NW>
@@ -1147,8 +1149,8 @@ __device__ __forceinline__ void load_words(const uint32_t* p, uint32_t (&d)[NW])
 template <bool WEIGHTED>
 __device__ __forceinline__ LaneData load_lane(const EvalArgs& A, size_t o /* tile*64 + lane */) {
     LaneData L;
-    load_words<HWORDS>(A.h + o * HWORDS, L.hw);
-    load_words<HWORDS>(A.a + o * HWORDS, L.aw);
+    L.hw[0] = A.h[o];
+    L.aw[0] = A.a[o];
     load_words<XWORDS>(A.x + o * XWORDS, L.xw);
     load_words<XWORDS>(A.y + o * XWORDS, L.yw);
     if (WEIGHTED) {
@@ -1414,7 +1416,9 @@ __global__ DC_LAUNCH_BOUNDS void dc_eval(EvalArgs A) {
             red[wave * N_SCAL + 2] = dSU;
             red[wave * N_SCAL + 3] = dCLIP;
         }
+        DC_STAMP(15);
         __syncthreads();
+        DC_STAMP(11);
         {   // publish only the slots this workgroup's fixtures touch (static list)
             double* cmpw = A.hbuf + (size_t)chain * A.hb_stride + A.zo_stride + A.n_wg * N_SCAL;
             for (int k = o0 + tid; k < o1; k += BLOCK) {

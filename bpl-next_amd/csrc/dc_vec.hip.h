@@ -50,16 +50,12 @@ struct LaneClass {
 template <bool WEIGHTED>
 __device__ __forceinline__ LaneClass classify(const LaneData& Ld, uint32_t& rem, uint32_t sentinel) {
     LaneClass c;
-    constexpr uint32_t ALL = (1u << LANE_FIX) - 1u;
-    const uint32_t h0 = Ld.hw[0] & 0xFFFFu, a0 = Ld.aw[0] & 0xFFFFu;
-    uint32_t mixed = 0;
-#pragma unroll
-    for (int q = 0; q < HWORDS; ++q)  // (halfword 1 of the home indices carries the lane's count)
-        mixed |= (q == 0 ? (Ld.hw[0] ^ h0) & 0xFFFFu : Ld.hw[q] ^ (h0 * 0x00010001u)) |
-                 (Ld.aw[q] ^ (a0 * 0x00010001u));
-    if (!WEIGHTED && rem == ALL && mixed == 0) {  // the common case: one pair, SWAR counts
+    // all fixtures of a lane share one pair (runs are padded to the lane width): one pass
+    c.key = (Ld.hw[0] & 0xFFFFu) | (Ld.aw[0] << 16);
+    rem = 0;
+    if (!WEIGHTED) {  // SWAR counts
         const uint32_t one = 0x01010101u;
-        int c00 = 0, c10 = 0, c01 = 0, c11 = 0, nz = 0;
+        int c00 = 0, c10 = 0, c01 = 0, c11 = 0;
         uint32_t ax = 0, ay = 0;
 #pragma unroll
         for (int q = 0; q < XWORDS; ++q) {
@@ -72,37 +68,20 @@ __device__ __forceinline__ LaneClass classify(const LaneData& Ld, uint32_t& rem,
             ay = __builtin_amdgcn_sad_u8(y, 0u, ay);
         }
         // null fixtures (goals (255, 255), never a low score) pad the end of a pair's run; the
-        // lane's number of REAL fixtures rides in the second home-index halfword, which nothing
-        // else reads (all fixtures of a lane share one pair)
-        nz = LANE_FIX - (int)(Ld.hw[0] >> 16);
-        c.key = h0 | (a0 << 16);
+        // lane's number of REAL fixtures rides above the home index
+        const int nz = LANE_FIX - (int)(Ld.hw[0] >> 16);
         c.n00 = (float)c00; c.n10 = (float)c10; c.n01 = (float)c01; c.n11 = (float)c11;
         c.nall = (float)(LANE_FIX - nz);
         c.sx = (float)((int)ax - 255 * nz);
         c.sy = (float)((int)ay - 255 * nz);
-        rem = 0;
         return c;
     }
-    uint32_t key = sentinel | (sentinel << 16);
-    bool have = false;
-    uint32_t members = 0;
     c.n00 = c.n10 = c.n01 = c.n11 = c.nall = c.sx = c.sy = 0.f;
 #pragma unroll
     for (int j = 0; j < LANE_FIX; ++j) {
-        const uint32_t hj = j == 1 ? h0 : (Ld.hw[j >> 1] >> (16 * (j & 1))) & 0xFFFFu;  // (1: the count)
-        const uint32_t aj = (Ld.aw[j >> 1] >> (16 * (j & 1))) & 0xFFFFu;
         const uint32_t xj = (Ld.xw[j >> 2] >> (8 * (j & 3))) & 0xFFu;
         const uint32_t yj = (Ld.yw[j >> 2] >> (8 * (j & 3))) & 0xFFu;
-        const uint32_t kj = hj | (aj << 16);
-        const bool r = (rem >> j) & 1u;
-        if (r && !have) {
-            key = kj;
-            have = true;
-        }
-        const bool m = r && kj == key;
-        members |= m ? (1u << j) : 0u;
-        const bool null_fx = (xj & yj) == 255u;  // padding of a pair's run (weight 0 when weighted)
-        const float wv = (m && !null_fx) ? (WEIGHTED ? Ld.wj[j] : 1.0f) : 0.0f;
+        const float wv = Ld.wj[j];  // (0 for null fixtures)
         c.n00 += (xj | yj) == 0 ? wv : 0.f;
         c.n10 += (xj == 1 && yj == 0) ? wv : 0.f;
         c.n01 += (xj == 0 && yj == 1) ? wv : 0.f;
@@ -111,8 +90,7 @@ __device__ __forceinline__ LaneClass classify(const LaneData& Ld, uint32_t& rem,
         c.sx += wv * (float)xj;
         c.sy += wv * (float)yj;
     }
-    c.key = key;
-    rem &= ~members;
+    (void)sentinel;
     return c;
 }
 

@@ -23,10 +23,11 @@ def run(n, model=MODEL_BASIC, max_wg=255):
     st = buf[: nwg * 16].reshape(nwg, 16).astype(np.int64)
     t0 = st[:, 0].min()
     rel = (st - t0) * 0.01  # us (100 MHz)
-    names = ["entry", "tables", "bounds", "stream", "slab", "drain", "ticket", "tail:start", "tail:loads", "tail:adj", "tail:end", "-", "loads-landed", "lane-math"]
+    names = ["entry", "tables", "bounds", "stream", "slab", "drain", "ticket", "tail:start", "tail:loads", "tail:adj", "tail:end", "barrier", "loads-landed", "lane-math"]
     print(f"--- N={n} model={model} blocks={nwg} (block 0 = prior workgroup)")
     print("  prior WG: entry=%.2f scalars=%.2f cells=%.2f bounds=%.2f sums=%.2f amx=%.2f div=%.2f done=%.2f drain=%.2f ticket=%.2f" % (rel[0, 0], rel[0, 1], rel[0, 2], rel[0, 3], rel[0, 12], rel[0, 13], rel[0, 15], rel[0, 4], rel[0, 5], rel[0, 6]))
-    for k in list(range(7)) + [12, 13]:
+    names = names + ["epi", "sums-done"]
+    for k in [0, 1, 2, 12, 13, 3, 15, 11, 4, 5, 6]:
         col = rel[1:, k][st[1:, k] > 0]
         if col.size: print(f"  {names[k]:10s} median {np.median(col):7.2f} us  min {col.min():7.2f}  max {col.max():7.2f}")
     last = int(np.argmax(st[:, 10]))
