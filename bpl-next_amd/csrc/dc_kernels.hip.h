@@ -36,10 +36,11 @@
 namespace dc {
 
 #ifndef DC_LANE_FIX
-#define DC_LANE_FIX 8
+#define DC_LANE_FIX 32
 #endif
-constexpr int LANE_FIX = DC_LANE_FIX;    // fixtures per lane per tile (4 or 8)
-static_assert(LANE_FIX == 4 || LANE_FIX == 8, "LANE_FIX must be 4 or 8");
+constexpr int LANE_FIX = DC_LANE_FIX;    // fixtures per lane per tile (4, 8, 16 or 32)
+static_assert(LANE_FIX == 4 || LANE_FIX == 8 || LANE_FIX == 16 || LANE_FIX == 32,
+              "LANE_FIX must be 4, 8, 16 or 32");
 constexpr int HWORDS = LANE_FIX / 2;     // packed u16 pairs per lane
 constexpr int XWORDS = LANE_FIX / 4;     // packed u8 quads per lane
 constexpr int TILE = 64 * LANE_FIX;      // fixtures per wave-tile
@@ -1136,7 +1137,11 @@ struct LaneData {
 };
 template <int NW>
 __device__ __forceinline__ void load_words(const uint32_t* p, uint32_t (&d)[NW]) {
-    if (NW == 4) {
+    if (NW == 8) {
+        const uint4 v = *reinterpret_cast<const uint4*>(p), u = *reinterpret_cast<const uint4*>(p + 4);
+        d[0] = v.x; d[1] = v.y; d[NW > 2 ? 2 : 0] = v.z; d[NW > 3 ? 3 : 0] = v.w;
+        d[NW > 4 ? 4 : 0] = u.x; d[NW > 5 ? 5 : 0] = u.y; d[NW > 6 ? 6 : 0] = u.z; d[NW > 7 ? 7 : 0] = u.w;
+    } else if (NW == 4) {
         const uint4 v = *reinterpret_cast<const uint4*>(p);
         d[0] = v.x; d[1] = v.y; d[NW > 2 ? 2 : 0] = v.z; d[NW > 3 ? 3 : 0] = v.w;
     } else if (NW == 2) {

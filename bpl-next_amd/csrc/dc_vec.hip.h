@@ -238,7 +238,7 @@ __global__ __launch_bounds__(BLOCK) void dc_vec_stream(EvalArgs A) {
         uint32_t pkey = sentinel | (sentinel << 16);
 #pragma unroll
         for (int b = 0; b < CB; ++b) prs[b] = pra[b] = 0.f;
-        uint32_t rem = (1u << LANE_FIX) - 1u;
+        uint32_t rem = LANE_FIX >= 32 ? 0xFFFFFFFFu : (1u << (LANE_FIX & 31)) - 1u;
         do {
             const bool act = rem != 0;
             const LaneClass lc = classify<WEIGHTED>(cur, rem, sentinel);
