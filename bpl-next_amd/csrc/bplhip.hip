@@ -80,7 +80,8 @@ struct bplhip_ctx {
     int opt_device_nuts = 1;  // 1: tree builder on the device (nuts_dev.hip.h) when supported
     int opt_max_wg = 255;  // streaming workgroups (+1 prior workgroup = one per CU)
     int opt_persistent_nuts = 1;  // bplhip_nuts_run_chains: whole chains on the device (0: lock step)
-    int opt_vec_min_chains = 4;  // batched calls with at least this many chains use dc_vec (0: never)
+    int opt_vec_min_chains = 5;  // batched calls with at least this many chains use dc_vec (0: never);
+                                 // fewer run as grid.y copies of the single-chain launch
     int opt_vec_tpw = 0;         // > 0: force this many tiles per wave for every chain count
     // chain-vectorised partitions (dc_vec.hip.h): fewer, fatter workgroups the more chains
     // share a launch (the per-workgroup prologue builds 8 chains' tables); each has its
@@ -343,13 +344,17 @@ dc::EvalArgs eval_args(bplhip_ctx* c, int chains, const double* z, double* pot, 
 
 int launch_eval(bplhip_ctx* c, int chains, const double* z, double* pot, double* grad,
                 double* aux, hipStream_t s, double* nuts_state = nullptr, int nuts_depth = 0,
-                const nd::Persist* persist = nullptr) {
+                const nd::Persist* persist = nullptr, int nuts_stride = 0) {
     if (c->neutral) return launch_eval_neutral(c, chains, z, pot, grad, aux, s);
     if (c->dynamic) return launch_eval_dynamic(c, chains, z, pot, grad, aux, s);
     dc::EvalArgs A = eval_args(c, chains, z, pot, grad, aux);
     A.nuts = nuts_state;
     A.nuts_max_depth = nuts_depth;
     A.persist = persist;
+    if (nuts_state && nuts_stride) {  // several chains (grid.y): everything lives in the state buffers
+        A.nuts_stride = nuts_stride;
+        A.z_stride = A.g_stride = A.p_stride = A.aux_stride = nuts_stride;
+    }
     const bool clip = c->L.model == dc::MODEL_EXTENDED;
     if (c->weighted) return clip ? launch_eval_t<true, true>(c, A, chains, s)
                                  : launch_eval_t<true, false>(c, A, chains, s);
@@ -1354,6 +1359,8 @@ struct VecDeviceEngine {
 // chain's random inputs (they are data independent), uploads them, and from then on only
 // enqueues evaluations -- C == 1: the single-chain kernel, else the chain-vectorised one --
 // checking the chains' "all done" flags once per chunk of launches.
+constexpr int GRIDY_CHAINS = 4;
+
 int run_chains_persistent(bplhip_ctx* c, hipStream_t s, const nuts::Config& nc, int C, const double* z0,
                           const tf::Key* keys, double* draws_out, std::vector<nuts::Result>* res) {
     const int D = bplhip_latent_dim(c), md = nc.max_tree_depth;
@@ -1489,8 +1496,11 @@ int run_chains_persistent(bplhip_ctx* c, hipStream_t s, const nuts::Config& nc, 
                 hipLaunchKernelGGL(nd::kp_leaf, dim3(C), dim3(64), (size_t)(D + 8) * 8, s, ns, stride, D, md, P);
                 continue;
             }
-            rc = C == 1 ? launch_eval(c, 1, nd::vec(ns, D, nd::V_ZN), ns + nd::H_LEAF_PE, nd::vec(ns, D, nd::V_GRAD),
-                                      ns + nd::H_LEAF_AUX0, s, ns, md, dP)
+            // up to GRIDY_CHAINS chains fit the chip side by side as copies of the single-chain
+            // launch (62 workgroups each at N = 1e6); more chains share the vectorised kernel
+            rc = C <= GRIDY_CHAINS
+                     ? launch_eval(c, C, nd::vec(ns, D, nd::V_ZN), ns + nd::H_LEAF_PE, nd::vec(ns, D, nd::V_GRAD),
+                                   ns + nd::H_LEAF_AUX0, s, ns, md, dP, C > 1 ? (int)stride : 0)
                         : launch_eval_vec(c, C, nd::vec(ns, D, nd::V_ZN), ns + nd::H_LEAF_PE,
                                           nd::vec(ns, D, nd::V_GRAD), ns + nd::H_LEAF_AUX0, s, ns, (int)stride,
                                           md, dP);
@@ -1727,7 +1737,7 @@ extern "C" int bplhip_nuts_run_chains(bplhip_ctx* c, const bplhip_nuts_cfg* cfg,
     const nuts::Config nc = make_nuts_config(c, cfg);
     if (c->opt_persistent_nuts) {
         if (!generic_ok) {
-            int rc0 = ensure_slabs(c, 1);
+            int rc0 = ensure_slabs(c, std::max(1, std::min(C, GRIDY_CHAINS)));
             if (rc0 != BPLHIP_OK) return rc0;
         }
         std::vector<tf::Key> pkeys(C);
