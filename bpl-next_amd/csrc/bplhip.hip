@@ -369,13 +369,13 @@ int vec_hb_stride(const bplhip_ctx* c) {
 size_t vec_tail_lds(const bplhip_ctx* c, bool staged) {
     return dc::tail_lds_bytes(c->L.T, c->L.D, zo_stride_of(c->L), c->vp->n_wg, c->vp->total_c, staged);
 }
-template <bool S, bool N>
+template <bool S, bool N, bool E>
 int launch_vec_tail(bplhip_ctx* c, const dc::EvalArgs& A, int chains, hipStream_t s) {
     const size_t tl = vec_tail_lds(c, S);
     if (tl > 48 * 1024)
-        HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(dc::dc_vec_tail<S, N>),
+        HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(dc::dc_vec_tail<S, N, E>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)tl));
-    hipLaunchKernelGGL((dc::dc_vec_tail<S, N>), dim3(chains), dim3(dc::BLOCK), tl, s, A);
+    hipLaunchKernelGGL((dc::dc_vec_tail<S, N, E>), dim3(chains), dim3(dc::BLOCK), tl, s, A);
     return BPLHIP_OK;
 }
 template <bool W, bool C, bool N>
@@ -387,8 +387,8 @@ int launch_vec_n(bplhip_ctx* c, const dc::EvalArgs& A, int chains, hipStream_t s
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL((dc::dc_vec_stream<W, C, N>), dim3(dc::CB + c->vp->n_wg, groups),
                        dim3(dc::BLOCK), lds, s, A);
-    const int rc = c->vp->staged ? launch_vec_tail<true, N>(c, A, chains, s)
-                                : launch_vec_tail<false, N>(c, A, chains, s);
+    const int rc = c->vp->staged ? launch_vec_tail<true, N, C>(c, A, chains, s)
+                                : launch_vec_tail<false, N, C>(c, A, chains, s);
     if (rc != BPLHIP_OK) return rc;
     HIP_TRY(c, hipGetLastError());
     return BPLHIP_OK;

@@ -317,6 +317,7 @@ struct F32Scalars {
 __device__ __forceinline__ float exp_f32(float x) {
     return __builtin_amdgcn_exp2f(x * 1.44269504088896341f);
 }
+template <bool EXT>
 __device__ __forceinline__ F32Scalars f32_scalars(const Layout& L, const double* z) {
     F32Scalars s;
     s.s_a = exp_f32((float)z[L.o_sa]);
@@ -325,7 +326,7 @@ __device__ __forceinline__ F32Scalars f32_scalars(const Layout& L, const double*
     const float zc = (float)z[L.o_corr];
     float q = __builtin_amdgcn_rcpf(1.0f + exp_f32(-zc));
     s.q = fminf(fmaxf(q, (float)SIG_LO), (float)SIG_HI);
-    if (L.model == MODEL_BASIC) {
+    if (!EXT) {
         s.gam = (float)z[L.o_ha];
         s.s_h = 0.f;
         s.mha = 0.f;
@@ -336,11 +337,12 @@ __device__ __forceinline__ F32Scalars f32_scalars(const Layout& L, const double*
     }
     return s;
 }
+template <bool EXT>
 __device__ __forceinline__ void f32_table_entry(const Layout& L, const F32Scalars& s,
                                                 const double* z, const float* xsf, int t,
                                                 float2* vh, float2* va) {
     float att, def, ha;
-    if (L.model == MODEL_BASIC) {
+    if (!EXT) {
         att = s.s_a * (float)z[L.o_adec + t];
         def = s.m + s.s_d * (float)z[L.o_ddec + t];
         ha = s.gam;
@@ -359,13 +361,14 @@ __device__ __forceinline__ void f32_table_entry(const Layout& L, const F32Scalar
     *vh = make_float2(exp_f32(att + ha), edn);
     *va = make_float2(exp_f32(att), edn);
 }
+template <bool EXT>
 __device__ __forceinline__ void build_tables_f32(const Layout& L, const double* z,
                                                  const float* xsf, float2* tabH, float2* tabA,
                                                  int tid, F32Scalars* out) {
-    const F32Scalars s = f32_scalars(L, z);
+    const F32Scalars s = f32_scalars<EXT>(L, z);
     for (int t = tid; t <= L.T; t += BLOCK) {
         float2 vh = make_float2(0.f, 0.f), va = vh;
-        if (t < L.T) f32_table_entry(L, s, z, xsf, t, &vh, &va);
+        if (t < L.T) f32_table_entry<EXT>(L, s, z, xsf, t, &vh, &va);
         tabH[t] = vh;
         tabA[t] = va;
     }
@@ -476,19 +479,19 @@ __device__ void prior_body(const EvalArgs& A, int chain, char* smem) {
     uint32_t pr0 = 0;
     if (tid < A.P) pr0 = A.pairs[tid];
     F32Scalars fs;
-    build_tables_f32(L, z, A.xsf, tabH, tabA, tid, &fs);
+    build_tables_f32<CLIP>(L, z, A.xsf, tabH, tabA, tid, &fs);
 
     // ---- z-only scalars, one transcendental chain per wave, in parallel
     //   0 s_a  1 s_d  2 s_h  3..8 corr site  9..14 u site
     if (tid == 0) sc[0] = exp(z[L.o_sa]);
     if (tid == 64) sc[1] = exp(z[L.o_sd]);
-    if (tid == 128) sc[2] = L.model == MODEL_EXTENDED ? exp(z[L.o_sh]) : 0.0;
+    if (tid == 128) sc[2] = CLIP ? exp(z[L.o_sh]) : 0.0;
     if (tid == 192) {
         const SigSite s = sig_site(z[L.o_corr]);
         sc[3] = s.v; sc[4] = s.dv; sc[5] = s.log_v; sc[6] = s.log_1mv; sc[7] = s.jac;
         sc[8] = s.sig;
     }
-    if (tid == 256 && L.model == MODEL_EXTENDED) {
+    if (tid == 256 && CLIP) {
         const SigSite s = sig_site(z[L.o_u]);
         sc[9] = s.v; sc[10] = s.dv; sc[11] = s.log_v; sc[12] = s.log_1mv; sc[13] = s.jac;
         sc[14] = s.sig;
@@ -512,7 +515,7 @@ __device__ void prior_body(const EvalArgs& A, int chain, char* smem) {
         st_sc1(&gz[L.o_md], m);
         st_sc1(&gz[L.o_sa], s_a * s_a - 1.0);
         st_sc1(&gz[L.o_sd], s_d * s_d - 1.0);
-        if (L.model == MODEL_BASIC) {
+        if (!CLIP) {
             const double gam = z[L.o_ha], r = (gam - 0.1) / 0.2;
             Lz += -0.5 * r * r + 1.6094379124341003 /*-log 0.2*/ - HALF_LOG_2PI;
             st_sc1(&gz[L.o_ha], (gam - 0.1) / 0.04);
@@ -538,7 +541,7 @@ __device__ void prior_body(const EvalArgs& A, int chain, char* smem) {
     for (int i = tid; i < 3 * T; i += BLOCK) {
         const int j = i / T, t = i - j * T;  // j: 0 EAg, 1 EA, 2 EDn
         double att, def, ha;
-        if (L.model == MODEL_BASIC) {
+        if (!CLIP) {
             att = s_a * z[L.o_adec + t];
             def = m + s_d * z[L.o_ddec + t];
             ha = z[L.o_ha];
@@ -632,15 +635,15 @@ __device__ void prior_body(const EvalArgs& A, int chain, char* smem) {
     // v: 0 team part of L (priors + att cA - def cD + ha cH); extended: 1 dL/d rho_p
     double v[2] = {0.0, 0.0};
     double rp = 0.0, vv = 1.0;
-    if (L.model == MODEL_EXTENDED) {
+    if (CLIP) {
         rp = 2.0 * sc[9] - 1.0;
         vv = 1.0 - rp * rp;
     }
-    const double log_vv = L.model == MODEL_EXTENDED ? log(vv) : 0.0;
+    const double log_vv = CLIP ? log(vv) : 0.0;
     for (int t = tid; t < T; t += BLOCK) {
         const double att = par[t], def = par[T + t], ha = par[2 * T + t];
         const double lin = att * A.cA[t] - def * A.cD[t] + ha * A.cH[t];
-        if (L.model == MODEL_BASIC) {
+        if (!CLIP) {
             const double ad = z[L.o_adec + t], dd = z[L.o_ddec + t];
             v[0] += -0.5 * ad * ad - 0.5 * dd * dd - 2.0 * HALF_LOG_2PI + lin;
             st_sc1(&gz[L.o_adec + t], ad);
@@ -721,7 +724,7 @@ __device__ void prior_body(const EvalArgs& A, int chain, char* smem) {
         st_sc1(&zo[ZO_FLAGS], (double)flags);
     }
     if (tid == 64) {  // what was waiting for the team sums
-        if (L.model == MODEL_EXTENDED) {
+        if (CLIP) {
             const double u = sc[9], du = sc[10];
             st_sc1(&gz[L.o_u], -(2.0 * v[1] * du + (1.0 / u - 3.0 / (1.0 - u)) * du +
                                  (1.0 - 2.0 * sc[14])));
@@ -737,7 +740,7 @@ __device__ void prior_body(const EvalArgs& A, int chain, char* smem) {
 //   wave 1  defence sites     (+ defence coefficients)      wave 3  the potential (value corrections)
 // Same arithmetic and the same summation order on every run (deterministic).  With NUTS the
 // workgroup then barriers and wave 0 books the leaf.
-template <bool NUTS>
+template <bool NUTS, bool EXT>
 __device__ void tail_waves(const EvalArgs& A, int chain, const double* zoL, const double* cL,
                            const double* zL, const double* col, const double* xsL,
                            double* gradL, const nd::LeafState& leaf) {
@@ -791,7 +794,7 @@ __device__ void tail_waves(const EvalArgs& A, int chain, const double* zoL, cons
             }
         }
     }
-    const bool basic = L.model == MODEL_BASIC;
+    const bool basic = !EXT;
     if (wave == 0) {  // ---- attack
         const double s_a = zoL[ZO_SA];
         const double ga = on ? cL[t] - col[t] + ja : 0.0;
@@ -875,7 +878,7 @@ __device__ void tail_waves(const EvalArgs& A, int chain, const double* zoL, cons
     }
 }
 
-template <bool STAGED, bool NUTS>
+template <bool STAGED, bool NUTS, bool EXT>
 __device__ void tail_body(const EvalArgs& A, int chain, char* smem) {
     const Layout& L = A.L;
     const int T = L.T, K = L.K, D = L.D;
@@ -986,7 +989,7 @@ __device__ void tail_body(const EvalArgs& A, int chain, char* smem) {
     __syncthreads();
     DC_STAMP(9);
     if (T <= 64) {  // lane = team: four waves, one output group each, no LDS traffic
-        tail_waves<NUTS>(A, chain, zoL, cL, zL, col, xs_staged ? xsL : nullptr, gradL, leaf);
+        tail_waves<NUTS, EXT>(A, chain, zoL, cL, zL, col, xs_staged ? xsL : nullptr, gradL, leaf);
         DC_STAMP(10);
         return;
     }
@@ -1054,7 +1057,7 @@ __device__ void tail_body(const EvalArgs& A, int chain, char* smem) {
     __syncthreads();
 
     // ---- 4. chain rule to z (adds and FMAs only); grad = gz - (fixture-sum terms)
-    if (L.model == MODEL_BASIC) {
+    if (!EXT) {
         // v: 0 sum g_def, 1 sum g_ha, 2 sum a~ g_att, 3 sum d~ g_def, 4 correction
         double v[5] = {0, 0, 0, 0, corr};
         for (int t = tid; t < T; t += BLOCK) {
@@ -1334,7 +1337,7 @@ __global__ DC_LAUNCH_BOUNDS void dc_eval(EvalArgs A) {
 
         // ---- 1. per-team tables (float32) + zero accumulators
         F32Scalars fs;
-        build_tables_f32(L, z, A.xsf, tabH, tabA, tid, &fs);
+        build_tables_f32<CLIP>(L, z, A.xsf, tabH, tabA, tid, &fs);
         for (int i = tid; i < 3 * T1; i += BLOCK) acc[i] = 0.0;
         __syncthreads();
         DC_STAMP(1);
@@ -1474,7 +1477,7 @@ __global__ DC_LAUNCH_BOUNDS void dc_eval(EvalArgs A) {
     DC_STAMP(6);
     if (*shflag == 0) return;
     __syncthreads();
-    tail_body<STAGED, NUTS>(A, chain, smem);
+    tail_body<STAGED, NUTS, CLIP>(A, chain, smem);
 }
 
 }  // namespace dc

@@ -188,12 +188,12 @@ __global__ __launch_bounds__(BLOCK) void dc_vec_stream(EvalArgs A) {
         const int b = wave;
         const int chain = min(chain0 + b, A.chains - 1);  // (a padding chain repeats the last)
         const double* z = z_of(A, chain);
-        const F32Scalars fs = f32_scalars(L, z);
+        const F32Scalars fs = f32_scalars<CLIP>(L, z);
         float2* tH = tab + (size_t)(2 * b) * tl;
         float2* tA = tH + tl;
         for (int t = lane; t <= T; t += 64) {
             float2 vh = make_float2(0.f, 0.f), va = vh;
-            if (t < T) f32_table_entry(L, fs, z, A.xsf, t, &vh, &va);
+            if (t < T) f32_table_entry<CLIP>(L, fs, z, A.xsf, t, &vh, &va);
             tH[t] = vh;
             tA[t] = va;
         }
@@ -330,11 +330,11 @@ __global__ __launch_bounds__(BLOCK) void dc_vec_stream(EvalArgs A) {
     }
 }
 
-template <bool STAGED, bool NUTS>
+template <bool STAGED, bool NUTS, bool EXT>
 __global__ __launch_bounds__(BLOCK) void dc_vec_tail(EvalArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (NUTS && nuts_of(A, blockIdx.x)[nd::H_S_DONE] != 0.0) return;
-    tail_body<STAGED, NUTS>(A, blockIdx.x, smem);
+    tail_body<STAGED, NUTS, EXT>(A, blockIdx.x, smem);
 }
 
 }  // namespace dc
