@@ -705,7 +705,8 @@ int bplhip_set_fixtures(bplhip_ctx* c, int model_kind, int64_t n, int32_t n_team
     c->h_pairs = std::move(pairs);
     c->slab_chains = 0;
     c->total_c = wg_off[n_wg];
-    c->staged = ctx_lds_bytes(c, true) <= 96 * 1024;
+    // staged <=> T <= 64: the tail's one-lane-per-team epilogue (and the device-resident NUTS)
+    c->staged = T <= 64 && ctx_lds_bytes(c, true) <= 96 * 1024;
     if (ctx_lds_bytes(c, c->staged) > LDS_LIMIT)
         return fail(c, BPLHIP_EUNSUPPORTED, "set_fixtures: tail LDS footprint too large");
     int rc = ensure_slabs(c, 1);
@@ -731,7 +732,7 @@ int bplhip_set_fixtures(bplhip_ctx* c, int model_kind, int64_t n, int32_t n_team
         HIP_TRY(c, hipMemcpy(vp.d_wg_slots.p, vs.wg_slots.data(), vs.wg_slots.size() * 4, hipMemcpyHostToDevice));
         HIP_TRY(c, hipMemcpy(vp.d_col_off.p, vs.col_off.data(), vs.col_off.size() * 4, hipMemcpyHostToDevice));
         HIP_TRY(c, hipMemcpy(vp.d_wg_dst.p, vs.wg_dst.data(), vs.wg_dst.size() * 4, hipMemcpyHostToDevice));
-        vp.staged = vec_tail_lds(c, true) <= 96 * 1024;
+        vp.staged = T <= 64 && vec_tail_lds(c, true) <= 96 * 1024;
         vp.ok = dc::vec_stream_lds_bytes(T) <= 64 * 1024 && vec_tail_lds(c, vp.staged) <= LDS_LIMIT;
     }
     c->vp = &c->vps[0];

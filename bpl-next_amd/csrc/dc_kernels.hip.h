@@ -904,7 +904,7 @@ __device__ void tail_body(const EvalArgs& A, int chain, char* smem) {
     // device-resident NUTS: wave 0 will book the leaf; its state (header, vectors, checkpoint)
     // is requested now, so those round trips overlap with the hand-off loads below
     nd::LeafState leaf{};
-    if (NUTS && wave == 0 && T <= 64)
+    if (NUTS && STAGED && wave == 0)
         leaf = nd::leaf_prefetch(nuts_of(A, chain), D, A.nuts_max_depth, lane);
 
     // ---- 1. ONE round of loads: every global value the tail needs is requested before
@@ -927,7 +927,7 @@ __device__ void tail_body(const EvalArgs& A, int chain, char* smem) {
             const int j = u * BLOCK + tid;
             v[u] = ld_sc1(&hb[j < nstage ? j : nstage - 1]);
         }
-        if (NUTS && wave == 0 && T <= 64)  // (header has landed by now or lands first)
+        if (NUTS && STAGED && wave == 0)  // (header has landed by now or lands first)
             nd::leaf_prefetch_ckpt(leaf, nuts_of(A, chain), D, A.nuts_max_depth, lane);
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
@@ -988,7 +988,9 @@ __device__ void tail_body(const EvalArgs& A, int chain, char* smem) {
     }
     __syncthreads();
     DC_STAMP(9);
-    if (T <= 64) {  // lane = team: four waves, one output group each, no LDS traffic
+    // STAGED <=> T <= 64 (host): the two epilogues never meet in one instantiation (code size
+    // matters at ~9 us per launch)
+    if (STAGED) {  // lane = team: four waves, one output group each, no LDS traffic
         tail_waves<NUTS, EXT>(A, chain, zoL, cL, zL, col, xs_staged ? xsL : nullptr, gradL, leaf);
         DC_STAMP(10);
         return;
