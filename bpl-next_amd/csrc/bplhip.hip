@@ -161,7 +161,7 @@ int ensure_slabs(bplhip_ctx* c, int chains) {
 }
 
 size_t ctx_lds_bytes(const bplhip_ctx* c, bool staged) {
-    return dc::eval_lds_bytes(c->L.T, c->L.D, zo_stride_of(c->L), c->n_wg, c->total_c, staged);
+    return dc::eval_lds_bytes(c->L.T, c->L.D, c->L.K, zo_stride_of(c->L), c->n_wg, c->total_c, staged);
 }
 
 template <bool W, bool C, bool S, bool N>
@@ -367,7 +367,7 @@ int vec_hb_stride(const bplhip_ctx* c) {
     return (zo_stride_of(c->L) + c->vp->n_wg * dc::N_SCAL + c->vp->total_c + 1) & ~1;
 }
 size_t vec_tail_lds(const bplhip_ctx* c, bool staged) {
-    return dc::tail_lds_bytes(c->L.T, c->L.D, zo_stride_of(c->L), c->vp->n_wg, c->vp->total_c, staged);
+    return dc::tail_lds_bytes(c->L.T, c->L.D, c->L.K, zo_stride_of(c->L), c->vp->n_wg, c->vp->total_c, staged);
 }
 template <bool S, bool N, bool E>
 int launch_vec_tail(bplhip_ctx* c, const dc::EvalArgs& A, int chains, hipStream_t s) {

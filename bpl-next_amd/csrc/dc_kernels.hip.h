@@ -282,10 +282,11 @@ __host__ __device__ inline size_t stream_lds_bytes(int T) {
     return b;
 }
 // tail: everything it needs is staged into LDS in one round of loads
-__host__ __device__ inline size_t tail_lds_bytes(int T, int D, int zo_stride, int n_wg,
+__host__ __device__ inline int xs_staged_k(int K) { return (K > 0 && K <= 16) ? K : 0; }
+__host__ __device__ inline size_t tail_lds_bytes(int T, int D, int K, int zo_stride, int n_wg,
                                                  int total_c, bool staged) {
     size_t d = (size_t)zo_stride + 3 * (size_t)T + D + (3 * (size_t)T + N_SCAL + 4) +
-               WAVES * 8 + (size_t)n_wg * N_SCAL + (size_t)T * 16 /* xs, K <= 16 staged */ +
+               WAVES * 8 + (size_t)n_wg * N_SCAL + (size_t)T * xs_staged_k(K) /* xs, K <= 16 staged */ +
                (size_t)D + 8 /* hand-over to the NUTS leaf */;
     size_t i = 3 * (size_t)T + 2;
     if (staged) d += (size_t)total_c;
@@ -298,10 +299,10 @@ __host__ __device__ inline size_t prior_lds_bytes(int T) {
     b += (32 + WAVES * 8 + WAVES * 8) * 8;                 // scalars, scratch, argmax
     return b;
 }
-__host__ __device__ inline size_t eval_lds_bytes(int T, int D, int zo_stride, int n_wg,
+__host__ __device__ inline size_t eval_lds_bytes(int T, int D, int K, int zo_stride, int n_wg,
                                                  int total_c, bool staged) {
     size_t b = stream_lds_bytes(T);
-    const size_t t = tail_lds_bytes(T, D, zo_stride, n_wg, total_c, staged),
+    const size_t t = tail_lds_bytes(T, D, K, zo_stride, n_wg, total_c, staged),
                  p = prior_lds_bytes(T);
     b = b > t ? b : t;
     return b > p ? b : p;
@@ -897,7 +898,7 @@ __device__ void tail_body(const EvalArgs& A, int chain, char* smem) {
     double* col = zL + D;                            // [3T + N_SCAL + 4] reduced sums
     double* scratch = col + ncol + N_SCAL + 4;       // [WAVES*8]
     double* xsL = scratch + WAVES * 8;               // [T*K] when K <= 16
-    double* gradL = xsL + (size_t)T * 16;             // [D+8] grad | U | aux (NUTS hand-over)
+    double* gradL = xsL + (size_t)T * xs_staged_k(K);  // [D+8] grad | U | aux (NUTS hand-over)
     int* coff = reinterpret_cast<int*>(gradL + D + 8);  // [3T+1]
     DC_STAMP(7);
 

@@ -43,6 +43,13 @@ def fixtures(name):
         n = int(float(name.split("_")[1]))
         h, a, x, y = O.synthetic_league(n)
         return O.Fixtures(h, a, x, y, 20)
+    if name.startswith("wide"):  # many teams (> 64: the general tail epilogue): wide_N_T
+        _, n, T = name.split("_")
+        n, T = int(n), int(T)
+        rs = np.random.RandomState(n + T)
+        h = rs.randint(0, T, n)
+        a = (h + 1 + rs.randint(0, T - 1, n)) % T
+        return O.Fixtures(h, a, rs.poisson(1.4, n), rs.poisson(1.1, n), T)
     if name.startswith("ragged"):
         # random (not tiled) pairs incl. teams that never play at home, odd N (tail tile)
         n = int(name.split("_")[1])

@@ -76,6 +76,10 @@ CASES = [
     (O.MODEL_EXTENDED, "ragged_5000"),
     (O.MODEL_EXTENDED, "league_1e5"),
     (O.MODEL_EXTENDED, "leaguew_3e4"),
+    # more than 64 teams: the general (LDS-resident) tail epilogue, host-side NUTS tree
+    (O.MODEL_BASIC, "wide_4000_100"),
+    (O.MODEL_EXTENDED, "wide_4000_100"),
+    (O.MODEL_BASIC, "wide_30000_700"),
 ]
 
 
@@ -247,3 +251,20 @@ def test_reserved_scoreline_and_lane_padding(hip_ctx):
         z = np.random.RandomState(9).uniform(-0.4, 0.4, hip_ctx.dim)
         U, g, aux = hip_ctx.logp_grad(torch.tensor(z, dtype=torch.float64, device=hip_ctx.device))
         _check(model, fx, "lane_padding/u", z, float(U.cpu()[0]), g.cpu().numpy(), aux.cpu().numpy()[0])
+
+
+def test_nuts_with_many_teams(hip_ctx):
+    """T > 64: bplhip_nuts_run takes the host tree engine (one evaluation + read-back per leapfrog)
+    and bplhip_nuts_run_chains reports EUNSUPPORTED (callers then run the chains one by one)."""
+    from bpl._ffi import BPLHIP_EUNSUPPORTED, BplHipError, default_nuts_cfg
+
+    fx = cases.fixtures("wide_4000_100")
+    hip_ctx.set_fixtures(O.MODEL_BASIC, fx.home_idx.astype(np.uint16), fx.away_idx.astype(np.uint16),
+                         fx.home_goals.astype(np.uint8), fx.away_goals.astype(np.uint8), fx.n_teams)
+    cfg = default_nuts_cfg()
+    cfg.num_warmup, cfg.num_samples = 30, 20
+    d, st = hip_ctx.nuts_run(cfg, (0, 3))
+    assert d.shape == (20, hip_ctx.dim) and np.isfinite(d).all() and st["total_leapfrogs"] > 50
+    with pytest.raises(BplHipError) as e:
+        hip_ctx.nuts_run_chains(cfg, [(0, 1), (0, 2)])
+    assert e.value.code == BPLHIP_EUNSUPPORTED
