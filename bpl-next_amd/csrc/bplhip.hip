@@ -80,8 +80,10 @@ struct bplhip_ctx {
     int opt_device_nuts = 1;  // 1: tree builder on the device (nuts_dev.hip.h) when supported
     int opt_max_wg = 255;  // streaming workgroups (+1 prior workgroup = one per CU)
     int opt_persistent_nuts = 1;  // bplhip_nuts_run_chains: whole chains on the device (0: lock step)
-    int opt_vec_min_chains = 5;  // batched calls with at least this many chains use dc_vec (0: never);
-                                 // fewer run as grid.y copies of the single-chain launch
+    int opt_vec_min_chains = 32;  // batched calls with at least this many chains use dc_vec (0: never);
+                                  // fewer run as grid.y copies of the single-chain launch (62
+                                  // workgroups per chain at N = 1e6: measured faster up to ~31)
+    int opt_gridy_max_chains = 32;  // persistent chains: grid.y copies of the NUTS-aware launch up to here
     int opt_vec_tpw = 0;         // > 0: force this many tiles per wave for every chain count
     // chain-vectorised partitions (dc_vec.hip.h): fewer, fatter workgroups the more chains
     // share a launch (the per-workgroup prologue builds 8 chains' tables); each has its
@@ -751,6 +753,11 @@ int bplhip_set_option(bplhip_ctx* c, const char* name, int value) {
         c->opt_persistent_nuts = value != 0;
         return BPLHIP_OK;
     }
+    if (n == "gridy_max_chains") {
+        if (value < 1 || value > 4096) return fail(c, BPLHIP_EINVAL, "gridy_max_chains out of range");
+        c->opt_gridy_max_chains = value;
+        return BPLHIP_OK;
+    }
     if (n == "vec_min_chains") {  // batched calls with >= value chains use the vectorised kernel
         if (value < 0) return fail(c, BPLHIP_EINVAL, "vec_min_chains must be >= 0");
         c->opt_vec_min_chains = value;
@@ -1360,7 +1367,6 @@ struct VecDeviceEngine {
 // chain's random inputs (they are data independent), uploads them, and from then on only
 // enqueues evaluations -- C == 1: the single-chain kernel, else the chain-vectorised one --
 // checking the chains' "all done" flags once per chunk of launches.
-constexpr int GRIDY_CHAINS = 4;
 
 int run_chains_persistent(bplhip_ctx* c, hipStream_t s, const nuts::Config& nc, int C, const double* z0,
                           const tf::Key* keys, double* draws_out, std::vector<nuts::Result>* res) {
@@ -1497,9 +1503,10 @@ int run_chains_persistent(bplhip_ctx* c, hipStream_t s, const nuts::Config& nc, 
                 hipLaunchKernelGGL(nd::kp_leaf, dim3(C), dim3(64), (size_t)(D + 8) * 8, s, ns, stride, D, md, P);
                 continue;
             }
-            // up to GRIDY_CHAINS chains fit the chip side by side as copies of the single-chain
-            // launch (62 workgroups each at N = 1e6); more chains share the vectorised kernel
-            rc = C <= GRIDY_CHAINS
+            // up to `gridy_max_chains` chains run as grid.y copies of the single-chain launch
+            // (62 workgroups each at N = 1e6; measured faster than sharing up to ~32 chains);
+            // more chains share the chain-vectorised kernel
+            rc = C <= c->opt_gridy_max_chains
                      ? launch_eval(c, C, nd::vec(ns, D, nd::V_ZN), ns + nd::H_LEAF_PE, nd::vec(ns, D, nd::V_GRAD),
                                    ns + nd::H_LEAF_AUX0, s, ns, md, dP, C > 1 ? (int)stride : 0)
                         : launch_eval_vec(c, C, nd::vec(ns, D, nd::V_ZN), ns + nd::H_LEAF_PE,
@@ -1738,7 +1745,7 @@ extern "C" int bplhip_nuts_run_chains(bplhip_ctx* c, const bplhip_nuts_cfg* cfg,
     const nuts::Config nc = make_nuts_config(c, cfg);
     if (c->opt_persistent_nuts) {
         if (!generic_ok) {
-            int rc0 = ensure_slabs(c, std::max(1, std::min(C, GRIDY_CHAINS)));
+            int rc0 = ensure_slabs(c, std::max(1, std::min(C, c->opt_gridy_max_chains)));
             if (rc0 != BPLHIP_OK) return rc0;
         }
         std::vector<tf::Key> pkeys(C);

@@ -38,7 +38,7 @@ def _run(ctx, model, fx, zs):
     Ub, gb, auxb = ctx.logp_grad(z)
     ctx.set_option("vec_min_chains", 1)      # chain-vectorised kernel (dc_vec.hip.h)
     Uv, gv, auxv = ctx.logp_grad(z)
-    ctx.set_option("vec_min_chains", 5)
+    ctx.set_option("vec_min_chains", 32)
     return outs, (Ub.cpu().numpy(), gb.cpu().numpy(), auxb.cpu().numpy()), \
         (Uv.cpu().numpy(), gv.cpu().numpy(), auxv.cpu().numpy())
 
@@ -132,7 +132,7 @@ def test_chain_vectorised_matches_single(hip_ctx, name, model, chains):
     hip_ctx.set_option("vec_min_chains", 1)
     U1, g1, _ = hip_ctx.logp_grad(z)
     U2, g2, _ = hip_ctx.logp_grad(z)
-    hip_ctx.set_option("vec_min_chains", 5)
+    hip_ctx.set_option("vec_min_chains", 32)
     assert torch.equal(U1, U2) and torch.equal(g1, g2)
 
 
@@ -184,7 +184,7 @@ def test_graph_replay_matches_direct(hip_ctx):
     z = torch.tensor(zs, dtype=torch.float64, device=hip_ctx.device)
     hip_ctx.set_option("vec_min_chains", 0)  # direct = 8 single-chain launches (grid.y)
     Ud, gd, _ = hip_ctx.logp_grad(z)
-    hip_ctx.set_option("vec_min_chains", 5)
+    hip_ctx.set_option("vec_min_chains", 32)
     U = torch.zeros(8, dtype=torch.float64, device=hip_ctx.device)
     g = torch.zeros_like(z)
     hip_ctx.logp_grad_graph(16, z, U, g, replays=3)
