@@ -36,6 +36,8 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-insitu", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--cpu-torch", action="store_true",
+                    help="also time torch-CPU float64 autograd of the same density (framework-AD comparator)")
     return ap.parse_args()
 
 
@@ -61,7 +63,7 @@ def synthetic_league(n, n_teams, seed=2024):
     return h, a, x, y
 
 
-def cpu_baseline(h, a, x, y, n_teams, zs, budget_s):
+def cpu_baseline(h, a, x, y, n_teams, zs, budget_s, with_torch=False):
     """The CPU path timed beside the GPU: the oracle's C restatement ("port") on the
     host cores of this box, same fixtures, same z cycle, bounded sample."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -83,7 +85,21 @@ def cpu_baseline(h, a, x, y, n_teams, zs, budget_s):
                 break
         out[label] = (k / el, nt, k, el)
     v, nt, k, el = out["all"]
+    extra = {}
+    if with_torch:  # "framework AD on CPU": torch float64 autograd of a literal transcription
+        import torch
+        import dc_torch_ref as TR
+
+        TR.potential_and_grad(O.MODEL_BASIC, fx, zs[0])
+        t0 = time.perf_counter()
+        kt = 0
+        while time.perf_counter() - t0 < budget_s / 2 and kt < 64:
+            TR.potential_and_grad(O.MODEL_BASIC, fx, zs[kt % len(zs)])
+            kt += 1
+        extra["torch_autograd_f64"] = {"value": kt / (time.perf_counter() - t0), "unit": "evals/s",
+                                        "threads": torch.get_num_threads(), "evals": kt}
     return {
+        **extra,
         "value": v,
         "unit": "evals/s",
         "cores": nt,
@@ -256,7 +272,7 @@ def main():
             aa = bc["away_idx"].cpu().numpy().view(np.uint16)
             out["cpu_baseline"] = cpu_baseline(hh, aa, bc["home_goals"].cpu().numpy(),
                                                bc["away_goals"].cpu().numpy(), T, zs,
-                                               args.cpu_seconds)
+                                               args.cpu_seconds, with_torch=args.cpu_torch)
         print(json.dumps(out))
     ctx.close()
     if world > 1:
