@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -1492,6 +1493,10 @@ int run_chains_persistent(bplhip_ctx* c, hipStream_t s, const nuts::Config& nc, 
         if (steps_done > max_steps)
             return fail(c, BPLHIP_EHIP, "persistent nuts: chains did not finish within the leapfrog bound");
         steps_done += chunk;
+#ifdef DC_STAMPS  // diagnostic build: stop mid-chain so the stamp record is an ordinary leapfrog's
+        if (const char* cap = getenv("BPLHIP_DEBUG_MAX_STEPS"))
+            if (steps_done > atof(cap)) return fail(c, BPLHIP_EHIP, "debug: step cap reached");
+#endif
         for (int k = 0; k < chunk; ++k) {
             if (generic) {
                 for (int ch = 0; ch < C && rc == BPLHIP_OK; ++ch) {
@@ -1671,9 +1676,9 @@ extern "C" int bplhip_nuts_run(bplhip_ctx* c, const bplhip_nuts_cfg* cfg, const 
     int st;
     int dev_rc = BPLHIP_OK;
     const bool device_tree = c->opt_device_nuts && !c->dynamic && !c->neutral && c->L.T <= 64 && c->staged &&
-                             c->L.D <= 64 * nd::LEAF_NE;
+                             c->L.D <= 64 * nd::LEAF_NE_MAX;
     const bool generic_persist = c->opt_device_nuts && c->opt_persistent_nuts && c->neutral &&
-                                 D <= 64 * nd::LEAF_NE;
+                                 D <= 64 * nd::LEAF_NE_MAX;
     if ((device_tree || generic_persist) && c->opt_persistent_nuts) {
         // the whole chain on the device (nuts_dev.hip.h, persistent chains)
         if (!generic_persist) {
@@ -1733,10 +1738,10 @@ extern "C" int bplhip_nuts_run_chains(bplhip_ctx* c, const bplhip_nuts_cfg* cfg,
         cfg->max_tree_depth > 20 || cfg->thinning < 1 || !(cfg->step_size > 0))
         return fail(c, BPLHIP_EINVAL, "nuts_run_chains: bad configuration");
     // neutral-venue family: persistent chains with the leaf as its own launch (kp_leaf)
-    const bool generic_ok = c->neutral && c->opt_persistent_nuts && bplhip_latent_dim(c) <= 64 * nd::LEAF_NE;
+    const bool generic_ok = c->neutral && c->opt_persistent_nuts && bplhip_latent_dim(c) <= 64 * nd::LEAF_NE_MAX;
     if (!generic_ok &&
         (!vec_ok(c) || c->L.T > 64 ||
-         !(c->vps[0].staged && c->vps[1].staged && c->vps[2].staged) || c->L.D > 64 * nd::LEAF_NE))
+         !(c->vps[0].staged && c->vps[1].staged && c->vps[2].staged) || c->L.D > 64 * nd::LEAF_NE_MAX))
         return fail(c, BPLHIP_EUNSUPPORTED,
                     "nuts_run_chains: chains on the device need <= 64 teams (basic / extended / neutral models)");
     HIP_TRY(c, hipSetDevice(c->device));

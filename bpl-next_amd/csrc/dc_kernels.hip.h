@@ -46,6 +46,13 @@ constexpr int XWORDS = LANE_FIX / 4;     // packed u8 quads per lane
 constexpr int TILE = 64 * LANE_FIX;      // fixtures per wave-tile
 constexpr int BLOCK = 512;               // 8 waves per workgroup
 constexpr int WAVES = BLOCK / 64;
+// device-resident NUTS: waves 4..7 of the tail workgroup idle during the per-team epilogue, so
+// the leaf's preparation is spread over them and costs nothing on the serial path
+constexpr int LEAF_WAVE = 4;             // books the leaf
+constexpr int RNG_WAVE = 5;              // draws the leaf's random numbers (threefry)
+// (Copying the whole checkpoint area into LDS on waves 6,7 -- so that a leaf closing several
+// subtrees needs no dependent load -- measured no gain for one chain and the larger LDS
+// footprint cost 20 % at 16 chains: not done.)
 constexpr int N_SCAL = 4;                // SLAM, SLOG2, SU, CLIPC
 constexpr int MAX_RG = 32;               // row groups of the slab reduction
 constexpr int RUN_LOOP_MAX = 4;          // runs per wave-tile handled by masked DPP sums
@@ -135,8 +142,14 @@ __device__ __forceinline__ double* nuts_of(const EvalArgs& A, int c) { return A.
         if (threadIdx.x == 0 && A.debug && blockIdx.y == 0)                            \
             A.debug[(size_t)blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); \
     } while (0)
+#define DC_STAMP_LEAF(k)                                                               \
+    do {                                                                               \
+        if (threadIdx.x == LEAF_WAVE * 64 && A.debug && blockIdx.y == 0)               \
+            A.debug[(size_t)blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
 #else
 #define DC_STAMP(k) do { } while (0)
+#define DC_STAMP_LEAF(k) do { } while (0)
 #endif
 
 // ------------------------------------------------------------------ wave helpers (DPP)
@@ -287,7 +300,8 @@ __host__ __device__ inline size_t tail_lds_bytes(int T, int D, int K, int zo_str
                                                  int total_c, bool staged) {
     size_t d = (size_t)zo_stride + 3 * (size_t)T + D + (3 * (size_t)T + N_SCAL + 4) +
                WAVES * 8 + (size_t)n_wg * N_SCAL + (size_t)T * xs_staged_k(K) /* xs, K <= 16 staged */ +
-               (size_t)D + 8 /* hand-over to the NUTS leaf */;
+               (size_t)D + 8 /* hand-over to the NUTS leaf */ +
+               (D > 64 ? (size_t)nd::LEAF_STAGE_VECS * D : 0) /* its vectors, when not in registers */;
     size_t i = 3 * (size_t)T + 2;
     if (staged) d += (size_t)total_c;
     return d * 8 + ((i * 4 + 15) & ~(size_t)15) + 16;
@@ -740,11 +754,12 @@ __device__ void prior_body(const EvalArgs& A, int chain, char* smem) {
 //   wave 0  attack sites      (+ attack coefficients)       wave 2  home-advantage sites, corr, u
 //   wave 1  defence sites     (+ defence coefficients)      wave 3  the potential (value corrections)
 // Same arithmetic and the same summation order on every run (deterministic).  With NUTS the
-// workgroup then barriers and wave 0 books the leaf.
+// workgroup then barriers and wave LEAF_WAVE (one of the four idle ones, so its header wait,
+// index arithmetic and threefry draws cost nothing) books the leaf.
 template <bool NUTS, bool EXT>
 __device__ void tail_waves(const EvalArgs& A, int chain, const double* zoL, const double* cL,
                            const double* zL, const double* col, const double* xsL,
-                           double* gradL, const nd::LeafState& leaf) {
+                           double* gradL, const nd::LeafState<1>& leaf1, double* stg) {
     const Layout& L = A.L;
     const int T = L.T, K = L.K, D = L.D;
     const int t = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -869,10 +884,25 @@ __device__ void tail_waves(const EvalArgs& A, int chain, const double* zoL, cons
         }
     }
     DC_STAMP(14);
-    if (nuts) {  // device-resident NUTS: wave 0 finishes the leapfrog and books the leaf
+    if (nuts) {  // device-resident NUTS: the leaf wave finishes the leapfrog and books the leaf
+        const bool small = D <= 64;  // one vector element per lane: the short leaf
+        nd::LeafState<1> lf1 = leaf1;
+        if (wave == LEAF_WAVE && small) nd::leaf_prepare<false>(lf1);  // (while waves 0..3 write the outputs)
+        DC_STAMP_LEAF(13);
         __syncthreads();
-        if (wave == 0) {
-            const bool sub_done = nd::nuts_leaf(nuts_of(A, chain), D, A.nuts_max_depth, t, gradL, leaf);
+        DC_STAMP_LEAF(12);
+        if (wave == LEAF_WAVE) {
+            const uint32_t nhi = (uint32_t)gradL[D + 5], nlo = (uint32_t)gradL[D + 6];  // RNG_WAVE's
+            const float u_take = (float)gradL[D + 7];
+            bool sub_done;
+            if (small) {
+                lf1.nhi = nhi; lf1.nlo = nlo; lf1.u_take = u_take;
+                sub_done = nd::nuts_leaf(nuts_of(A, chain), D, A.nuts_max_depth, t, gradL, lf1);
+            } else {  // D > 64: the vectors are in LDS (staged by waves 4..7)
+                sub_done = nd::nuts_leaf_staged(nuts_of(A, chain), D, A.nuts_max_depth, t, gradL, stg,
+                                                lf1.hv, nhi, nlo, u_take);
+            }
+            DC_STAMP_LEAF(11);
             if (A.persist != nullptr && sub_done)
                 nd::persist_advance(nuts_of(A, chain), *A.persist, chain, t);
         }
@@ -899,14 +929,17 @@ __device__ void tail_body(const EvalArgs& A, int chain, char* smem) {
     double* scratch = col + ncol + N_SCAL + 4;       // [WAVES*8]
     double* xsL = scratch + WAVES * 8;               // [T*K] when K <= 16
     double* gradL = xsL + (size_t)T * xs_staged_k(K);  // [D+8] grad | U | aux (NUTS hand-over)
-    int* coff = reinterpret_cast<int*>(gradL + D + 8);  // [3T+1]
+    double* stg = gradL + D + 8;                        // [6*D] NUTS leaf vectors when D > 64
+    int* coff = reinterpret_cast<int*>(stg + (D > 64 ? nd::LEAF_STAGE_VECS * D : 0));  // [3T+1]
     DC_STAMP(7);
 
-    // device-resident NUTS: wave 0 will book the leaf; its state (header, vectors, checkpoint)
-    // is requested now, so those round trips overlap with the hand-off loads below
-    nd::LeafState leaf{};
-    if (NUTS && STAGED && wave == 0)
-        leaf = nd::leaf_prefetch(nuts_of(A, chain), D, A.nuts_max_depth, lane);
+    // device-resident NUTS: wave LEAF_WAVE (idle during the per-team epilogue) will book the
+    // leaf; its state is requested right after its hand-off loads below -- loads return in
+    // order, so the (colder) state lines must not sit in front of them
+    nd::LeafState<1> leaf1{};            // D <= 64: the leaf's vectors in registers
+    double bigv[nd::LEAF_STAGE_VECS];    // D > 64: waves 4..7 stage one 64-element slice each
+    const bool small = D <= 64;
+    double hv_rng = 0.0;                 // RNG_WAVE: the header word of its lane
 
     // ---- 1. ONE round of loads: every global value the tail needs is requested before
     // the first one is used (a rolled load -> LDS-store loop would serialise them)
@@ -928,8 +961,22 @@ __device__ void tail_body(const EvalArgs& A, int chain, char* smem) {
             const int j = u * BLOCK + tid;
             v[u] = ld_sc1(&hb[j < nstage ? j : nstage - 1]);
         }
-        if (NUTS && STAGED && wave == 0)  // (header has landed by now or lands first)
-            nd::leaf_prefetch_ckpt(leaf, nuts_of(A, chain), D, A.nuts_max_depth, lane);
+        if (NUTS && STAGED) {
+            double* ns = nuts_of(A, chain);
+            if (small) {
+                if (wave == LEAF_WAVE) leaf1 = nd::leaf_prefetch<1>(ns, D, A.nuts_max_depth, lane);
+            } else if (wave >= 4) {
+                static_assert(WAVES - 4 == nd::LEAF_NE_MAX, "one idle wave per 64-element slice");
+                const int i = tid - 4 * 64;
+                const int which[nd::LEAF_STAGE_VECS] = {nd::V_INVM, nd::V_ZN, nd::V_RH, nd::V_S_RSUM,
+                                                        nd::V_SL_R, nd::V_SR_R};
+#pragma unroll
+                for (int k = 0; k < nd::LEAF_STAGE_VECS; ++k)
+                    bigv[k] = i < D ? nd::vec(ns, D, which[k])[i] : 0.0;
+                if (wave == LEAF_WAVE) leaf1.hv = lane < nd::H_N ? ns[lane] : 0.0;
+            }
+            if (wave == RNG_WAVE) hv_rng = lane < nd::H_N ? ns[lane] : 0.0;
+        }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int j = u * BLOCK + tid;
@@ -992,7 +1039,25 @@ __device__ void tail_body(const EvalArgs& A, int chain, char* smem) {
     // STAGED <=> T <= 64 (host): the two epilogues never meet in one instantiation (code size
     // matters at ~9 us per launch)
     if (STAGED) {  // lane = team: four waves, one output group each, no LDS traffic
-        tail_waves<NUTS, EXT>(A, chain, zoL, cL, zL, col, xs_staged ? xsL : nullptr, gradL, leaf);
+        if (NUTS) {  // the idle waves' shares of the leaf preparation (see LEAF_WAVE)
+            if (!small && wave >= 4) {
+                const int i = tid - 4 * 64;
+#pragma unroll
+                for (int k = 0; k < nd::LEAF_STAGE_VECS; ++k)
+                    if (i < D) stg[k * D + i] = bigv[k];
+            }
+            if (wave == RNG_WAVE) {
+                uint32_t nhi, nlo;
+                float u_take;
+                nd::leaf_rng(hv_rng, &nhi, &nlo, &u_take);
+                if (lane == 0) {
+                    gradL[D + 5] = (double)nhi;
+                    gradL[D + 6] = (double)nlo;
+                    gradL[D + 7] = (double)u_take;
+                }
+            }
+        }
+        tail_waves<NUTS, EXT>(A, chain, zoL, cL, zL, col, xs_staged ? xsL : nullptr, gradL, leaf1, stg);
         DC_STAMP(10);
         return;
     }
@@ -1304,9 +1369,15 @@ __global__ DC_LAUNCH_BOUNDS void dc_eval(EvalArgs A) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int chain = blockIdx.y;
     const double* z = z_of(A, chain);
-    DC_STAMP(0);
+#ifdef DC_STAMPS
+    const unsigned long long t_entry = __builtin_amdgcn_s_memrealtime();
+#endif
     // device-resident NUTS: the subtree this launch belonged to may already be complete
     const double nuts_done = NUTS ? nuts_of(A, chain)[nd::H_S_DONE] : 0.0;
+#ifdef DC_STAMPS  // (launches that return at once leave the last real launch's record alone)
+    if (!(NUTS && nuts_done != 0.0) && threadIdx.x == 0 && A.debug && blockIdx.y == 0)
+        A.debug[(size_t)blockIdx.x * 16] = t_entry;
+#endif
 
     // LDS carve of the streaming part (all offsets multiples of 16 B)
     float2* tabH = reinterpret_cast<float2*>(smem);            // {exp(att+ha), exp(-def)}

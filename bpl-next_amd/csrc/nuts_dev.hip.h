@@ -94,18 +94,36 @@ __device__ inline void tf_split2(uint32_t khi, uint32_t klo, uint32_t* a_hi, uin
     *b_hi = q0; *b_lo = q1;
 }
 // jax.random.bernoulli(key, p): uniform(key, ()) < p, float32 mantissa trick
-__device__ inline bool tf_bernoulli(uint32_t khi, uint32_t klo, double p) {
+__device__ inline float tf_uniform_f32(uint32_t khi, uint32_t klo) {
     uint32_t b0, b1;
     tf_block(khi, klo, 0u, 0u, &b0, &b1);
-    const float u = __uint_as_float((b0 >> 9) | 0x3F800000u) - 1.0f;
-    return (double)u < p;
+    return __uint_as_float((b0 >> 9) | 0x3F800000u) - 1.0f;
+}
+__device__ inline bool tf_bernoulli(uint32_t khi, uint32_t klo, double p) {
+    return (double)tf_uniform_f32(khi, klo) < p;
 }
 
 // ---------------------------------------------------------------- wave helpers
+// Wave-uniform sum over the 64 lanes by DPP (row shuffles + row broadcasts; no LDS crossbar
+// round trips -- six dependent ds_bpermute pairs cost ~0.2 us on the chain's serial path).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double nd_dpp_add(double v) {
+    const long long x = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)x, CTRL, ROW_MASK, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(x >> 32), CTRL, ROW_MASK, 0xF, false);
+    return v + __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
 __device__ __forceinline__ double nd_wave_sum(double v) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-    return v;
+    v = nd_dpp_add<0xB1, 0xF>(v);   // quad_perm [1,0,3,2]
+    v = nd_dpp_add<0x4E, 0xF>(v);   // quad_perm [2,3,0,1]
+    v = nd_dpp_add<0x124, 0xF>(v);  // row_ror:4
+    v = nd_dpp_add<0x128, 0xF>(v);  // row_ror:8
+    v = nd_dpp_add<0x142, 0xA>(v);  // row_bcast:15 into rows 1,3
+    v = nd_dpp_add<0x143, 0xC>(v);  // row_bcast:31 into rows 2,3
+    const long long x = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)x, 63);
+    const int hi = __builtin_amdgcn_readlane((int)(x >> 32), 63);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 // numpyro _is_turning with a diagonal inverse mass matrix
 __device__ inline bool is_turning(const double* invM, const double* r_left, const double* r_right,
@@ -137,31 +155,42 @@ __device__ __forceinline__ double logaddexp(double a, double b) {
 // The leaf sits on the serial path of the chain (the next evaluation needs the position it
 // writes), so it is organised by memory round trips, not by statement order: (A) the whole
 // header (one word per lane) and every vector it reads are requested at once; (B) all
-// arithmetic runs from registers; (C) the checkpoint reads -- their address depends on the
-// leaf index from the header -- are the second and last dependent round; (D) stores.
-constexpr int LEAF_NE = 4;  // vector elements per lane: D <= 256
+// arithmetic runs from registers -- including the first checkpoint of an odd leaf, see
+// LeafState; (C) only a leaf that closes several subtrees reads deeper checkpoints, one
+// dependent round per further level; (D) stores.
+// NE = vector elements per lane: 1 for D <= 64 (a third of the instructions), 4 for D <= 256
+constexpr int LEAF_NE_MAX = 4;
 __device__ __forceinline__ double hdr_word(double hv, int k) {  // k wave-uniform constant
     const long long x = __double_as_longlong(hv);
     const int lo = __builtin_amdgcn_readlane((int)x, k);
     const int hi = __builtin_amdgcn_readlane((int)(x >> 32), k);
     return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
-// everything the leaf reads from the state buffer, requested before the gradient exists
-// (the tail issues this ahead of its own hand-off loads, so the round trips overlap)
+// everything the leaf reads from the state buffer, requested before the gradient exists.
+// ONE round, nothing depends on the header: the first checkpoint an odd leaf compares against
+// is the one the previous (even) leaf wrote -- that leaf's momentum (still in V_SL_R / V_SR_R,
+// by direction) and the running sum it left in V_S_RSUM -- so it needs no indexed load.
+template <int LEAF_NE>
 struct LeafState {
     double hv;                      // header word `lane`
     double invM[LEAF_NE], zn[LEAF_NE], r[LEAF_NE], rs[LEAF_NE];
+    double sl_r[LEAF_NE], sr_r[LEAF_NE];
+    // filled by leaf_prepare (header-dependent, no memory access)
     double c_r[LEAF_NE], c_s[LEAF_NE];   // first checkpoint an odd leaf compares against
     int num, idx_max, idx_min;
+    uint32_t nhi, nlo;              // the subtree's next rng key
+    float u_take;                   // uniform of this leaf's transition bernoulli
 };
-__device__ __forceinline__ LeafState leaf_prefetch(double* ns, int D, int max_depth, int lane) {
-    LeafState S;
-    // ---- (A) one round of loads
+template <int LEAF_NE>
+__device__ __forceinline__ LeafState<LEAF_NE> leaf_prefetch(double* ns, int D, int max_depth, int lane) {
+    LeafState<LEAF_NE> S;
     S.hv = lane < H_N ? ns[lane] : 0.0;
     const double* p_invM = vec(ns, D, V_INVM);
     const double* p_zn = vec(ns, D, V_ZN);
     const double* p_rh = vec(ns, D, V_RH);
     const double* p_rsum = vec(ns, D, V_S_RSUM);
+    const double* p_slr = vec(ns, D, V_SL_R);
+    const double* p_srr = vec(ns, D, V_SR_R);
 #pragma unroll
     for (int e = 0; e < LEAF_NE; ++e) {
         const int i = lane + 64 * e;
@@ -170,35 +199,38 @@ __device__ __forceinline__ LeafState leaf_prefetch(double* ns, int D, int max_de
         S.zn[e] = ok ? p_zn[i] : 0.0;
         S.r[e] = ok ? p_rh[i] : 0.0;
         S.rs[e] = ok ? p_rsum[i] : 0.0;
+        S.sl_r[e] = ok ? p_slr[i] : 0.0;
+        S.sr_r[e] = ok ? p_srr[i] : 0.0;
     }
     return S;
 }
-// second, dependent round (needs the header): issued after the caller has put its own loads
-// in flight, so waiting for the header does not delay them
-__device__ __forceinline__ void leaf_prefetch_ckpt(LeafState& S, double* ns, int D, int max_depth,
-                                                   int lane) {
+// header-dependent preparation, registers only: leaf index -> checkpoint indices (numpyro
+// _leaf_idx_to_ckpt_idxs), the first checkpoint, and the leaf's random numbers (which depend
+// on the key alone).  The caller runs this wherever the leaf wave would otherwise idle.
+__device__ __forceinline__ void leaf_rng(double hv, uint32_t* nhi, uint32_t* nlo, float* u_take) {
+    const uint32_t khi = (uint32_t)hdr_word(hv, H_KEY_HI), klo = (uint32_t)hdr_word(hv, H_KEY_LO);
+    uint32_t thi, tlo;
+    tf_split2(khi, klo, nhi, nlo, &thi, &tlo);  // rng_key, transition_rng_key = split(rng_key)
+    *u_take = tf_uniform_f32(thi, tlo);
+}
+template <bool DRAW, int LEAF_NE>
+__device__ __forceinline__ void leaf_prepare(LeafState<LEAF_NE>& S) {
     S.num = (int)hdr_word(S.hv, H_S_NUM);  // leaves so far = index of this leaf
-    // checkpoint indices (numpyro _leaf_idx_to_ckpt_idxs)
-    int idx_max = 0, trail = 0;
-    for (int v = S.num >> 1; v > 0; v >>= 1) idx_max += v & 1;
-    for (int v = S.num; v & 1; v >>= 1) trail += 1;
-    S.idx_max = idx_max;
-    S.idx_min = idx_max - trail + 1;
-    // ---- (C) the second, dependent round: the first checkpoint an odd leaf compares against
-    const double* ck_r = vec(ns, D, V_CKPT);
-    const double* ck_s = ck_r + (size_t)max_depth * D;
-    const bool has_ck = S.idx_max >= S.idx_min;
+    S.idx_max = __popc((unsigned)S.num >> 1);
+    const int trail = __ffs(~S.num) - 1;   // trailing one bits
+    S.idx_min = S.idx_max - trail + 1;
+    const bool right = hdr_word(S.hv, H_DIR) > 0.0;
 #pragma unroll
     for (int e = 0; e < LEAF_NE; ++e) {
-        const int i = lane + 64 * e;
-        const bool ok = has_ck && i < D;
-        S.c_r[e] = ok ? ck_r[(size_t)idx_max * D + i] : 0.0;
-        S.c_s[e] = ok ? ck_s[(size_t)idx_max * D + i] : 0.0;
+        S.c_r[e] = right ? S.sr_r[e] : S.sl_r[e];
+        S.c_s[e] = S.rs[e];
     }
+    if (DRAW) leaf_rng(S.hv, &S.nhi, &S.nlo, &S.u_take);  // (else: the caller fills them in)
 }
 
+template <int LEAF_NE>
 __device__ inline bool nuts_leaf(double* ns, int D, int max_depth, int lane, const double* gL,
-                                 const LeafState& S) {
+                                 const LeafState<LEAF_NE>& S) {
     const double hv = S.hv;
     double* p_zn = vec(ns, D, V_ZN);
     double* p_rh = vec(ns, D, V_RH);
@@ -234,9 +266,7 @@ __device__ inline bool nuts_leaf(double* ns, int D, int max_depth, int lane, con
     const bool div_leaf = delta > hdr_word(hv, H_MAXDE);
     const double acc_leaf = fmin(1.0, exp(-delta));
 
-    uint32_t khi = (uint32_t)hdr_word(hv, H_KEY_HI), klo = (uint32_t)hdr_word(hv, H_KEY_LO);
-    uint32_t nhi, nlo, thi, tlo;
-    tf_split2(khi, klo, &nhi, &nlo, &thi, &tlo);  // rng_key, transition_rng_key = split(rng_key)
+    const uint32_t nhi = S.nhi, nlo = S.nlo;
 
     bool take = true;
     double w_sub = w_leaf, sum_acc = acc_leaf;
@@ -248,9 +278,12 @@ __device__ inline bool nuts_leaf(double* ns, int D, int max_depth, int lane, con
 #pragma unroll
         for (int e = 0; e < LEAF_NE; ++e) rs[e] += r[e];
         const double w_cur = hdr_word(hv, H_S_WEIGHT);
-        const double prob = 1.0 / (1.0 + exp(-(w_leaf - w_cur)));  // expit: uniform transition
-        take = tf_bernoulli(thi, tlo, prob);
-        w_sub = logaddexp(w_cur, w_leaf);
+        // expit(d) for the uniform transition and logaddexp(w_cur, w_leaf) share one exp
+        const double d = w_leaf - w_cur;
+        const double ex = exp(-fabs(d));
+        const double prob = (d >= 0.0 ? 1.0 : ex) / (1.0 + ex);
+        take = (double)S.u_take < prob;
+        w_sub = w_cur == w_leaf ? w_cur + 0.6931471805599453 : fmax(w_cur, w_leaf) + log1p(ex);
         sum_acc = hdr_word(hv, H_S_SUMACC) + acc_leaf;
     }
     // checkpointed U-turn test (numpyro _is_iterative_turning)
@@ -321,6 +354,139 @@ __device__ inline bool nuts_leaf(double* ns, int D, int max_depth, int lane, con
         }
     }
     return done;  // (wave uniform) the subtree of this doubling is complete
+}
+
+// The same leaf for D > 64 inside dc_eval's tail, with the vectors staged in LDS instead of
+// registers (a register-resident LeafState<4> pushes dc_eval past 128 VGPRs, i.e. down to one
+// workgroup per CU -- the cliff that matters when several chains share a GPU):
+//   stg = invM[D] | zn[D] | r_half[D] | r_sum[D] | sl_r[D] | sr_r[D]   (LEAF_STAGE_VECS * D)
+// copied by the tail's idle waves.  Lane l owns elements l, l+64, ...: it alone reads and
+// rewrites them between the passes, so no barrier is needed.  Per-lane summation order and
+// arithmetic equal nuts_leaf<LEAF_NE_MAX>, so both walk the same trajectory bit for bit.
+constexpr int LEAF_STAGE_VECS = 6;
+__device__ inline bool nuts_leaf_staged(double* ns, int D, int max_depth, int lane, const double* gL,
+                                        double* stg, double hv, uint32_t nhi, uint32_t nlo,
+                                        float u_take) {
+    const double* s_invM = stg;
+    const double* s_zn = stg + D;
+    double* s_r = stg + 2 * D;    // half-stepped on entry, full-step momentum after pass 1
+    double* s_rs = stg + 3 * D;   // running sum: before / after this leaf
+    const double* s_slr = stg + 4 * D;
+    const double* s_srr = stg + 5 * D;
+    const double pe = gL[D];
+    const double h_eps = hdr_word(hv, H_EPS), h_dir = hdr_word(hv, H_DIR);
+    const double eps = h_eps * h_dir;
+    const bool going_right = h_dir > 0.0;
+    const int num = (int)hdr_word(hv, H_S_NUM);
+    const int idx_max = __popc((unsigned)num >> 1);
+    const int idx_min = idx_max - (__ffs(~num) - 1) + 1;
+    double* ck_r = vec(ns, D, V_CKPT);
+    double* ck_s = ck_r + (size_t)max_depth * D;
+
+    // ---- pass 1: second half step, kinetic energy
+    double kin = 0.0;
+    for (int i = lane; i < D; i += 64) {
+        const double r = s_r[i] - 0.5 * eps * gL[i];
+        s_r[i] = r;
+        kin += s_invM[i] * r * r;
+    }
+    kin = 0.5 * nd_wave_sum(kin);
+    const double e_new = pe + kin;
+    double delta = e_new - hdr_word(hv, H_E0);
+    if (delta != delta) delta = __builtin_inf();
+    const double w_leaf = -delta;
+    const bool div_leaf = delta > hdr_word(hv, H_MAXDE);
+    const double acc_leaf = fmin(1.0, exp(-delta));
+    bool take = true;
+    double w_sub = w_leaf, sum_acc = acc_leaf;
+    if (num != 0) {
+        const double w_cur = hdr_word(hv, H_S_WEIGHT);
+        const double d = w_leaf - w_cur;
+        const double ex = exp(-fabs(d));
+        const double prob = (d >= 0.0 ? 1.0 : ex) / (1.0 + ex);
+        take = (double)u_take < prob;
+        w_sub = w_cur == w_leaf ? w_cur + 0.6931471805599453 : fmax(w_cur, w_leaf) + log1p(ex);
+        sum_acc = hdr_word(hv, H_S_SUMACC) + acc_leaf;
+    }
+
+    // ---- pass 2: running sum; an odd leaf's first checkpoint is the previous leaf (LeafState)
+    const bool cmp = idx_max >= idx_min;
+    const double* c_r1 = going_right ? s_srr : s_slr;
+    double dl = 0.0, dr = 0.0;
+    for (int i = lane; i < D; i += 64) {
+        const double r = s_r[i], rs_old = s_rs[i];
+        const double rs = num == 0 ? r : rs_old + r;
+        s_rs[i] = rs;
+        if (cmp) {
+            const double c_r = c_r1[i];
+            const double sub = rs - rs_old + c_r;
+            const double rsm = sub - 0.5 * (c_r + r);
+            dl += s_invM[i] * c_r * rsm;
+            dr += s_invM[i] * r * rsm;
+        }
+    }
+    bool turning = false;
+    if (cmp) {
+        dl = nd_wave_sum(dl);
+        dr = nd_wave_sum(dr);
+        turning = (dl <= 0.0) | (dr <= 0.0);
+    }
+    for (int ci = idx_max - 1; ci >= idx_min && !turning; --ci) {  // deeper levels: from memory
+        dl = 0.0; dr = 0.0;
+        for (int i = lane; i < D; i += 64) {
+            const double c_r = ck_r[(size_t)ci * D + i], c_s = ck_s[(size_t)ci * D + i];
+            const double r = s_r[i];
+            const double sub = s_rs[i] - c_s + c_r;
+            const double rsm = sub - 0.5 * (c_r + r);
+            dl += s_invM[i] * c_r * rsm;
+            dr += s_invM[i] * r * rsm;
+        }
+        dl = nd_wave_sum(dl);
+        dr = nd_wave_sum(dr);
+        turning = (dl <= 0.0) | (dr <= 0.0);
+    }
+    const int new_num = num + 1;
+    const bool done = turning || div_leaf || new_num >= (int)hdr_word(hv, H_S_MAX);
+
+    // ---- pass 3: stores
+    double* p_zn = vec(ns, D, V_ZN); double* p_rh = vec(ns, D, V_RH); double* p_rsum = vec(ns, D, V_S_RSUM);
+    double* sl_z = vec(ns, D, V_SL_Z); double* sl_r = vec(ns, D, V_SL_R); double* sl_g = vec(ns, D, V_SL_G);
+    double* sr_z = vec(ns, D, V_SR_Z); double* sr_r = vec(ns, D, V_SR_R); double* sr_g = vec(ns, D, V_SR_G);
+    double* sp_z = vec(ns, D, V_SP_Z); double* sp_g = vec(ns, D, V_SP_G);
+    const bool wl = num == 0 || !going_right, wr = num == 0 || going_right;
+    const bool wck = (num & 1) == 0;
+    for (int i = lane; i < D; i += 64) {
+        const double r = s_r[i], g = gL[i], zn = s_zn[i], rs = s_rs[i];
+        const double rn = r - 0.5 * eps * g;
+        p_zn[i] = done ? zn : zn + eps * s_invM[i] * rn;
+        p_rh[i] = done ? r : rn;
+        p_rsum[i] = rs;
+        if (wl) { sl_z[i] = zn; sl_r[i] = r; sl_g[i] = g; }
+        if (wr) { sr_z[i] = zn; sr_r[i] = r; sr_g[i] = g; }
+        if (take) { sp_z[i] = zn; sp_g[i] = g; }
+        if (wck) {
+            ck_r[(size_t)idx_max * D + i] = r;
+            ck_s[(size_t)idx_max * D + i] = rs;
+        }
+    }
+    if (lane == 0) {
+        ns[H_S_NUM] = (double)new_num;
+        ns[H_S_WEIGHT] = w_sub;
+        ns[H_S_SUMACC] = sum_acc;
+        ns[H_S_DIV] = div_leaf ? 1.0 : 0.0;
+        ns[H_S_TURN] = turning ? 1.0 : 0.0;
+        ns[H_S_DONE] = done ? 1.0 : 0.0;
+        ns[H_KEY_HI] = (double)nhi;
+        ns[H_KEY_LO] = (double)nlo;
+        ns[H_EVALS] = hdr_word(hv, H_EVALS) + 1.0;
+        if (take) {
+            ns[H_S_PE] = pe;
+            ns[H_S_EPROP] = e_new;
+            ns[H_S_AUX0] = gL[D + 1]; ns[H_S_AUX1] = gL[D + 2];
+            ns[H_S_AUX2] = gL[D + 3]; ns[H_S_AUX3] = gL[D + 4];
+        }
+    }
+    return done;
 }
 
 // ---------------------------------------------------------------- small kernels (1 wave)
@@ -653,7 +819,7 @@ __global__ __launch_bounds__(64) void kp_leaf(double* ns_all, size_t stride, int
     double* ns = ns_all + blockIdx.x * stride;
     const int lane = threadIdx.x;
     if (ns[H_S_DONE] != 0.0) return;  // chain finished
-    LeafState leaf = leaf_prefetch(ns, D, max_depth, lane);
+    LeafState<LEAF_NE_MAX> leaf = leaf_prefetch<LEAF_NE_MAX>(ns, D, max_depth, lane);
     const double* gr = vec(ns, D, V_GRAD);
     for (int i = lane; i < D; i += 64) gL[i] = gr[i];
     if (lane == 0) {
@@ -661,7 +827,7 @@ __global__ __launch_bounds__(64) void kp_leaf(double* ns_all, size_t stride, int
         gL[D + 1] = ns[H_LEAF_AUX0]; gL[D + 2] = ns[H_LEAF_AUX1];
         gL[D + 3] = ns[H_LEAF_AUX2]; gL[D + 4] = ns[H_LEAF_AUX3];
     }
-    leaf_prefetch_ckpt(leaf, ns, D, max_depth, lane);
+    leaf_prepare<true>(leaf);
     __syncthreads();
     const bool sub_done = nuts_leaf(ns, D, max_depth, lane, gL, leaf);
     if (sub_done) persist_advance(ns, P, blockIdx.x, lane);

@@ -35,6 +35,37 @@ def run(n, model=MODEL_BASIC, max_wg=255):
           f"epi:sums={rel[last, 11]:.2f} epi:puts={rel[last, 14]:.2f}")
     c.close()
 
-for n in (1_000_000,):
-    run(n)
-run(1_000_000, MODEL_EXTENDED)
+def run_nuts(n=1_000_000):
+    """timeline of an ordinary leapfrog of a persistent chain (NUTS-aware launch): the run is
+    cut after BPLHIP_DEBUG_MAX_STEPS launches, so the record is the last launch's"""
+    from bpl._ffi import default_nuts_cfg, BplHipError
+    os.environ["BPLHIP_DEBUG_MAX_STEPS"] = "3000"
+    h, a, x, y = synthetic_league(n, 20)
+    c = HipContext(0); c.set_fixtures(MODEL_BASIC, h, a, x, y, 20)
+    lib = c._lib
+    lib.bplhip_debug_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int]; lib.bplhip_debug_stamps.restype = C.c_int
+    nwg = lib.bplhip_debug_stamps(c._h, None, 0)
+    cfg = default_nuts_cfg(); cfg.num_warmup, cfg.num_samples = 300, 100
+    try:
+        c.nuts_run(cfg, (0, 42))
+    except BplHipError as e:
+        print("   (run cut:", e, ")")
+    buf = np.zeros((nwg + 1) * 16, dtype=np.uint64)
+    lib.bplhip_debug_stamps(c._h, buf.ctypes.data_as(C.c_void_p), buf.size)
+    st = buf[: nwg * 16].reshape(nwg, 16).astype(np.int64)
+    rel = (st - st[:, 0].min()) * 0.01
+    print(f"--- NUTS-aware launch, N={n}, blocks={nwg}")
+    print("  prior WG: entry=%.2f scalars=%.2f cells=%.2f bounds=%.2f done=%.2f ticket=%.2f" % (rel[0, 0], rel[0, 1], rel[0, 2], rel[0, 3], rel[0, 4], rel[0, 6]))
+    for k, nm in [(0, "entry"), (1, "tables"), (2, "bounds"), (12, "loads-landed"), (3, "stream"), (4, "slab"), (6, "ticket")]:
+        col = rel[1:, k]
+        print(f"  {nm:12s} median {np.median(col):7.2f} us  min {col.min():7.2f}  max {col.max():7.2f}")
+    last = int(np.argmax(st[:, 10]))
+    print("  tail WG", last, " ".join(f"{nm}={rel[last, k]:.2f}" for k, nm in [(6, "ticket"), (7, "tail:start"), (8, "tail:loads"), (9, "tail:colsums"), (14, "outputs"), (13, "leaf:prepared"), (12, "leaf:start"), (11, "leaf:end")]))
+    c.close()
+
+if len(sys.argv) > 1 and sys.argv[1] == "nuts":
+    run_nuts()
+else:
+    for n in (1_000_000,):
+        run(n)
+    run(1_000_000, MODEL_EXTENDED)
