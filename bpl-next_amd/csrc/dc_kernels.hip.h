@@ -301,7 +301,7 @@ __host__ __device__ inline size_t tail_lds_bytes(int T, int D, int K, int zo_str
     size_t d = (size_t)zo_stride + 3 * (size_t)T + D + (3 * (size_t)T + N_SCAL + 4) +
                WAVES * 8 + (size_t)n_wg * N_SCAL + (size_t)T * xs_staged_k(K) /* xs, K <= 16 staged */ +
                (size_t)D + 8 /* hand-over to the NUTS leaf */ +
-               (D > 64 ? (size_t)nd::LEAF_STAGE_VECS * D : 0) /* its vectors, when not in registers */;
+               (staged && D > 64 ? (size_t)nd::LEAF_STAGE_VECS * D : 0) /* its vectors, when not in registers */;
     size_t i = 3 * (size_t)T + 2;
     if (staged) d += (size_t)total_c;
     return d * 8 + ((i * 4 + 15) & ~(size_t)15) + 16;
@@ -885,27 +885,35 @@ __device__ void tail_waves(const EvalArgs& A, int chain, const double* zoL, cons
     }
     DC_STAMP(14);
     if (nuts) {  // device-resident NUTS: the leaf wave finishes the leapfrog and books the leaf
-        const bool small = D <= 64;  // one vector element per lane: the short leaf
+        const bool small = D <= 64;  // one vector element per lane: registers; else LDS (stg)
         nd::LeafState<1> lf1 = leaf1;
-        if (wave == LEAF_WAVE && small) nd::leaf_prepare<false>(lf1);  // (while waves 0..3 write the outputs)
+        double* ns = nuts_of(A, chain);
+        // preparation that needs the header only, while waves 0..3 write the outputs
+        if (wave == LEAF_WAVE && small) nd::leaf_prepare<false>(lf1);
+        if (wave == RNG_WAVE) nd::leaf_rng(lf1.hv, &lf1.nhi, &lf1.nlo, &lf1.u_take);
         DC_STAMP_LEAF(13);
         __syncthreads();
         DC_STAMP_LEAF(12);
+        if (wave != LEAF_WAVE && wave != RNG_WAVE) return;  // (barriers below: these two only)
+        // the two halves of the leaf (nuts_dev.hip.h), one wave each
         if (wave == LEAF_WAVE) {
-            const uint32_t nhi = (uint32_t)gradL[D + 5], nlo = (uint32_t)gradL[D + 6];  // RNG_WAVE's
-            const float u_take = (float)gradL[D + 7];
-            bool sub_done;
-            if (small) {
-                lf1.nhi = nhi; lf1.nlo = nlo; lf1.u_take = u_take;
-                sub_done = nd::nuts_leaf(nuts_of(A, chain), D, A.nuts_max_depth, t, gradL, lf1);
-            } else {  // D > 64: the vectors are in LDS (staged by waves 4..7)
-                sub_done = nd::nuts_leaf_staged(nuts_of(A, chain), D, A.nuts_max_depth, t, gradL, stg,
-                                                lf1.hv, nhi, nlo, u_take);
-            }
+            const bool sub_done =
+                small ? nd::leaf_moves(ns, D, A.nuts_max_depth, t, gradL, lf1)
+                      : nd::leaf_moves_staged(ns, D, A.nuts_max_depth, t, gradL, stg, lf1.hv);
             DC_STAMP_LEAF(11);
-            if (A.persist != nullptr && sub_done)
-                nd::persist_advance(nuts_of(A, chain), *A.persist, chain, t);
+            if (t == 0) gradL[D + 5] = sub_done ? 1.0 : 0.0;
+        } else {
+            if (small) nd::leaf_weights(ns, D, t, gradL, lf1);
+            else nd::leaf_weights_staged(ns, D, t, gradL, stg, lf1.hv, lf1.nhi, lf1.nlo, lf1.u_take);
         }
+        if (A.persist == nullptr) return;
+        // persistent chains: a finished subtree (rare) is combined by the leaf wave, which must
+        // then see the other half's stores -- release + barrier, acquire in persist_advance
+        __syncthreads();
+        if (gradL[D + 5] == 0.0) return;
+        if (wave == RNG_WAVE) nd::wave_mem_sync();
+        __syncthreads();
+        if (wave == LEAF_WAVE) nd::persist_advance(ns, *A.persist, chain, t);
     }
 }
 
@@ -930,16 +938,15 @@ __device__ void tail_body(const EvalArgs& A, int chain, char* smem) {
     double* xsL = scratch + WAVES * 8;               // [T*K] when K <= 16
     double* gradL = xsL + (size_t)T * xs_staged_k(K);  // [D+8] grad | U | aux (NUTS hand-over)
     double* stg = gradL + D + 8;                        // [6*D] NUTS leaf vectors when D > 64
-    int* coff = reinterpret_cast<int*>(stg + (D > 64 ? nd::LEAF_STAGE_VECS * D : 0));  // [3T+1]
+    int* coff = reinterpret_cast<int*>(stg + (STAGED && D > 64 ? nd::LEAF_STAGE_VECS * D : 0));  // [3T+1]
     DC_STAMP(7);
 
     // device-resident NUTS: wave LEAF_WAVE (idle during the per-team epilogue) will book the
     // leaf; its state is requested right after its hand-off loads below -- loads return in
     // order, so the (colder) state lines must not sit in front of them
-    nd::LeafState<1> leaf1{};            // D <= 64: the leaf's vectors in registers
-    double bigv[nd::LEAF_STAGE_VECS];    // D > 64: waves 4..7 stage one 64-element slice each
+    nd::LeafState<1> leaf1{};            // D <= 64: the leaf's vectors in registers (waves 4, 5)
+    double bigv[nd::LEAF_STAGE_LOADS];   // D > 64: waves 4..7 stage one 64-element slice each
     const bool small = D <= 64;
-    double hv_rng = 0.0;                 // RNG_WAVE: the header word of its lane
 
     // ---- 1. ONE round of loads: every global value the tail needs is requested before
     // the first one is used (a rolled load -> LDS-store loop would serialise them)
@@ -964,18 +971,18 @@ __device__ void tail_body(const EvalArgs& A, int chain, char* smem) {
         if (NUTS && STAGED) {
             double* ns = nuts_of(A, chain);
             if (small) {
-                if (wave == LEAF_WAVE) leaf1 = nd::leaf_prefetch<1>(ns, D, A.nuts_max_depth, lane);
+                if (wave == LEAF_WAVE || wave == RNG_WAVE)
+                    leaf1 = nd::leaf_prefetch<1>(ns, D, A.nuts_max_depth, lane);
             } else if (wave >= 4) {
                 static_assert(WAVES - 4 == nd::LEAF_NE_MAX, "one idle wave per 64-element slice");
                 const int i = tid - 4 * 64;
-                const int which[nd::LEAF_STAGE_VECS] = {nd::V_INVM, nd::V_ZN, nd::V_RH, nd::V_S_RSUM,
-                                                        nd::V_SL_R, nd::V_SR_R};
+                const int which[nd::LEAF_STAGE_LOADS] = {nd::V_INVM, nd::V_ZN, nd::V_RH, nd::V_S_RSUM,
+                                                         nd::V_SL_R, nd::V_SR_R};
 #pragma unroll
-                for (int k = 0; k < nd::LEAF_STAGE_VECS; ++k)
+                for (int k = 0; k < nd::LEAF_STAGE_LOADS; ++k)
                     bigv[k] = i < D ? nd::vec(ns, D, which[k])[i] : 0.0;
-                if (wave == LEAF_WAVE) leaf1.hv = lane < nd::H_N ? ns[lane] : 0.0;
+                if (wave == LEAF_WAVE || wave == RNG_WAVE) leaf1.hv = lane < nd::H_N ? ns[lane] : 0.0;
             }
-            if (wave == RNG_WAVE) hv_rng = lane < nd::H_N ? ns[lane] : 0.0;
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
@@ -1043,18 +1050,8 @@ __device__ void tail_body(const EvalArgs& A, int chain, char* smem) {
             if (!small && wave >= 4) {
                 const int i = tid - 4 * 64;
 #pragma unroll
-                for (int k = 0; k < nd::LEAF_STAGE_VECS; ++k)
+                for (int k = 0; k < nd::LEAF_STAGE_LOADS; ++k)
                     if (i < D) stg[k * D + i] = bigv[k];
-            }
-            if (wave == RNG_WAVE) {
-                uint32_t nhi, nlo;
-                float u_take;
-                nd::leaf_rng(hv_rng, &nhi, &nlo, &u_take);
-                if (lane == 0) {
-                    gradL[D + 5] = (double)nhi;
-                    gradL[D + 6] = (double)nlo;
-                    gradL[D + 7] = (double)u_take;
-                }
             }
         }
         tail_waves<NUTS, EXT>(A, chain, zoL, cL, zL, col, xs_staged ? xsL : nullptr, gradL, leaf1, stg);

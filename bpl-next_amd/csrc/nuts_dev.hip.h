@@ -228,22 +228,104 @@ __device__ __forceinline__ void leaf_prepare(LeafState<LEAF_NE>& S) {
     if (DRAW) leaf_rng(S.hv, &S.nhi, &S.nlo, &S.u_take);  // (else: the caller fills them in)
 }
 
+// The leaf is instruction-issue bound on one wave (~1.3 us), so it is cut into two halves
+// that need nothing from each other and run on two waves of the tail workgroup at once:
+//   leaf_moves    integrator and tree geometry: full-step momentum, divergence test, running
+//                 momentum sum, checkpointed U-turn test, `done`, the NEXT position, edges
+//                 and checkpoints of the subtree
+//   leaf_weights  the subtree's multinomial bookkeeping: exp/log1p/expit of the energy error,
+//                 the transition bernoulli, the proposal, the rng key
+// Both recompute the (cheap) kinetic energy with the same instruction sequence.  They write
+// disjoint header words and vectors.  nuts_leaf runs them back to back on one wave.
+struct LeafEnergy {
+    double e_new, delta;
+};
 template <int LEAF_NE>
-__device__ inline bool nuts_leaf(double* ns, int D, int max_depth, int lane, const double* gL,
-                                 const LeafState<LEAF_NE>& S) {
-    const double hv = S.hv;
-    double* p_zn = vec(ns, D, V_ZN);
-    double* p_rh = vec(ns, D, V_RH);
-    double* p_rsum = vec(ns, D, V_S_RSUM);
-    double invM[LEAF_NE], zn[LEAF_NE], r[LEAF_NE], rs[LEAF_NE], g[LEAF_NE], c_r[LEAF_NE], c_s[LEAF_NE];
+__device__ __forceinline__ LeafEnergy leaf_energy(const LeafState<LEAF_NE>& S, int D, int lane,
+                                                  const double* gL, double eps, double (&r)[LEAF_NE],
+                                                  double (&g)[LEAF_NE]) {
+    double kin = 0.0;
 #pragma unroll
     for (int e = 0; e < LEAF_NE; ++e) {
         const int i = lane + 64 * e;
-        invM[e] = S.invM[e]; zn[e] = S.zn[e]; r[e] = S.r[e]; rs[e] = S.rs[e];
-        c_r[e] = S.c_r[e]; c_s[e] = S.c_s[e];
         g[e] = i < D ? gL[i] : 0.0;
+        r[e] = S.r[e] - 0.5 * eps * g[e];  // the leaf's full-step momentum
+        kin += S.invM[e] * r[e] * r[e];
     }
-    const double pe = gL[D];
+    kin = 0.5 * nd_wave_sum(kin);
+    LeafEnergy E;
+    E.e_new = gL[D] + kin;
+    E.delta = E.e_new - hdr_word(S.hv, H_E0);
+    if (E.delta != E.delta) E.delta = __builtin_inf();
+    return E;
+}
+// the scalar half of _combine_tree(current, leaf, biased_transition=False) for one leaf
+struct LeafWeights {
+    bool take;
+    double w_sub, sum_acc;
+};
+__device__ __forceinline__ LeafWeights leaf_weigh(double hv, int num, double delta, float u_take) {
+    const double w_leaf = -delta;
+    const double acc_leaf = fmin(1.0, exp(-delta));
+    LeafWeights W{true, w_leaf, acc_leaf};
+    if (num != 0) {
+        const double w_cur = hdr_word(hv, H_S_WEIGHT);
+        // expit(d) for the uniform transition and logaddexp(w_cur, w_leaf) share one exp
+        const double d = w_leaf - w_cur;
+        const double ex = exp(-fabs(d));
+        const double prob = (d >= 0.0 ? 1.0 : ex) / (1.0 + ex);
+        W.take = (double)u_take < prob;
+        W.w_sub = w_cur == w_leaf ? w_cur + 0.6931471805599453 : fmax(w_cur, w_leaf) + log1p(ex);
+        W.sum_acc = hdr_word(hv, H_S_SUMACC) + acc_leaf;
+    }
+    return W;
+}
+__device__ __forceinline__ void leaf_weights_header(double* ns, const double* gL, int D, const LeafWeights& W,
+                                                    double e_new, uint32_t nhi, uint32_t nlo) {
+    ns[H_S_WEIGHT] = W.w_sub;
+    ns[H_S_SUMACC] = W.sum_acc;
+    ns[H_KEY_HI] = (double)nhi;
+    ns[H_KEY_LO] = (double)nlo;
+    if (W.take) {
+        ns[H_S_PE] = gL[D];
+        ns[H_S_EPROP] = e_new;
+        ns[H_S_AUX0] = gL[D + 1]; ns[H_S_AUX1] = gL[D + 2];
+        ns[H_S_AUX2] = gL[D + 3]; ns[H_S_AUX3] = gL[D + 4];
+    }
+}
+__device__ __forceinline__ void leaf_moves_header(double* ns, double hv, int new_num, bool div_leaf,
+                                                  bool turning, bool done) {
+    ns[H_S_NUM] = (double)new_num;
+    ns[H_S_DIV] = div_leaf ? 1.0 : 0.0;
+    ns[H_S_TURN] = turning ? 1.0 : 0.0;
+    ns[H_S_DONE] = done ? 1.0 : 0.0;
+    ns[H_EVALS] = hdr_word(hv, H_EVALS) + 1.0;
+}
+
+// S needs hv, invM, zn, r (half-stepped) and the rng fields
+template <int LEAF_NE>
+__device__ inline void leaf_weights(double* ns, int D, int lane, const double* gL,
+                                    const LeafState<LEAF_NE>& S) {
+    const double eps = hdr_word(S.hv, H_EPS) * hdr_word(S.hv, H_DIR);
+    double r[LEAF_NE], g[LEAF_NE];
+    const LeafEnergy E = leaf_energy(S, D, lane, gL, eps, r, g);
+    const LeafWeights W = leaf_weigh(S.hv, (int)hdr_word(S.hv, H_S_NUM), E.delta, S.u_take);
+    if (W.take) {
+        double* sp_z = vec(ns, D, V_SP_Z); double* sp_g = vec(ns, D, V_SP_G);
+#pragma unroll
+        for (int e = 0; e < LEAF_NE; ++e) {
+            const int i = lane + 64 * e;
+            if (i < D) { sp_z[i] = S.zn[e]; sp_g[i] = g[e]; }
+        }
+    }
+    if (lane == 0) leaf_weights_header(ns, gL, D, W, E.e_new, S.nhi, S.nlo);
+}
+
+// S fully prefetched and prepared; returns (wave uniform) whether the subtree is complete
+template <int LEAF_NE>
+__device__ inline bool leaf_moves(double* ns, int D, int max_depth, int lane, const double* gL,
+                                  const LeafState<LEAF_NE>& S) {
+    const double hv = S.hv;
     const double h_eps = hdr_word(hv, H_EPS), h_dir = hdr_word(hv, H_DIR);
     const double eps = h_eps * h_dir;
     const bool going_right = h_dir > 0.0;
@@ -251,40 +333,14 @@ __device__ inline bool nuts_leaf(double* ns, int D, int max_depth, int lane, con
     double* ck_r = vec(ns, D, V_CKPT);
     double* ck_s = ck_r + (size_t)max_depth * D;
 
-    // ---- (B) second half step, kinetic energy
-    double kin = 0.0;
+    // ---- (B) second half step, kinetic energy -> divergence
+    double r[LEAF_NE], g[LEAF_NE], rs[LEAF_NE], c_r[LEAF_NE], c_s[LEAF_NE];
+    const LeafEnergy E = leaf_energy(S, D, lane, gL, eps, r, g);
+    const bool div_leaf = E.delta > hdr_word(hv, H_MAXDE);
 #pragma unroll
     for (int e = 0; e < LEAF_NE; ++e) {
-        r[e] = r[e] - 0.5 * eps * g[e];  // the leaf's full-step momentum
-        kin += invM[e] * r[e] * r[e];
-    }
-    kin = 0.5 * nd_wave_sum(kin);
-    const double e_new = pe + kin;
-    double delta = e_new - hdr_word(hv, H_E0);
-    if (delta != delta) delta = __builtin_inf();
-    const double w_leaf = -delta;
-    const bool div_leaf = delta > hdr_word(hv, H_MAXDE);
-    const double acc_leaf = fmin(1.0, exp(-delta));
-
-    const uint32_t nhi = S.nhi, nlo = S.nlo;
-
-    bool take = true;
-    double w_sub = w_leaf, sum_acc = acc_leaf;
-    if (num == 0) {
-#pragma unroll
-        for (int e = 0; e < LEAF_NE; ++e) rs[e] = r[e];
-    } else {
-        // _combine_tree(current, leaf, biased_transition=False)
-#pragma unroll
-        for (int e = 0; e < LEAF_NE; ++e) rs[e] += r[e];
-        const double w_cur = hdr_word(hv, H_S_WEIGHT);
-        // expit(d) for the uniform transition and logaddexp(w_cur, w_leaf) share one exp
-        const double d = w_leaf - w_cur;
-        const double ex = exp(-fabs(d));
-        const double prob = (d >= 0.0 ? 1.0 : ex) / (1.0 + ex);
-        take = (double)S.u_take < prob;
-        w_sub = w_cur == w_leaf ? w_cur + 0.6931471805599453 : fmax(w_cur, w_leaf) + log1p(ex);
-        sum_acc = hdr_word(hv, H_S_SUMACC) + acc_leaf;
+        rs[e] = num == 0 ? r[e] : S.rs[e] + r[e];  // _combine_tree: r_sum
+        c_r[e] = S.c_r[e]; c_s[e] = S.c_s[e];
     }
     // checkpointed U-turn test (numpyro _is_iterative_turning)
     bool turning = false;
@@ -302,8 +358,8 @@ __device__ inline bool nuts_leaf(double* ns, int D, int max_depth, int lane, con
         for (int e = 0; e < LEAF_NE; ++e) {
             const double sub = rs[e] - c_s[e] + c_r[e];
             const double rsm = sub - 0.5 * (c_r[e] + r[e]);
-            dl += invM[e] * c_r[e] * rsm;
-            dr += invM[e] * r[e] * rsm;
+            dl += S.invM[e] * c_r[e] * rsm;
+            dr += S.invM[e] * r[e] * rsm;
         }
         dl = nd_wave_sum(dl);
         dr = nd_wave_sum(dr);
@@ -313,9 +369,9 @@ __device__ inline bool nuts_leaf(double* ns, int D, int max_depth, int lane, con
     const bool done = turning || div_leaf || new_num >= (int)hdr_word(hv, H_S_MAX);
 
     // ---- (D) stores
+    double* p_zn = vec(ns, D, V_ZN); double* p_rh = vec(ns, D, V_RH); double* p_rsum = vec(ns, D, V_S_RSUM);
     double* sl_z = vec(ns, D, V_SL_Z); double* sl_r = vec(ns, D, V_SL_R); double* sl_g = vec(ns, D, V_SL_G);
     double* sr_z = vec(ns, D, V_SR_Z); double* sr_r = vec(ns, D, V_SR_R); double* sr_g = vec(ns, D, V_SR_G);
-    double* sp_z = vec(ns, D, V_SP_Z); double* sp_g = vec(ns, D, V_SP_G);
     const bool wl = num == 0 || !going_right, wr = num == 0 || going_right;
     const bool wck = (num & 1) == 0;
 #pragma unroll
@@ -323,57 +379,80 @@ __device__ inline bool nuts_leaf(double* ns, int D, int max_depth, int lane, con
         const int i = lane + 64 * e;
         if (i < D) {
             // next leapfrog starts from this leaf (the subtree grows in one direction)
+            const double zn = S.zn[e];
             const double rn = r[e] - 0.5 * eps * g[e];
-            p_zn[i] = done ? zn[e] : zn[e] + eps * invM[e] * rn;
+            p_zn[i] = done ? zn : zn + eps * S.invM[e] * rn;
             p_rh[i] = done ? r[e] : rn;
             p_rsum[i] = rs[e];
-            if (wl) { sl_z[i] = zn[e]; sl_r[i] = r[e]; sl_g[i] = g[e]; }
-            if (wr) { sr_z[i] = zn[e]; sr_r[i] = r[e]; sr_g[i] = g[e]; }
-            if (take) { sp_z[i] = zn[e]; sp_g[i] = g[e]; }
+            if (wl) { sl_z[i] = zn; sl_r[i] = r[e]; sl_g[i] = g[e]; }
+            if (wr) { sr_z[i] = zn; sr_r[i] = r[e]; sr_g[i] = g[e]; }
             if (wck) {
                 ck_r[(size_t)idx_max * D + i] = r[e];
                 ck_s[(size_t)idx_max * D + i] = rs[e];
             }
         }
     }
-    if (lane == 0) {
-        ns[H_S_NUM] = (double)new_num;
-        ns[H_S_WEIGHT] = w_sub;
-        ns[H_S_SUMACC] = sum_acc;
-        ns[H_S_DIV] = div_leaf ? 1.0 : 0.0;
-        ns[H_S_TURN] = turning ? 1.0 : 0.0;
-        ns[H_S_DONE] = done ? 1.0 : 0.0;
-        ns[H_KEY_HI] = (double)nhi;
-        ns[H_KEY_LO] = (double)nlo;
-        ns[H_EVALS] = hdr_word(hv, H_EVALS) + 1.0;
-        if (take) {
-            ns[H_S_PE] = pe;
-            ns[H_S_EPROP] = e_new;
-            ns[H_S_AUX0] = gL[D + 1]; ns[H_S_AUX1] = gL[D + 2];
-            ns[H_S_AUX2] = gL[D + 3]; ns[H_S_AUX3] = gL[D + 4];
-        }
-    }
-    return done;  // (wave uniform) the subtree of this doubling is complete
+    if (lane == 0) leaf_moves_header(ns, hv, new_num, div_leaf, turning, done);
+    return done;
 }
 
-// The same leaf for D > 64 inside dc_eval's tail, with the vectors staged in LDS instead of
-// registers (a register-resident LeafState<4> pushes dc_eval past 128 VGPRs, i.e. down to one
-// workgroup per CU -- the cliff that matters when several chains share a GPU):
-//   stg = invM[D] | zn[D] | r_half[D] | r_sum[D] | sl_r[D] | sr_r[D]   (LEAF_STAGE_VECS * D)
-// copied by the tail's idle waves.  Lane l owns elements l, l+64, ...: it alone reads and
-// rewrites them between the passes, so no barrier is needed.  Per-lane summation order and
-// arithmetic equal nuts_leaf<LEAF_NE_MAX>, so both walk the same trajectory bit for bit.
-constexpr int LEAF_STAGE_VECS = 6;
-__device__ inline bool nuts_leaf_staged(double* ns, int D, int max_depth, int lane, const double* gL,
-                                        double* stg, double hv, uint32_t nhi, uint32_t nlo,
-                                        float u_take) {
+// both halves on one wave (the leaf as its own launch: kp_leaf)
+template <int LEAF_NE>
+__device__ inline bool nuts_leaf(double* ns, int D, int max_depth, int lane, const double* gL,
+                                 const LeafState<LEAF_NE>& S) {
+    const bool done = leaf_moves(ns, D, max_depth, lane, gL, S);
+    leaf_weights(ns, D, lane, gL, S);
+    return done;
+}
+
+// The same two halves for D > 64 inside dc_eval's tail, with the vectors staged in LDS
+// instead of registers (a register-resident LeafState<4> pushes dc_eval past 128 VGPRs, i.e.
+// down to one workgroup per CU -- the cliff that matters when several chains share a GPU):
+//   stg = invM[D] | zn[D] | r_half[D] | r_sum[D] | sl_r[D] | sr_r[D] | r_full[D]
+// (the first six copied by the tail's idle waves, the last written by leaf_moves_staged).
+// Lane l owns elements l, l+64, ...: it alone reads and rewrites them between the passes of
+// one half, so no barrier is needed; leaf_weights_staged only reads what the copy wrote.
+// Per-lane summation order and arithmetic equal the LeafState<LEAF_NE_MAX> register version,
+// so both walk the same trajectory bit for bit.
+constexpr int LEAF_STAGE_LOADS = 6;   // vectors copied from the state buffer
+constexpr int LEAF_STAGE_VECS = 7;    // + the full-step momentum
+__device__ __forceinline__ LeafEnergy leaf_energy_staged(const double* stg, double hv, int D, int lane,
+                                                         const double* gL, double eps, double* r_out) {
+    const double* s_invM = stg;
+    const double* s_rh = stg + 2 * D;
+    double kin = 0.0;
+    for (int i = lane; i < D; i += 64) {
+        const double r = s_rh[i] - 0.5 * eps * gL[i];
+        if (r_out) r_out[i] = r;
+        kin += s_invM[i] * r * r;
+    }
+    kin = 0.5 * nd_wave_sum(kin);
+    LeafEnergy E;
+    E.e_new = gL[D] + kin;
+    E.delta = E.e_new - hdr_word(hv, H_E0);
+    if (E.delta != E.delta) E.delta = __builtin_inf();
+    return E;
+}
+__device__ inline void leaf_weights_staged(double* ns, int D, int lane, const double* gL, const double* stg,
+                                           double hv, uint32_t nhi, uint32_t nlo, float u_take) {
+    const double eps = hdr_word(hv, H_EPS) * hdr_word(hv, H_DIR);
+    const LeafEnergy E = leaf_energy_staged(stg, hv, D, lane, gL, eps, nullptr);
+    const LeafWeights W = leaf_weigh(hv, (int)hdr_word(hv, H_S_NUM), E.delta, u_take);
+    if (W.take) {
+        const double* s_zn = stg + D;
+        double* sp_z = vec(ns, D, V_SP_Z); double* sp_g = vec(ns, D, V_SP_G);
+        for (int i = lane; i < D; i += 64) { sp_z[i] = s_zn[i]; sp_g[i] = gL[i]; }
+    }
+    if (lane == 0) leaf_weights_header(ns, gL, D, W, E.e_new, nhi, nlo);
+}
+__device__ inline bool leaf_moves_staged(double* ns, int D, int max_depth, int lane, const double* gL,
+                                         double* stg, double hv) {
     const double* s_invM = stg;
     const double* s_zn = stg + D;
-    double* s_r = stg + 2 * D;    // half-stepped on entry, full-step momentum after pass 1
     double* s_rs = stg + 3 * D;   // running sum: before / after this leaf
     const double* s_slr = stg + 4 * D;
     const double* s_srr = stg + 5 * D;
-    const double pe = gL[D];
+    double* s_r = stg + 6 * D;    // full-step momentum
     const double h_eps = hdr_word(hv, H_EPS), h_dir = hdr_word(hv, H_DIR);
     const double eps = h_eps * h_dir;
     const bool going_right = h_dir > 0.0;
@@ -383,31 +462,9 @@ __device__ inline bool nuts_leaf_staged(double* ns, int D, int max_depth, int la
     double* ck_r = vec(ns, D, V_CKPT);
     double* ck_s = ck_r + (size_t)max_depth * D;
 
-    // ---- pass 1: second half step, kinetic energy
-    double kin = 0.0;
-    for (int i = lane; i < D; i += 64) {
-        const double r = s_r[i] - 0.5 * eps * gL[i];
-        s_r[i] = r;
-        kin += s_invM[i] * r * r;
-    }
-    kin = 0.5 * nd_wave_sum(kin);
-    const double e_new = pe + kin;
-    double delta = e_new - hdr_word(hv, H_E0);
-    if (delta != delta) delta = __builtin_inf();
-    const double w_leaf = -delta;
-    const bool div_leaf = delta > hdr_word(hv, H_MAXDE);
-    const double acc_leaf = fmin(1.0, exp(-delta));
-    bool take = true;
-    double w_sub = w_leaf, sum_acc = acc_leaf;
-    if (num != 0) {
-        const double w_cur = hdr_word(hv, H_S_WEIGHT);
-        const double d = w_leaf - w_cur;
-        const double ex = exp(-fabs(d));
-        const double prob = (d >= 0.0 ? 1.0 : ex) / (1.0 + ex);
-        take = (double)u_take < prob;
-        w_sub = w_cur == w_leaf ? w_cur + 0.6931471805599453 : fmax(w_cur, w_leaf) + log1p(ex);
-        sum_acc = hdr_word(hv, H_S_SUMACC) + acc_leaf;
-    }
+    // ---- pass 1: second half step, kinetic energy -> divergence
+    const LeafEnergy E = leaf_energy_staged(stg, hv, D, lane, gL, eps, s_r);
+    const bool div_leaf = E.delta > hdr_word(hv, H_MAXDE);
 
     // ---- pass 2: running sum; an odd leaf's first checkpoint is the previous leaf (LeafState)
     const bool cmp = idx_max >= idx_min;
@@ -452,7 +509,6 @@ __device__ inline bool nuts_leaf_staged(double* ns, int D, int max_depth, int la
     double* p_zn = vec(ns, D, V_ZN); double* p_rh = vec(ns, D, V_RH); double* p_rsum = vec(ns, D, V_S_RSUM);
     double* sl_z = vec(ns, D, V_SL_Z); double* sl_r = vec(ns, D, V_SL_R); double* sl_g = vec(ns, D, V_SL_G);
     double* sr_z = vec(ns, D, V_SR_Z); double* sr_r = vec(ns, D, V_SR_R); double* sr_g = vec(ns, D, V_SR_G);
-    double* sp_z = vec(ns, D, V_SP_Z); double* sp_g = vec(ns, D, V_SP_G);
     const bool wl = num == 0 || !going_right, wr = num == 0 || going_right;
     const bool wck = (num & 1) == 0;
     for (int i = lane; i < D; i += 64) {
@@ -463,29 +519,12 @@ __device__ inline bool nuts_leaf_staged(double* ns, int D, int max_depth, int la
         p_rsum[i] = rs;
         if (wl) { sl_z[i] = zn; sl_r[i] = r; sl_g[i] = g; }
         if (wr) { sr_z[i] = zn; sr_r[i] = r; sr_g[i] = g; }
-        if (take) { sp_z[i] = zn; sp_g[i] = g; }
         if (wck) {
             ck_r[(size_t)idx_max * D + i] = r;
             ck_s[(size_t)idx_max * D + i] = rs;
         }
     }
-    if (lane == 0) {
-        ns[H_S_NUM] = (double)new_num;
-        ns[H_S_WEIGHT] = w_sub;
-        ns[H_S_SUMACC] = sum_acc;
-        ns[H_S_DIV] = div_leaf ? 1.0 : 0.0;
-        ns[H_S_TURN] = turning ? 1.0 : 0.0;
-        ns[H_S_DONE] = done ? 1.0 : 0.0;
-        ns[H_KEY_HI] = (double)nhi;
-        ns[H_KEY_LO] = (double)nlo;
-        ns[H_EVALS] = hdr_word(hv, H_EVALS) + 1.0;
-        if (take) {
-            ns[H_S_PE] = pe;
-            ns[H_S_EPROP] = e_new;
-            ns[H_S_AUX0] = gL[D + 1]; ns[H_S_AUX1] = gL[D + 2];
-            ns[H_S_AUX2] = gL[D + 3]; ns[H_S_AUX3] = gL[D + 4];
-        }
-    }
+    if (lane == 0) leaf_moves_header(ns, hv, new_num, div_leaf, turning, done);
     return done;
 }
 
