@@ -142,14 +142,16 @@ __device__ __forceinline__ double* nuts_of(const EvalArgs& A, int c) { return A.
         if (threadIdx.x == 0 && A.debug && blockIdx.y == 0)                            \
             A.debug[(size_t)blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); \
     } while (0)
-#define DC_STAMP_LEAF(k)                                                               \
+#define DC_STAMP_LEAF(k) DC_STAMP_WAVE(LEAF_WAVE, k)
+#define DC_STAMP_WAVE(w, k)                                                            \
     do {                                                                               \
-        if (threadIdx.x == LEAF_WAVE * 64 && A.debug && blockIdx.y == 0)               \
+        if (threadIdx.x == (w) * 64 && A.debug && blockIdx.y == 0)                     \
             A.debug[(size_t)blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); \
     } while (0)
 #else
 #define DC_STAMP(k) do { } while (0)
 #define DC_STAMP_LEAF(k) do { } while (0)
+#define DC_STAMP_WAVE(w, k) do { } while (0)
 #endif
 
 // ------------------------------------------------------------------ wave helpers (DPP)
@@ -905,6 +907,7 @@ __device__ void tail_waves(const EvalArgs& A, int chain, const double* zoL, cons
         } else {
             if (small) nd::leaf_weights(ns, D, t, gradL, lf1);
             else nd::leaf_weights_staged(ns, D, t, gradL, stg, lf1.hv, lf1.nhi, lf1.nlo, lf1.u_take);
+            DC_STAMP_WAVE(RNG_WAVE, 15);
         }
         if (A.persist == nullptr) return;
         // persistent chains: a finished subtree (rare) is combined by the leaf wave, which must
@@ -1404,7 +1407,9 @@ __global__ DC_LAUNCH_BOUNDS void dc_eval(EvalArgs A) {
             slot0 = A.wg_slots[o0 + tid];
             dst0 = A.wg_dst[o0 + tid];
         }
-        if (NUTS && nuts_done != 0.0) return;  // (uniform over the whole grid)
+        // (uniform over the whole grid.  Checking this after the table loads are in flight
+        // measured no gain: the flag's latency is not what delays z, z itself is cold.)
+        if (NUTS && nuts_done != 0.0) return;
 
         // ---- 1. per-team tables (float32) + zero accumulators
         F32Scalars fs;
