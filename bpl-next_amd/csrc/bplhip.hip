@@ -12,6 +12,7 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <thread>
 #include <tuple>
 #include <vector>
 
@@ -1369,10 +1370,24 @@ struct VecDeviceEngine {
 // enqueues evaluations -- C == 1: the single-chain kernel, else the chain-vectorised one --
 // checking the chains' "all done" flags once per chunk of launches.
 
+// the leaf can run in dc_eval's tail (nuts_dev.hip.h): the basic / extended models, <= 64 teams
+static bool leaf_in_tail(const bplhip_ctx* c) {
+    return !c->neutral && !c->dynamic && c->L.T <= 64 && c->staged && c->L.D <= 64 * nd::LEAF_NE_MAX;
+}
+// persistent chains keep all momentum draws of a run on the device: [C][n_iter][D] doubles
+static bool persistent_fits(const bplhip_ctx* c, const bplhip_nuts_cfg* cfg, int C) {
+    const double bytes = (double)C * (cfg->num_warmup + cfg->num_samples) * bplhip_latent_dim(c) * 8.0;
+    return bytes <= 16.0 * 1024 * 1024 * 1024;
+}
+
 int run_chains_persistent(bplhip_ctx* c, hipStream_t s, const nuts::Config& nc, int C, const double* z0,
                           const tf::Key* keys, double* draws_out, std::vector<nuts::Result>* res) {
     const int D = bplhip_latent_dim(c), md = nc.max_tree_depth;
-    const bool generic = c->neutral || c->dynamic;  // evaluation != dc_eval: leaf as its own launch
+    // the leaf as its own launch(es) after a plain evaluation: one wave per chain (kp_leaf) up
+    // to 256 latent entries, GW workgroups per chain (kw_leaf_a/b) beyond
+    const bool generic = !leaf_in_tail(c);
+    const bool wide = generic && D > 64 * nd::LEAF_NE_MAX;
+    const int GW = nd::kw_workgroups(D, nd::KW_NT), GWB = nd::kw_workgroups(D, nd::KW_NTB);
     const int n_iter = nc.num_warmup + nc.num_samples;
     const int kept = nc.num_samples / nc.thinning;
     const size_t nsd = (nd::ns_doubles(D, md) + 1) & ~(size_t)1;
@@ -1382,7 +1397,12 @@ int run_chains_persistent(bplhip_ctx* c, hipStream_t s, const nuts::Config& nc, 
     for (const auto& w : sched) win_end.push_back(w.end);
     if (win_end.empty()) win_end.push_back(-1);
 
-    DevBuf d_ns, d_norm, d_par, d_win, d_draws, d_stats, d_desc;
+    DevBuf d_ns, d_norm, d_par, d_win, d_draws, d_stats, d_desc, d_part, d_tick;
+    if (wide) {
+        HIP_TRY(c, d_part.ensure((size_t)C * GW * nd::KW_PW * 8));
+        HIP_TRY(c, d_tick.ensure((size_t)C * 4));
+        HIP_TRY(c, hipMemsetAsync(d_tick.p, 0, (size_t)C * 4, s));
+    }
     HIP_TRY(c, d_ns.ensure((size_t)C * stride * 8));
     HIP_TRY(c, hipMemsetAsync(d_ns.p, 0, (size_t)C * stride * 8, s));
     HIP_TRY(c, d_norm.ensure((size_t)C * n_iter * D * 8));
@@ -1429,12 +1449,13 @@ int run_chains_persistent(bplhip_ctx* c, hipStream_t s, const nuts::Config& nc, 
     // ---- all random inputs of every chain (sample_kernel / build_tree / _double_tree splits)
     {
         std::vector<double> nrm((size_t)C * n_iter * D), par((size_t)C * n_iter * md * 5);
+        std::vector<tf::Key> k_moms((size_t)C * n_iter);
         for (int ch = 0; ch < C; ++ch) {
             tf::Key key_hmc = cds[ch].key_hmc;
             for (int it = 0; it < n_iter; ++it) {
                 tf::Key k_mom, k_tr;
                 tf::split3(key_hmc, &key_hmc, &k_mom, &k_tr);
-                tf::normal(k_mom, D, nrm.data() + ((size_t)ch * n_iter + it) * D);
+                k_moms[(size_t)ch * n_iter + it] = k_mom;
                 tf::Key key = k_tr;
                 for (int j = 0; j < md; ++j) {
                     tf::Key k_next, k_dir, k_dbl, k_sub, k_t2;
@@ -1446,6 +1467,21 @@ int run_chains_persistent(bplhip_ctx* c, hipStream_t s, const nuts::Config& nc, 
                     q[1] = (double)k_sub.hi; q[2] = (double)k_sub.lo;
                     q[3] = (double)k_t2.hi;  q[4] = (double)k_t2.lo;
                 }
+            }
+        }
+        {   // the momentum draws themselves (C * n_iter * D normals): host threads for long vectors
+            const size_t jobs = (size_t)C * n_iter;
+            unsigned nthr = nrm.size() > (size_t)1 << 20 ? std::thread::hardware_concurrency() : 1;
+            nthr = std::max(1u, std::min(nthr, 32u));
+            auto work = [&](unsigned t) {
+                for (size_t j = t; j < jobs; j += nthr) tf::normal(k_moms[j], D, nrm.data() + j * D);
+            };
+            if (nthr == 1) {
+                work(0);
+            } else {
+                std::vector<std::thread> pool;
+                for (unsigned t = 0; t < nthr; ++t) pool.emplace_back(work, t);
+                for (auto& th : pool) th.join();
             }
         }
         HIP_TRY(c, hipMemcpy(d_norm.p, nrm.data(), nrm.size() * 8, hipMemcpyHostToDevice));
@@ -1481,7 +1517,8 @@ int run_chains_persistent(bplhip_ctx* c, hipStream_t s, const nuts::Config& nc, 
     HIP_TRY(c, hipMemcpy2D(evals0.data(), 8, ns + nd::H_EVALS, stride * 8, 8, C, hipMemcpyDeviceToHost));
 
     // ---- run: first transitions, then blind chunks of evaluations
-    hipLaunchKernelGGL(nd::kp_start, dim3(C), dim3(64), 0, s, ns, stride, P);
+    if (wide) hipLaunchKernelGGL(nd::kw_start, dim3(C), dim3(nd::KW_NTB), 0, s, ns, stride, P);
+    else hipLaunchKernelGGL(nd::kp_start, dim3(C), dim3(64), 0, s, ns, stride, P);
     const nd::Persist* dP = d_desc.as<const nd::Persist>();
     std::vector<double> flags(C);
     const int chunk = 256;
@@ -1505,7 +1542,15 @@ int run_chains_persistent(bplhip_ctx* c, hipStream_t s, const nuts::Config& nc, 
                                      nd::vec(nsc, D, nd::V_GRAD), nsc + nd::H_LEAF_AUX0, s);
                 }
                 if (rc != BPLHIP_OK) return rc;
-                hipLaunchKernelGGL(nd::kp_leaf, dim3(C), dim3(64), (size_t)(D + 8) * 8, s, ns, stride, D, md, P);
+                if (wide) {
+                    hipLaunchKernelGGL(nd::kw_leaf_a, dim3(GW, C), dim3(nd::KW_NT), 0, s, ns, stride, D, md,
+                                       d_part.as<double>());
+                    hipLaunchKernelGGL(nd::kw_leaf_b, dim3(GWB, C), dim3(nd::KW_NTB), 0, s, ns, stride, D, md,
+                                       d_part.as<const double>(), GW, d_tick.as<unsigned int>(), P, 1);
+                } else {
+                    hipLaunchKernelGGL(nd::kp_leaf, dim3(C), dim3(64), (size_t)(D + 8) * 8, s, ns, stride, D,
+                                       md, P);
+                }
                 continue;
             }
             // up to `gridy_max_chains` chains run as grid.y copies of the single-chain launch
@@ -1675,10 +1720,9 @@ extern "C" int bplhip_nuts_run(bplhip_ctx* c, const bplhip_nuts_cfg* cfg, const 
     const auto t0 = std::chrono::steady_clock::now();
     int st;
     int dev_rc = BPLHIP_OK;
-    const bool device_tree = c->opt_device_nuts && !c->dynamic && !c->neutral && c->L.T <= 64 && c->staged &&
-                             c->L.D <= 64 * nd::LEAF_NE_MAX;
-    const bool generic_persist = c->opt_device_nuts && c->opt_persistent_nuts && c->neutral &&
-                                 D <= 64 * nd::LEAF_NE_MAX;
+    const bool device_tree = c->opt_device_nuts && leaf_in_tail(c);
+    const bool generic_persist = c->opt_device_nuts && c->opt_persistent_nuts && !leaf_in_tail(c) &&
+                                 persistent_fits(c, cfg, 1);
     if ((device_tree || generic_persist) && c->opt_persistent_nuts) {
         // the whole chain on the device (nuts_dev.hip.h, persistent chains)
         if (!generic_persist) {
@@ -1737,13 +1781,14 @@ extern "C" int bplhip_nuts_run_chains(bplhip_ctx* c, const bplhip_nuts_cfg* cfg,
     if (cfg->num_warmup < 0 || cfg->num_samples < 1 || cfg->max_tree_depth < 1 ||
         cfg->max_tree_depth > 20 || cfg->thinning < 1 || !(cfg->step_size > 0))
         return fail(c, BPLHIP_EINVAL, "nuts_run_chains: bad configuration");
-    // neutral-venue family: persistent chains with the leaf as its own launch (kp_leaf)
-    const bool generic_ok = c->neutral && c->opt_persistent_nuts && bplhip_latent_dim(c) <= 64 * nd::LEAF_NE_MAX;
+    // every model whose leaf does not fit dc_eval's tail: persistent chains with the leaf as its
+    // own launch(es) (kp_leaf / kw_leaf_*)
+    const bool generic_ok = !leaf_in_tail(c) && c->opt_persistent_nuts && persistent_fits(c, cfg, n_chains);
     if (!generic_ok &&
-        (!vec_ok(c) || c->L.T > 64 ||
-         !(c->vps[0].staged && c->vps[1].staged && c->vps[2].staged) || c->L.D > 64 * nd::LEAF_NE_MAX))
+        (!leaf_in_tail(c) || !vec_ok(c) || !(c->vps[0].staged && c->vps[1].staged && c->vps[2].staged)))
         return fail(c, BPLHIP_EUNSUPPORTED,
-                    "nuts_run_chains: chains on the device need <= 64 teams (basic / extended / neutral models)");
+                    "nuts_run_chains: these chains do not fit on the device (momentum draws > 16 GiB, or "
+                    "persistent_nuts=0 with a model outside dc_eval's tail)");
     HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int D = bplhip_latent_dim(c), C = n_chains;

@@ -125,21 +125,54 @@ __device__ __forceinline__ double nd_wave_sum(double v) {
     const int hi = __builtin_amdgcn_readlane((int)(x >> 32), 63);
     return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
+// The tree bookkeeping below is written for a "team" of NT threads working on one chain's
+// state: one wave (NT = 64, no barriers: the leaf's wave inside dc_eval, or a 64-thread launch)
+// or a whole workgroup (NT > 64, for latent vectors of 10^4..10^5 entries: kw_leaf_b).  Thread
+// `tid` owns elements tid, tid + NT, ... in every loop, so element-wise read-after-write
+// between loops needs no synchronisation; header words are written by thread 0 only.
+// scr: LDS scratch of NT/64 doubles (unused for NT = 64).
+template <int NT>
+__device__ __forceinline__ double team_sum(double v, int tid, double* scr) {
+    v = nd_wave_sum(v);
+    if (NT == 64) return v;
+    __syncthreads();  // (scr may still be read from the previous sum)
+    if ((tid & 63) == 0) scr[tid >> 6] = v;
+    __syncthreads();
+    double s = 0.0;
+#pragma unroll
+    for (int w = 0; w < NT / 64; ++w) s += scr[w];
+    return s;
+}
+// stores of the team visible to its later loads (header words written by thread 0, vectors)
+template <int NT>
+__device__ __forceinline__ void team_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __builtin_amdgcn_s_waitcnt(0);
+    if (NT > 64) __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
 // numpyro _is_turning with a diagonal inverse mass matrix
+template <int NT = 64>
 __device__ inline bool is_turning(const double* invM, const double* r_left, const double* r_right,
-                                  const double* r_sum, int D, int lane) {
+                                  const double* r_sum, int D, int tid, double* scr = nullptr) {
     double dl = 0.0, dr = 0.0;
-    for (int i = lane; i < D; i += 64) {
+#pragma unroll 4
+    for (int i = tid; i < D; i += NT) {
         const double rs = r_sum[i] - 0.5 * (r_left[i] + r_right[i]);
         dl += invM[i] * r_left[i] * rs;
         dr += invM[i] * r_right[i] * rs;
     }
-    dl = nd_wave_sum(dl);
-    dr = nd_wave_sum(dr);
+    dl = team_sum<NT>(dl, tid, scr);
+    dr = team_sum<NT>(dr, tid, scr);
     return (dl <= 0.0) | (dr <= 0.0);
 }
-__device__ __forceinline__ void vcopy(double* dst, const double* src, int D, int lane) {
-    for (int i = lane; i < D; i += 64) dst[i] = src[i];
+// (restrict + unroll: the loads of a batch are in flight together; a loop of load -> store
+// pairs on possibly aliasing pointers is one memory round trip per element)
+template <int NT = 64>
+__device__ __forceinline__ void vcopy(double* __restrict__ dst, const double* __restrict__ src, int D,
+                                      int tid) {
+#pragma unroll 4
+    for (int i = tid; i < D; i += NT) dst[i] = src[i];
 }
 __device__ __forceinline__ double logaddexp(double a, double b) {
     if (a == b) return a + 0.6931471805599453;
@@ -207,6 +240,12 @@ __device__ __forceinline__ LeafState<LEAF_NE> leaf_prefetch(double* ns, int D, i
 // header-dependent preparation, registers only: leaf index -> checkpoint indices (numpyro
 // _leaf_idx_to_ckpt_idxs), the first checkpoint, and the leaf's random numbers (which depend
 // on the key alone).  The caller runs this wherever the leaf wave would otherwise idle.
+__device__ __forceinline__ void leaf_rng_k(uint32_t khi, uint32_t klo, uint32_t* nhi, uint32_t* nlo,
+                                           float* u_take) {
+    uint32_t thi, tlo;
+    tf_split2(khi, klo, nhi, nlo, &thi, &tlo);  // rng_key, transition_rng_key = split(rng_key)
+    *u_take = tf_uniform_f32(thi, tlo);
+}
 __device__ __forceinline__ void leaf_rng(double hv, uint32_t* nhi, uint32_t* nlo, float* u_take) {
     const uint32_t khi = (uint32_t)hdr_word(hv, H_KEY_HI), klo = (uint32_t)hdr_word(hv, H_KEY_LO);
     uint32_t thi, tlo;
@@ -264,21 +303,26 @@ struct LeafWeights {
     bool take;
     double w_sub, sum_acc;
 };
-__device__ __forceinline__ LeafWeights leaf_weigh(double hv, int num, double delta, float u_take) {
+// (w_cur, s_sumacc: the subtree's weight and accept sum so far; only read when num != 0)
+template <class F>
+__device__ __forceinline__ LeafWeights leaf_weigh_f(int num, double delta, float u_take, F hdr) {
     const double w_leaf = -delta;
     const double acc_leaf = fmin(1.0, exp(-delta));
     LeafWeights W{true, w_leaf, acc_leaf};
     if (num != 0) {
-        const double w_cur = hdr_word(hv, H_S_WEIGHT);
+        const double w_cur = hdr(H_S_WEIGHT);
         // expit(d) for the uniform transition and logaddexp(w_cur, w_leaf) share one exp
         const double d = w_leaf - w_cur;
         const double ex = exp(-fabs(d));
         const double prob = (d >= 0.0 ? 1.0 : ex) / (1.0 + ex);
         W.take = (double)u_take < prob;
         W.w_sub = w_cur == w_leaf ? w_cur + 0.6931471805599453 : fmax(w_cur, w_leaf) + log1p(ex);
-        W.sum_acc = hdr_word(hv, H_S_SUMACC) + acc_leaf;
+        W.sum_acc = hdr(H_S_SUMACC) + acc_leaf;
     }
     return W;
+}
+__device__ __forceinline__ LeafWeights leaf_weigh(double hv, int num, double delta, float u_take) {
+    return leaf_weigh_f(num, delta, u_take, [hv](int k) { return hdr_word(hv, k); });
 }
 __device__ __forceinline__ void leaf_weights_header(double* ns, const double* gL, int D, const LeafWeights& W,
                                                     double e_new, uint32_t nhi, uint32_t nlo) {
@@ -531,20 +575,23 @@ __device__ inline bool leaf_moves_staged(double* ns, int D, int max_depth, int l
 // ---------------------------------------------------------------- small kernels (1 wave)
 
 // start of a transition: tree = the current state with momentum r (uploaded to V_TL_R)
-__device__ inline void init_body(double* ns, int D, double eps, double max_de, int lane) {
+template <int NT = 64>
+__device__ inline void init_body(double* ns, int D, double eps, double max_de, int lane,
+                                 double* scr = nullptr) {
     double* invM = vec(ns, D, V_INVM);
     double* r = vec(ns, D, V_TL_R);
     double kin = 0.0;
-    for (int i = lane; i < D; i += 64) kin += invM[i] * r[i] * r[i];
-    kin = 0.5 * nd_wave_sum(kin);
-    vcopy(vec(ns, D, V_TL_Z), vec(ns, D, V_Z), D, lane);
-    vcopy(vec(ns, D, V_TL_G), vec(ns, D, V_G), D, lane);
-    vcopy(vec(ns, D, V_TR_Z), vec(ns, D, V_Z), D, lane);
-    vcopy(vec(ns, D, V_TR_R), r, D, lane);
-    vcopy(vec(ns, D, V_TR_G), vec(ns, D, V_G), D, lane);
-    vcopy(vec(ns, D, V_TP_Z), vec(ns, D, V_Z), D, lane);
-    vcopy(vec(ns, D, V_TP_G), vec(ns, D, V_G), D, lane);
-    vcopy(vec(ns, D, V_T_RSUM), r, D, lane);
+#pragma unroll 4
+    for (int i = lane; i < D; i += NT) kin += invM[i] * r[i] * r[i];
+    kin = 0.5 * team_sum<NT>(kin, lane, scr);
+    vcopy<NT>(vec(ns, D, V_TL_Z), vec(ns, D, V_Z), D, lane);
+    vcopy<NT>(vec(ns, D, V_TL_G), vec(ns, D, V_G), D, lane);
+    vcopy<NT>(vec(ns, D, V_TR_Z), vec(ns, D, V_Z), D, lane);
+    vcopy<NT>(vec(ns, D, V_TR_R), r, D, lane);
+    vcopy<NT>(vec(ns, D, V_TR_G), vec(ns, D, V_G), D, lane);
+    vcopy<NT>(vec(ns, D, V_TP_Z), vec(ns, D, V_Z), D, lane);
+    vcopy<NT>(vec(ns, D, V_TP_G), vec(ns, D, V_G), D, lane);
+    vcopy<NT>(vec(ns, D, V_T_RSUM), r, D, lane);
     if (lane == 0) {
         const double e0 = ns[H_CUR_PE] + kin;
         ns[H_EPS] = eps;
@@ -558,6 +605,7 @@ __device__ inline void init_body(double* ns, int D, double eps, double max_de, i
 }
 
 // start of doubling `j`: runs only if the tree is still at depth j and not finished
+template <int NT = 64>
 __device__ inline void begin_body(double* ns, int D, int j, int going_right, uint32_t khi,
                                   uint32_t klo, int lane) {
     const bool active = ns[H_STOP] == 0.0 && (int)ns[H_T_DEPTH] == j;
@@ -567,13 +615,14 @@ __device__ inline void begin_body(double* ns, int D, int j, int going_right, uin
     }
     const double dir = going_right ? 1.0 : -1.0;
     const double eps = ns[H_EPS] * dir;
-    const double* invM = vec(ns, D, V_INVM);
-    const double* ez = vec(ns, D, going_right ? V_TR_Z : V_TL_Z);
-    const double* er = vec(ns, D, going_right ? V_TR_R : V_TL_R);
-    const double* eg = vec(ns, D, going_right ? V_TR_G : V_TL_G);
-    double* zn = vec(ns, D, V_ZN);
-    double* rh = vec(ns, D, V_RH);
-    for (int i = lane; i < D; i += 64) {
+    const double* __restrict__ invM = vec(ns, D, V_INVM);
+    const double* __restrict__ ez = vec(ns, D, going_right ? V_TR_Z : V_TL_Z);
+    const double* __restrict__ er = vec(ns, D, going_right ? V_TR_R : V_TL_R);
+    const double* __restrict__ eg = vec(ns, D, going_right ? V_TR_G : V_TL_G);
+    double* __restrict__ zn = vec(ns, D, V_ZN);
+    double* __restrict__ rh = vec(ns, D, V_RH);
+#pragma unroll 4
+    for (int i = lane; i < D; i += NT) {
         const double r = er[i] - 0.5 * eps * eg[i];
         rh[i] = r;
         zn[i] = ez[i] + eps * invM[i] * r;
@@ -589,35 +638,37 @@ __device__ inline void begin_body(double* ns, int D, int j, int going_right, uin
 }
 
 // end of a doubling: _combine_tree(tree, subtree, biased_transition=True)
+template <int NT = 64>
 __device__ inline void end_body(double* ns, int D, int max_depth, uint32_t thi, uint32_t tlo,
-                                int lane) {
+                                int lane, double* scr = nullptr) {
     if (ns[H_S_ACTIVE] == 0.0) return;
     const bool going_right = ns[H_DIR] > 0.0;
     const double* invM = vec(ns, D, V_INVM);
     // outer leaves of the combined tree
     if (going_right) {
-        vcopy(vec(ns, D, V_TR_Z), vec(ns, D, V_SR_Z), D, lane);
-        vcopy(vec(ns, D, V_TR_R), vec(ns, D, V_SR_R), D, lane);
-        vcopy(vec(ns, D, V_TR_G), vec(ns, D, V_SR_G), D, lane);
+        vcopy<NT>(vec(ns, D, V_TR_Z), vec(ns, D, V_SR_Z), D, lane);
+        vcopy<NT>(vec(ns, D, V_TR_R), vec(ns, D, V_SR_R), D, lane);
+        vcopy<NT>(vec(ns, D, V_TR_G), vec(ns, D, V_SR_G), D, lane);
     } else {
-        vcopy(vec(ns, D, V_TL_Z), vec(ns, D, V_SL_Z), D, lane);
-        vcopy(vec(ns, D, V_TL_R), vec(ns, D, V_SL_R), D, lane);
-        vcopy(vec(ns, D, V_TL_G), vec(ns, D, V_SL_G), D, lane);
+        vcopy<NT>(vec(ns, D, V_TL_Z), vec(ns, D, V_SL_Z), D, lane);
+        vcopy<NT>(vec(ns, D, V_TL_R), vec(ns, D, V_SL_R), D, lane);
+        vcopy<NT>(vec(ns, D, V_TL_G), vec(ns, D, V_SL_G), D, lane);
     }
-    double* t_rsum = vec(ns, D, V_T_RSUM);
-    const double* s_rsum = vec(ns, D, V_S_RSUM);
-    for (int i = lane; i < D; i += 64) t_rsum[i] += s_rsum[i];
+    double* __restrict__ t_rsum = vec(ns, D, V_T_RSUM);
+    const double* __restrict__ s_rsum = vec(ns, D, V_S_RSUM);
+#pragma unroll 4
+    for (int i = lane; i < D; i += NT) t_rsum[i] += s_rsum[i];
     const bool s_turn = ns[H_S_TURN] != 0.0, s_div = ns[H_S_DIV] != 0.0;
     const double w_cur = ns[H_T_WEIGHT], w_new = ns[H_S_WEIGHT];
     double prob = exp(w_new - w_cur);
     if (s_turn || s_div) prob = 0.0;
     prob = fmin(prob, 1.0);
     const bool turning =
-        s_turn | is_turning(invM, vec(ns, D, V_TL_R), vec(ns, D, V_TR_R), t_rsum, D, lane);
+        s_turn | is_turning<NT>(invM, vec(ns, D, V_TL_R), vec(ns, D, V_TR_R), t_rsum, D, lane, scr);
     const bool take = tf_bernoulli(thi, tlo, prob);
     if (take) {
-        vcopy(vec(ns, D, V_TP_Z), vec(ns, D, V_SP_Z), D, lane);
-        vcopy(vec(ns, D, V_TP_G), vec(ns, D, V_SP_G), D, lane);
+        vcopy<NT>(vec(ns, D, V_TP_Z), vec(ns, D, V_SP_Z), D, lane);
+        vcopy<NT>(vec(ns, D, V_TP_G), vec(ns, D, V_SP_G), D, lane);
     }
     if (lane == 0) {
         if (take) {
@@ -640,9 +691,10 @@ __device__ inline void end_body(double* ns, int D, int max_depth, uint32_t thi, 
 }
 
 // end of the transition: the proposal becomes the current state
+template <int NT = 64>
 __device__ inline void finish_body(double* ns, int D, int lane) {
-    vcopy(vec(ns, D, V_Z), vec(ns, D, V_TP_Z), D, lane);
-    vcopy(vec(ns, D, V_G), vec(ns, D, V_TP_G), D, lane);
+    vcopy<NT>(vec(ns, D, V_Z), vec(ns, D, V_TP_Z), D, lane);
+    vcopy<NT>(vec(ns, D, V_G), vec(ns, D, V_TP_G), D, lane);
     if (lane == 0) ns[H_CUR_PE] = ns[H_T_PE];
 }
 
@@ -719,38 +771,42 @@ __device__ __forceinline__ void wave_mem_sync() {  // stores of this wave visibl
 }
 
 // momentum of iteration `it` (r = mass_sqrt * unit normal), tree := current state, doubling 0
+template <int NT = 64>
 __device__ inline void persist_start_transition(double* ns, const Persist& P, int chain, int it,
-                                                int lane) {
+                                                int lane, double* scr = nullptr) {
     const int D = P.D;
     double* pd = ns + P.pd_off;
     const double* msq = pd + P_N + 2 * (size_t)D;
     const double* nrm = P.normals + ((size_t)chain * P.n_iter + it) * D;
-    double* r = vec(ns, D, V_TL_R);
-    for (int i = lane; i < D; i += 64) r[i] = msq[i] * nrm[i];
-    wave_mem_sync();
-    init_body(ns, D, pd[P_STEP], pd[P_MAXDE], lane);
-    wave_mem_sync();
+    double* __restrict__ r = vec(ns, D, V_TL_R);
+#pragma unroll 4
+    for (int i = lane; i < D; i += NT) r[i] = msq[i] * nrm[i];
+    team_sync<NT>();
+    init_body<NT>(ns, D, pd[P_STEP], pd[P_MAXDE], lane, scr);
+    team_sync<NT>();
     const double* q = P.par + ((size_t)chain * P.n_iter + it) * P.max_depth * 5;
-    begin_body(ns, D, 0, q[0] != 0.0, (uint32_t)q[1], (uint32_t)q[2], lane);
+    begin_body<NT>(ns, D, 0, q[0] != 0.0, (uint32_t)q[1], (uint32_t)q[2], lane);
 }
 
 // called by the leaf's wave when the subtree of the current doubling is complete
-__device__ inline void persist_advance(double* ns, const Persist& P, int chain, int lane) {
+template <int NT = 64>
+__device__ inline void persist_advance(double* ns, const Persist& P, int chain, int lane,
+                                       double* scr = nullptr) {
     const int D = P.D, md = P.max_depth;
     double* pd = ns + P.pd_off;
-    wave_mem_sync();
+    team_sync<NT>();
     if (pd[P_ALLDONE] != 0.0) return;
     const int it = (int)pd[P_ITER];
     {   // end of the doubling: _combine_tree(tree, subtree, biased_transition=True)
         const int j = (int)ns[H_T_DEPTH];
         const double* q = P.par + (((size_t)chain * P.n_iter + it) * md + j) * 5;
-        end_body(ns, D, md, (uint32_t)q[3], (uint32_t)q[4], lane);
-        wave_mem_sync();
+        end_body<NT>(ns, D, md, (uint32_t)q[3], (uint32_t)q[4], lane, scr);
+        team_sync<NT>();
     }
     if (ns[H_STOP] == 0.0) {  // next doubling of the same transition
         const int j = (int)ns[H_T_DEPTH];
         const double* q = P.par + (((size_t)chain * P.n_iter + it) * md + j) * 5;
-        begin_body(ns, D, j, q[0] != 0.0, (uint32_t)q[1], (uint32_t)q[2], lane);
+        begin_body<NT>(ns, D, j, q[0] != 0.0, (uint32_t)q[1], (uint32_t)q[2], lane);
         return;
     }
     // ---- the transition is complete: proposal -> state, statistics, adaptation, next one
@@ -758,8 +814,8 @@ __device__ inline void persist_advance(double* ns, const Persist& P, int chain, 
     const double accept_prob = num > 0 ? ns[H_T_SUMACC] / num : 0.0;
     const bool diverging = ns[H_T_DIV] != 0.0;
     const double used_step = ns[H_EPS], t_pe = ns[H_T_PE], t_aux0 = ns[H_T_AUX0];
-    finish_body(ns, D, lane);
-    wave_mem_sync();
+    finish_body<NT>(ns, D, lane);
+    team_sync<NT>();
     const double* zc = vec(ns, D, V_Z);
     double* w_mean = pd + P_N;
     double* w_m2 = w_mean + D;
@@ -786,7 +842,7 @@ __device__ inline void persist_advance(double* ns, const Persist& P, int chain, 
         double w_n = pd[P_W_N];
         if (adapt_mm && is_middle) {  // welford_covariance(diagonal=True)
             w_n += 1.0;
-            for (int i = lane; i < D; i += 64) {
+            for (int i = lane; i < D; i += NT) {
                 const double d_pre = zc[i] - w_mean[i];
                 const double mnew = w_mean[i] + d_pre / w_n;
                 w_mean[i] = mnew;
@@ -798,7 +854,7 @@ __device__ inline void persist_advance(double* ns, const Persist& P, int chain, 
         double prox = pd[P_DA_PROX];
         if (at_end && is_middle) {
             if (adapt_mm) {
-                for (int i = lane; i < D; i += 64) {
+                for (int i = lane; i < D; i += NT) {
                     double c = w_m2[i] / (w_n - 1.0);
                     c = (w_n / (w_n + 5.0)) * c + 1e-3 * (5.0 / (w_n + 5.0));
                     invM[i] = c;
@@ -813,6 +869,7 @@ __device__ inline void persist_advance(double* ns, const Persist& P, int chain, 
                 prox = log(10.0 * step);
             }
         }
+        if (NT > 64) __syncthreads();  // every thread has read the scalars rewritten below
         if (lane == 0) {
             pd[P_DA_T] = da_t; pd[P_DA_XT] = x_t; pd[P_DA_XAVG] = x_avg; pd[P_DA_GAVG] = g_avg;
             pd[P_DA_PROX] = prox; pd[P_WIN] = (double)win; pd[P_W_N] = w_n; pd[P_STEP] = step;
@@ -823,7 +880,7 @@ __device__ inline void persist_advance(double* ns, const Persist& P, int chain, 
         if (it >= start_idx && (it - start_idx) % thin == thin - 1) {
             const int idx = (it - start_idx) / thin;
             double* dr = P.draws + ((size_t)chain * P.kept + idx) * D;
-            for (int i = lane; i < D; i += 64) dr[i] = zc[i];
+            vcopy<NT>(dr, zc, D, lane);
             if (lane == 0) {
                 double* st = P.stats + ((size_t)chain * P.kept + idx) * 6;
                 st[0] = t_pe; st[1] = accept_prob; st[2] = used_step; st[3] = num;
@@ -845,8 +902,8 @@ __device__ inline void persist_advance(double* ns, const Persist& P, int chain, 
         return;
     }
     if (lane == 0) pd[P_ITER] = (double)(it + 1);
-    wave_mem_sync();
-    persist_start_transition(ns, P, chain, it + 1, lane);
+    team_sync<NT>();
+    persist_start_transition<NT>(ns, P, chain, it + 1, lane, scr);
 }
 
 // Leaf bookkeeping as its own launch, for models whose evaluation is not dc_eval (the float64
@@ -875,6 +932,192 @@ __global__ __launch_bounds__(64) void kp_leaf(double* ns_all, size_t stride, int
 // first transition of every chain (after the host has set the initial state)
 __global__ __launch_bounds__(64) void kp_start(double* ns, size_t stride, Persist P) {
     persist_start_transition(ns + blockIdx.x * stride, P, blockIdx.x, 0, threadIdx.x);
+}
+
+
+// ---------------------------------------------------------------- wide leaf (any D)
+// The leaf for latent vectors too long for one wave (dynamic model: D ~ 10^4..10^5, leagues of
+// more than 64 teams), as two launches of GW workgroups per chain after the evaluation:
+//   kw_leaf_a  partial sums of every reduction the leaf needs -- the kinetic energy and, for
+//              each checkpoint level this leaf closes, the two U-turn dot products -- into
+//              part[chain][workgroup][KW_PW]
+//   kw_leaf_b  every workgroup adds the partials in a fixed order (same totals everywhere,
+//              deterministic), takes the leaf's decisions and writes its slice of the vectors;
+//              the last workgroup to finish (ticket) writes the header and, when the subtree
+//              is complete, advances the chain with the whole workgroup as the team.
+// Same arithmetic per element as leaf_moves / leaf_weights; only the order of the sums differs.
+constexpr int KW_NT = 256;              // kw_leaf_a
+constexpr int KW_NTB = 1024;            // kw_leaf_b / kw_start: the team that also advances the chain
+constexpr int KW_MAXL = 21;            // levels one leaf can close (max_tree_depth <= 20)
+constexpr int KW_PW = 1 + 2 * KW_MAXL; // kin | (dl, dr) per level
+constexpr int KW_MAX_WG = 64;
+__host__ __device__ inline int kw_workgroups(int D, int nt) {
+    const int g = (D + 2 * nt - 1) / (2 * nt);
+    return g < 1 ? 1 : (g > KW_MAX_WG ? KW_MAX_WG : g);
+}
+struct WideLeaf {  // what both launches derive from the header (identical in every thread)
+    double eps;
+    bool going_right;
+    int num, idx_max, idx_min, n_lev;
+};
+__device__ __forceinline__ WideLeaf wide_leaf(const double* ns) {
+    WideLeaf W;
+    const double dir = ns[H_DIR];
+    W.eps = ns[H_EPS] * dir;
+    W.going_right = dir > 0.0;
+    W.num = (int)ns[H_S_NUM];
+    W.idx_max = __popc((unsigned)W.num >> 1);
+    W.idx_min = W.idx_max - (__ffs(~W.num) - 1) + 1;
+    W.n_lev = W.idx_max >= W.idx_min ? W.idx_max - W.idx_min + 1 : 0;
+    return W;
+}
+__global__ __launch_bounds__(KW_NT) void kw_leaf_a(double* ns_all, size_t stride, int D, int max_depth,
+                                                   double* part) {
+    __shared__ double scr[KW_NT / 64];
+    double* ns = ns_all + blockIdx.y * stride;
+    if (ns[H_S_DONE] != 0.0) return;  // chain finished (uniform over the grid row)
+    const int tid = threadIdx.x, GW = gridDim.x;
+    const WideLeaf W = wide_leaf(ns);
+    const double* invM = vec(ns, D, V_INVM);
+    const double* rh = vec(ns, D, V_RH);
+    const double* g = vec(ns, D, V_GRAD);
+    const double* rsum = vec(ns, D, V_S_RSUM);
+    const double* c_r1 = vec(ns, D, W.going_right ? V_SR_R : V_SL_R);
+    const double* ck_r = vec(ns, D, V_CKPT);
+    const double* ck_s = ck_r + (size_t)max_depth * D;
+    double* out = part + ((size_t)blockIdx.y * GW + blockIdx.x) * KW_PW;
+    const int i0 = blockIdx.x * KW_NT + tid, step = GW * KW_NT;
+
+    double kin = 0.0;
+    for (int i = i0; i < D; i += step) {
+        const double r = rh[i] - 0.5 * W.eps * g[i];
+        kin += invM[i] * r * r;
+    }
+    kin = team_sum<KW_NT>(kin, tid, scr);
+    if (tid == 0) out[0] = kin;
+    for (int l = 0; l < W.n_lev; ++l) {  // (an odd leaf: num >= 1)
+        const int ci = W.idx_max - l;
+        double dl = 0.0, dr = 0.0;
+        for (int i = i0; i < D; i += step) {
+            const double r = rh[i] - 0.5 * W.eps * g[i];
+            const double rs_old = rsum[i], rs = rs_old + r;
+            // the first level is the previous leaf itself (see LeafState)
+            const double c_r = l == 0 ? c_r1[i] : ck_r[(size_t)ci * D + i];
+            const double c_s = l == 0 ? rs_old : ck_s[(size_t)ci * D + i];
+            const double sub = rs - c_s + c_r;
+            const double rsm = sub - 0.5 * (c_r + r);
+            dl += invM[i] * c_r * rsm;
+            dr += invM[i] * r * rsm;
+        }
+        dl = team_sum<KW_NT>(dl, tid, scr);
+        dr = team_sum<KW_NT>(dr, tid, scr);
+        if (tid == 0) { out[1 + 2 * l] = dl; out[2 + 2 * l] = dr; }
+    }
+}
+__global__ __launch_bounds__(KW_NTB) void kw_leaf_b(double* ns_all, size_t stride, int D, int max_depth,
+                                                    const double* part, int gw_a,
+                                                    unsigned int* tickets, Persist P, int persist) {
+    __shared__ double scr[KW_NTB / 64];
+    __shared__ double tot[KW_PW];
+    __shared__ int s_last;
+    const int chain = blockIdx.y;
+    double* ns = ns_all + chain * stride;
+    if (ns[H_S_DONE] != 0.0) return;
+    const int tid = threadIdx.x, GW = gridDim.x;
+    const WideLeaf W = wide_leaf(ns);
+    // totals: one wave per value, lane b reads workgroup b's partial (gw_a <= 64): one round of
+    // loads and a fixed-order wave sum (a serial loop is one memory round trip per workgroup)
+    static_assert(KW_MAX_WG <= 64, "one lane per partial");
+    for (int k = tid >> 6; k < 1 + 2 * W.n_lev; k += KW_NTB / 64) {
+        const int b = tid & 63;
+        const double v = b < gw_a ? part[((size_t)chain * gw_a + b) * KW_PW + k] : 0.0;
+        const double sum = nd_wave_sum(v);
+        if (b == 0) tot[k] = sum;
+    }
+    // everything the decisions read from the header, before anyone rewrites it
+    const double pe = ns[H_LEAF_PE], e0 = ns[H_E0], max_de = ns[H_MAXDE];
+    const double aux0 = ns[H_LEAF_AUX0], aux1 = ns[H_LEAF_AUX1], aux2 = ns[H_LEAF_AUX2],
+                 aux3 = ns[H_LEAF_AUX3];
+    const double w_cur = ns[H_S_WEIGHT], s_sumacc = ns[H_S_SUMACC], evals = ns[H_EVALS];
+    const int s_max = (int)ns[H_S_MAX];
+    uint32_t nhi, nlo;
+    float u_take;
+    leaf_rng_k((uint32_t)ns[H_KEY_HI], (uint32_t)ns[H_KEY_LO], &nhi, &nlo, &u_take);
+    __syncthreads();
+
+    const double e_new = pe + 0.5 * tot[0];
+    double delta = e_new - e0;
+    if (delta != delta) delta = __builtin_inf();
+    const bool div_leaf = delta > max_de;
+    const LeafWeights LW = leaf_weigh_f(W.num, delta, u_take, [&](int k) {
+        return k == H_S_WEIGHT ? w_cur : s_sumacc;
+    });
+    bool turning = false;
+    for (int l = 0; l < W.n_lev; ++l) turning = turning || tot[1 + 2 * l] <= 0.0 || tot[2 + 2 * l] <= 0.0;
+    const int new_num = W.num + 1;
+    const bool done = turning || div_leaf || new_num >= s_max;
+
+    // ---- this workgroup's slice of the vectors
+    const double* invM = vec(ns, D, V_INVM);
+    const double* g = vec(ns, D, V_GRAD);
+    double* p_zn = vec(ns, D, V_ZN); double* p_rh = vec(ns, D, V_RH); double* p_rsum = vec(ns, D, V_S_RSUM);
+    double* sl_z = vec(ns, D, V_SL_Z); double* sl_r = vec(ns, D, V_SL_R); double* sl_g = vec(ns, D, V_SL_G);
+    double* sr_z = vec(ns, D, V_SR_Z); double* sr_r = vec(ns, D, V_SR_R); double* sr_g = vec(ns, D, V_SR_G);
+    double* sp_z = vec(ns, D, V_SP_Z); double* sp_g = vec(ns, D, V_SP_G);
+    double* ck_r = vec(ns, D, V_CKPT);
+    double* ck_s = ck_r + (size_t)max_depth * D;
+    const bool wl = W.num == 0 || !W.going_right, wr = W.num == 0 || W.going_right;
+    const bool wck = (W.num & 1) == 0;
+    for (int i = blockIdx.x * KW_NTB + tid; i < D; i += GW * KW_NTB) {
+        const double gi = g[i], zn = p_zn[i];
+        const double r = p_rh[i] - 0.5 * W.eps * gi;
+        const double rs = W.num == 0 ? r : p_rsum[i] + r;
+        const double rn = r - 0.5 * W.eps * gi;
+        p_zn[i] = done ? zn : zn + W.eps * invM[i] * rn;
+        p_rh[i] = done ? r : rn;
+        p_rsum[i] = rs;
+        if (wl) { sl_z[i] = zn; sl_r[i] = r; sl_g[i] = gi; }
+        if (wr) { sr_z[i] = zn; sr_r[i] = r; sr_g[i] = gi; }
+        if (LW.take) { sp_z[i] = zn; sp_g[i] = gi; }
+        if (wck) {
+            ck_r[(size_t)W.idx_max * D + i] = r;
+            ck_s[(size_t)W.idx_max * D + i] = rs;
+        }
+    }
+    // ---- the last workgroup of the chain writes the header (every other one has read it --
+    // the ticket alone orders that).  Only when the subtree is complete does it go on to read
+    // the other workgroups' slices: release them first (an agent-scope fence writes the L2
+    // back, ~10 us with these vectors: not on the common path).
+    const bool advance = persist && done;
+    if (advance) __threadfence();
+    __syncthreads();
+    if (tid == 0) s_last = atomicAdd(&tickets[chain], 1u) == (unsigned)(GW - 1);
+    __syncthreads();
+    if (!s_last) return;
+    if (advance) __threadfence();
+    if (tid == 0) {
+        tickets[chain] = 0u;
+        ns[H_S_NUM] = (double)new_num;
+        ns[H_S_DIV] = div_leaf ? 1.0 : 0.0;
+        ns[H_S_TURN] = turning ? 1.0 : 0.0;
+        ns[H_S_DONE] = done ? 1.0 : 0.0;
+        ns[H_EVALS] = evals + 1.0;
+        ns[H_S_WEIGHT] = LW.w_sub;
+        ns[H_S_SUMACC] = LW.sum_acc;
+        ns[H_KEY_HI] = (double)nhi;
+        ns[H_KEY_LO] = (double)nlo;
+        if (LW.take) {
+            ns[H_S_PE] = pe;
+            ns[H_S_EPROP] = e_new;
+            ns[H_S_AUX0] = aux0; ns[H_S_AUX1] = aux1; ns[H_S_AUX2] = aux2; ns[H_S_AUX3] = aux3;
+        }
+    }
+    if (advance) persist_advance<KW_NTB>(ns, P, chain, tid, scr);
+}
+// first transition of every chain, one workgroup per chain
+__global__ __launch_bounds__(KW_NTB) void kw_start(double* ns, size_t stride, Persist P) {
+    __shared__ double scr[KW_NTB / 64];
+    persist_start_transition<KW_NTB>(ns + blockIdx.x * stride, P, blockIdx.x, 0, threadIdx.x, scr);
 }
 
 }  // namespace nd

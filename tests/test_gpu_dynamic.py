@@ -85,3 +85,37 @@ def test_dynamic_fit_smoke(hip_ctx):
     p = m.predict_outcome_proba(["t0", "t1"], ["t2", "t3"], [0, 1])
     assert np.allclose(p["home_win"] + p["draw"] + p["away_win"], 1.0, atol=1e-5)
     assert m.predict_score_proba("t0", "t1", 1, 0, 0).shape == (1,)
+
+
+def test_dynamic_chain_on_device_matches_host_tree(hip_ctx):
+    """The dynamic model's latent vector (here D = 700+) is booked by the wide leaf launches
+    (nuts_dev.hip.h kw_leaf_a/b) with the whole chain on the device; with a fixed step size it
+    builds the same trees as the host tree engine on the same threefry streams."""
+    from bpl._ffi import default_nuts_cfg
+
+    T, G, n = 10, 8, 600
+    rs = np.random.RandomState(3)
+    h = rs.randint(0, T, n)
+    a = (h + 1 + rs.randint(0, T - 1, n)) % T
+    fx = DO.DynFixtures(h, a, rs.poisson(1.5, n), rs.poisson(1.2, n), np.sort(rs.randint(0, G, n)),
+                        (rs.rand(n) < 0.2).astype(int), T, G)
+    hip_ctx.set_fixtures_dynamic(fx.home_idx, fx.away_idx, fx.home_goals, fx.away_goals, fx.gameweek,
+                                 fx.neutral, T, G)
+    assert hip_ctx.dim == DO.latent_dim(G, T) > 256
+    cfg = default_nuts_cfg()
+    cfg.num_warmup, cfg.num_samples, cfg.step_size, cfg.max_tree_depth = 0, 6, 0.02, 6
+    z0 = np.random.RandomState(5).uniform(-0.1, 0.1, hip_ctx.dim)
+    hip_ctx.set_option("device_nuts", 0)
+    try:
+        d0, s0 = hip_ctx.nuts_run(cfg, (0, 9), z0)
+    finally:
+        hip_ctx.set_option("device_nuts", 1)
+    d1, s1 = hip_ctx.nuts_run(cfg, (0, 9), z0)
+    assert s0["total_leapfrogs"] > 30
+    assert s1["num_steps"].tolist() == s0["num_steps"].tolist()
+    assert np.abs(d1[:3] - d0[:3]).max() < 1e-9 and np.abs(d1 - d0).max() < 1e-4
+    assert np.abs(s1["potential_energy"][:3] - s0["potential_energy"][:3]).max() < 1e-7
+    # adaptation on the device (step size + Welford mass matrix with the workgroup as the team)
+    cfg.num_warmup, cfg.num_samples, cfg.step_size = 120, 30, 1.0
+    d, st = hip_ctx.nuts_run(cfg, (0, 9))
+    assert np.isfinite(d).all() and st["total_divergences"] <= 2 and 0.5 < st["mean_accept_prob"] <= 1.0

@@ -254,17 +254,41 @@ def test_reserved_scoreline_and_lane_padding(hip_ctx):
 
 
 def test_nuts_with_many_teams(hip_ctx):
-    """T > 64: bplhip_nuts_run takes the host tree engine (one evaluation + read-back per leapfrog)
-    and bplhip_nuts_run_chains reports EUNSUPPORTED (callers then run the chains one by one)."""
+    """T > 64: the leaf does not fit dc_eval's tail, so the chain still lives on the device but
+    books its leaves in separate launches -- one wave per chain up to 256 latent entries
+    (T = 100: D = 205), GW workgroups per chain beyond (T = 700: D = 1405).  With a fixed step
+    size both must build the same trees as the host tree engine (same threefry streams)."""
     from bpl._ffi import BPLHIP_EUNSUPPORTED, BplHipError, default_nuts_cfg
 
-    fx = cases.fixtures("wide_4000_100")
-    hip_ctx.set_fixtures(O.MODEL_BASIC, fx.home_idx.astype(np.uint16), fx.away_idx.astype(np.uint16),
-                         fx.home_goals.astype(np.uint8), fx.away_goals.astype(np.uint8), fx.n_teams)
-    cfg = default_nuts_cfg()
-    cfg.num_warmup, cfg.num_samples = 30, 20
-    d, st = hip_ctx.nuts_run(cfg, (0, 3))
-    assert d.shape == (20, hip_ctx.dim) and np.isfinite(d).all() and st["total_leapfrogs"] > 50
-    with pytest.raises(BplHipError) as e:
-        hip_ctx.nuts_run_chains(cfg, [(0, 1), (0, 2)])
-    assert e.value.code == BPLHIP_EUNSUPPORTED
+    for name in ("wide_4000_100", "wide_30000_700"):
+        fx = cases.fixtures(name)
+        hip_ctx.set_fixtures(O.MODEL_BASIC, fx.home_idx.astype(np.uint16), fx.away_idx.astype(np.uint16),
+                             fx.home_goals.astype(np.uint8), fx.away_goals.astype(np.uint8), fx.n_teams)
+        cfg = default_nuts_cfg()
+        cfg.num_warmup, cfg.num_samples, cfg.step_size = 0, 6, 0.002
+        z0 = np.random.RandomState(5).uniform(-0.1, 0.1, hip_ctx.dim)
+        hip_ctx.set_option("device_nuts", 0)
+        try:
+            d0, s0 = hip_ctx.nuts_run(cfg, (0, 3), z0)
+        finally:
+            hip_ctx.set_option("device_nuts", 1)
+        d1, s1 = hip_ctx.nuts_run(cfg, (0, 3), z0)
+        assert s0["total_leapfrogs"] > 20
+        assert s1["num_steps"].tolist() == s0["num_steps"].tolist()
+        assert np.abs(d1[:3] - d0[:3]).max() < 1e-9 and np.abs(d1 - d0).max() < 1e-4
+        assert np.abs(s1["accept_prob"][:3] - s0["accept_prob"][:3]).max() < 1e-8
+        # with adaptation, and several chains on the device at once
+        cfg.num_warmup, cfg.num_samples, cfg.step_size = 30, 20, 1.0
+        d, st = hip_ctx.nuts_run(cfg, (0, 3))
+        assert d.shape == (20, hip_ctx.dim) and np.isfinite(d).all() and st["total_leapfrogs"] > 50
+        res = hip_ctx.nuts_run_chains(cfg, [(0, 3), (0, 4)])
+        assert np.array_equal(res[0][0], d), "a chain does not depend on its neighbours"
+        assert np.isfinite(res[1][0]).all()
+    # persistent_nuts = 0: lock-step chains exist only for the models of dc_eval's tail
+    hip_ctx.set_option("persistent_nuts", 0)
+    try:
+        with pytest.raises(BplHipError) as e:
+            hip_ctx.nuts_run_chains(cfg, [(0, 1), (0, 2)])
+        assert e.value.code == BPLHIP_EUNSUPPORTED
+    finally:
+        hip_ctx.set_option("persistent_nuts", 1)

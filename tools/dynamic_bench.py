@@ -28,3 +28,14 @@ for name, (h, a, x, y, g, nv) in (("config4 N=2500", config4()), ("N=1e6", big()
         ts.append(e0.elapsed_time(e1) * 1e3 / 128)
     t = float(np.median(ts))
     print(f"dynamic {name:16s} D={D}: {t:9.2f} us/eval  {1e6 / t:10.1f} evals/s  algorithmic GB/s={h.size * 9 / t / 1e3:8.2f}", flush=True)
+    if os.environ.get('INSITU', '1') == '1' and h.size <= 10000:
+        from bpl._ffi import default_nuts_cfg
+        cfg = default_nuts_cfg(); cfg.num_warmup, cfg.num_samples, cfg.max_tree_depth = 150, 50, 8
+        for eng, dn in (("chain on the device (wide leaf launches)", 1), ("host tree engine", 0)):
+            if dn == 0 and os.environ.get('HOST_ENGINE', '1') != '1': continue
+            c.set_option('device_nuts', dn)
+            _, st = c.nuts_run(cfg, (0, 42))
+            c.set_option('device_nuts', 1)
+            print(f"    in situ, {eng}: NUTS {cfg.num_warmup}+{cfg.num_samples} transitions, depth <= 8: "
+                  f"{st['total_leapfrogs'] / st['wall_seconds']:9.0f} leapfrogs/s "
+                  f"({st['total_leapfrogs']} in {st['wall_seconds']:.2f} s)", flush=True)
