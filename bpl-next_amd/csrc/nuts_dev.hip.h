@@ -156,7 +156,7 @@ template <int NT = 64>
 __device__ inline bool is_turning(const double* invM, const double* r_left, const double* r_right,
                                   const double* r_sum, int D, int tid, double* scr = nullptr) {
     double dl = 0.0, dr = 0.0;
-#pragma unroll 4
+#pragma clang loop unroll_count(NT > 64 ? 4 : 1)
     for (int i = tid; i < D; i += NT) {
         const double rs = r_sum[i] - 0.5 * (r_left[i] + r_right[i]);
         dl += invM[i] * r_left[i] * rs;
@@ -171,7 +171,7 @@ __device__ inline bool is_turning(const double* invM, const double* r_left, cons
 template <int NT = 64>
 __device__ __forceinline__ void vcopy(double* __restrict__ dst, const double* __restrict__ src, int D,
                                       int tid) {
-#pragma unroll 4
+#pragma clang loop unroll_count(NT > 64 ? 4 : 1)
     for (int i = tid; i < D; i += NT) dst[i] = src[i];
 }
 __device__ __forceinline__ double logaddexp(double a, double b) {
@@ -581,7 +581,7 @@ __device__ inline void init_body(double* ns, int D, double eps, double max_de, i
     double* invM = vec(ns, D, V_INVM);
     double* r = vec(ns, D, V_TL_R);
     double kin = 0.0;
-#pragma unroll 4
+#pragma clang loop unroll_count(NT > 64 ? 4 : 1)
     for (int i = lane; i < D; i += NT) kin += invM[i] * r[i] * r[i];
     kin = 0.5 * team_sum<NT>(kin, lane, scr);
     vcopy<NT>(vec(ns, D, V_TL_Z), vec(ns, D, V_Z), D, lane);
@@ -621,7 +621,7 @@ __device__ inline void begin_body(double* ns, int D, int j, int going_right, uin
     const double* __restrict__ eg = vec(ns, D, going_right ? V_TR_G : V_TL_G);
     double* __restrict__ zn = vec(ns, D, V_ZN);
     double* __restrict__ rh = vec(ns, D, V_RH);
-#pragma unroll 4
+#pragma clang loop unroll_count(NT > 64 ? 4 : 1)
     for (int i = lane; i < D; i += NT) {
         const double r = er[i] - 0.5 * eps * eg[i];
         rh[i] = r;
@@ -656,7 +656,7 @@ __device__ inline void end_body(double* ns, int D, int max_depth, uint32_t thi, 
     }
     double* __restrict__ t_rsum = vec(ns, D, V_T_RSUM);
     const double* __restrict__ s_rsum = vec(ns, D, V_S_RSUM);
-#pragma unroll 4
+#pragma clang loop unroll_count(NT > 64 ? 4 : 1)
     for (int i = lane; i < D; i += NT) t_rsum[i] += s_rsum[i];
     const bool s_turn = ns[H_S_TURN] != 0.0, s_div = ns[H_S_DIV] != 0.0;
     const double w_cur = ns[H_T_WEIGHT], w_new = ns[H_S_WEIGHT];
@@ -779,7 +779,7 @@ __device__ inline void persist_start_transition(double* ns, const Persist& P, in
     const double* msq = pd + P_N + 2 * (size_t)D;
     const double* nrm = P.normals + ((size_t)chain * P.n_iter + it) * D;
     double* __restrict__ r = vec(ns, D, V_TL_R);
-#pragma unroll 4
+#pragma clang loop unroll_count(NT > 64 ? 4 : 1)
     for (int i = lane; i < D; i += NT) r[i] = msq[i] * nrm[i];
     team_sync<NT>();
     init_body<NT>(ns, D, pd[P_STEP], pd[P_MAXDE], lane, scr);

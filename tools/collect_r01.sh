@@ -8,10 +8,11 @@ mkdir -p $OUT
 cd $ROOT
 python bench.py > $OUT/bench.json 2> $OUT/bench.err
 python tools/stamps.py > $OUT/stamps_timeline.txt 2>&1
+python tools/stamps.py nuts >> $OUT/stamps_timeline.txt 2>&1
 python tools/n_sweep.py > $OUT/n_sweep.txt 2>&1
 python tools/batched_bench.py > $OUT/batched_vec.txt 2>&1
 VEC=0 CHAINS=8,64 python tools/batched_bench.py > $OUT/batched_gridy.txt 2>&1
-CHAINS=4,8,16,64 python tools/lockstep_bench.py > $OUT/lockstep.txt 2>&1
+CHAINS=4,8,16,32,64 python tools/lockstep_bench.py > $OUT/lockstep.txt 2>&1
 python tools/dynamic_bench.py > $OUT/dynamic.txt 2>&1
 python tools/predict_bench.py > $OUT/predict.txt 2>&1
 python tools/neutral_bench.py > $OUT/neutral.txt 2>&1
