@@ -149,10 +149,13 @@ int bplhip_set_fixtures_neutral(bplhip_ctx* ctx, int64_t n, int32_t n_teams,
                                 const double* covariates, int32_t k, void* stream);
 
 /* Tuning knobs (no reference counterpart; defaults are the measured best):
- *   "device_nuts" 1 (default) = NUTS tree builder on the device: leaf bookkeeping in the
- *            tail of the evaluation kernel, one host synchronisation per batch of
- *            doublings; 0 = host tree builder (one read-back per leapfrog).  The device
- *            builder is used for the basic/extended models with n_teams <= 64.
+ *   "device_nuts" 1 (default) = NUTS tree builder on the device for every model: leaf
+ *            bookkeeping in the tail of the evaluation kernel (basic/extended models,
+ *            n_teams <= 64) or in leaf launches after it (everything else);
+ *            0 = host tree builder (one read-back per leapfrog; the cross-check engine).
+ *   "persistent_nuts" 1 (default) = the whole chain on the device (adaptation included, the
+ *            host only enqueues evaluations); 0 = device trees with host-side adaptation
+ *            (models of the evaluation kernel's tail only).
  *   "max_wg" streaming workgroups per evaluation (default 255: with the prior workgroup
  *            one per CU); applies at the next bplhip_set_fixtures */
 int bplhip_set_option(bplhip_ctx* ctx, const char* name, int value);
@@ -233,10 +236,12 @@ int bplhip_nuts_run(bplhip_ctx* ctx, const bplhip_nuts_cfg* cfg, const double* z
                     uint32_t seed_hi, uint32_t seed_lo, double* draws_out,
                     bplhip_nuts_stats* stats, void* stream);
 
-/* Run `n_chains` chains in lock step on this GPU (numpyro chain_method="vectorized",
- * MCMC(num_chains=...) at bpl/dixon_coles.py:101-106): every leapfrog of all chains is one
- * chain-vectorised evaluation.  Basic / extended model, n_teams <= 64; otherwise
- * BPLHIP_EUNSUPPORTED (run the chains one after another with bplhip_nuts_run).
+/* Run `n_chains` chains together on this GPU (numpyro chain_method="vectorized",
+ * MCMC(num_chains=...) at bpl/dixon_coles.py:101-106): persistent chains, every launch
+ * advances every unfinished chain by one leapfrog.  Every model; BPLHIP_EUNSUPPORTED only
+ * when the run's momentum draws (n_chains * iterations * D doubles) exceed 16 GiB or with
+ * "persistent_nuts" 0 outside the basic / extended models with n_teams <= 64 (then run the
+ * chains one after another with bplhip_nuts_run).
  *   z0        HOST f64[n_chains, D] or NULL       seeds  HOST u32[n_chains, 2] (hi, lo)
  *   draws_out HOST f64[n_chains, num_samples/thinning, D]
  *   stats     n_chains statistics records, or NULL; wall_seconds is the whole run's.
