@@ -50,6 +50,7 @@ constexpr int WAVES = BLOCK / 64;
 // the leaf's preparation is spread over them and costs nothing on the serial path
 constexpr int LEAF_WAVE = 4;             // books the leaf
 constexpr int RNG_WAVE = 5;              // draws the leaf's random numbers (threefry)
+constexpr int COV_WAVE_A = 6, COV_WAVE_D = 7;  // covariate-coefficient gradients (any launch)
 // (Copying the whole checkpoint area into LDS on waves 6,7 -- so that a leaf closing several
 // subtrees needs no dependent load -- measured no gain for one chain and the larger LDS
 // footprint cost 20 % at 16 chains: not done.)
@@ -221,6 +222,24 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
     v += dpp_f64<0x142, 0xA>(0.0, v);
     v += dpp_f64<0x143, 0xC>(0.0, v);
     return readlane63_f64(v);
+}
+// four independent sums, interleaved step by step: a single wave issues a dependent DPP + add
+// only every ~20 cycles, so one sum after another leaves the pipeline three quarters empty
+__device__ __forceinline__ void wave_sum4_f64(double (&v)[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] += dpp_f64<0xB1>(0.0, v[j]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] += dpp_f64<0x4E>(0.0, v[j]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] += dpp_f64<0x124>(0.0, v[j]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] += dpp_f64<0x128>(0.0, v[j]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] += dpp_f64<0x142, 0xA>(0.0, v[j]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] += dpp_f64<0x143, 0xC>(0.0, v[j]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = readlane63_f64(v[j]);
 }
 __device__ __forceinline__ double wave_max_f64(double v) {  // v >= 0
     v = fmax(v, dpp_f64<0xB1>(0.0, v));
@@ -780,7 +799,10 @@ __device__ void tail_waves(const EvalArgs& A, int chain, const double* zoL, cons
     // adjoint of the bounds (Appendix A.3): what the arg-extremal pairs add to team t's
     // d/d attack (ja), d/d defence (jd), d/d home advantage (jh)
     double ja = 0.0, jd = 0.0, jh = 0.0;
-    if (A.P > 0 && wave < 3) {
+    // (waves COV_WAVE_A / COV_WAVE_D, otherwise idle, take the covariate coefficients: they
+    // rebuild the attack / defence adjoint themselves and run beside waves 0..3)
+    const bool cov_a = K > 0 && wave == COV_WAVE_A, cov_d = K > 0 && wave == COV_WAVE_D;
+    if (A.P > 0 && (wave < 3 || cov_a || cov_d)) {
         const double M = zoL[ZO_M], Lh = zoL[ZO_LH], La = zoL[ZO_LA];
         const uint32_t pP = (uint32_t)zoL[ZO_PP], pQ = (uint32_t)zoL[ZO_PQ],
                        pR = (uint32_t)zoL[ZO_PR];
@@ -813,6 +835,23 @@ __device__ void tail_waves(const EvalArgs& A, int chain, const double* zoL, cons
         }
     }
     const bool basic = !EXT;
+    // covariate coefficients: sum_t Xs[t,k] g_t for every k, four sums in flight; lane j of a
+    // batch stores its coefficient
+    auto cov_grad = [&](int o, double gt) {
+        for (int k0 = 0; k0 < K; k0 += 4) {
+            double v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = k0 + j;
+                const double xv =
+                    on && k < K ? (xsL ? xsL[(size_t)t * K + k] : A.xs[(size_t)t * K + k]) : 0.0;
+                v[j] = xv * gt;
+            }
+            wave_sum4_f64(v);
+            const double mine = t == 0 ? v[0] : t == 1 ? v[1] : t == 2 ? v[2] : v[3];
+            if (t < 4 && k0 + t < K) put(o + k0 + t, gz[o + k0 + t] - mine);
+        }
+    };
     if (wave == 0) {  // ---- attack
         const double s_a = zoL[ZO_SA];
         const double ga = on ? cL[t] - col[t] + ja : 0.0;
@@ -821,11 +860,10 @@ __device__ void tail_waves(const EvalArgs& A, int chain, const double* zoL, cons
         if (on) put(o + t, gz[o + t] - s_a * ga);
         const double dot_a = wave_sum_f64(dec * ga);
         if (t == 0) put(L.o_sa, gz[L.o_sa] - s_a * dot_a);
-        for (int k = 0; k < K; ++k) {  // d/d beta_k: sum_t Xs[t,k] g_t
-            const double xv = on ? (xsL ? xsL[(size_t)t * K + k] : A.xs[(size_t)t * K + k]) : 0.0;
-            const double sA = wave_sum_f64(xv * ga);
-            if (t == 0) put(L.o_bA + k, gz[L.o_bA + k] - sA);
-        }
+    } else if (cov_a) {  // ---- attack coefficients, d/d beta_k: sum_t Xs[t,k] g_t
+        cov_grad(L.o_bA, on ? cL[t] - col[t] + ja : 0.0);
+    } else if (cov_d) {  // ---- defence coefficients
+        cov_grad(L.o_bD, on ? -(cL[T + t] - col[T + t]) + jd : 0.0);
     } else if (wave == 1) {  // ---- defence
         const double s_d = zoL[ZO_SD];
         const double gd = on ? -(cL[T + t] - col[T + t]) + jd : 0.0;
@@ -838,11 +876,6 @@ __device__ void tail_waves(const EvalArgs& A, int chain, const double* zoL, cons
         if (t == 0) {
             put(L.o_md, gz[L.o_md] - sum_gd);
             put(L.o_sd, gz[L.o_sd] - s_d * dot_d);
-        }
-        for (int k = 0; k < K; ++k) {
-            const double xv = on ? (xsL ? xsL[(size_t)t * K + k] : A.xs[(size_t)t * K + k]) : 0.0;
-            const double sD = wave_sum_f64(xv * gd);
-            if (t == 0) put(L.o_bD + k, gz[L.o_bD + k] - sD);
         }
     } else if (wave == 2) {  // ---- home advantage, corr_coef_raw, u
         const double gh = on ? cL[2 * T + t] - col[2 * T + t] + jh : 0.0;
