@@ -331,7 +331,7 @@ __host__ __device__ inline size_t prior_lds_bytes(int T) {
     size_t b = 2 * (size_t)tab_len(T) * 8;                 // tabH, tabA (float2)
     b += 3 * (size_t)T * 8;                                // true tables (double)
     b += 3 * (size_t)T * 8;                                // att, def, ha (double)
-    b += (32 + WAVES * 8 + WAVES * 8) * 8;                 // scalars, scratch, argmax
+    b += (40 + WAVES * 8 + WAVES * 8) * 8;                 // scalars, scratch, argmax
     return b;
 }
 __host__ __device__ inline size_t eval_lds_bytes(int T, int D, int K, int zo_stride, int n_wg,
@@ -507,13 +507,22 @@ __device__ void prior_body(const EvalArgs& A, int chain, char* smem) {
     float2* tabA = tabH + tab_len(T);
     double* tru = reinterpret_cast<double*>(tabA + tab_len(T));  // EAg[T] | EA[T] | EDn[T]
     double* par = tru + 3 * T;                                    // att[T] | def[T] | ha[T]
-    double* sc = par + 3 * T;                                     // [32] scalars
-    double* scratch = sc + 32;                                    // [WAVES*8]
+    double* sc = par + 3 * T;                                     // [40] scalars
+    double* scratch = sc + 40;                                    // [WAVES*8]
     double* amx = scratch + WAVES * 8;                            // [WAVES*8] argmax
 
     // ---- float32 tables and rho exactly as the streaming workgroups build them
     uint32_t pr0 = 0;
     if (tid < A.P) pr0 = A.pairs[tid];
+    // the team-sum wave (see below) requests its inputs now: its loads queue behind nothing
+    const bool sums_on_wave = T <= 64;
+    double pre[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    if (sums_on_wave && wave == WAVES - 1 && lane < T) {
+        pre[0] = A.cA[lane]; pre[1] = A.cD[lane]; pre[2] = A.cH[lane];
+        pre[3] = z[CLIP ? L.o_sat + lane : L.o_adec + lane];
+        pre[4] = z[CLIP ? L.o_sdt + lane : L.o_ddec + lane];
+        pre[5] = CLIP ? z[L.o_hadec + lane] : 0.0;
+    }
     F32Scalars fs;
     build_tables_f32<CLIP>(L, z, A.xsf, tabH, tabA, tid, &fs);
 
@@ -616,6 +625,47 @@ __device__ void prior_body(const EvalArgs& A, int chain, char* smem) {
     // its pairs in ascending order and keeps the first, lanes and waves are in ascending
     // pair order too.)
     float* redm = reinterpret_cast<float*>(sc + 16);  // [WAVES*4] (sc[16..32) is free; scratch is reused by block_sum)
+
+    // ---- team sums of the z-only part of L and of its gradient (gz = -dL_prior/dz)
+    // v: 0 team part of L (priors + att cA - def cD + ha cH); extended: 1 dL/d rho_p.
+    // They need nothing from the bounds: for T <= 64 the last wave (idle in the pair loop up to
+    // 448 pairs) computes them with lane = team while the others walk the pairs, instead of the
+    // whole workgroup doing so afterwards (1.1 us of the extended model's longest pole).
+    double v[2] = {0.0, 0.0};
+    double rp = 0.0, vv = 1.0;
+    if (CLIP) {
+        rp = 2.0 * sc[9] - 1.0;
+        vv = 1.0 - rp * rp;
+    }
+    const double log_vv = CLIP ? log(vv) : 0.0;
+    const double ivv = 1.0 / vv;  // (one division for the workgroup instead of six per team)
+    auto team_term = [&](int t, double cAt, double cDt, double cHt, double z0, double z1, double z2) {
+        const double att = par[t], def = par[T + t], ha = par[2 * T + t];
+        const double lin = att * cAt - def * cDt + ha * cHt;
+        if (!CLIP) {
+            const double ad = z0, dd = z1;
+            v[0] += -0.5 * ad * ad - 0.5 * dd * dd - 2.0 * HALF_LOG_2PI + lin;
+            st_sc1(&gz[L.o_adec + t], ad);
+            st_sc1(&gz[L.o_ddec + t], dd);
+        } else {
+            const double sa = z0, sd = z1, hd = z2;
+            const double e = sd - rp * sa;
+            v[0] += -0.5 * sa * sa - 0.5 * e * e * ivv - 0.5 * log_vv - 0.5 * hd * hd -
+                    3.0 * HALF_LOG_2PI + lin;
+            v[1] += e * sa * ivv - rp * e * e * (ivv * ivv) + rp * ivv;
+            st_sc1(&gz[L.o_sat + t], sa - rp * e * ivv);
+            st_sc1(&gz[L.o_sdt + t], e * ivv);
+            st_sc1(&gz[L.o_hadec + t], hd);
+        }
+    };
+    if (sums_on_wave && wave == WAVES - 1) {
+        if (lane < T) team_term(lane, pre[0], pre[1], pre[2], pre[3], pre[4], pre[5]);
+        const double s0 = wave_sum_f64(v[0]), s1 = wave_sum_f64(v[1]);
+        if (lane == 0) {
+            sc[32] = s0;
+            sc[33] = s1;
+        }
+    }
     float mPf = 0.f, mQf = 0.f, mRf = 0.f;
     double mP = 0.0, mQ = 0.0, mR = 0.0;
     uint32_t aP = 0, aQ = 0, aR = 0;  // arg-pairs (home | away << 16)
@@ -667,35 +717,16 @@ __device__ void prior_body(const EvalArgs& A, int chain, char* smem) {
     __syncthreads();
     DC_STAMP(3);
 
-    // ---- team sums of the z-only part of L and of its gradient (gz = -dL_prior/dz)
-    // v: 0 team part of L (priors + att cA - def cD + ha cH); extended: 1 dL/d rho_p
-    double v[2] = {0.0, 0.0};
-    double rp = 0.0, vv = 1.0;
-    if (CLIP) {
-        rp = 2.0 * sc[9] - 1.0;
-        vv = 1.0 - rp * rp;
+    // ---- team sums: see above (one wave, beside the pair loop) or, for T > 64, here
+    if (!sums_on_wave) {
+        for (int t = tid; t < T; t += BLOCK)
+            team_term(t, A.cA[t], A.cD[t], A.cH[t], z[CLIP ? L.o_sat + t : L.o_adec + t],
+                      z[CLIP ? L.o_sdt + t : L.o_ddec + t], CLIP ? z[L.o_hadec + t] : 0.0);
+        block_sum<2>(v, scratch, tid);
+    } else {
+        v[0] = sc[32];
+        v[1] = sc[33];
     }
-    const double log_vv = CLIP ? log(vv) : 0.0;
-    for (int t = tid; t < T; t += BLOCK) {
-        const double att = par[t], def = par[T + t], ha = par[2 * T + t];
-        const double lin = att * A.cA[t] - def * A.cD[t] + ha * A.cH[t];
-        if (!CLIP) {
-            const double ad = z[L.o_adec + t], dd = z[L.o_ddec + t];
-            v[0] += -0.5 * ad * ad - 0.5 * dd * dd - 2.0 * HALF_LOG_2PI + lin;
-            st_sc1(&gz[L.o_adec + t], ad);
-            st_sc1(&gz[L.o_ddec + t], dd);
-        } else {
-            const double sa = z[L.o_sat + t], sd = z[L.o_sdt + t], hd = z[L.o_hadec + t];
-            const double e = sd - rp * sa;
-            v[0] += -0.5 * sa * sa - 0.5 * e * e / vv - 0.5 * log_vv - 0.5 * hd * hd -
-                    3.0 * HALF_LOG_2PI + lin;
-            v[1] += e * sa / vv - rp * e * e / (vv * vv) + rp / vv;
-            st_sc1(&gz[L.o_sat + t], sa - rp * e / vv);
-            st_sc1(&gz[L.o_sdt + t], e / vv);
-            st_sc1(&gz[L.o_hadec + t], hd);
-        }
-    }
-    block_sum<2>(v, scratch, tid);
     DC_STAMP(12);
 
     if (tid < 2 * K) {  // covariate coefficients ~ N(0,1)
