@@ -1024,6 +1024,20 @@ __global__ __launch_bounds__(KW_NTB) void kw_leaf_b(double* ns_all, size_t strid
     double* ns = ns_all + chain * stride;
     if (ns[H_S_DONE] != 0.0) return;
     const int tid = threadIdx.x, GW = gridDim.x;
+    // this thread's first two elements, requested before anything that waits for the header
+    // (one memory round trip less on the chain's serial path)
+    const int el0 = blockIdx.x * KW_NTB + tid, estep = GW * KW_NTB;
+    double pre[2][5];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int i = el0 + u * estep;
+        const bool ok = i < D;
+        pre[u][0] = ok ? vec(ns, D, V_GRAD)[i] : 0.0;
+        pre[u][1] = ok ? vec(ns, D, V_ZN)[i] : 0.0;
+        pre[u][2] = ok ? vec(ns, D, V_RH)[i] : 0.0;
+        pre[u][3] = ok ? vec(ns, D, V_S_RSUM)[i] : 0.0;
+        pre[u][4] = ok ? vec(ns, D, V_INVM)[i] : 0.0;
+    }
     const WideLeaf W = wide_leaf(ns);
     // totals: one wave per value, lane b reads workgroup b's partial (gw_a <= 64): one round of
     // loads and a fixed-order wave sum (a serial loop is one memory round trip per workgroup)
@@ -1068,12 +1082,16 @@ __global__ __launch_bounds__(KW_NTB) void kw_leaf_b(double* ns_all, size_t strid
     double* ck_s = ck_r + (size_t)max_depth * D;
     const bool wl = W.num == 0 || !W.going_right, wr = W.num == 0 || W.going_right;
     const bool wck = (W.num & 1) == 0;
-    for (int i = blockIdx.x * KW_NTB + tid; i < D; i += GW * KW_NTB) {
-        const double gi = g[i], zn = p_zn[i];
-        const double r = p_rh[i] - 0.5 * W.eps * gi;
-        const double rs = W.num == 0 ? r : p_rsum[i] + r;
+    int it = 0;
+    for (int i = el0; i < D; i += estep, ++it) {
+        const bool fromreg = it < 2;
+        const double gi = fromreg ? pre[it & 1][0] : g[i], zn = fromreg ? pre[it & 1][1] : p_zn[i];
+        const double rh_i = fromreg ? pre[it & 1][2] : p_rh[i], rs_old = fromreg ? pre[it & 1][3] : p_rsum[i];
+        const double im = fromreg ? pre[it & 1][4] : invM[i];
+        const double r = rh_i - 0.5 * W.eps * gi;
+        const double rs = W.num == 0 ? r : rs_old + r;
         const double rn = r - 0.5 * W.eps * gi;
-        p_zn[i] = done ? zn : zn + W.eps * invM[i] * rn;
+        p_zn[i] = done ? zn : zn + W.eps * im * rn;
         p_rh[i] = done ? r : rn;
         p_rsum[i] = rs;
         if (wl) { sl_z[i] = zn; sl_r[i] = r; sl_g[i] = gi; }
