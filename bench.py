@@ -12,7 +12,6 @@ the hipGraph path the NUTS driver uses for tree doublings.  Prints ONE JSON line
 """
 import argparse
 import json
-import math
 import os
 import sys
 import time
@@ -151,19 +150,27 @@ def main():
     U = torch.zeros(64, dtype=torch.float64, device=dev)
     g = torch.zeros_like(z)
 
-    glen = args.graph_len
-    if glen > 0:  # the graph length must divide both the timed and the warm-up count
-        glen = math.gcd(glen, args.steps)
-        if args.warmup:
-            glen = math.gcd(glen, args.warmup)
+    # K evaluations = whole replays of a hipGraph of `graph_len` evaluations + one shorter graph
+    # for the remainder, so any --steps / --warmup is timed at the kernel's rate (a graph of
+    # gcd(K, W, graph_len) evaluations would be launch bound for odd counts)
+    glen = min(args.graph_len, 64)
 
     def run(k):
         if glen > 0:
-            ctx.logp_grad_graph(glen, z, U, g, replays=k // glen)
+            q, r = divmod(k, glen)
+            if q:
+                ctx.logp_grad_graph(glen, z, U, g, replays=q)
+            if r:
+                ctx.logp_grad_graph(r, z, U, g, replays=1)
         else:
             for i in range(k):
                 j = i % 64
                 ctx.logp_grad(z[j], U[j:j + 1], g[j], None)
+
+    if glen > 0:  # capture + instantiate outside the timed region
+        for k in (args.warmup, args.steps):
+            for n in ((glen,) if k >= glen else ()) + ((k % glen,) if k % glen else ()):
+                ctx.logp_grad_graph(n, z, U, g, replays=0)
 
     run(args.warmup)
     torch.cuda.synchronize()
@@ -187,8 +194,10 @@ def main():
     wall_max = float(tmax.item())
 
     # sanity: the timed outputs are the real thing (compare one point with a direct call)
-    Uc, gc, _ = ctx.logp_grad(z[5].contiguous())
-    assert torch.equal(Uc[0], U[5]) and torch.equal(gc, g[5]), "graph path != direct path"
+    # (a point the timed run did evaluate: the graph covers z[0 .. glen-1])
+    chk = min(args.steps, glen if glen > 0 else 64) - 1
+    Uc, gc, _ = ctx.logp_grad(z[chk].contiguous())
+    assert torch.equal(Uc[0], U[chk]) and torch.equal(gc, g[chk]), "graph path != direct path"
 
     # dominant kernel alone (dc_stream is >90% of the bytes): HIP-event timed period of
     # back-to-back evaluations on this stream = ev_ms / steps (includes the epilogue
@@ -249,7 +258,7 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"dixon_coles_basic logp+grad, {n_fix} fixtures, {T} teams, "
-                            f"D={D}, 1 chain per GPU, hipGraph of {glen} evals",
+                            f"D={D}, 1 chain per GPU, hipGraph of {min(glen, args.steps)} evals",
                 "fixtures": n_fix,
                 "teams": T,
                 "parallelism": f"{world} independent chain(s), one per GPU",
