@@ -632,13 +632,14 @@ __device__ void prior_body(const EvalArgs& A, int chain, char* smem) {
     // 448 pairs) computes them with lane = team while the others walk the pairs, instead of the
     // whole workgroup doing so afterwards (1.1 us of the extended model's longest pole).
     double v[2] = {0.0, 0.0};
-    double rp = 0.0, vv = 1.0;
-    if (CLIP) {
+    // (only the waves that evaluate team terms pay for the log and the division)
+    double rp = 0.0, log_vv = 0.0, ivv = 1.0;
+    if (CLIP && (!sums_on_wave || wave == WAVES - 1)) {
         rp = 2.0 * sc[9] - 1.0;
-        vv = 1.0 - rp * rp;
+        const double vv = 1.0 - rp * rp;
+        log_vv = log(vv);
+        ivv = 1.0 / vv;  // one division instead of six per team
     }
-    const double log_vv = CLIP ? log(vv) : 0.0;
-    const double ivv = 1.0 / vv;  // (one division for the workgroup instead of six per team)
     auto team_term = [&](int t, double cAt, double cDt, double cHt, double z0, double z1, double z2) {
         const double att = par[t], def = par[T + t], ha = par[2 * T + t];
         const double lin = att * cAt - def * cDt + ha * cHt;
