@@ -9,12 +9,13 @@ from bpl import _ffi
 _ffi._LIB_NAME = "libbplhip_stamps.so"
 from bpl._ffi import HipContext, MODEL_BASIC, MODEL_EXTENDED
 
-def run(n, model=MODEL_BASIC, max_wg=255, k=0):
+def run(n, model=MODEL_BASIC, max_wg=255, k=0, weighted=False):
     h, a, x, y = synthetic_league(n, 20)
+    w = np.exp(-np.linspace(5.0, 0.0, n)).astype(np.float32) if weighted else None
     cov = None
     if k:
         cov = np.random.RandomState(0).normal(size=(20, k)); cov = (cov - cov.mean(0)) / cov.std(0)
-    c = HipContext(0); c.set_option("max_wg", max_wg); c.set_fixtures(model, h, a, x, y, 20, covariates_std=cov)
+    c = HipContext(0); c.set_option("max_wg", max_wg); c.set_fixtures(model, h, a, x, y, 20, weights=w, covariates_std=cov)
     lib = c._lib
     lib.bplhip_debug_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int]; lib.bplhip_debug_stamps.restype = C.c_int
     nwg = lib.bplhip_debug_stamps(c._h, None, 0)
@@ -27,7 +28,7 @@ def run(n, model=MODEL_BASIC, max_wg=255, k=0):
     t0 = st[:, 0].min()
     rel = (st - t0) * 0.01  # us (100 MHz)
     names = ["entry", "tables", "bounds", "stream", "slab", "drain", "ticket", "tail:start", "tail:loads", "tail:adj", "tail:end", "barrier", "loads-landed", "lane-math"]
-    print(f"--- N={n} model={model} covariates={k} blocks={nwg} (block 0 = prior workgroup)")
+    print(f"--- N={n} model={model} covariates={k} weighted={weighted} blocks={nwg} (block 0 = prior workgroup)")
     print("  prior WG: entry=%.2f scalars=%.2f cells=%.2f bounds=%.2f sums=%.2f amx=%.2f div=%.2f done=%.2f drain=%.2f ticket=%.2f" % (rel[0, 0], rel[0, 1], rel[0, 2], rel[0, 3], rel[0, 12], rel[0, 13], rel[0, 15], rel[0, 4], rel[0, 5], rel[0, 6]))
     names = names + ["epi", "sums-done"]
     for k in [0, 1, 2, 12, 13, 3, 15, 11, 4, 5, 6]:
@@ -73,3 +74,4 @@ else:
         run(n)
     run(1_000_000, MODEL_EXTENDED)
     run(1_000_000, MODEL_EXTENDED, k=5)
+    run(1_000_000, MODEL_EXTENDED, k=5, weighted=True)
