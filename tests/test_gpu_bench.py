@@ -44,3 +44,22 @@ def test_bench_tiny_step_counts():
     for steps, warmup in ((5, 1), (1, 0), (64, 64)):
         out = _run("--steps", str(steps), "--warmup", str(warmup), "--no-cpu-baseline", "--no-insitu")
         assert out["steps"] == steps and out["value"] > 0
+
+
+def test_bench_two_ranks_flow():
+    """The multi-rank flow of bench.py (fixture broadcast, barriers, max over ranks, rank 0 prints)
+    with two ranks forced onto this box's single GPU: RCCL refuses two ranks on one device, so this
+    also exercises the recorded fall-back of the control plane to gloo."""
+    env = dict(os.environ, BENCH_FORCE_DEVICE="0")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29517", os.path.join(ROOT, "bench.py"),
+                        "--gpus", "2", "--steps", "128", "--warmup", "64", "--no-cpu-baseline", "--no-insitu"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 128 and out["scaling"] == "weak"
+    assert abs(out["value"] - 2 * 1e3 / out["ms_per_step"]) < 1e-6 * out["value"]
+    assert "cpu_baseline" not in out  # rank 0 at N = 1 only
+    assert out["config"]["collectives"] in ("nccl", "gloo (RCCL init failed)")
