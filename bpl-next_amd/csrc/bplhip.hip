@@ -486,11 +486,26 @@ void drop_graphs(bplhip_ctx* c) {
 
 }  // namespace
 
+// The C-ABI never lets a C++ exception escape (std::bad_alloc from a host buffer, std::system_error
+// from a host thread, ...): the entry points that allocate run inside this guard.
+template <class F>
+static int guarded(bplhip_ctx* c, const char* where, F&& body) {
+    try {
+        return body();
+    } catch (const std::bad_alloc&) {
+        return c ? fail(c, BPLHIP_ENOMEM, "%s: out of host memory", where) : BPLHIP_ENOMEM;
+    } catch (const std::exception& e) {
+        return c ? fail(c, BPLHIP_EHIP, "%s: %s", where, e.what()) : BPLHIP_EHIP;
+    } catch (...) {
+        return c ? fail(c, BPLHIP_EHIP, "%s: unknown C++ exception", where) : BPLHIP_EHIP;
+    }
+}
+
 extern "C" {
 
 int bplhip_abi_version(void) { return BPLHIP_ABI_VERSION; }
 
-int bplhip_create(bplhip_ctx** out, int device_id) {
+static int bplhip_create_impl(bplhip_ctx** out, int device_id) {
     if (!out) return fail(nullptr, BPLHIP_EINVAL, "bplhip_create: out is NULL");
     *out = nullptr;
     int ndev = 0;
@@ -522,7 +537,7 @@ const char* bplhip_last_error(const bplhip_ctx* ctx) {
     return ctx ? ctx->err.c_str() : g_create_error.c_str();
 }
 
-int bplhip_set_fixtures(bplhip_ctx* c, int model_kind, int64_t n, int32_t n_teams,
+static int bplhip_set_fixtures_impl(bplhip_ctx* c, int model_kind, int64_t n, int32_t n_teams,
                         const uint16_t* home_idx, const uint16_t* away_idx,
                         const uint8_t* home_goals, const uint8_t* away_goals,
                         const float* weights, const double* covariates, int32_t k,
@@ -784,7 +799,7 @@ int bplhip_latent_dim(const bplhip_ctx* c) {
     return c->neutral ? c->NL.D : (c->dynamic ? c->DL.D : c->L.D);
 }
 
-int bplhip_set_fixtures_neutral(bplhip_ctx* c, int64_t n, int32_t n_teams, const uint16_t* home_idx,
+static int bplhip_set_fixtures_neutral_impl(bplhip_ctx* c, int64_t n, int32_t n_teams, const uint16_t* home_idx,
                                 const uint16_t* away_idx, const uint8_t* home_goals,
                                 const uint8_t* away_goals, const uint8_t* neutral_venue,
                                 const uint8_t* home_conf, const uint8_t* away_conf, int32_t n_conf,
@@ -896,7 +911,7 @@ int bplhip_set_fixtures_neutral(bplhip_ctx* c, int64_t n, int32_t n_teams, const
     return BPLHIP_OK;
 }
 
-int bplhip_set_fixtures_dynamic(bplhip_ctx* c, int64_t n, int32_t n_teams, int32_t n_gameweeks,
+static int bplhip_set_fixtures_dynamic_impl(bplhip_ctx* c, int64_t n, int32_t n_teams, int32_t n_gameweeks,
                                 const uint16_t* home_idx, const uint16_t* away_idx,
                                 const uint8_t* home_goals, const uint8_t* away_goals,
                                 const uint16_t* gameweek, const uint8_t* neutral_venue,
@@ -977,7 +992,7 @@ int bplhip_set_fixtures_dynamic(bplhip_ctx* c, int64_t n, int32_t n_teams, int32
     return BPLHIP_OK;
 }
 
-int bplhip_logp_grad_batched(bplhip_ctx* c, int32_t n_chains, const double* z,
+static int bplhip_logp_grad_batched_impl(bplhip_ctx* c, int32_t n_chains, const double* z,
                              double* potential, double* grad, double* aux, void* stream) {
     if (!c) return BPLHIP_EINVAL;
     if (!c->bound) return fail(c, BPLHIP_ESTATE, "logp_grad: no fixtures bound");
@@ -999,7 +1014,7 @@ int bplhip_logp_grad(bplhip_ctx* c, const double* z, double* potential, double* 
     return bplhip_logp_grad_batched(c, 1, z, potential, grad, aux, stream);
 }
 
-int bplhip_logp_grad_graph(bplhip_ctx* c, int32_t count, int32_t n_z, const double* z,
+static int bplhip_logp_grad_graph_impl(bplhip_ctx* c, int32_t count, int32_t n_z, const double* z,
                            double* potential, double* grad, int32_t replays, void* stream) {
     if (!c) return BPLHIP_EINVAL;
     if (!c->bound) return fail(c, BPLHIP_ESTATE, "logp_grad_graph: no fixtures bound");
@@ -1688,7 +1703,7 @@ void fill_stats(bplhip_nuts_stats* stats, const nuts::Result& res, double wall, 
 
 }  // namespace
 
-extern "C" int bplhip_nuts_run(bplhip_ctx* c, const bplhip_nuts_cfg* cfg, const double* z0,
+static int bplhip_nuts_run_impl(bplhip_ctx* c, const bplhip_nuts_cfg* cfg, const double* z0,
                                uint32_t seed_hi, uint32_t seed_lo, double* draws_out,
                                bplhip_nuts_stats* stats, void* stream) {
     if (!c) return BPLHIP_EINVAL;
@@ -1771,7 +1786,7 @@ extern "C" int bplhip_nuts_run(bplhip_ctx* c, const bplhip_nuts_cfg* cfg, const 
     return BPLHIP_OK;
 }
 
-extern "C" int bplhip_nuts_run_chains(bplhip_ctx* c, const bplhip_nuts_cfg* cfg, int32_t n_chains,
+static int bplhip_nuts_run_chains_impl(bplhip_ctx* c, const bplhip_nuts_cfg* cfg, int32_t n_chains,
                                       const double* z0, const uint32_t* seeds, double* draws_out,
                                       bplhip_nuts_stats* stats, void* stream) {
     if (!c) return BPLHIP_EINVAL;
@@ -1859,7 +1874,7 @@ extern "C" int bplhip_nuts_run_chains(bplhip_ctx* c, const bplhip_nuts_cfg* cfg,
     return BPLHIP_OK;
 }
 
-extern "C" int bplhip_constrain(bplhip_ctx* c, const double* z_draws, int64_t s,
+static int bplhip_constrain_impl(bplhip_ctx* c, const double* z_draws, int64_t s,
                                 double* attack, double* defence, double* home_advantage,
                                 double* corr_coef) {
     if (!c) return BPLHIP_EINVAL;
@@ -1909,7 +1924,7 @@ extern "C" int bplhip_constrain(bplhip_ctx* c, const double* z_draws, int64_t s,
 // Dynamic model: constrained / deterministic sites per draw.  HOST in, HOST out; outputs
 // [s, G, T] each (any may be NULL): attack, defence (the walk), home_attack, away_attack,
 // home_defence, away_defence.  corr_coef comes from the sampler statistics.
-extern "C" int bplhip_constrain_dynamic(bplhip_ctx* c, const double* z_draws, int64_t s,
+static int bplhip_constrain_dynamic_impl(bplhip_ctx* c, const double* z_draws, int64_t s,
                                         double* attack, double* defence, double* home_attack,
                                         double* away_attack, double* home_defence,
                                         double* away_defence) {
@@ -1949,7 +1964,7 @@ extern "C" int bplhip_constrain_dynamic(bplhip_ctx* c, const double* z_draws, in
 }
 
 // ---- predict path on the device (row f-2)
-extern "C" int bplhip_predict_set_posterior(bplhip_ctx* c, int32_t s, int32_t t,
+static int bplhip_predict_set_posterior_impl(bplhip_ctx* c, int32_t s, int32_t t,
                                             const double* attack, const double* defence,
                                             const double* home_advantage,
                                             int32_t home_advantage_per_team,
@@ -1973,7 +1988,7 @@ extern "C" int bplhip_predict_set_posterior(bplhip_ctx* c, int32_t s, int32_t t,
     return BPLHIP_OK;
 }
 
-extern "C" int bplhip_predict_score_proba(bplhip_ctx* c, int64_t m, const uint16_t* home_idx,
+static int bplhip_predict_score_proba_impl(bplhip_ctx* c, int64_t m, const uint16_t* home_idx,
                                           const uint16_t* away_idx, const uint16_t* home_goals,
                                           const uint16_t* away_goals, double* out, void* stream) {
     if (!c) return BPLHIP_EINVAL;
@@ -2013,4 +2028,73 @@ extern "C" int bplhip_predict_score_proba(bplhip_ctx* c, int64_t m, const uint16
     HIP_TRY(c, hipMemcpyAsync(out, d_out, (size_t)m * 8, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
     return BPLHIP_OK;
+}
+
+// ---- guarded C-ABI entry points (see `guarded`)
+extern "C" int bplhip_create(bplhip_ctx** out, int device_id) {
+    return guarded(nullptr, "bplhip_create", [&] { return bplhip_create_impl(out, device_id); });
+}
+extern "C" int bplhip_set_fixtures(bplhip_ctx* c, int model_kind, int64_t n, int32_t n_teams,
+                        const uint16_t* home_idx, const uint16_t* away_idx,
+                        const uint8_t* home_goals, const uint8_t* away_goals,
+                        const float* weights, const double* covariates, int32_t k,
+                        void* stream) {
+    return guarded(c, "bplhip_set_fixtures", [&] { return bplhip_set_fixtures_impl(c, model_kind, n, n_teams, home_idx, away_idx, home_goals, away_goals, weights, covariates, k, stream); });
+}
+extern "C" int bplhip_set_fixtures_neutral(bplhip_ctx* c, int64_t n, int32_t n_teams, const uint16_t* home_idx,
+                                const uint16_t* away_idx, const uint8_t* home_goals,
+                                const uint8_t* away_goals, const uint8_t* neutral_venue,
+                                const uint8_t* home_conf, const uint8_t* away_conf, int32_t n_conf,
+                                const float* weights, const double* covariates, int32_t k,
+                                void* stream) {
+    return guarded(c, "bplhip_set_fixtures_neutral", [&] { return bplhip_set_fixtures_neutral_impl(c, n, n_teams, home_idx, away_idx, home_goals, away_goals, neutral_venue, home_conf, away_conf, n_conf, weights, covariates, k, stream); });
+}
+extern "C" int bplhip_set_fixtures_dynamic(bplhip_ctx* c, int64_t n, int32_t n_teams, int32_t n_gameweeks,
+                                const uint16_t* home_idx, const uint16_t* away_idx,
+                                const uint8_t* home_goals, const uint8_t* away_goals,
+                                const uint16_t* gameweek, const uint8_t* neutral_venue,
+                                const double* covariates, int32_t k, int32_t random_walk,
+                                void* stream) {
+    return guarded(c, "bplhip_set_fixtures_dynamic", [&] { return bplhip_set_fixtures_dynamic_impl(c, n, n_teams, n_gameweeks, home_idx, away_idx, home_goals, away_goals, gameweek, neutral_venue, covariates, k, random_walk, stream); });
+}
+extern "C" int bplhip_logp_grad_batched(bplhip_ctx* c, int32_t n_chains, const double* z,
+                             double* potential, double* grad, double* aux, void* stream) {
+    return guarded(c, "bplhip_logp_grad_batched", [&] { return bplhip_logp_grad_batched_impl(c, n_chains, z, potential, grad, aux, stream); });
+}
+extern "C" int bplhip_logp_grad_graph(bplhip_ctx* c, int32_t count, int32_t n_z, const double* z,
+                           double* potential, double* grad, int32_t replays, void* stream) {
+    return guarded(c, "bplhip_logp_grad_graph", [&] { return bplhip_logp_grad_graph_impl(c, count, n_z, z, potential, grad, replays, stream); });
+}
+extern "C" int bplhip_nuts_run(bplhip_ctx* c, const bplhip_nuts_cfg* cfg, const double* z0,
+                               uint32_t seed_hi, uint32_t seed_lo, double* draws_out,
+                               bplhip_nuts_stats* stats, void* stream) {
+    return guarded(c, "bplhip_nuts_run", [&] { return bplhip_nuts_run_impl(c, cfg, z0, seed_hi, seed_lo, draws_out, stats, stream); });
+}
+extern "C" int bplhip_nuts_run_chains(bplhip_ctx* c, const bplhip_nuts_cfg* cfg, int32_t n_chains,
+                                      const double* z0, const uint32_t* seeds, double* draws_out,
+                                      bplhip_nuts_stats* stats, void* stream) {
+    return guarded(c, "bplhip_nuts_run_chains", [&] { return bplhip_nuts_run_chains_impl(c, cfg, n_chains, z0, seeds, draws_out, stats, stream); });
+}
+extern "C" int bplhip_constrain(bplhip_ctx* c, const double* z_draws, int64_t s,
+                                double* attack, double* defence, double* home_advantage,
+                                double* corr_coef) {
+    return guarded(c, "bplhip_constrain", [&] { return bplhip_constrain_impl(c, z_draws, s, attack, defence, home_advantage, corr_coef); });
+}
+extern "C" int bplhip_constrain_dynamic(bplhip_ctx* c, const double* z_draws, int64_t s,
+                                        double* attack, double* defence, double* home_attack,
+                                        double* away_attack, double* home_defence,
+                                        double* away_defence) {
+    return guarded(c, "bplhip_constrain_dynamic", [&] { return bplhip_constrain_dynamic_impl(c, z_draws, s, attack, defence, home_attack, away_attack, home_defence, away_defence); });
+}
+extern "C" int bplhip_predict_set_posterior(bplhip_ctx* c, int32_t s, int32_t t,
+                                            const double* attack, const double* defence,
+                                            const double* home_advantage,
+                                            int32_t home_advantage_per_team,
+                                            const double* corr_coef) {
+    return guarded(c, "bplhip_predict_set_posterior", [&] { return bplhip_predict_set_posterior_impl(c, s, t, attack, defence, home_advantage, home_advantage_per_team, corr_coef); });
+}
+extern "C" int bplhip_predict_score_proba(bplhip_ctx* c, int64_t m, const uint16_t* home_idx,
+                                          const uint16_t* away_idx, const uint16_t* home_goals,
+                                          const uint16_t* away_goals, double* out, void* stream) {
+    return guarded(c, "bplhip_predict_score_proba", [&] { return bplhip_predict_score_proba_impl(c, m, home_idx, away_idx, home_goals, away_goals, out, stream); });
 }
