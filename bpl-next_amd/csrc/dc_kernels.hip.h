@@ -373,14 +373,26 @@ __device__ __forceinline__ F32Scalars f32_scalars(const Layout& L, const double*
     }
     return s;
 }
+// the per-team entries of z a table entry needs (basic: attack, defence; extended: + home adv.)
+struct TeamZ {
+    double a, d, h;
+};
+template <bool EXT>
+__device__ __forceinline__ TeamZ load_team_z(const Layout& L, const double* z, int t) {
+    TeamZ v;
+    v.a = z[(EXT ? L.o_sat : L.o_adec) + t];
+    v.d = z[(EXT ? L.o_sdt : L.o_ddec) + t];
+    v.h = EXT ? z[L.o_hadec + t] : 0.0;
+    return v;
+}
 template <bool EXT>
 __device__ __forceinline__ void f32_table_entry(const Layout& L, const F32Scalars& s,
                                                 const double* z, const float* xsf, int t,
-                                                float2* vh, float2* va) {
+                                                const TeamZ& tz, float2* vh, float2* va) {
     float att, def, ha;
     if (!EXT) {
-        att = s.s_a * (float)z[L.o_adec + t];
-        def = s.m + s.s_d * (float)z[L.o_ddec + t];
+        att = s.s_a * (float)tz.a;
+        def = s.m + s.s_d * (float)tz.d;
         ha = s.gam;
     } else {
         float apm = 0.f, dpm = s.m;
@@ -389,26 +401,26 @@ __device__ __forceinline__ void f32_table_entry(const Layout& L, const F32Scalar
             apm += xv * (float)z[L.o_bA + k];
             dpm += xv * (float)z[L.o_bD + k];
         }
-        att = apm + (float)z[L.o_sat + t] * s.s_a;
-        def = dpm + (float)z[L.o_sdt + t] * s.s_d;
-        ha = s.mha + s.s_h * (float)z[L.o_hadec + t];
+        att = apm + (float)tz.a * s.s_a;
+        def = dpm + (float)tz.d * s.s_d;
+        ha = s.mha + s.s_h * (float)tz.h;
     }
     const float edn = exp_f32(-def);
     *vh = make_float2(exp_f32(att + ha), edn);
     *va = make_float2(exp_f32(att), edn);
 }
+// `first`: team `tid`'s entries of z, loaded by the caller BEFORE its bulk loads -- vector loads
+// return in order, and behind a tile's worth of fixture loads they would wait for HBM
 template <bool EXT>
 __device__ __forceinline__ void build_tables_f32(const Layout& L, const double* z,
                                                  const float* xsf, float2* tabH, float2* tabA,
-                                                 int tid, F32Scalars* out) {
-    const F32Scalars s = f32_scalars<EXT>(L, z);
+                                                 int tid, const TeamZ& first, const F32Scalars& s) {
     for (int t = tid; t <= L.T; t += BLOCK) {
         float2 vh = make_float2(0.f, 0.f), va = vh;
-        if (t < L.T) f32_table_entry<EXT>(L, s, z, xsf, t, &vh, &va);
+        if (t < L.T) f32_table_entry<EXT>(L, s, z, xsf, t, t == tid ? first : load_team_z<EXT>(L, z, t), &vh, &va);
         tabH[t] = vh;
         tabA[t] = va;
     }
-    *out = s;
 }
 // rho in float32 from the three float32 maxima (identical code in stream and prior)
 __device__ __forceinline__ float rho_f32(float mP, float mQ, float mR, float q) {
@@ -523,8 +535,8 @@ __device__ void prior_body(const EvalArgs& A, int chain, char* smem) {
         pre[4] = z[CLIP ? L.o_sdt + lane : L.o_ddec + lane];
         pre[5] = CLIP ? z[L.o_hadec + lane] : 0.0;
     }
-    F32Scalars fs;
-    build_tables_f32<CLIP>(L, z, A.xsf, tabH, tabA, tid, &fs);
+    const F32Scalars fs = f32_scalars<CLIP>(L, z);
+    build_tables_f32<CLIP>(L, z, A.xsf, tabH, tabA, tid, load_team_z<CLIP>(L, z, min(tid, T - 1)), fs);
 
     // ---- z-only scalars, one transcendental chain per wave, in parallel
     //   0 s_a  1 s_d  2 s_h  3..8 corr site  9..14 u site
@@ -1458,27 +1470,37 @@ __global__ DC_LAUNCH_BOUNDS void dc_eval(EvalArgs A) {
         DC_STAMP(4);
     } else {
         const int wgi = blockIdx.x - 1;
-        // ---- 0. issue the first tile's loads (and this thread's pair) before anything else
+        // ---- 0. every load the prologue needs, in the order the data is wanted: this thread's pair
+        // and its entries of z (L2 hits) first, then the first tile (HBM), then the slab slots.
+        // Vector loads return in order, so the tables must not queue behind the tile; and the loads
+        // are unconditional (indices clamped) wherever possible: behind a branch the compiler can
+        // no longer count how many younger loads may stay outstanding and waits for all of them,
+        // and a load that a branch also zeroes is waited for on the spot.
+        uint32_t pr0 = 0;
+        if (tid < A.P) pr0 = A.pairs[tid];
+        const TeamZ tz0 = load_team_z<CLIP>(L, z, min(tid, T - 1));
+        const F32Scalars fs = f32_scalars<CLIP>(L, z);
+        // (basic model: every read of z is above, so a compiler barrier can pin them in front of
+        // the tile loads -- without it the per-team loads are sunk to their use, behind the tile.
+        // With covariates z is read again in the table loop, and behind a barrier those reads
+        // would stop being scalar loads.)
+        if (!CLIP) asm volatile("" ::: "memory");
         const int gw = wgi * WAVES + wave;
         int tile = gw * A.tiles_per_wave;
         const int tile_end = min(tile + A.tiles_per_wave, A.n_tiles);
-        LaneData cur{};
-        if (tile < tile_end) cur = load_lane<WEIGHTED>(A, (size_t)tile * 64 + lane);
-        uint32_t pr0 = 0;
-        if (tid < A.P) pr0 = A.pairs[tid];
+        // (a wave without tiles loads the last one and never uses it)
+        LaneData cur = load_lane<WEIGHTED>(A, (size_t)min(tile, A.n_tiles - 1) * 64 + lane);
         const int o0 = A.wg_off[wgi], o1 = A.wg_off[wgi + 1];  // static sparse-slab slots
-        int slot0 = 0, dst0 = 0;
-        if (o0 + tid < o1) {
-            slot0 = A.wg_slots[o0 + tid];
-            dst0 = A.wg_dst[o0 + tid];
-        }
+        // (unconditional, index clamped: a load into a register that a branch also zeroes made the
+        // compiler wait for it -- and, in order, for the whole tile -- right here)
+        const int kq = min(o0 + tid, A.total_c - 1);
+        const int slot0 = A.wg_slots[kq], dst0 = A.wg_dst[kq];
         // (uniform over the whole grid.  Checking this after the table loads are in flight
         // measured no gain: the flag's latency is not what delays z, z itself is cold.)
         if (NUTS && nuts_done != 0.0) return;
 
         // ---- 1. per-team tables (float32) + zero accumulators
-        F32Scalars fs;
-        build_tables_f32<CLIP>(L, z, A.xsf, tabH, tabA, tid, &fs);
+        build_tables_f32<CLIP>(L, z, A.xsf, tabH, tabA, tid, tz0, fs);
         for (int i = tid; i < 3 * T1; i += BLOCK) acc[i] = 0.0;
         __syncthreads();
         DC_STAMP(1);

@@ -193,7 +193,7 @@ __global__ __launch_bounds__(BLOCK) void dc_vec_stream(EvalArgs A) {
         float2* tA = tH + tl;
         for (int t = lane; t <= T; t += 64) {
             float2 vh = make_float2(0.f, 0.f), va = vh;
-            if (t < T) f32_table_entry<CLIP>(L, fs, z, A.xsf, t, &vh, &va);
+            if (t < T) f32_table_entry<CLIP>(L, fs, z, A.xsf, t, load_team_z<CLIP>(L, z, t), &vh, &va);
             tH[t] = vh;
             tA[t] = va;
         }
