@@ -1517,9 +1517,11 @@ __global__ DC_LAUNCH_BOUNDS void dc_eval(EvalArgs A) {
         // ---- 3. stream the fixtures
         double dSLAM = 0.0, dSLOG = 0.0, dSU = 0.0, dCLIP = 0.0;  // per lane
         while (tile < tile_end) {
-            LaneData nxt = cur;
-            if (tile + 1 < tile_end)  // prefetch the next tile
-                nxt = load_lane<WEIGHTED>(A, (size_t)(tile + 1) * 64 + lane);
+            // prefetch the next tile: unconditional (the last iteration re-requests its own tile
+            // and drops it) -- behind a branch the compiler waits for the prefetch as well when it
+            // waits for the current tile
+            const LaneData pre = load_lane<WEIGHTED>(A, (size_t)min(tile + 1, tile_end - 1) * 64 + lane);
+            LaneData nxt = pre;
             // One lane = LANE_FIX consecutive fixtures of ONE (home, away) pair (runs are padded
             // with null fixtures): the two rates and the four score-class tau terms are computed
             // once for the lane and each fixture is only classified.
