@@ -1048,6 +1048,18 @@ __device__ void tail_body(const EvalArgs& A, int chain, char* smem) {
             const int j = u * BLOCK + tid;
             v[u] = ld_sc1(&hb[j < nstage ? j : nstage - 1]);
         }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int j = u * BLOCK + tid;
+            if (j < nstage) hL[j] = v[u];
+        }
+        if (i < ncol) cL[i] = c0;
+        if (i < D) zL[i] = z0;
+        if (i <= ncol) coff[i] = o0;
+        if (xs_staged && i < T * K) xsL[i] = x0;
+        // (the leaf's state is requested after these stores: behind the branch on the wave the compiler
+        // would make the stores wait for the -- colder -- state loads as well.  They still land long
+        // before the leaf starts.)
         if (NUTS && STAGED) {
             double* ns = nuts_of(A, chain);
             if (small) {
@@ -1064,15 +1076,6 @@ __device__ void tail_body(const EvalArgs& A, int chain, char* smem) {
                 if (wave == LEAF_WAVE || wave == RNG_WAVE) leaf1.hv = lane < nd::H_N ? ns[lane] : 0.0;
             }
         }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int j = u * BLOCK + tid;
-            if (j < nstage) hL[j] = v[u];
-        }
-        if (i < ncol) cL[i] = c0;
-        if (i < D) zL[i] = z0;
-        if (i <= ncol) coff[i] = o0;
-        if (xs_staged && i < T * K) xsL[i] = x0;
     }
 #pragma unroll 1
     for (int i0 = 8 * BLOCK; i0 < nstage; i0 += 8 * BLOCK) {  // larger records: more batches
