@@ -187,29 +187,39 @@ __global__ __launch_bounds__(CELL_BLOCK) void dyn_cells(DynArgs A) {
     for (int g0 = 0; g0 < G; g0 += 64) {
         const int g = g0 + lane;
         const bool on = g < G;
-        const int c = g * T + t;
+        // every load of this chunk first, unconditional with the gameweek clamped: a load behind
+        // `on ? ... : 0` is waited for on the spot (13 dependent round trips in this kernel before)
+        const int gc = on ? g : G - 1;
+        const int c = gc * T + t;
+        const int o_std[6] = {L.o_s_att, L.o_s_def, L.o_s_ha, L.o_s_aa, L.o_s_hd, L.o_s_ad};
+        double zs[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) zs[j] = z[o_std[j] + gc];
+        const double z_sat = z[L.o_sat + c], z_sdt = z[L.o_sdt + c];
+        const double z_mha = z[L.o_mha + gc], z_maa = z[L.o_maa + gc], z_mhd = z[L.o_mhd + gc],
+                     z_mad = z[L.o_mad + gc];
+        const double z_hat = z[L.o_hat + c], z_aat = z[L.o_aat + c], z_hdf = z[L.o_hdf + c],
+                     z_adf = z[L.o_adf + c];
         double s[6];
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
-            const int o = j == 0 ? L.o_s_att : j == 1 ? L.o_s_def : j == 2 ? L.o_s_ha
-                        : j == 3 ? L.o_s_aa : j == 4 ? L.o_s_hd : L.o_s_ad;
-            s[j] = on ? exp(z[o + g]) : 0.0;
+            s[j] = on ? exp(zs[j]) : 0.0;
             if (on && t == 0) A.hyp[j * G + g] = s[j];
         }
         double a_ = 0.0, d_ = 0.0;
         if (A.random_walk) {
-            const double ia = on ? z[L.o_sat + c] * s[0] : 0.0;
-            const double id = on ? z[L.o_sdt + c] * s[1] : 0.0;
+            const double ia = on ? z_sat * s[0] : 0.0;
+            const double id = on ? z_sdt * s[1] : 0.0;
             a_ = carry_a + wave_prefix(ia, lane);
             d_ = carry_d + wave_prefix(id, lane);
             carry_a = __shfl(a_, 63, 64);
             carry_d = __shfl(d_, 63, 64);
         }
         if (on) {
-            const double hat = z[L.o_mha + g] + s[2] * z[L.o_hat + c];
-            const double aat = z[L.o_maa + g] + s[3] * z[L.o_aat + c];
-            const double hdf = z[L.o_mhd + g] + s[4] * z[L.o_hdf + c];
-            const double adf = z[L.o_mad + g] + s[5] * z[L.o_adf + c];
+            const double hat = z_mha + s[2] * z_hat;
+            const double aat = z_maa + s[3] * z_aat;
+            const double hdf = z_mhd + s[4] * z_hdf;
+            const double adf = z_mad + s[5] * z_adf;
             double* P = A.cells + (size_t)c * P_N;
             P[P_AH] = a_ + hat;
             P[P_AA] = a_ + aat;
