@@ -960,12 +960,14 @@ struct WideLeaf {  // what both launches derive from the header (identical in ev
     bool going_right;
     int num, idx_max, idx_min, n_lev;
 };
-__device__ __forceinline__ WideLeaf wide_leaf(const double* ns) {
+// hv: header word `lane` (one coalesced load per wave instead of a chain of scalar loads, each
+// waited for before the next is issued)
+__device__ __forceinline__ WideLeaf wide_leaf(double hv) {
     WideLeaf W;
-    const double dir = ns[H_DIR];
-    W.eps = ns[H_EPS] * dir;
+    const double dir = hdr_word(hv, H_DIR);
+    W.eps = hdr_word(hv, H_EPS) * dir;
     W.going_right = dir > 0.0;
-    W.num = (int)ns[H_S_NUM];
+    W.num = (int)hdr_word(hv, H_S_NUM);
     W.idx_max = __popc((unsigned)W.num >> 1);
     W.idx_min = W.idx_max - (__ffs(~W.num) - 1) + 1;
     W.n_lev = W.idx_max >= W.idx_min ? W.idx_max - W.idx_min + 1 : 0;
@@ -975,9 +977,10 @@ __global__ __launch_bounds__(KW_NT) void kw_leaf_a(double* ns_all, size_t stride
                                                    double* part) {
     __shared__ double scr[KW_NT / 64];
     double* ns = ns_all + blockIdx.y * stride;
-    if (ns[H_S_DONE] != 0.0) return;  // chain finished (uniform over the grid row)
     const int tid = threadIdx.x, GW = gridDim.x;
-    const WideLeaf W = wide_leaf(ns);
+    const double hv = (tid & 63) < H_N ? ns[tid & 63] : 0.0;
+    if (hdr_word(hv, H_S_DONE) != 0.0) return;  // chain finished (uniform over the grid row)
+    const WideLeaf W = wide_leaf(hv);
     const double* invM = vec(ns, D, V_INVM);
     const double* rh = vec(ns, D, V_RH);
     const double* g = vec(ns, D, V_GRAD);
@@ -1022,8 +1025,8 @@ __global__ __launch_bounds__(KW_NTB) void kw_leaf_b(double* ns_all, size_t strid
     __shared__ int s_last;
     const int chain = blockIdx.y;
     double* ns = ns_all + chain * stride;
-    if (ns[H_S_DONE] != 0.0) return;
     const int tid = threadIdx.x, GW = gridDim.x;
+    const double hv = (tid & 63) < H_N ? ns[tid & 63] : 0.0;
     // this thread's first two elements, requested before anything that waits for the header
     // (one memory round trip less on the chain's serial path)
     const int el0 = blockIdx.x * KW_NTB + tid, estep = GW * KW_NTB;
@@ -1038,7 +1041,8 @@ __global__ __launch_bounds__(KW_NTB) void kw_leaf_b(double* ns_all, size_t strid
         pre[u][3] = ok ? vec(ns, D, V_S_RSUM)[i] : 0.0;
         pre[u][4] = ok ? vec(ns, D, V_INVM)[i] : 0.0;
     }
-    const WideLeaf W = wide_leaf(ns);
+    if (hdr_word(hv, H_S_DONE) != 0.0) return;  // chain finished (uniform over the grid row)
+    const WideLeaf W = wide_leaf(hv);
     // totals: one wave per value, lane b reads workgroup b's partial (gw_a <= 64): one round of
     // loads and a fixed-order wave sum (a serial loop is one memory round trip per workgroup)
     static_assert(KW_MAX_WG <= 64, "one lane per partial");
@@ -1049,14 +1053,15 @@ __global__ __launch_bounds__(KW_NTB) void kw_leaf_b(double* ns_all, size_t strid
         if (b == 0) tot[k] = sum;
     }
     // everything the decisions read from the header, before anyone rewrites it
-    const double pe = ns[H_LEAF_PE], e0 = ns[H_E0], max_de = ns[H_MAXDE];
-    const double aux0 = ns[H_LEAF_AUX0], aux1 = ns[H_LEAF_AUX1], aux2 = ns[H_LEAF_AUX2],
-                 aux3 = ns[H_LEAF_AUX3];
-    const double w_cur = ns[H_S_WEIGHT], s_sumacc = ns[H_S_SUMACC], evals = ns[H_EVALS];
-    const int s_max = (int)ns[H_S_MAX];
+    const double pe = hdr_word(hv, H_LEAF_PE), e0 = hdr_word(hv, H_E0), max_de = hdr_word(hv, H_MAXDE);
+    const double aux0 = hdr_word(hv, H_LEAF_AUX0), aux1 = hdr_word(hv, H_LEAF_AUX1),
+                 aux2 = hdr_word(hv, H_LEAF_AUX2), aux3 = hdr_word(hv, H_LEAF_AUX3);
+    const double w_cur = hdr_word(hv, H_S_WEIGHT), s_sumacc = hdr_word(hv, H_S_SUMACC),
+                 evals = hdr_word(hv, H_EVALS);
+    const int s_max = (int)hdr_word(hv, H_S_MAX);
     uint32_t nhi, nlo;
     float u_take;
-    leaf_rng_k((uint32_t)ns[H_KEY_HI], (uint32_t)ns[H_KEY_LO], &nhi, &nlo, &u_take);
+    leaf_rng(hv, &nhi, &nlo, &u_take);
     __syncthreads();
 
     const double e_new = pe + 0.5 * tot[0];
