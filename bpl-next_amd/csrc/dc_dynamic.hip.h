@@ -240,13 +240,13 @@ __device__ __forceinline__ void fixture_etas(const DynArgs& A, long long i, int*
     *neutral = A.nv[i];
     const double* Ph = A.cells + (size_t)(*ch) * P_N;
     const double* Pa = A.cells + (size_t)(*ca) * P_N;
-    if (*neutral) {
-        *eh = Ph[P_ATT] - Pa[P_DEF];
-        *ea = Pa[P_ATT] - Ph[P_DEF];
-    } else {
-        *eh = Ph[P_AH] - Pa[P_BA];
-        *ea = Pa[P_AA] - Ph[P_BH];
-    }
+    // (the four parameters by selected offsets, not by a branch: a divergent branch around loads
+    // is two dependent round trips)
+    const bool nvf = *neutral != 0;
+    const double ph_att = Ph[nvf ? P_ATT : P_AH], pa_def = Pa[nvf ? P_DEF : P_BA];
+    const double pa_att = Pa[nvf ? P_ATT : P_AA], ph_def = Ph[nvf ? P_DEF : P_BH];
+    *eh = ph_att - pa_def;
+    *ea = pa_att - ph_def;
     if (A.hc) {  // bpl/neutral_dixon_coles_WC.py:188-203
         const double d = A.cs[A.hc[i]] - A.cs[A.ac[i]];
         *eh += d;
