@@ -68,19 +68,31 @@ struct bplhip_ctx {
     bool bound = false;
     dc::Layout L{};
     int64_t n = 0;
-    int n_tiles = 0, tiles_per_wave = 1, n_wg = 1;
+    int n_tiles = 0;
+    // Launch geometry of dc_eval ("partition"): which waves of a workgroup own tiles, tiles per
+    // wave, workgroups, and the sparse-slab structure that follows from it.  Two of them when the
+    // stream is short: with idle CUs a chain runs on twice the workgroups with 4 of 8 waves owning
+    // tiles (two waves share a SIMD and a tile's lane arithmetic is issue bound: -3 % at N = 1e6,
+    // -13 % at 1e5); several chains per launch fill the chip with the 8-wave partition (the
+    // 4-wave one cost them 15-25 %).  ep = the one selected for the current launch.
+    struct EvalPart {
+        int aw = dc::WAVES, tpw = 1, n_wg = 1, total_c = 0;
+        bool staged = true;   // the tail stages the compact array in LDS
+        DevBuf d_wg_off, d_wg_slots, d_col_off, d_wg_dst;
+    } parts[2];
+    int n_parts = 1;
+    EvalPart* ep = &parts[0];
+    int n_cu = 256;
     bool weighted = false;
     int P = 0;
     double lgsum = 0.0;
     // device buffers (library owned)
-    DevBuf d_h, d_a, d_x, d_y, d_w, d_pairs, d_xs, d_cA, d_cD, d_cH, d_tickets, d_debug, d_xsf, d_hbuf,
-        d_wg_off, d_wg_slots, d_col_off, d_wg_dst;
+    DevBuf d_h, d_a, d_x, d_y, d_w, d_pairs, d_xs, d_cA, d_cD, d_cH, d_tickets, d_debug, d_xsf, d_hbuf;
     int slab_chains = 0;
-    int total_c = 0;      // entries of the sparse (compact) slab array
-    bool staged = true;   // the tail stages the compact array in LDS
     // tuning options (bplhip_set_option)
     int opt_device_nuts = 1;  // 1: tree builder on the device (nuts_dev.hip.h) when supported
     int opt_max_wg = 255;  // streaming workgroups (+1 prior workgroup = one per CU)
+    int opt_active_waves = 0;  // waves per workgroup that own tiles (0 = automatic, see set_fixtures)
     int opt_persistent_nuts = 1;  // bplhip_nuts_run_chains: whole chains on the device (0: lock step)
     int opt_vec_min_chains = 32;  // batched calls with at least this many chains use dc_vec (0: never);
                                   // fewer run as grid.y copies of the single-chain launch (62
@@ -152,12 +164,28 @@ constexpr size_t LDS_LIMIT = 160 * 1024;
 int zo_stride_of(const dc::Layout& L) { return (dc::ZO_HDR + L.D + 3 * L.T + 1) & ~1; }
 
 int hb_stride_of(const bplhip_ctx* c) {
-    return (zo_stride_of(c->L) + c->n_wg * dc::N_SCAL + c->total_c + 1) & ~1;
+    return (zo_stride_of(c->L) + c->ep->n_wg * dc::N_SCAL + c->ep->total_c + 1) & ~1;
+}
+
+// the partition a launch of `chains` chains uses: the short-stream one (part 0 of two) while its
+// workgroups still find a CU each
+void select_part(bplhip_ctx* c, int chains) {
+    int pi = 0;
+    if (c->n_parts > 1 && (long long)chains * (c->parts[0].n_wg + 1) > c->n_cu) pi = 1;
+    c->ep = &c->parts[pi];
 }
 
 int ensure_slabs(bplhip_ctx* c, int chains) {
+    select_part(c, chains);
     if (chains <= c->slab_chains) return BPLHIP_OK;
-    HIP_TRY(c, c->d_hbuf.ensure((size_t)chains * hb_stride_of(c) * sizeof(double)));
+    size_t stride = 0;  // (the hand-off buffer fits either partition)
+    for (int pi = 0; pi < c->n_parts; ++pi) {
+        bplhip_ctx::EvalPart* keep = c->ep;
+        c->ep = &c->parts[pi];
+        stride = std::max(stride, (size_t)hb_stride_of(c));
+        c->ep = keep;
+    }
+    HIP_TRY(c, c->d_hbuf.ensure((size_t)chains * stride * sizeof(double)));
     HIP_TRY(c, c->d_tickets.ensure((size_t)chains * dc::TK_WORDS * sizeof(unsigned int)));
     HIP_TRY(c, hipMemset(c->d_tickets.p, 0, (size_t)chains * dc::TK_WORDS * sizeof(unsigned int)));
     c->slab_chains = chains;
@@ -165,12 +193,12 @@ int ensure_slabs(bplhip_ctx* c, int chains) {
 }
 
 size_t ctx_lds_bytes(const bplhip_ctx* c, bool staged) {
-    return dc::eval_lds_bytes(c->L.T, c->L.D, c->L.K, zo_stride_of(c->L), c->n_wg, c->total_c, staged);
+    return dc::eval_lds_bytes(c->L.T, c->L.D, c->L.K, zo_stride_of(c->L), c->ep->n_wg, c->ep->total_c, staged);
 }
 
 template <bool W, bool C, bool S, bool N>
 int launch_eval_n(bplhip_ctx* c, const dc::EvalArgs& A, int chains, hipStream_t s) {
-    const dim3 grid(c->n_wg + 1, chains), block(dc::BLOCK);
+    const dim3 grid(c->ep->n_wg + 1, chains), block(dc::BLOCK);
     const size_t lds = ctx_lds_bytes(c, S);
     if (lds > 48 * 1024) {  // (idempotent; only for large team counts)
         HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(dc::dc_eval<W, C, S, N>),
@@ -189,7 +217,7 @@ int launch_eval_s(bplhip_ctx* c, const dc::EvalArgs& A, int chains, hipStream_t 
 }
 template <bool W, bool C>
 int launch_eval_t(bplhip_ctx* c, const dc::EvalArgs& A, int chains, hipStream_t s) {
-    return c->staged ? launch_eval_s<W, C, true>(c, A, chains, s)
+    return c->ep->staged ? launch_eval_s<W, C, true>(c, A, chains, s)
                      : launch_eval_s<W, C, false>(c, A, chains, s);
 }
 
@@ -313,7 +341,8 @@ dc::EvalArgs eval_args(bplhip_ctx* c, int chains, const double* z, double* pot, 
     A.y = c->d_y.as<const uint32_t>();
     A.w = c->weighted ? c->d_w.as<const float>() : nullptr;
     A.n_tiles = c->n_tiles;
-    A.tiles_per_wave = c->tiles_per_wave;
+    A.active_waves = c->ep->aw;
+    A.tiles_per_wave = c->ep->tpw;
     A.pairs = c->d_pairs.as<const uint32_t>();
     A.P = c->P;
     A.xs = c->L.K ? c->d_xs.as<const double>() : nullptr;
@@ -322,14 +351,14 @@ dc::EvalArgs eval_args(bplhip_ctx* c, int chains, const double* z, double* pot, 
     A.cD = c->d_cD.as<const double>();
     A.cH = c->d_cH.as<const double>();
     A.lgsum = c->lgsum;
-    A.wg_off = c->d_wg_off.as<const int>();
-    A.wg_slots = c->d_wg_slots.as<const int>();
-    A.col_off = c->d_col_off.as<const int>();
-    A.wg_dst = c->d_wg_dst.as<const int>();
-    A.total_c = c->total_c;
+    A.wg_off = c->ep->d_wg_off.as<const int>();
+    A.wg_slots = c->ep->d_wg_slots.as<const int>();
+    A.col_off = c->ep->d_col_off.as<const int>();
+    A.wg_dst = c->ep->d_wg_dst.as<const int>();
+    A.total_c = c->ep->total_c;
     A.hbuf = c->d_hbuf.as<double>();
     A.hb_stride = hb_stride_of(c);
-    A.n_wg = c->n_wg;
+    A.n_wg = c->ep->n_wg;
     A.zo_stride = zo_stride_of(c->L);
     A.tickets = c->d_tickets.as<unsigned int>();
     A.chains = chains;
@@ -351,6 +380,7 @@ int launch_eval(bplhip_ctx* c, int chains, const double* z, double* pot, double*
                 const nd::Persist* persist = nullptr, int nuts_stride = 0) {
     if (c->neutral) return launch_eval_neutral(c, chains, z, pot, grad, aux, s);
     if (c->dynamic) return launch_eval_dynamic(c, chains, z, pot, grad, aux, s);
+    select_part(c, chains);
     dc::EvalArgs A = eval_args(c, chains, z, pot, grad, aux);
     A.nuts = nuts_state;
     A.nuts_max_depth = nuts_depth;
@@ -450,13 +480,14 @@ bool use_vec(const bplhip_ctx* c, int chains) {
 struct SparseSlabs {
     std::vector<int> wg_off, wg_slots, col_off, wg_dst;
 };
+// tiles_per_wg: contiguous tiles of one workgroup
 SparseSlabs build_sparse_slabs(const std::vector<uint16_t>& hs, const std::vector<uint16_t>& as,
-                               int64_t n, int T, int tpw, int n_wg) {
+                               int64_t n, int T, int tiles_per_wg, int n_wg) {
     SparseSlabs o;
     o.wg_off.assign(n_wg + 1, 0);
     o.col_off.assign(3 * T + 1, 0);
     std::vector<char> touched(3 * (size_t)T);
-    const int64_t per_wg = (int64_t)tpw * dc::WAVES * dc::TILE;
+    const int64_t per_wg = (int64_t)tiles_per_wg * dc::TILE;
     for (int w = 0; w < n_wg; ++w) {
         std::fill(touched.begin(), touched.end(), 0);
         const int64_t r0 = (int64_t)w * per_wg, r1 = std::min<int64_t>(n, r0 + per_wg);
@@ -523,6 +554,9 @@ static int bplhip_create_impl(bplhip_ctx** out, int device_id) {
     bplhip_ctx* c = new (std::nothrow) bplhip_ctx();
     if (!c) return fail(nullptr, BPLHIP_ENOMEM, "bplhip_create: out of host memory");
     c->device = device_id;
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess && cus > 0)
+        c->n_cu = cus;
     *out = c;
     return BPLHIP_OK;
 }
@@ -647,12 +681,16 @@ static int bplhip_set_fixtures_impl(bplhip_ctx* c, int model_kind, int64_t n, in
 
     // ---- launch geometry: 8 waves per workgroup, contiguous tiles per wave
     const int max_wg = c->opt_max_wg;  // one workgroup per CU by default
-    int tpw = (n_tiles + max_wg * dc::WAVES - 1) / (max_wg * dc::WAVES);
-    if (tpw < 1) tpw = 1;
-    const int waves = (n_tiles + tpw - 1) / tpw;
-    const int n_wg = (waves + dc::WAVES - 1) / dc::WAVES;
-
-    SparseSlabs sp = build_sparse_slabs(hs, as, n_lanefix, T, tpw, n_wg);
+    // partitions (see EvalPart): part 0 for one chain (or few: while the chip has idle CUs), with
+    // 4 of 8 waves owning tiles when that costs no extra tiles per wave; part 1 = all 8 waves
+    int aw0 = c->opt_active_waves;
+    if (aw0 <= 0 || aw0 > dc::WAVES) aw0 = n_tiles <= max_wg * (dc::WAVES / 2) ? dc::WAVES / 2 : dc::WAVES;
+    c->n_parts = aw0 < dc::WAVES && c->opt_active_waves <= 0 ? 2 : 1;
+    int tpw = 1;  // of the 8-wave geometry (the chain-vectorised partitions scale it)
+    {
+        tpw = (n_tiles + max_wg * dc::WAVES - 1) / (max_wg * dc::WAVES);
+        if (tpw < 1) tpw = 1;
+    }
     // device copies of the indices, run-length encoded: ONE word per lane (all fixtures of a
     // lane share one pair): home | (number of real fixtures of the lane) << 16, and away
     const int64_t n_lanes = n_pad / dc::LANE_FIX;
@@ -666,18 +704,27 @@ static int bplhip_set_fixtures_impl(bplhip_ctx* c, int model_kind, int64_t n, in
         h_lane[l] = (uint32_t)hs[l * dc::LANE_FIX] | (cnt << 16);
         a_lane[l] = (uint32_t)as[l * dc::LANE_FIX];
     }
-    std::vector<int>&wg_off = sp.wg_off, &wg_slots = sp.wg_slots, &col_off = sp.col_off,
-    &wg_dst = sp.wg_dst;
 
     // ---- upload
-    HIP_TRY(c, c->d_wg_off.ensure(wg_off.size() * 4));
-    HIP_TRY(c, c->d_wg_slots.ensure(wg_slots.size() * 4));
-    HIP_TRY(c, c->d_col_off.ensure(col_off.size() * 4));
-    HIP_TRY(c, c->d_wg_dst.ensure(wg_dst.size() * 4));
-    HIP_TRY(c, hipMemcpyAsync(c->d_wg_off.p, wg_off.data(), wg_off.size() * 4, hipMemcpyHostToDevice, s));
-    HIP_TRY(c, hipMemcpyAsync(c->d_wg_slots.p, wg_slots.data(), wg_slots.size() * 4, hipMemcpyHostToDevice, s));
-    HIP_TRY(c, hipMemcpyAsync(c->d_col_off.p, col_off.data(), col_off.size() * 4, hipMemcpyHostToDevice, s));
-    HIP_TRY(c, hipMemcpyAsync(c->d_wg_dst.p, wg_dst.data(), wg_dst.size() * 4, hipMemcpyHostToDevice, s));
+    for (int pi = 0; pi < c->n_parts; ++pi) {
+        bplhip_ctx::EvalPart& ep = c->parts[pi];
+        ep.aw = pi == 0 ? aw0 : dc::WAVES;
+        ep.tpw = (n_tiles + max_wg * ep.aw - 1) / (max_wg * ep.aw);
+        if (ep.tpw < 1) ep.tpw = 1;
+        const int waves = (n_tiles + ep.tpw - 1) / ep.tpw;
+        ep.n_wg = (waves + ep.aw - 1) / ep.aw;
+        const SparseSlabs sp = build_sparse_slabs(hs, as, n_lanefix, T, ep.tpw * ep.aw, ep.n_wg);
+        ep.total_c = sp.wg_off[ep.n_wg];
+        HIP_TRY(c, ep.d_wg_off.ensure(sp.wg_off.size() * 4));
+        HIP_TRY(c, ep.d_wg_slots.ensure(sp.wg_slots.size() * 4));
+        HIP_TRY(c, ep.d_col_off.ensure(sp.col_off.size() * 4));
+        HIP_TRY(c, ep.d_wg_dst.ensure(sp.wg_dst.size() * 4));
+        // (synchronous copies: the host vectors die with this iteration)
+        HIP_TRY(c, hipMemcpy(ep.d_wg_off.p, sp.wg_off.data(), sp.wg_off.size() * 4, hipMemcpyHostToDevice));
+        HIP_TRY(c, hipMemcpy(ep.d_wg_slots.p, sp.wg_slots.data(), sp.wg_slots.size() * 4, hipMemcpyHostToDevice));
+        HIP_TRY(c, hipMemcpy(ep.d_col_off.p, sp.col_off.data(), sp.col_off.size() * 4, hipMemcpyHostToDevice));
+        HIP_TRY(c, hipMemcpy(ep.d_wg_dst.p, sp.wg_dst.data(), sp.wg_dst.size() * 4, hipMemcpyHostToDevice));
+    }
     HIP_TRY(c, c->d_h.ensure(n_lanes * 4));
     HIP_TRY(c, c->d_a.ensure(n_lanes * 4));
     HIP_TRY(c, c->d_x.ensure(n_pad));
@@ -716,18 +763,19 @@ static int bplhip_set_fixtures_impl(bplhip_ctx* c, int model_kind, int64_t n, in
     c->lds_attr_set = false;
     c->n = n;
     c->n_tiles = n_tiles;
-    c->tiles_per_wave = tpw;
-    c->n_wg = n_wg;
     c->weighted = weights != nullptr;
     c->P = (int)pairs.size();
     c->lgsum = lgsum;
     c->h_pairs = std::move(pairs);
     c->slab_chains = 0;
-    c->total_c = wg_off[n_wg];
     // staged <=> T <= 64: the tail's one-lane-per-team epilogue (and the device-resident NUTS)
-    c->staged = T <= 64 && ctx_lds_bytes(c, true) <= 96 * 1024;
-    if (ctx_lds_bytes(c, c->staged) > LDS_LIMIT)
-        return fail(c, BPLHIP_EUNSUPPORTED, "set_fixtures: tail LDS footprint too large");
+    for (int pi = 0; pi < c->n_parts; ++pi) {
+        c->ep = &c->parts[pi];
+        c->ep->staged = T <= 64 && ctx_lds_bytes(c, true) <= 96 * 1024;
+        if (ctx_lds_bytes(c, c->ep->staged) > LDS_LIMIT)
+            return fail(c, BPLHIP_EUNSUPPORTED, "set_fixtures: tail LDS footprint too large");
+    }
+    select_part(c, 1);
     int rc = ensure_slabs(c, 1);
     if (rc != BPLHIP_OK) return rc;
 
@@ -741,7 +789,7 @@ static int bplhip_set_fixtures_impl(bplhip_ctx* c, int model_kind, int64_t n, in
         vp.tpw = c->opt_vec_tpw > 0 ? std::max(tpw, c->opt_vec_tpw) : tpw << pi;
         const int vwaves = (n_tiles + vp.tpw - 1) / vp.tpw;
         vp.n_wg = (vwaves + dc::WAVES - 1) / dc::WAVES;
-        const SparseSlabs vs = build_sparse_slabs(hs, as, n_lanefix, T, vp.tpw, vp.n_wg);
+        const SparseSlabs vs = build_sparse_slabs(hs, as, n_lanefix, T, vp.tpw * dc::WAVES, vp.n_wg);
         vp.total_c = vs.wg_off[vp.n_wg];
         HIP_TRY(c, vp.d_wg_off.ensure(vs.wg_off.size() * 4));
         HIP_TRY(c, vp.d_wg_slots.ensure(vs.wg_slots.size() * 4));
@@ -788,6 +836,11 @@ int bplhip_set_option(bplhip_ctx* c, const char* name, int value) {
     if (n == "max_wg") {  // takes effect at the next bplhip_set_fixtures
         if (value < 1 || value > 1024) return fail(c, BPLHIP_EINVAL, "max_wg out of range [1,1024]");
         c->opt_max_wg = value;
+        return BPLHIP_OK;
+    }
+    if (n == "active_waves") {  // waves per workgroup that own tiles; 0 = automatic; next set_fixtures
+        if (value < 0 || value > dc::WAVES) return fail(c, BPLHIP_EINVAL, "active_waves: 0 (automatic) .. 8");
+        c->opt_active_waves = value;
         return BPLHIP_OK;
     }
     return fail(c, BPLHIP_EINVAL, "unknown option '%s'", name);
@@ -1055,16 +1108,16 @@ static int bplhip_logp_grad_graph_impl(bplhip_ctx* c, int32_t count, int32_t n_z
 // diagnostic build only: allocate / read the per-workgroup timestamp buffer [n_wg][16]
 int bplhip_debug_stamps(bplhip_ctx* c, unsigned long long* out, int n_words) {
     if (!c || !c->bound) return BPLHIP_ESTATE;
-    const size_t bytes = (size_t)(c->n_wg + 2) * 16 * 8;
+    const size_t bytes = (size_t)(c->ep->n_wg + 2) * 16 * 8;
     if (!c->d_debug.p) {
         HIP_TRY(c, c->d_debug.ensure(bytes));
         HIP_TRY(c, hipMemset(c->d_debug.p, 0, bytes));
-        return c->n_wg + 1;
+        return c->ep->n_wg + 1;
     }
     HIP_TRY(c, hipDeviceSynchronize());
     const size_t want = std::min(bytes, (size_t)n_words * 8);
     HIP_TRY(c, hipMemcpy(out, c->d_debug.p, want, hipMemcpyDeviceToHost));
-    return c->n_wg + 1;
+    return c->ep->n_wg + 1;
 }
 #endif
 
@@ -1387,7 +1440,9 @@ struct VecDeviceEngine {
 
 // the leaf can run in dc_eval's tail (nuts_dev.hip.h): the basic / extended models, <= 64 teams
 static bool leaf_in_tail(const bplhip_ctx* c) {
-    return !c->neutral && !c->dynamic && c->L.T <= 64 && c->staged && c->L.D <= 64 * nd::LEAF_NE_MAX;
+    bool staged = true;
+    for (int pi = 0; pi < c->n_parts; ++pi) staged = staged && c->parts[pi].staged;
+    return !c->neutral && !c->dynamic && c->L.T <= 64 && staged && c->L.D <= 64 * nd::LEAF_NE_MAX;
 }
 // persistent chains keep all momentum draws of a run on the device: [C][n_iter][D] doubles
 static bool persistent_fits(const bplhip_ctx* c, const bplhip_nuts_cfg* cfg, int C) {

@@ -87,6 +87,7 @@ struct EvalArgs {
     const float* w;     // [n_tiles*64*LANE_FIX] f32 weights, or nullptr
     int n_tiles;
     int tiles_per_wave;
+    int active_waves;       // waves of a workgroup that own tiles (the first ones)
     const uint32_t* pairs;  // [P] unique (home | away<<16)
     int P;
     const double* xs;       // [T,K] standardised covariates (float64) or nullptr
@@ -1488,8 +1489,8 @@ __global__ DC_LAUNCH_BOUNDS void dc_eval(EvalArgs A) {
         // With covariates z is read again in the table loop, and behind a barrier those reads
         // would stop being scalar loads.)
         if (!CLIP) asm volatile("" ::: "memory");
-        const int gw = wgi * WAVES + wave;
-        int tile = gw * A.tiles_per_wave;
+        const int gw = wgi * A.active_waves + wave;
+        int tile = wave < A.active_waves ? gw * A.tiles_per_wave : A.n_tiles;
         const int tile_end = min(tile + A.tiles_per_wave, A.n_tiles);
         // (a wave without tiles loads the last one and never uses it)
         LaneData cur = load_lane<WEIGHTED>(A, (size_t)min(tile, A.n_tiles - 1) * 64 + lane);
