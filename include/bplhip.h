@@ -157,7 +157,11 @@ int bplhip_set_fixtures_neutral(bplhip_ctx* ctx, int64_t n, int32_t n_teams,
  *            host only enqueues evaluations); 0 = device trees with host-side adaptation
  *            (models of the evaluation kernel's tail only).
  *   "max_wg" streaming workgroups per evaluation (default 255: with the prior workgroup
- *            one per CU); applies at the next bplhip_set_fixtures */
+ *            one per CU); applies at the next bplhip_set_fixtures
+ *   "active_waves" waves per workgroup that own tiles: 0 (default) = automatic -- short
+ *            streams get a second partition with 4 of 8 waves owning tiles, used while the
+ *            launch's workgroups still find a CU each; 1..8 = one fixed partition; applies
+ *            at the next bplhip_set_fixtures */
 int bplhip_set_option(bplhip_ctx* ctx, const char* name, int value);
 
 /* D of the bound model (negative error code if no fixtures are bound). */
