@@ -2,12 +2,17 @@ import sys, os
 ROOT=os.environ.get('GRAFT_REPO_ROOT','/root/repo'); sys.path[:0]=[ROOT+'/bpl-next_amd', ROOT]
 import numpy as np, torch
 from bench import synthetic_league
-from bpl._ffi import HipContext, MODEL_BASIC
+from bpl._ffi import HipContext, MODEL_BASIC, MODEL_EXTENDED
 c=HipContext(0)
+EXT = os.environ.get('EXT', '0') == '1'
+cov = None
+if EXT:
+    cov = np.random.RandomState(0).normal(size=(20, 5)); cov = (cov - cov.mean(0)) / cov.std(0)
 for n in (1_000_000, 100_000, 2_000_000, 3_000_000):
     h,a,x,y = synthetic_league(n, 20)
     for aw in (8, 4, 2, 8, 4):
-        c.set_option('active_waves', aw); c.set_fixtures(MODEL_BASIC,h,a,x,y,20)
+        c.set_option('active_waves', aw)
+        c.set_fixtures(MODEL_EXTENDED if EXT else MODEL_BASIC,h,a,x,y,20, covariates_std=cov)
         D=c.dim
         z=torch.tensor(np.random.RandomState(7).uniform(-.5,.5,(64,D)),dtype=torch.float64,device=c.device)
         U=torch.zeros(64,dtype=torch.float64,device=c.device); g=torch.zeros_like(z)
