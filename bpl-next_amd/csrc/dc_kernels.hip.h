@@ -57,7 +57,10 @@ constexpr int COV_WAVE_A = 6, COV_WAVE_D = 7;  // covariate-coefficient gradient
 constexpr int N_SCAL = 4;                // SLAM, SLOG2, SU, CLIPC
 constexpr int MAX_RG = 32;               // row groups of the slab reduction
 constexpr int RUN_LOOP_MAX = 4;          // runs per wave-tile handled by masked DPP sums
-constexpr int TK_GROUPS = 16;            // two-level arrival tickets: group counters ...
+#ifndef DC_TK_GROUPS
+#define DC_TK_GROUPS 16
+#endif
+constexpr int TK_GROUPS = DC_TK_GROUPS;            // two-level arrival tickets: group counters ...
 constexpr int TK_STRIDE = 32;            // ... one per 128-byte line
 constexpr int TK_WORDS = (1 + TK_GROUPS) * TK_STRIDE;  // u32 words per chain
 
