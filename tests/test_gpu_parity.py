@@ -292,3 +292,40 @@ def test_nuts_with_many_teams(hip_ctx):
         assert e.value.code == BPLHIP_EUNSUPPORTED
     finally:
         hip_ctx.set_option("persistent_nuts", 1)
+
+
+def test_launch_partitions_agree(hip_ctx):
+    """dc_eval has two launch partitions for short streams (4 or 8 waves of a workgroup own tiles;
+    the launch picks by its workgroup count) and the "active_waves" option pins one: every choice
+    must give the same potential and gradient up to summation order, for one chain and for several
+    chains in one launch (which switch to the 8-wave partition on their own)."""
+    import torch
+
+    fx = cases.fixtures("league_200000")
+    z = torch.tensor(np.random.RandomState(3).uniform(-0.4, 0.4, (6, 45)), dtype=torch.float64,
+                     device=hip_ctx.device)
+    ref = None
+    try:
+        for aw in (0, 8, 4, 2, 1):
+            hip_ctx.set_option("active_waves", aw)
+            hip_ctx.set_fixtures(O.MODEL_BASIC, fx.home_idx.astype(np.uint16), fx.away_idx.astype(np.uint16),
+                                 fx.home_goals.astype(np.uint8), fx.away_goals.astype(np.uint8), fx.n_teams)
+            U1, g1, _ = hip_ctx.logp_grad(z[0].contiguous())                      # one chain
+            U = torch.zeros(6, dtype=torch.float64, device=hip_ctx.device)
+            g = torch.zeros_like(z)
+            aux = torch.zeros((6, 4), dtype=torch.float64, device=hip_ctx.device)
+            hip_ctx.set_option("vec_min_chains", 0)                               # grid.y copies
+            hip_ctx.logp_grad(z, U, g, aux)
+            hip_ctx.set_option("vec_min_chains", 32)
+            got = (U1.cpu().numpy()[0], g1.cpu().numpy(), U.cpu().numpy(), g.cpu().numpy())
+            assert abs(got[2][0] - got[0]) <= 1e-12 * abs(got[0])
+            if ref is None:
+                ref = got
+                continue
+            assert abs(got[0] - ref[0]) <= 1e-12 * abs(ref[0])
+            assert np.abs(got[1] - ref[1]).max() <= 1e-10 * np.abs(ref[1]).max()
+            assert np.abs(got[2] - ref[2]).max() <= 1e-12 * np.abs(ref[2]).max()
+            assert np.abs(got[3] - ref[3]).max() <= 1e-10 * np.abs(ref[3]).max()
+    finally:
+        hip_ctx.set_option("active_waves", 0)
+        hip_ctx.set_option("vec_min_chains", 32)
