@@ -489,15 +489,20 @@ __device__ inline void build_coupling(const DynArgs& A, const Bounds& b, Couplin
         const unsigned long long w = tid == 0 ? scu[SC_IDXP] : (lb_home ? scu[SC_IDXQ] : scu[SC_IDXR]);
         CouplingFix f{};
         f.have = w != 0 && (tid == 1 || b.M > 1.0);
-        if (f.have) {
-            const long long i = (long long)(~0ull - w);
-            f.g = A.gw ? A.gw[i] : 0;
-            f.h = A.h[i];
-            f.a = A.a[i];
-            f.nv = A.nv[i];
-            f.hc = A.hc ? A.hc[i] : 0;
-            f.ac = A.hc ? A.ac[i] : 0;
-        }
+        // all six fields in one round of loads: index clamped instead of a branch, absent arrays
+        // (one gameweek, no confederations) read through a valid stand-in and are zeroed after --
+        // behind `have ? ... : 0` each load was a dependent round trip of its own
+        const long long i = f.have ? (long long)(~0ull - w) : 0;
+        const uint16_t* gwp = A.gw ? A.gw : A.h;
+        const uint8_t* hcp = A.hc ? A.hc : A.nv;
+        const uint8_t* acp = A.hc ? A.ac : A.nv;
+        const int vg = gwp[i], vh = A.h[i], va = A.a[i], vn = A.nv[i], vhc = hcp[i], vac = acp[i];
+        f.g = f.have && A.gw ? vg : 0;
+        f.h = f.have ? vh : 0;
+        f.a = f.have ? va : 0;
+        f.nv = f.have ? vn : 0;
+        f.hc = f.have && A.hc ? vhc : 0;
+        f.ac = f.have && A.hc ? vac : 0;
         F[tid] = f;
     }
     __syncthreads();
