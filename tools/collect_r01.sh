@@ -18,6 +18,7 @@ python tools/predict_bench.py > $OUT/predict.txt 2>&1
 python tools/neutral_bench.py > $OUT/neutral.txt 2>&1
 python tools/small_n_bench.py > $OUT/small_n.txt 2>&1
 python tools/configs_bench.py > $OUT/configs.txt 2>&1
+python tools/teams_sweep.py > $OUT/teams_sweep.txt 2>&1
 bash tools/profile.sh $TAG > $OUT/profile.log 2>&1
 mkdir -p $OUT/nt && (cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --output-format csv -d $OUT/nt -- python3 $ROOT/tools/nuts_trace.py > $OUT/nuts_trace.log 2>&1)
 python tools/trace_gaps.py $OUT/nt > $OUT/nuts_trace_gaps.txt 2>&1
