@@ -48,6 +48,7 @@ constexpr int BLOCK = 512;               // 8 waves per workgroup
 constexpr int WAVES = BLOCK / 64;
 // device-resident NUTS: waves 4..7 of the tail workgroup idle during the per-team epilogue, so
 // the leaf's preparation is spread over them and costs nothing on the serial path
+constexpr int PAIR_BATCH = 4;            // pairs requested per round of the rho-bound loops
 constexpr int LEAF_WAVE = 4;             // books the leaf
 constexpr int RNG_WAVE = 5;              // draws the leaf's random numbers (threefry)
 constexpr int COV_WAVE_A = 6, COV_WAVE_D = 7;  // covariate-coefficient gradients (any launch)
@@ -439,8 +440,7 @@ __device__ __forceinline__ void pair_maxima_f32(const EvalArgs& A, const float2*
                                                 int tid, float* oP, float* oQ, float* oR) {
     const int lane = tid & 63, wave = tid >> 6;
     float mP = 0.f, mQ = 0.f, mR = 0.f;
-    for (int p = tid; p < A.P; p += BLOCK) {
-        const uint32_t pr = p == tid ? pr0 : A.pairs[p];
+    auto take = [&](uint32_t pr) {
         const float2 th = tabH[pr & 0xFFFFu], ta = tabA[pr >> 16];
         float lh = th.x * ta.y, la = ta.x * th.y;
         if (CLIP) {
@@ -450,6 +450,17 @@ __device__ __forceinline__ void pair_maxima_f32(const EvalArgs& A, const float2*
         mP = fmaxf(mP, lh * la);  // (a NaN rate reaches U through the rate sum anyway)
         mQ = fmaxf(mQ, lh);
         mR = fmaxf(mR, la);
+    };
+    if (tid < A.P) take(pr0);  // (requested in the prologue)
+    // leagues with more pairs than threads: four unconditional loads per round, index clamped (a
+    // repeat of the last pair changes no maximum) -- `p == tid ? pr0 : pairs[p]` in a rolled loop was
+    // one dependent L2 round trip per pair
+    for (int p0 = tid + BLOCK; p0 < A.P; p0 += PAIR_BATCH * BLOCK) {
+        uint32_t q[PAIR_BATCH];
+#pragma unroll
+        for (int u = 0; u < PAIR_BATCH; ++u) q[u] = A.pairs[min(p0 + u * BLOCK, A.P - 1)];
+#pragma unroll
+        for (int u = 0; u < PAIR_BATCH; ++u) take(q[u]);
     }
     mP = wave_max_f32(mP);
     mQ = wave_max_f32(mQ);
@@ -686,8 +697,7 @@ __device__ void prior_body(const EvalArgs& A, int chain, char* smem) {
     float mPf = 0.f, mQf = 0.f, mRf = 0.f;
     double mP = 0.0, mQ = 0.0, mR = 0.0;
     uint32_t aP = 0, aQ = 0, aR = 0;  // arg-pairs (home | away << 16)
-    for (int p = tid; p < A.P; p += BLOCK) {
-        const uint32_t pr = p == tid ? pr0 : A.pairs[p];
+    auto take = [&](uint32_t pr, bool valid) {
         const int h = pr & 0xFFFFu, a = pr >> 16;
         {
             const float2 th = tabH[h], ta = tabA[a];
@@ -705,9 +715,18 @@ __device__ void prior_body(const EvalArgs& A, int chain, char* smem) {
             lh = fmin(lh, RATE_CLIP);
             la = fmin(la, RATE_CLIP);
         }
-        if (lh * la > mP) { mP = lh * la; aP = pr; }
-        if (lh > mQ) { mQ = lh; aQ = pr; }
-        if (la > mR) { mR = la; aR = pr; }
+        // (a clamped repeat of the last pair must not take part in the tie rule)
+        if (valid && lh * la > mP) { mP = lh * la; aP = pr; }
+        if (valid && lh > mQ) { mQ = lh; aQ = pr; }
+        if (valid && la > mR) { mR = la; aR = pr; }
+    };
+    if (tid < A.P) take(pr0, true);
+    for (int p0 = tid + BLOCK; p0 < A.P; p0 += PAIR_BATCH * BLOCK) {  // (see pair_maxima_f32)
+        uint32_t q[PAIR_BATCH];
+#pragma unroll
+        for (int u = 0; u < PAIR_BATCH; ++u) q[u] = A.pairs[min(p0 + u * BLOCK, A.P - 1)];
+#pragma unroll
+        for (int u = 0; u < PAIR_BATCH; ++u) take(q[u], p0 + u * BLOCK < A.P);
     }
     mPf = wave_max_f32(mPf);
     mQf = wave_max_f32(mQf);
@@ -1114,7 +1133,15 @@ __device__ void tail_body(const EvalArgs& A, int chain, char* smem) {
             if (STAGED) {
                 for (int k = coff[c] + j; k < k1; k += 8) s += cmp[k];
             } else {
-                for (int k = coff[c] + j; k < k1; k += 8) s += ld_sc1(&compact[k]);
+                // (the compact array does not fit LDS here: straight from memory, eight loads in
+                // flight per lane -- one at a time was a ~1 us round trip per 8 workgroups)
+                for (int k = coff[c] + j; k < k1; k += 64) {
+                    double v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) v[u] = ld_sc1(&compact[min(k + 8 * u, k1 - 1)]);
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) s += k + 8 * u < k1 ? v[u] : 0.0;
+                }
             }
         }
         s += dpp_f64<0xB1>(0.0, s);   // quad_perm [1,0,3,2]

@@ -9,13 +9,14 @@ from bpl import _ffi
 _ffi._LIB_NAME = "libbplhip_stamps.so"
 from bpl._ffi import HipContext, MODEL_BASIC, MODEL_EXTENDED
 
+TEAMS = int(os.environ.get('TEAMS', '20'))
 def run(n, model=MODEL_BASIC, max_wg=255, k=0, weighted=False):
-    h, a, x, y = synthetic_league(n, 20)
+    h, a, x, y = synthetic_league(n, TEAMS)
     w = np.exp(-np.linspace(5.0, 0.0, n)).astype(np.float32) if weighted else None
     cov = None
     if k:
-        cov = np.random.RandomState(0).normal(size=(20, k)); cov = (cov - cov.mean(0)) / cov.std(0)
-    c = HipContext(0); c.set_option("max_wg", max_wg); c.set_fixtures(model, h, a, x, y, 20, weights=w, covariates_std=cov)
+        cov = np.random.RandomState(0).normal(size=(TEAMS, k)); cov = (cov - cov.mean(0)) / cov.std(0)
+    c = HipContext(0); c.set_option("max_wg", max_wg); c.set_fixtures(model, h, a, x, y, TEAMS, weights=w, covariates_std=cov)
     lib = c._lib
     lib.bplhip_debug_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int]; lib.bplhip_debug_stamps.restype = C.c_int
     nwg = lib.bplhip_debug_stamps(c._h, None, 0)
