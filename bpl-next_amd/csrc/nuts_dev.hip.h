@@ -578,20 +578,27 @@ __device__ inline bool leaf_moves_staged(double* ns, int D, int max_depth, int l
 template <int NT = 64>
 __device__ inline void init_body(double* ns, int D, double eps, double max_de, int lane,
                                  double* scr = nullptr) {
-    double* invM = vec(ns, D, V_INVM);
-    double* r = vec(ns, D, V_TL_R);
+    // one pass: every element is loaded once (four loads in flight) and fanned out -- a chain of
+    // copy loops was one dependent memory round trip each on the chain's serial path
+    const double* __restrict__ invM = vec(ns, D, V_INVM);
+    const double* __restrict__ r = vec(ns, D, V_TL_R);
+    const double* __restrict__ zc = vec(ns, D, V_Z);
+    const double* __restrict__ gc = vec(ns, D, V_G);
+    double* __restrict__ tl_z = vec(ns, D, V_TL_Z); double* __restrict__ tl_g = vec(ns, D, V_TL_G);
+    double* __restrict__ tr_z = vec(ns, D, V_TR_Z); double* __restrict__ tr_r = vec(ns, D, V_TR_R);
+    double* __restrict__ tr_g = vec(ns, D, V_TR_G); double* __restrict__ tp_z = vec(ns, D, V_TP_Z);
+    double* __restrict__ tp_g = vec(ns, D, V_TP_G); double* __restrict__ t_rs = vec(ns, D, V_T_RSUM);
     double kin = 0.0;
 #pragma clang loop unroll_count(NT > 64 ? 4 : 1)
-    for (int i = lane; i < D; i += NT) kin += invM[i] * r[i] * r[i];
+    for (int i = lane; i < D; i += NT) {
+        const double ri = r[i], zi = zc[i], gi = gc[i];
+        kin += invM[i] * ri * ri;
+        tl_z[i] = zi; tl_g[i] = gi;
+        tr_z[i] = zi; tr_r[i] = ri; tr_g[i] = gi;
+        tp_z[i] = zi; tp_g[i] = gi;
+        t_rs[i] = ri;
+    }
     kin = 0.5 * team_sum<NT>(kin, lane, scr);
-    vcopy<NT>(vec(ns, D, V_TL_Z), vec(ns, D, V_Z), D, lane);
-    vcopy<NT>(vec(ns, D, V_TL_G), vec(ns, D, V_G), D, lane);
-    vcopy<NT>(vec(ns, D, V_TR_Z), vec(ns, D, V_Z), D, lane);
-    vcopy<NT>(vec(ns, D, V_TR_R), r, D, lane);
-    vcopy<NT>(vec(ns, D, V_TR_G), vec(ns, D, V_G), D, lane);
-    vcopy<NT>(vec(ns, D, V_TP_Z), vec(ns, D, V_Z), D, lane);
-    vcopy<NT>(vec(ns, D, V_TP_G), vec(ns, D, V_G), D, lane);
-    vcopy<NT>(vec(ns, D, V_T_RSUM), r, D, lane);
     if (lane == 0) {
         const double e0 = ns[H_CUR_PE] + kin;
         ns[H_EPS] = eps;
@@ -643,33 +650,47 @@ __device__ inline void end_body(double* ns, int D, int max_depth, uint32_t thi, 
                                 int lane, double* scr = nullptr) {
     if (ns[H_S_ACTIVE] == 0.0) return;
     const bool going_right = ns[H_DIR] > 0.0;
-    const double* invM = vec(ns, D, V_INVM);
-    // outer leaves of the combined tree
-    if (going_right) {
-        vcopy<NT>(vec(ns, D, V_TR_Z), vec(ns, D, V_SR_Z), D, lane);
-        vcopy<NT>(vec(ns, D, V_TR_R), vec(ns, D, V_SR_R), D, lane);
-        vcopy<NT>(vec(ns, D, V_TR_G), vec(ns, D, V_SR_G), D, lane);
-    } else {
-        vcopy<NT>(vec(ns, D, V_TL_Z), vec(ns, D, V_SL_Z), D, lane);
-        vcopy<NT>(vec(ns, D, V_TL_R), vec(ns, D, V_SL_R), D, lane);
-        vcopy<NT>(vec(ns, D, V_TL_G), vec(ns, D, V_SL_G), D, lane);
-    }
-    double* __restrict__ t_rsum = vec(ns, D, V_T_RSUM);
-    const double* __restrict__ s_rsum = vec(ns, D, V_S_RSUM);
-#pragma clang loop unroll_count(NT > 64 ? 4 : 1)
-    for (int i = lane; i < D; i += NT) t_rsum[i] += s_rsum[i];
     const bool s_turn = ns[H_S_TURN] != 0.0, s_div = ns[H_S_DIV] != 0.0;
     const double w_cur = ns[H_T_WEIGHT], w_new = ns[H_S_WEIGHT];
     double prob = exp(w_new - w_cur);
     if (s_turn || s_div) prob = 0.0;
     prob = fmin(prob, 1.0);
-    const bool turning =
-        s_turn | is_turning<NT>(invM, vec(ns, D, V_TL_R), vec(ns, D, V_TR_R), t_rsum, D, lane, scr);
     const bool take = tf_bernoulli(thi, tlo, prob);
-    if (take) {
-        vcopy<NT>(vec(ns, D, V_TP_Z), vec(ns, D, V_SP_Z), D, lane);
-        vcopy<NT>(vec(ns, D, V_TP_G), vec(ns, D, V_SP_G), D, lane);
+    // one pass over the vectors: the subtree's outer leaf becomes the tree's (edge vectors), the
+    // momentum sums are added, the proposal is taken over when the biased transition says so, and
+    // the U-turn test of the combined tree (numpyro _is_turning: left edge, right edge, r_sum)
+    // accumulates -- same arithmetic per element as the separate loops this replaces
+    const double* __restrict__ invM = vec(ns, D, V_INVM);
+    const double* __restrict__ se_z = vec(ns, D, going_right ? V_SR_Z : V_SL_Z);
+    const double* __restrict__ se_r = vec(ns, D, going_right ? V_SR_R : V_SL_R);
+    const double* __restrict__ se_g = vec(ns, D, going_right ? V_SR_G : V_SL_G);
+    const double* __restrict__ other_r = vec(ns, D, going_right ? V_TL_R : V_TR_R);  // the far edge stays
+    const double* __restrict__ s_rsum = vec(ns, D, V_S_RSUM);
+    const double* __restrict__ sp_z = vec(ns, D, V_SP_Z);
+    const double* __restrict__ sp_g = vec(ns, D, V_SP_G);
+    double* __restrict__ te_z = vec(ns, D, going_right ? V_TR_Z : V_TL_Z);
+    double* __restrict__ te_r = vec(ns, D, going_right ? V_TR_R : V_TL_R);
+    double* __restrict__ te_g = vec(ns, D, going_right ? V_TR_G : V_TL_G);
+    double* __restrict__ t_rsum = vec(ns, D, V_T_RSUM);
+    double* __restrict__ tp_z = vec(ns, D, V_TP_Z);
+    double* __restrict__ tp_g = vec(ns, D, V_TP_G);
+    double dl = 0.0, dr = 0.0;
+#pragma clang loop unroll_count(NT > 64 ? 4 : 1)
+    for (int i = lane; i < D; i += NT) {
+        const double ez = se_z[i], er = se_r[i], eg = se_g[i], orr = other_r[i];
+        const double rsum = t_rsum[i] + s_rsum[i], im = invM[i];
+        const double pz = sp_z[i], pg = sp_g[i];
+        te_z[i] = ez; te_r[i] = er; te_g[i] = eg;
+        t_rsum[i] = rsum;
+        if (take) { tp_z[i] = pz; tp_g[i] = pg; }
+        const double r_left = going_right ? orr : er, r_right = going_right ? er : orr;
+        const double rs = rsum - 0.5 * (r_left + r_right);
+        dl += im * r_left * rs;
+        dr += im * r_right * rs;
     }
+    dl = team_sum<NT>(dl, lane, scr);
+    dr = team_sum<NT>(dr, lane, scr);
+    const bool turning = s_turn | ((dl <= 0.0) | (dr <= 0.0));
     if (lane == 0) {
         if (take) {
             ns[H_T_PE] = ns[H_S_PE];
@@ -693,8 +714,16 @@ __device__ inline void end_body(double* ns, int D, int max_depth, uint32_t thi, 
 // end of the transition: the proposal becomes the current state
 template <int NT = 64>
 __device__ inline void finish_body(double* ns, int D, int lane) {
-    vcopy<NT>(vec(ns, D, V_Z), vec(ns, D, V_TP_Z), D, lane);
-    vcopy<NT>(vec(ns, D, V_G), vec(ns, D, V_TP_G), D, lane);
+    const double* __restrict__ tp_z = vec(ns, D, V_TP_Z);
+    const double* __restrict__ tp_g = vec(ns, D, V_TP_G);
+    double* __restrict__ zc = vec(ns, D, V_Z);
+    double* __restrict__ gc = vec(ns, D, V_G);
+#pragma clang loop unroll_count(NT > 64 ? 4 : 1)
+    for (int i = lane; i < D; i += NT) {
+        const double a = tp_z[i], b = tp_g[i];
+        zc[i] = a;
+        gc[i] = b;
+    }
     if (lane == 0) ns[H_CUR_PE] = ns[H_T_PE];
 }
 
