@@ -170,12 +170,14 @@ __global__ __launch_bounds__(BLOCK) void dc_vec_stream(EvalArgs A) {
         if (all_done) return;
     }
 
-    // ---- 0. the first tile's loads before anything else
+    // ---- 0. loads in the order the data is wanted, unconditional with clamped indices (see the
+    // prologue of dc_eval): this wave's chain's per-team entries of z, then the first tile
+    const double* zb = z_of(A, min(chain0 + wave, A.chains - 1));
+    const TeamZ tz0 = load_team_z<CLIP>(L, zb, min(lane, T - 1));
     const int gw = wgi * WAVES + wave;
     int tile = gw * A.tiles_per_wave;
     const int tile_end = min(tile + A.tiles_per_wave, A.n_tiles);
-    LaneData cur{};
-    if (tile < tile_end) cur = load_lane<WEIGHTED>(A, (size_t)tile * 64 + lane);
+    LaneData cur = load_lane<WEIGHTED>(A, (size_t)min(tile, A.n_tiles - 1) * 64 + lane);
     const int o0 = A.wg_off[wgi], o1 = A.wg_off[wgi + 1];
 
     float2* tab = reinterpret_cast<float2*>(smem);                   // [CB][2][tl]
@@ -193,24 +195,33 @@ __global__ __launch_bounds__(BLOCK) void dc_vec_stream(EvalArgs A) {
         float2* tA = tH + tl;
         for (int t = lane; t <= T; t += 64) {
             float2 vh = make_float2(0.f, 0.f), va = vh;
-            if (t < T) f32_table_entry<CLIP>(L, fs, z, A.xsf, t, load_team_z<CLIP>(L, z, t), &vh, &va);
+            if (t < T)
+                f32_table_entry<CLIP>(L, fs, z, A.xsf, t, t == lane ? tz0 : load_team_z<CLIP>(L, z, t), &vh, &va);
             tH[t] = vh;
             tA[t] = va;
         }
         for (int i = lane; i < accn; i += 64) acc[(size_t)b * accn + i] = 0.0;
         __syncthreads();
         float mP = 0.f, mQ = 0.f, mR = 0.f;  // bpl/_util.py:23-30 over the unique pairs
-        for (int p = lane; p < A.P; p += 64) {
-            const uint32_t pr = A.pairs[p];
-            const float2 th = tH[pr & 0xFFFFu], ta = tA[pr >> 16];
-            float lh = th.x * ta.y, la = ta.x * th.y;
-            if (CLIP) {
-                lh = fminf(lh, (float)RATE_CLIP);
-                la = fminf(la, (float)RATE_CLIP);
+        // (eight pairs per round, index clamped: a repeat of the last pair changes no maximum; one
+        // pair per round was a dependent L2 round trip each)
+        for (int p0 = lane; p0 < A.P; p0 += 8 * 64) {
+            uint32_t q[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) q[u] = A.pairs[min(p0 + 64 * u, A.P - 1)];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const uint32_t pr = q[u];
+                const float2 th = tH[pr & 0xFFFFu], ta = tA[pr >> 16];
+                float lh = th.x * ta.y, la = ta.x * th.y;
+                if (CLIP) {
+                    lh = fminf(lh, (float)RATE_CLIP);
+                    la = fminf(la, (float)RATE_CLIP);
+                }
+                mP = fmaxf(mP, lh * la);
+                mQ = fmaxf(mQ, lh);
+                mR = fmaxf(mR, la);
             }
-            mP = fmaxf(mP, lh * la);
-            mQ = fmaxf(mQ, lh);
-            mR = fmaxf(mR, la);
         }
         mP = wave_max_f32(mP);
         mQ = wave_max_f32(mQ);
@@ -231,8 +242,8 @@ __global__ __launch_bounds__(BLOCK) void dc_vec_stream(EvalArgs A) {
     for (int b = 0; b < CB; ++b) dV[b] = dSU[b] = 0.0;
     const uint32_t sentinel = (uint32_t)T;
     while (tile < tile_end) {
-        LaneData nxt = cur;
-        if (tile + 1 < tile_end) nxt = load_lane<WEIGHTED>(A, (size_t)(tile + 1) * 64 + lane);
+        // (unconditional prefetch: the last round re-requests its own tile and drops it)
+        LaneData nxt = load_lane<WEIGHTED>(A, (size_t)min(tile + 1, tile_end - 1) * 64 + lane);
 
         float prs[CB], pra[CB];  // the lane's last run stays pending (merges across lanes)
         uint32_t pkey = sentinel | (sentinel << 16);
