@@ -111,6 +111,10 @@ void harness_ckpt_idxs(int n, int* idx_min, int* idx_max) {
     nuts::leaf_idx_to_ckpt_idxs(n, idx_min, idx_max);
 }
 
+// one raw Threefry-2x32-20 block (known-answer tests)
+void harness_threefry_block(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t* out) {
+    tf::block(k0, k1, c0, c1, &out[0], &out[1]);
+}
 void harness_normal(uint32_t khi, uint32_t klo, int n, double* out) {
     tf::normal(tf::Key{khi, klo}, n, out);
 }

@@ -46,15 +46,19 @@ def test_bench_tiny_step_counts():
         assert out["steps"] == steps and out["value"] > 0
 
 
+def _two_ranks(port, **env_extra):
+    env = dict(os.environ, BENCH_FORCE_DEVICE="0", **env_extra)
+    return subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                           "--gpus", "2", "--steps", "128", "--warmup", "64", "--no-cpu-baseline", "--no-insitu"],
+                          capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+
+
 def test_bench_two_ranks_flow():
     """The multi-rank flow of bench.py (fixture broadcast, barriers, max over ranks, rank 0 prints)
-    with two ranks forced onto this box's single GPU: RCCL refuses two ranks on one device, so this
-    also exercises the recorded fall-back of the control plane to gloo."""
-    env = dict(os.environ, BENCH_FORCE_DEVICE="0")
-    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                        "--master-addr", "127.0.0.1", "--master-port", "29517", os.path.join(ROOT, "bench.py"),
-                        "--gpus", "2", "--steps", "128", "--warmup", "64", "--no-cpu-baseline", "--no-insitu"],
-                       capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    with two ranks forced onto this box's single GPU.  RCCL refuses two ranks on one device, so the
+    control plane runs on gloo through the explicit test hook (recorded in the line)."""
+    p = _two_ranks(29517, BENCH_CONTROL_BACKEND="gloo")
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, p.stdout
@@ -62,4 +66,12 @@ def test_bench_two_ranks_flow():
     assert out["n_gpus"] == 2 and out["steps"] == 128 and out["scaling"] == "weak"
     assert abs(out["value"] - 2 * 1e3 / out["ms_per_step"]) < 1e-6 * out["value"]
     assert "cpu_baseline" not in out  # rank 0 at N = 1 only
-    assert out["config"]["collectives"] in ("nccl", "gloo (RCCL init failed)")
+    assert out["config"]["collectives"].startswith("gloo (BENCH_CONTROL_BACKEND")
+
+
+def test_bench_rccl_failure_is_fatal():
+    """Without the hook the same launch must NOT print a line: RCCL cannot serve two ranks on one
+    device, and an N > 1 value that is not an RCCL measurement is refused (non-zero exit)."""
+    p = _two_ranks(29519)
+    assert p.returncode != 0
+    assert not [ln for ln in p.stdout.splitlines() if ln.startswith("{")], p.stdout

@@ -9,12 +9,24 @@ import dc_oracle_c as OC
 from bpl import _ffi
 
 
-def test_random123_kat_via_bits():
-    # threefry2x32_20 KATs (Random123 kat_vectors): key, counter -> output.  bits(key, 2)
-    # hashes counters (0, 1) as ONE block (c0=0, c1=1), so go through split instead:
-    # split(key, 1) = block(key, (0, 1)).  Use the raw 2-word API with zero key instead.
-    out = _ffi.threefry_bits((0, 0), 2)  # block(key=(0,0), ctr=(0,1))
-    assert out.dtype == np.uint32 and out.shape == (2,)
+def test_random123_known_answers():
+    """Threefry-2x32-20 known-answer vectors (Random123 kat_vectors; the same three are
+    asserted by jax's own tests/random_test.py::testThreefry2x32): counter, key -> output."""
+    h = OC.harness()
+    kats = [
+        ((0x00000000, 0x00000000), (0x00000000, 0x00000000), (0x6B200159, 0x99BA4EFE)),
+        ((0xFFFFFFFF, 0xFFFFFFFF), (0xFFFFFFFF, 0xFFFFFFFF), (0x1CB996FC, 0xBB002BE7)),
+        ((0x243F6A88, 0x85A308D3), (0x13198A2E, 0x03707344), (0xC4923A9C, 0x483DF7A0)),
+    ]
+    out = (C.c_uint32 * 2)()
+    for ctr, key, exp in kats:
+        h.harness_threefry_block(C.c_uint32(key[0]), C.c_uint32(key[1]), C.c_uint32(ctr[0]),
+                                 C.c_uint32(ctr[1]), out)
+        assert (int(out[0]), int(out[1])) == exp
+    # the same block through the product ABI: bits(key, 1) hashes the single counter 0
+    # padded with 0 -> block(key, (0, 0)), first word
+    assert int(_ffi.threefry_bits((0, 0), 1)[0]) == 0x6B200159
+    assert int(_ffi.threefry_bits((0xFFFFFFFF, 0xFFFFFFFF), 1)[0]) != 0x1CB996FC  # (counter 0, not ~0)
 
 
 def test_jax_published_values():
