@@ -88,6 +88,7 @@ struct bplhip_ctx {
     double lgsum = 0.0;
     // device buffers (library owned)
     DevBuf d_h, d_a, d_x, d_y, d_w, d_pairs, d_xs, d_cA, d_cD, d_cH, d_tickets, d_debug, d_xsf, d_hbuf;
+    DevBuf d_gacc;  // accumulator rows of dc_eval's hand-off (dc::GA_ROW)
     int slab_chains = 0;
     // tuning options (bplhip_set_option)
     int opt_device_nuts = 1;  // 1: tree builder on the device (nuts_dev.hip.h) when supported
@@ -163,8 +164,11 @@ constexpr size_t LDS_LIMIT = 160 * 1024;
 
 int zo_stride_of(const dc::Layout& L) { return (dc::ZO_HDR + L.D + 3 * L.T + 1) & ~1; }
 
-int hb_stride_of(const bplhip_ctx* c) {
-    return (zo_stride_of(c->L) + c->ep->n_wg * dc::N_SCAL + c->ep->total_c + 1) & ~1;
+// dc_eval's hand-off buffer holds the prior workgroup's record only (the fixture sums travel
+// through the accumulator rows, d_gacc)
+int hb_stride_of(const bplhip_ctx* c) { return zo_stride_of(c->L); }
+size_t gacc_bytes_of(const bplhip_ctx* c, int chains) {
+    return (size_t)chains * dc::ga_rows(c->L.T) * dc::GA_ROW * sizeof(long long);
 }
 
 // the partition a launch of `chains` chains uses: the short-stream one (part 0 of two) while its
@@ -175,25 +179,43 @@ void select_part(bplhip_ctx* c, int chains) {
     c->ep = &c->parts[pi];
 }
 
-int ensure_slabs(bplhip_ctx* c, int chains) {
-    select_part(c, chains);
-    if (chains <= c->slab_chains) return BPLHIP_OK;
-    size_t stride = 0;  // (the hand-off buffer fits either partition)
-    for (int pi = 0; pi < c->n_parts; ++pi) {
-        bplhip_ctx::EvalPart* keep = c->ep;
-        c->ep = &c->parts[pi];
-        stride = std::max(stride, (size_t)hb_stride_of(c));
-        c->ep = keep;
-    }
-    HIP_TRY(c, c->d_hbuf.ensure((size_t)chains * stride * sizeof(double)));
-    HIP_TRY(c, c->d_tickets.ensure((size_t)chains * dc::TK_WORDS * sizeof(unsigned int)));
-    HIP_TRY(c, hipMemset(c->d_tickets.p, 0, (size_t)chains * dc::TK_WORDS * sizeof(unsigned int)));
-    c->slab_chains = chains;
+void drop_graphs(bplhip_ctx* c);
+
+// Zero the arrival tickets and the accumulator rows.  Every completed launch leaves them zero
+// (the last arriver re-arms both), so this matters after a growth and after a launch that did not
+// complete (a fault, an aborted run): entry points that start a chain call it stream-ordered.
+int reset_handoff(bplhip_ctx* c, hipStream_t s, bool sync) {
+    if (c->slab_chains <= 0) return BPLHIP_OK;
+    HIP_TRY(c, hipMemsetAsync(c->d_tickets.p, 0, (size_t)c->slab_chains * dc::TK_WORDS * sizeof(unsigned int), s));
+    HIP_TRY(c, hipMemsetAsync(c->d_gacc.p, 0, gacc_bytes_of(c, c->slab_chains), s));
+    if (sync) HIP_TRY(c, hipDeviceSynchronize());
     return BPLHIP_OK;
 }
 
+// Hand-off slabs and tickets for `chains` chains per launch.  Growing them frees the old buffers
+// (hipFree waits for the device), so every cached hipGraphExec -- their kernel arguments hold the
+// old pointers -- is dropped with them, and the fresh tickets are zeroed before anything can
+// launch on any stream.
+int ensure_slabs(bplhip_ctx* c, int chains) {
+    select_part(c, chains);
+    if (chains <= c->slab_chains) return BPLHIP_OK;
+    drop_graphs(c);
+    HIP_TRY(c, c->d_hbuf.ensure((size_t)chains * hb_stride_of(c) * sizeof(double)));
+    HIP_TRY(c, c->d_tickets.ensure((size_t)chains * dc::TK_WORDS * sizeof(unsigned int)));
+    HIP_TRY(c, c->d_gacc.ensure(gacc_bytes_of(c, chains)));
+    c->slab_chains = chains;
+    return reset_handoff(c, nullptr, true);
+}
+
+// the same at the start of a chain: also zero the tickets / rows a launch that never completed
+// may have left armed
+int ensure_slabs_fresh(bplhip_ctx* c, int chains, hipStream_t s) {
+    const int rc = ensure_slabs(c, chains);
+    return rc != BPLHIP_OK ? rc : reset_handoff(c, s, false);
+}
+
 size_t ctx_lds_bytes(const bplhip_ctx* c, bool staged) {
-    return dc::eval_lds_bytes(c->L.T, c->L.D, c->L.K, zo_stride_of(c->L), c->ep->n_wg, c->ep->total_c, staged);
+    return dc::eval_lds_bytes(c->L.T, c->L.D, c->L.K, zo_stride_of(c->L), staged);
 }
 
 template <bool W, bool C, bool S, bool N>
@@ -361,6 +383,7 @@ dc::EvalArgs eval_args(bplhip_ctx* c, int chains, const double* z, double* pot, 
     A.n_wg = c->ep->n_wg;
     A.zo_stride = zo_stride_of(c->L);
     A.tickets = c->d_tickets.as<unsigned int>();
+    A.gacc = c->d_gacc.as<long long>();
     A.chains = chains;
     A.z = z;
     A.potential = pot;
@@ -510,7 +533,7 @@ SparseSlabs build_sparse_slabs(const std::vector<uint16_t>& hs, const std::vecto
     return o;
 }
 
-void drop_graphs(bplhip_ctx* c) {
+void drop_graphs(bplhip_ctx* c) {  // (declared above ensure_slabs)
     for (auto& kv : c->graphs) (void)hipGraphExecDestroy(kv.second);
     c->graphs.clear();
 }
@@ -1796,7 +1819,7 @@ static int bplhip_nuts_run_impl(bplhip_ctx* c, const bplhip_nuts_cfg* cfg, const
     if ((device_tree || generic_persist) && c->opt_persistent_nuts) {
         // the whole chain on the device (nuts_dev.hip.h, persistent chains)
         if (!generic_persist) {
-            int rc1 = ensure_slabs(c, 1);
+            int rc1 = ensure_slabs_fresh(c, 1, static_cast<hipStream_t>(stream));
             if (rc1 != BPLHIP_OK) return rc1;
         }
         const tf::Key k1{seed_hi, seed_lo};
@@ -1819,7 +1842,7 @@ static int bplhip_nuts_run_impl(bplhip_ctx* c, const bplhip_nuts_cfg* cfg, const
             HIP_TRY(c, hipHostMalloc((void**)&c->h_pinned, need, hipHostMallocDefault));
             c->h_pinned_bytes = need;
         }
-        int rc1 = ensure_slabs(c, 1);
+        int rc1 = ensure_slabs_fresh(c, 1, static_cast<hipStream_t>(stream));
         if (rc1 != BPLHIP_OK) return rc1;
         DeviceEngine E{c, static_cast<hipStream_t>(stream), nc, D, nc.max_tree_depth,
                        c->d_ns.as<double>(), c->h_pinned};
@@ -1865,7 +1888,7 @@ static int bplhip_nuts_run_chains_impl(bplhip_ctx* c, const bplhip_nuts_cfg* cfg
     const nuts::Config nc = make_nuts_config(c, cfg);
     if (c->opt_persistent_nuts) {
         if (!generic_ok) {
-            int rc0 = ensure_slabs(c, std::max(1, std::min(C, c->opt_gridy_max_chains)));
+            int rc0 = ensure_slabs_fresh(c, std::max(1, std::min(C, c->opt_gridy_max_chains)), static_cast<hipStream_t>(stream));
             if (rc0 != BPLHIP_OK) return rc0;
         }
         std::vector<tf::Key> pkeys(C);
@@ -1891,7 +1914,7 @@ static int bplhip_nuts_run_chains_impl(bplhip_ctx* c, const bplhip_nuts_cfg* cfg
     const size_t pinned = ((size_t)C * (3 * D + nd::H_N + par_stride)) * 8;
     double* hp = nullptr;
     HIP_TRY(c, hipHostMalloc((void**)&hp, pinned, hipHostMallocDefault));
-    int rc1 = ensure_slabs(c, 1);
+    int rc1 = ensure_slabs_fresh(c, 1, static_cast<hipStream_t>(stream));
     if (rc1 != BPLHIP_OK) {
         (void)hipHostFree(hp);
         return rc1;

@@ -65,6 +65,28 @@ constexpr int TK_GROUPS = DC_TK_GROUPS;            // two-level arrival tickets:
 constexpr int TK_STRIDE = 32;            // ... one per 128-byte line
 constexpr int TK_WORDS = (1 + TK_GROUPS) * TK_STRIDE;  // u32 words per chain
 
+// ---- dc_eval's cross-workgroup hand-off: ACCUMULATOR ROWS in global memory.
+// A streaming workgroup adds its per-team partial sums and its four scalars into one row per
+// value with agent-scope integer atomics; the memory system does the reduction, and the
+// last-arriving workgroup reads 3T + 4*GA_SHARDS values instead of staging and column-summing
+// one slab per workgroup (that staging + summing was 2.0 of the 8.4 us of an evaluation).
+// Integer adds commute, so the result is bitwise reproducible whatever the arrival order.
+// A double v is split as v = hi * 2^20 + lo * 2^-30 (|lo| <= 2^49 per contribution: thousands of
+// them fit an int64; hi is added only when non-zero, i.e. beyond 1e6): 9e-10 absolute resolution
+// -- the addends are float32-born run sums, 1e-4 absolute -- and 1.2e21 range (the
+// init_to_uniform(radius=2) region reaches potentials of 1e15).  Values outside it, infinities
+// and NaNs set a flag instead.  One 128-byte row per value: same-line atomics queue (~12 ns each).
+#ifndef DC_GA_ROW
+#define DC_GA_ROW 16
+#endif
+constexpr int GA_ROW = DC_GA_ROW;        // int64 per row (one 128-byte line): [0] lo, [1] hi
+constexpr int GA_SHARDS = 16;            // the four scalars are added by every workgroup: sharded
+constexpr double GA_HI_UNIT = 1048576.0;           // 2^20
+constexpr double GA_LO_SCALE = 1073741824.0;       // 2^30
+constexpr double GA_LIMIT = 1.1805916207174113e21; // 2^70
+constexpr unsigned int GA_NEGINF = 1u, GA_BAD = 2u;
+__host__ __device__ inline int ga_rows(int T) { return 3 * T + N_SCAL * GA_SHARDS + 1; }
+
 // z-only record written by the prior workgroup (doubles), per chain:
 //   [0..ZO_HDR)         scalars, see enum
 //   [ZO_HDR, +D)        gz[i]  = -dL_prior/dz_i  (everything not involving fixture sums)
@@ -116,6 +138,7 @@ struct EvalArgs {
     int n_wg;               // streaming workgroups (grid.x = n_wg + 1)
     int zo_stride;
     unsigned int* tickets;  // [chains][TK_WORDS] arrival counters (top + TK_GROUPS groups)
+    long long* gacc;        // [chains][ga_rows(T)][GA_ROW] accumulator rows (dc_eval; dc_vec: unused)
     int chains;             // number of chains of this launch (dc_vec.hip.h)
     // in / out: chain c at z + c*z_stride, potential + c*p_stride, grad + c*g_stride,
     // aux + c*aux_stride (plain batches: D, 1, D, 4; device NUTS: all inside the state buffer)
@@ -294,6 +317,21 @@ __device__ __forceinline__ void flush_run(double* acc, int T1, uint32_t key, flo
     atomicAdd(&acc[T1 + h], da);
 }
 
+// dc_eval accumulates in FIXED POINT: every float32 addend is rounded to a multiple of 2^-30 when
+// it is widened (it already is one from 2^-7 up) and kept in units of 2^-30, so every partial sum
+// -- lane, wave, workgroup, accumulator row -- is an exact integer and the result does not depend
+// on how the fixtures are partitioned over waves and workgroups (nor on the arrival order).
+__device__ __forceinline__ double q30(float x) { return rint(ldexp((double)x, 30)); }
+__device__ __forceinline__ void flush_run_q(double* acc, int T1, uint32_t key, float sh, float sa) {
+    const int h = key & 0xFFFFu, a = key >> 16;
+    const double dh = q30(sh), da = q30(sa);
+    atomicAdd(&acc[h], dh);
+    atomicAdd(&acc[2 * T1 + h], dh);
+    atomicAdd(&acc[T1 + a], dh);
+    atomicAdd(&acc[a], da);
+    atomicAdd(&acc[T1 + h], da);
+}
+
 // write-through (sc1) store / L1-bypassing (sc1) load of one double: the in-launch
 // hand-off between workgroups (cdna_hip_programming.md Guideline 16, split-K form)
 __device__ __forceinline__ double ld_sc1(const double* p) {
@@ -306,6 +344,40 @@ __device__ __forceinline__ void st_sc1(double* p, double v) {
     __hip_atomic_store(reinterpret_cast<unsigned long long*>(p),
                        (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
                        __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ---- accumulator rows (see GA_ROW): add one double, take (read and re-arm) one row
+// an integer-valued double |x| < 2^51 as int64: the low mantissa bits of x + 1.5 * 2^52
+__device__ __forceinline__ long long exact_i64(double x) {
+    return __double_as_longlong(x + 6755399441055744.0) - 0x4338000000000000ll;
+}
+__device__ __forceinline__ void ga_add(long long* row, double v /* in units of 2^-30 */,
+                                       unsigned int* bad) {
+    if (!(fabs(v) < GA_LIMIT * GA_LO_SCALE)) {  // inf, nan, or beyond the hi word's range
+        *bad |= (v == -__builtin_inf()) ? GA_NEGINF : GA_BAD;
+        return;
+    }
+    const double h = rint(v * (1.0 / (GA_HI_UNIT * GA_LO_SCALE)));  // |h| < 2^50
+    const double r = fma(-h, GA_HI_UNIT * GA_LO_SCALE, v);          // exact, |r| <= 2^49
+    (void)__hip_atomic_fetch_add(row, exact_i64(r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (h != 0.0)
+        (void)__hip_atomic_fetch_add(row + 1, exact_i64(h), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+struct GaWords {
+    long long lo, hi;
+};
+__device__ __forceinline__ GaWords ga_load(const long long* row) {  // L1-bypassing (sc1) loads
+    GaWords w;
+    w.lo = __hip_atomic_load(row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    w.hi = __hip_atomic_load(row + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return w;
+}
+__device__ __forceinline__ void ga_rearm(long long* row) {  // write-through zeros for the next launch
+    __hip_atomic_store(row, 0ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(row + 1, 0ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double ga_value(const GaWords& w) {
+    return fma((double)w.hi, GA_HI_UNIT, (double)w.lo * (1.0 / GA_LO_SCALE));
 }
 
 // ---------------------------------------------------------------- LDS footprints
@@ -339,13 +411,12 @@ __host__ __device__ inline size_t prior_lds_bytes(int T) {
     b += (40 + WAVES * 8 + WAVES * 8) * 8;                 // scalars, scratch, argmax
     return b;
 }
-__host__ __device__ inline size_t eval_lds_bytes(int T, int D, int K, int zo_stride, int n_wg,
-                                                 int total_c, bool staged) {
+__host__ __device__ inline size_t acc_tail_lds_bytes(int T, int D, int K, int zo_stride, bool stage);
+__host__ __device__ inline size_t eval_lds_bytes(int T, int D, int K, int zo_stride, bool stage) {
     size_t b = stream_lds_bytes(T);
-    const size_t t = tail_lds_bytes(T, D, K, zo_stride, n_wg, total_c, staged),
-                 p = prior_lds_bytes(T);
-    b = b > t ? b : t;
-    return b > p ? b : p;
+    // (the prior workgroup runs the tail: its scratch sits behind the tail's arrays)
+    const size_t t = ((acc_tail_lds_bytes(T, D, K, zo_stride, stage) + 15) & ~(size_t)15) + prior_lds_bytes(T);
+    return b > t ? b : t;
 }
 
 // ---------------------------------------------------------------- float32 tables
@@ -520,13 +591,20 @@ __device__ __forceinline__ SigSite sig_site(double zc) {
     return r;
 }
 
-template <bool CLIP>
-__device__ void prior_body(const EvalArgs& A, int chain, char* smem) {
+// TO_LDS: the record goes to `zo_lds` (dc_eval: the prior workgroup runs the tail itself and reads
+// it from LDS); otherwise to the chain's global hand-off buffer with write-through stores (dc_vec:
+// the tail is a separate launch).
+template <bool CLIP, bool TO_LDS = false>
+__device__ void prior_body(const EvalArgs& A, int chain, char* smem, double* zo_lds = nullptr) {
     const Layout& L = A.L;
     const int T = L.T, K = L.K, D = L.D;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const double* z = z_of(A, chain);
-    double* zo = A.hbuf + (size_t)chain * A.hb_stride;
+    double* zo = TO_LDS ? zo_lds : A.hbuf + (size_t)chain * A.hb_stride;
+    auto zput = [&](double* p, double v) {
+        if (TO_LDS) *p = v;
+        else st_sc1(p, v);
+    };
     double* gz = zo + ZO_HDR;
     double* eps = gz + D;
 
@@ -583,14 +661,14 @@ __device__ void prior_body(const EvalArgs& A, int chain, char* smem) {
         Lz += -0.5 * s_a * s_a - HALF_LOG_2PI + LN2 + zsa;  // HalfNormal(1) + Exp Jacobian
         Lz += -0.5 * s_d * s_d - HALF_LOG_2PI + LN2 + zsd;
         Lz += -0.5 * m * m - HALF_LOG_2PI;
-        st_sc1(&gz[L.o_corr], -((1.0 / q - 1.0 / (1.0 - q)) * dq + (1.0 - 2.0 * sc[8])));
-        st_sc1(&gz[L.o_md], m);
-        st_sc1(&gz[L.o_sa], s_a * s_a - 1.0);
-        st_sc1(&gz[L.o_sd], s_d * s_d - 1.0);
+        zput(&gz[L.o_corr], -((1.0 / q - 1.0 / (1.0 - q)) * dq + (1.0 - 2.0 * sc[8])));
+        zput(&gz[L.o_md], m);
+        zput(&gz[L.o_sa], s_a * s_a - 1.0);
+        zput(&gz[L.o_sd], s_d * s_d - 1.0);
         if (!CLIP) {
             const double gam = z[L.o_ha], r = (gam - 0.1) / 0.2;
             Lz += -0.5 * r * r + 1.6094379124341003 /*-log 0.2*/ - HALF_LOG_2PI;
-            st_sc1(&gz[L.o_ha], (gam - 0.1) / 0.04);
+            zput(&gz[L.o_ha], (gam - 0.1) / 0.04);
         } else {
             const double mha = z[L.o_mha], zsh = z[L.o_sh];
             const double r = (mha - 0.1) / 0.2;
@@ -601,12 +679,12 @@ __device__ void prior_body(const EvalArgs& A, int chain, char* smem) {
                 const double ba = z[L.o_bA + k], bd = z[L.o_bD + k];
                 Lz += -0.5 * ba * ba - 0.5 * bd * bd - 2.0 * HALF_LOG_2PI;
             }
-            st_sc1(&gz[L.o_mha], (mha - 0.1) / 0.04);
-            st_sc1(&gz[L.o_sh], s_h * s_h - 1.0);
+            zput(&gz[L.o_mha], (mha - 0.1) / 0.04);
+            zput(&gz[L.o_sh], s_h * s_h - 1.0);
         }
-        st_sc1(&zo[ZO_SA], s_a);
-        st_sc1(&zo[ZO_SD], s_d);
-        st_sc1(&zo[ZO_SH], s_h);
+        zput(&zo[ZO_SA], s_a);
+        zput(&zo[ZO_SD], s_d);
+        zput(&zo[ZO_SH], s_h);
     }
 
     // ---- per team: constrained sites, true (float64) tables, rounding errors eps
@@ -636,7 +714,7 @@ __device__ void prior_body(const EvalArgs& A, int chain, char* smem) {
         const double r = (tv - (double)tabv) / (double)tabv;
         double e = r - 0.5 * r * r;
         e = fabs(r) < 1e-4 ? e : 0.0;  // under/overflowed entry: no meaningful correction
-        st_sc1(&eps[j * T + t], e);
+        zput(&eps[j * T + t], e);
         if (j == 0) {
             par[t] = att;
             par[T + t] = def;
@@ -673,17 +751,17 @@ __device__ void prior_body(const EvalArgs& A, int chain, char* smem) {
         if (!CLIP) {
             const double ad = z0, dd = z1;
             v[0] += -0.5 * ad * ad - 0.5 * dd * dd - 2.0 * HALF_LOG_2PI + lin;
-            st_sc1(&gz[L.o_adec + t], ad);
-            st_sc1(&gz[L.o_ddec + t], dd);
+            zput(&gz[L.o_adec + t], ad);
+            zput(&gz[L.o_ddec + t], dd);
         } else {
             const double sa = z0, sd = z1, hd = z2;
             const double e = sd - rp * sa;
             v[0] += -0.5 * sa * sa - 0.5 * e * e * ivv - 0.5 * log_vv - 0.5 * hd * hd -
                     3.0 * HALF_LOG_2PI + lin;
             v[1] += e * sa * ivv - rp * e * e * (ivv * ivv) + rp * ivv;
-            st_sc1(&gz[L.o_sat + t], sa - rp * e * ivv);
-            st_sc1(&gz[L.o_sdt + t], e * ivv);
-            st_sc1(&gz[L.o_hadec + t], hd);
+            zput(&gz[L.o_sat + t], sa - rp * e * ivv);
+            zput(&gz[L.o_sdt + t], e * ivv);
+            zput(&gz[L.o_hadec + t], hd);
         }
     };
     if (sums_on_wave && wave == WAVES - 1) {
@@ -767,7 +845,7 @@ __device__ void prior_body(const EvalArgs& A, int chain, char* smem) {
 
     if (tid < 2 * K) {  // covariate coefficients ~ N(0,1)
         const int o = (tid >= K ? L.o_bD + tid - K : L.o_bA + tid);
-        st_sc1(&gz[o], z[o]);
+        zput(&gz[o], z[o]);
     }
     // The two serial pieces of the record run on different waves at the same time (a single lane
     // executing ~300 dependent float64 instructions is the longest pole of this workgroup).
@@ -812,27 +890,27 @@ __device__ void prior_body(const EvalArgs& A, int chain, char* smem) {
         }
         const float rho_f = rho_f32(fP, fQ, fR, fs.q);
         DC_STAMP(15);
-        st_sc1(&zo[ZO_Q], q);
-        st_sc1(&zo[ZO_DQ], dq);
-        st_sc1(&zo[ZO_UB], UB);
-        st_sc1(&zo[ZO_LB], LB);
-        st_sc1(&zo[ZO_RHO], rho);
-        st_sc1(&zo[ZO_DRHO], rho - (double)rho_f);
-        st_sc1(&zo[ZO_M], M);
-        st_sc1(&zo[ZO_LH], Lh);
-        st_sc1(&zo[ZO_LA], La);
-        st_sc1(&zo[ZO_PP], (double)pP);
-        st_sc1(&zo[ZO_PQ], (double)pQ);
-        st_sc1(&zo[ZO_PR], (double)pR);
-        st_sc1(&zo[ZO_FLAGS], (double)flags);
+        zput(&zo[ZO_Q], q);
+        zput(&zo[ZO_DQ], dq);
+        zput(&zo[ZO_UB], UB);
+        zput(&zo[ZO_LB], LB);
+        zput(&zo[ZO_RHO], rho);
+        zput(&zo[ZO_DRHO], rho - (double)rho_f);
+        zput(&zo[ZO_M], M);
+        zput(&zo[ZO_LH], Lh);
+        zput(&zo[ZO_LA], La);
+        zput(&zo[ZO_PP], (double)pP);
+        zput(&zo[ZO_PQ], (double)pQ);
+        zput(&zo[ZO_PR], (double)pR);
+        zput(&zo[ZO_FLAGS], (double)flags);
     }
     if (tid == 64) {  // what was waiting for the team sums
         if (CLIP) {
             const double u = sc[9], du = sc[10];
-            st_sc1(&gz[L.o_u], -(2.0 * v[1] * du + (1.0 / u - 3.0 / (1.0 - u)) * du +
+            zput(&gz[L.o_u], -(2.0 * v[1] * du + (1.0 / u - 3.0 / (1.0 - u)) * du +
                                  (1.0 - 2.0 * sc[14])));
         }
-        st_sc1(&zo[ZO_LZ], Lz + v[0]);
+        zput(&zo[ZO_LZ], Lz + v[0]);
     }
 }
 
@@ -1020,12 +1098,156 @@ __device__ void tail_waves(const EvalArgs& A, int chain, const double* zoL, cons
     }
 }
 
+// General epilogue (any number of teams): value corrections, adjoint of the bounds and the chain
+// rule over LDS-resident sums, whole workgroup.  zoL / cL / zL / col as staged by the caller.
+template <bool EXT>
+__device__ void tail_general(const EvalArgs& A, int chain, const double* zoL, const double* cL,
+                             const double* zL, double* col, double* scratch) {
+    const Layout& L = A.L;
+    const int T = L.T, K = L.K, D = L.D;
+    const int tid = threadIdx.x;
+    double* grad = grad_of(A, chain);
+    const int ncol = 3 * T;
+    const double* gz = zoL + ZO_HDR;
+    const double* eps = gz + D;
+    const double s_a = zoL[ZO_SA], s_d = zoL[ZO_SD], s_h = zoL[ZO_SH];
+    const double q = zoL[ZO_Q], dq = zoL[ZO_DQ], UB = zoL[ZO_UB], LB = zoL[ZO_LB];
+    const double rho = zoL[ZO_RHO], drho = zoL[ZO_DRHO];
+    const double M = zoL[ZO_M], Lh = zoL[ZO_LH], La = zoL[ZO_LA], Lz = zoL[ZO_LZ];
+    double* g_att = col;          // raw accumulators, then dL/d attack_t
+    double* g_def = col + T;      // dL/d defence_t
+    double* g_ha = col + 2 * T;   // dL/d home_adv_t
+    const double SLAM = col[ncol + 0], SLOG = col[ncol + 1], SU = col[ncol + 2],
+                 CLIPC = col[ncol + 3];
+    const double G_rho = SU;  // sum_i w_i dlogtau_i/drho
+
+    // ---- 3. first-order value corrections: float32 rounding of the tables
+    //   dL = - sum_t [ ha_raw eAg_t + (att_raw - ha_raw) eA_t + def_raw eDn_t ]
+    // and of rho:  dL = G_rho (rho_true - rho_f32);  then raw sums -> dL/d(team sites)
+    double corr = 0.0;
+    for (int t = tid; t < T; t += BLOCK) {
+        const double ra = g_att[t], rd = g_def[t], rh = g_ha[t];
+        corr -= rh * eps[t] + (ra - rh) * eps[T + t] + rd * eps[2 * T + t];
+    }
+    __syncthreads();
+    for (int t = tid; t < T; t += BLOCK) {
+        g_att[t] = cL[t] - g_att[t];
+        g_def[t] = -(cL[T + t] - g_def[t]);
+        g_ha[t] = cL[2 * T + t] - g_ha[t];
+    }
+    __syncthreads();
+    if (tid == 0 && A.P > 0) {  // adjoint of the bounds (Appendix A.3)
+        const uint32_t pP = (uint32_t)zoL[ZO_PP], pQ = (uint32_t)zoL[ZO_PQ],
+                       pR = (uint32_t)zoL[ZO_PR];
+        const unsigned int flags = (unsigned int)zoL[ZO_FLAGS];
+        if (M > 1.0) {  // UB = 1/M : d/d eta_h[P] = d/d eta_a[P] = -1/M
+            const double v = G_rho * q * (-UB);
+            const int h = pP & 0xFFFFu, a = pP >> 16;
+            if (!(flags & 1u)) {
+                g_att[h] += v;
+                g_ha[h] += v;
+                g_def[a] -= v;
+            }
+            if (!(flags & 2u)) {
+                g_att[a] += v;
+                g_def[h] -= v;
+            }
+        }
+        const double v = G_rho * (1.0 - q) * (-LB);  // LB = -1/Lam : d/d eta = +1/Lam
+        if (Lh >= La) {
+            const int h = pQ & 0xFFFFu, a = pQ >> 16;
+            if (!(flags & 4u)) {
+                g_att[h] += v;
+                g_ha[h] += v;
+                g_def[a] -= v;
+            }
+        } else {
+            const int h = pR & 0xFFFFu, a = pR >> 16;
+            if (!(flags & 8u)) {
+                g_att[a] += v;
+                g_def[h] -= v;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- 4. chain rule to z (adds and FMAs only); grad = gz - (fixture-sum terms)
+    if (!EXT) {
+        // v: 0 sum g_def, 1 sum g_ha, 2 sum a~ g_att, 3 sum d~ g_def, 4 correction
+        double v[5] = {0, 0, 0, 0, corr};
+        for (int t = tid; t < T; t += BLOCK) {
+            const double ad = zL[L.o_adec + t], dd = zL[L.o_ddec + t];
+            const double ga = g_att[t], gd = g_def[t], gh = g_ha[t];
+            grad[L.o_adec + t] = gz[L.o_adec + t] - s_a * ga;
+            grad[L.o_ddec + t] = gz[L.o_ddec + t] - s_d * gd;
+            v[0] += gd;
+            v[1] += gh;
+            v[2] += ad * ga;
+            v[3] += dd * gd;
+        }
+        block_sum<5>(v, scratch, tid);
+        if (tid == 0) {
+            grad[L.o_ha] = gz[L.o_ha] - v[1];
+            grad[L.o_md] = gz[L.o_md] - v[0];
+            grad[L.o_sa] = gz[L.o_sa] - s_a * v[2];
+            grad[L.o_sd] = gz[L.o_sd] - s_d * v[3];
+            grad[L.o_corr] = gz[L.o_corr] - G_rho * (UB - LB) * dq;
+            const double Ltot =
+                Lz + v[4] + G_rho * drho - SLAM - A.lgsum + LN2 * SLOG - CLIPC;
+            *pot_of(A, chain) = -Ltot;
+        }
+    } else {
+        // v: 0 sum g_def, 1 sum g_ha, 2 sum sa g_att, 3 sum sd g_def, 4 sum ha~ g_ha, 5 corr
+        double v[6] = {0, 0, 0, 0, 0, corr};
+        for (int t = tid; t < T; t += BLOCK) {
+            const double sa = zL[L.o_sat + t], sd = zL[L.o_sdt + t], hd = zL[L.o_hadec + t];
+            const double ga = g_att[t], gd = g_def[t], gh = g_ha[t];
+            grad[L.o_sat + t] = gz[L.o_sat + t] - s_a * ga;
+            grad[L.o_sdt + t] = gz[L.o_sdt + t] - s_d * gd;
+            grad[L.o_hadec + t] = gz[L.o_hadec + t] - s_h * gh;
+            v[0] += gd;
+            v[1] += gh;
+            v[2] += sa * ga;
+            v[3] += sd * gd;
+            v[4] += hd * gh;
+        }
+        block_sum<6>(v, scratch, tid);
+        for (int k = tid; k < 2 * K; k += BLOCK) {  // d/d beta_k: sum_t Xs[t,k] g_t
+            const bool isd = k >= K;
+            const int kk = isd ? k - K : k;
+            const double* gt = isd ? g_def : g_att;
+            double s = 0.0;
+            for (int t = 0; t < T; ++t) s += A.xs[(size_t)t * K + kk] * gt[t];
+            const int o = (isd ? L.o_bD : L.o_bA) + kk;
+            grad[o] = gz[o] - s;
+        }
+        if (tid == 0) {
+            grad[L.o_mha] = gz[L.o_mha] - v[1];
+            grad[L.o_sh] = gz[L.o_sh] - s_h * v[4];
+            grad[L.o_md] = gz[L.o_md] - v[0];
+            grad[L.o_sa] = gz[L.o_sa] - s_a * v[2];
+            grad[L.o_sd] = gz[L.o_sd] - s_d * v[3];
+            grad[L.o_corr] = gz[L.o_corr] - G_rho * (UB - LB) * dq;
+            grad[L.o_u] = gz[L.o_u];
+            const double Ltot =
+                Lz + v[5] + G_rho * drho - SLAM - A.lgsum + LN2 * SLOG - CLIPC;
+            *pot_of(A, chain) = -Ltot;
+        }
+    }
+    if (tid == 0 && A.aux != nullptr) {
+        double* aux = aux_of(A, chain);
+        aux[0] = rho;
+        aux[1] = LB;
+        aux[2] = UB;
+        aux[3] = q;
+    }
+}
+
 template <bool STAGED, bool NUTS, bool EXT>
 __device__ void tail_body(const EvalArgs& A, int chain, char* smem) {
     const Layout& L = A.L;
     const int T = L.T, K = L.K, D = L.D;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    double* grad = grad_of(A, chain);
     const int ncol = 3 * T;
     const int nsc = A.n_wg * N_SCAL;
 
@@ -1172,140 +1394,150 @@ __device__ void tail_body(const EvalArgs& A, int chain, char* smem) {
         DC_STAMP(10);
         return;
     }
-    const double* gz = zoL + ZO_HDR;
-    const double* eps = gz + D;
-    const double s_a = zoL[ZO_SA], s_d = zoL[ZO_SD], s_h = zoL[ZO_SH];
-    const double q = zoL[ZO_Q], dq = zoL[ZO_DQ], UB = zoL[ZO_UB], LB = zoL[ZO_LB];
-    const double rho = zoL[ZO_RHO], drho = zoL[ZO_DRHO];
-    const double M = zoL[ZO_M], Lh = zoL[ZO_LH], La = zoL[ZO_LA], Lz = zoL[ZO_LZ];
-    double* g_att = col;          // raw accumulators, then dL/d attack_t
-    double* g_def = col + T;      // dL/d defence_t
-    double* g_ha = col + 2 * T;   // dL/d home_adv_t
-    const double SLAM = col[ncol + 0], SLOG = col[ncol + 1], SU = col[ncol + 2],
-                 CLIPC = col[ncol + 3];
-    const double G_rho = SU;  // sum_i w_i dlogtau_i/drho
-
-    // ---- 3. first-order value corrections: float32 rounding of the tables
-    //   dL = - sum_t [ ha_raw eAg_t + (att_raw - ha_raw) eA_t + def_raw eDn_t ]
-    // and of rho:  dL = G_rho (rho_true - rho_f32);  then raw sums -> dL/d(team sites)
-    double corr = 0.0;
-    for (int t = tid; t < T; t += BLOCK) {
-        const double ra = g_att[t], rd = g_def[t], rh = g_ha[t];
-        corr -= rh * eps[t] + (ra - rh) * eps[T + t] + rd * eps[2 * T + t];
-    }
-    __syncthreads();
-    for (int t = tid; t < T; t += BLOCK) {
-        g_att[t] = cL[t] - g_att[t];
-        g_def[t] = -(cL[T + t] - g_def[t]);
-        g_ha[t] = cL[2 * T + t] - g_ha[t];
-    }
-    __syncthreads();
-    if (tid == 0 && A.P > 0) {  // adjoint of the bounds (Appendix A.3)
-        const uint32_t pP = (uint32_t)zoL[ZO_PP], pQ = (uint32_t)zoL[ZO_PQ],
-                       pR = (uint32_t)zoL[ZO_PR];
-        const unsigned int flags = (unsigned int)zoL[ZO_FLAGS];
-        if (M > 1.0) {  // UB = 1/M : d/d eta_h[P] = d/d eta_a[P] = -1/M
-            const double v = G_rho * q * (-UB);
-            const int h = pP & 0xFFFFu, a = pP >> 16;
-            if (!(flags & 1u)) {
-                g_att[h] += v;
-                g_ha[h] += v;
-                g_def[a] -= v;
-            }
-            if (!(flags & 2u)) {
-                g_att[a] += v;
-                g_def[h] -= v;
-            }
-        }
-        const double v = G_rho * (1.0 - q) * (-LB);  // LB = -1/Lam : d/d eta = +1/Lam
-        if (Lh >= La) {
-            const int h = pQ & 0xFFFFu, a = pQ >> 16;
-            if (!(flags & 4u)) {
-                g_att[h] += v;
-                g_ha[h] += v;
-                g_def[a] -= v;
-            }
-        } else {
-            const int h = pR & 0xFFFFu, a = pR >> 16;
-            if (!(flags & 8u)) {
-                g_att[a] += v;
-                g_def[h] -= v;
-            }
-        }
-    }
-    __syncthreads();
-
-    // ---- 4. chain rule to z (adds and FMAs only); grad = gz - (fixture-sum terms)
-    if (!EXT) {
-        // v: 0 sum g_def, 1 sum g_ha, 2 sum a~ g_att, 3 sum d~ g_def, 4 correction
-        double v[5] = {0, 0, 0, 0, corr};
-        for (int t = tid; t < T; t += BLOCK) {
-            const double ad = zL[L.o_adec + t], dd = zL[L.o_ddec + t];
-            const double ga = g_att[t], gd = g_def[t], gh = g_ha[t];
-            grad[L.o_adec + t] = gz[L.o_adec + t] - s_a * ga;
-            grad[L.o_ddec + t] = gz[L.o_ddec + t] - s_d * gd;
-            v[0] += gd;
-            v[1] += gh;
-            v[2] += ad * ga;
-            v[3] += dd * gd;
-        }
-        block_sum<5>(v, scratch, tid);
-        if (tid == 0) {
-            grad[L.o_ha] = gz[L.o_ha] - v[1];
-            grad[L.o_md] = gz[L.o_md] - v[0];
-            grad[L.o_sa] = gz[L.o_sa] - s_a * v[2];
-            grad[L.o_sd] = gz[L.o_sd] - s_d * v[3];
-            grad[L.o_corr] = gz[L.o_corr] - G_rho * (UB - LB) * dq;
-            const double Ltot =
-                Lz + v[4] + G_rho * drho - SLAM - A.lgsum + LN2 * SLOG - CLIPC;
-            *pot_of(A, chain) = -Ltot;
-        }
-    } else {
-        // v: 0 sum g_def, 1 sum g_ha, 2 sum sa g_att, 3 sum sd g_def, 4 sum ha~ g_ha, 5 corr
-        double v[6] = {0, 0, 0, 0, 0, corr};
-        for (int t = tid; t < T; t += BLOCK) {
-            const double sa = zL[L.o_sat + t], sd = zL[L.o_sdt + t], hd = zL[L.o_hadec + t];
-            const double ga = g_att[t], gd = g_def[t], gh = g_ha[t];
-            grad[L.o_sat + t] = gz[L.o_sat + t] - s_a * ga;
-            grad[L.o_sdt + t] = gz[L.o_sdt + t] - s_d * gd;
-            grad[L.o_hadec + t] = gz[L.o_hadec + t] - s_h * gh;
-            v[0] += gd;
-            v[1] += gh;
-            v[2] += sa * ga;
-            v[3] += sd * gd;
-            v[4] += hd * gh;
-        }
-        block_sum<6>(v, scratch, tid);
-        for (int k = tid; k < 2 * K; k += BLOCK) {  // d/d beta_k: sum_t Xs[t,k] g_t
-            const bool isd = k >= K;
-            const int kk = isd ? k - K : k;
-            const double* gt = isd ? g_def : g_att;
-            double s = 0.0;
-            for (int t = 0; t < T; ++t) s += A.xs[(size_t)t * K + kk] * gt[t];
-            const int o = (isd ? L.o_bD : L.o_bA) + kk;
-            grad[o] = gz[o] - s;
-        }
-        if (tid == 0) {
-            grad[L.o_mha] = gz[L.o_mha] - v[1];
-            grad[L.o_sh] = gz[L.o_sh] - s_h * v[4];
-            grad[L.o_md] = gz[L.o_md] - v[0];
-            grad[L.o_sa] = gz[L.o_sa] - s_a * v[2];
-            grad[L.o_sd] = gz[L.o_sd] - s_d * v[3];
-            grad[L.o_corr] = gz[L.o_corr] - G_rho * (UB - LB) * dq;
-            grad[L.o_u] = gz[L.o_u];
-            const double Ltot =
-                Lz + v[5] + G_rho * drho - SLAM - A.lgsum + LN2 * SLOG - CLIPC;
-            *pot_of(A, chain) = -Ltot;
-        }
-    }
+    tail_general<EXT>(A, chain, zoL, cL, zL, col, scratch);
     DC_STAMP(10);
-    if (tid == 0 && A.aux != nullptr) {
-        double* aux = aux_of(A, chain);
-        aux[0] = rho;
-        aux[1] = LB;
-        aux[2] = UB;
-        aux[3] = q;
+}
+
+// dc_eval's tail over the accumulator rows (GA_ROW), run by the prior workgroup once every
+// streaming workgroup has arrived: ONE round of loads -- the 3T + 4*GA_SHARDS reduced values, z
+// and the static per-team sums (the prior record is already in LDS) -- then one barrier and the
+// epilogue.  The rows are re-armed (zeroed, write-through) for the next launch of this chain.  LDS: [zo | cL | zL | col | scratch | xs | gradL |
+// leaf stage].  Waves 0..6 take the team rows, wave 7 the scalar rows: lane = 16*scalar + shard,
+// so the shard sums are 16-lane DPP row sums.
+__host__ __device__ inline size_t acc_tail_lds_bytes(int T, int D, int K, int zo_stride, bool stage) {
+    size_t d = (size_t)zo_stride + 3 * (size_t)T + D + (3 * (size_t)T + N_SCAL + 4) + WAVES * 8 +
+               (size_t)T * xs_staged_k(K) + (size_t)D + 8 +
+               (stage && D > 64 ? (size_t)nd::LEAF_STAGE_VECS * D : 0);
+    return d * 8 + 16;
+}
+// Everything the tail needs that does NOT depend on the streaming workgroups is requested by
+// tail_preload before the prior workgroup starts waiting for them (z, the static per-team sums,
+// the covariates, the NUTS leaf's state); after the wait only the accumulator rows are loaded.
+struct TailPre {
+    double c0, z0, x0;
+};
+template <bool SMALLT, bool NUTS>
+__device__ __forceinline__ void tail_preload(const EvalArgs& A, int chain, TailPre& P,
+                                             nd::LeafState<1>& leaf1,
+                                             double (&bigv)[nd::LEAF_STAGE_LOADS]) {
+    const Layout& L = A.L;
+    const int T = L.T, K = L.K, D = L.D;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ncol = 3 * T, i = tid;
+    const double* z = z_of(A, chain);
+    const bool xs_staged = K > 0 && K <= 16;
+    P.c0 = i < ncol ? (i < T ? A.cA[i] : (i < 2 * T ? A.cD[i - T] : A.cH[i - 2 * T])) : 0.0;
+    P.z0 = i < D ? z[i] : 0.0;
+    P.x0 = (xs_staged && i < T * K) ? A.xs[i] : 0.0;
+    if (NUTS && SMALLT) {
+        double* ns = nuts_of(A, chain);
+        if (D <= 64) {
+            if (wave == LEAF_WAVE || wave == RNG_WAVE)
+                leaf1 = nd::leaf_prefetch<1>(ns, D, A.nuts_max_depth, lane);
+        } else if (wave >= 4) {
+            static_assert(WAVES - 4 == nd::LEAF_NE_MAX, "one idle wave per 64-element slice");
+            const int i4 = tid - 4 * 64;
+            const int which[nd::LEAF_STAGE_LOADS] = {nd::V_INVM, nd::V_ZN, nd::V_RH, nd::V_S_RSUM,
+                                                     nd::V_SL_R, nd::V_SR_R};
+#pragma unroll
+            for (int k = 0; k < nd::LEAF_STAGE_LOADS; ++k)
+                bigv[k] = i4 < D ? nd::vec(ns, D, which[k])[i4] : 0.0;
+            if (wave == LEAF_WAVE || wave == RNG_WAVE) leaf1.hv = lane < nd::H_N ? ns[lane] : 0.0;
+        }
     }
+}
+template <bool SMALLT, bool NUTS, bool EXT>
+__device__ __forceinline__ void tail_acc(const EvalArgs& A, int chain, char* smem, const TailPre& P,
+                                         const nd::LeafState<1>& leaf1,
+                                         const double (&bigv)[nd::LEAF_STAGE_LOADS]) {
+    const Layout& L = A.L;
+    const int T = L.T, K = L.K, D = L.D;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ncol = 3 * T;
+    static_assert(N_SCAL * GA_SHARDS == 64 && WAVES == 8, "wave 7 = the scalar rows");
+    constexpr int ROW_THREADS = (WAVES - 1) * 64;
+
+    double* zoL = reinterpret_cast<double*>(smem);      // [zo_stride]  prior workgroup record
+    double* cL = zoL + A.zo_stride;                     // [3T] cA | cD | cH
+    double* zL = cL + ncol;                             // [D]
+    double* col = zL + D;                               // [3T + N_SCAL + 4] reduced sums
+    double* scratch = col + ncol + N_SCAL + 4;          // [WAVES*8]
+    double* xsL = scratch + WAVES * 8;                  // [T*K] when K <= 16
+    double* gradL = xsL + (size_t)T * xs_staged_k(K);   // [D+8] grad | U | aux (NUTS hand-over)
+    double* stg = gradL + D + 8;                        // [7*D] NUTS leaf vectors when D > 64
+    DC_STAMP(7);
+
+    const bool small = D <= 64;
+    const double* z = z_of(A, chain);
+    long long* ga = A.gacc + (size_t)chain * ga_rows(T) * GA_ROW;
+    const bool xs_staged = K > 0 && K <= 16;
+    {
+        // ---- 1. ONE round of loads: the rows (and the flag word)
+        const int i = tid;
+        const int r0 = wave < WAVES - 1 ? min(i, ncol - 1) : ncol + (lane & 15) * N_SCAL + (lane >> 4);
+        const GaWords w0 = ga_load(ga + (size_t)r0 * GA_ROW);
+        const unsigned long long fl0 = __hip_atomic_load(
+            reinterpret_cast<const unsigned long long*>(ga + (size_t)(ncol + N_SCAL * GA_SHARDS) * GA_ROW),
+            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (i < ncol) cL[i] = P.c0;
+        if (i < D) zL[i] = P.z0;
+        if (xs_staged && i < T * K) xsL[i] = P.x0;
+        if (wave < WAVES - 1) {
+            if (i < ncol) col[i] = ga_value(w0);
+        } else {  // scalar rows: sum the shards (16-lane rows), apply the non-finite flags
+            double v = ga_value(w0);
+            v += dpp_f64<0xB1>(0.0, v);   // quad_perm [1,0,3,2]
+            v += dpp_f64<0x4E>(0.0, v);   // quad_perm [2,3,0,1]
+            v += dpp_f64<0x124>(0.0, v);  // row_ror:4
+            v += dpp_f64<0x128>(0.0, v);  // row_ror:8
+            const unsigned int fl = (unsigned int)fl0;
+            if (fl != 0u) {  // (uniform) a clipped tau term: log 0 = -inf; anything else: NaN
+                if (lane == 16 && (fl & GA_NEGINF)) v = -__builtin_inf();
+                if (lane == 0 && (fl & GA_BAD)) v = __builtin_nan("");
+                if (lane == 0)
+                    __hip_atomic_store(reinterpret_cast<unsigned long long*>(
+                                           ga + (size_t)(ncol + N_SCAL * GA_SHARDS) * GA_ROW),
+                                       0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if ((lane & 15) == 0) col[ncol + (lane >> 4)] = v;
+        }
+    }
+    // larger models: the remaining team rows and static entries, one round per pass
+    for (int i = tid + ROW_THREADS; i < ncol; i += ROW_THREADS) {
+        if (wave == WAVES - 1) break;
+        const GaWords w = ga_load(ga + (size_t)i * GA_ROW);
+        col[i] = ga_value(w);
+    }
+    for (int i = tid + BLOCK; i < ncol; i += BLOCK)
+        cL[i] = i < T ? A.cA[i] : (i < 2 * T ? A.cD[i - T] : A.cH[i - 2 * T]);
+    for (int i = tid + BLOCK; i < D; i += BLOCK) zL[i] = z[i];
+    if (xs_staged)
+        for (int i = tid + BLOCK; i < T * K; i += BLOCK) xsL[i] = A.xs[i];
+    __syncthreads();
+    DC_STAMP(8);
+    // re-arm the rows for this chain's next launch: write-through zeros, issued only now -- a
+    // barrier waits for the wave's outstanding stores, and these take a memory round trip
+    if (wave < WAVES - 1) {
+        for (int i = tid; i < ncol; i += ROW_THREADS) ga_rearm(ga + (size_t)i * GA_ROW);
+    } else {
+        ga_rearm(ga + (size_t)(ncol + (lane & 15) * N_SCAL + (lane >> 4)) * GA_ROW);
+    }
+    DC_STAMP(9);
+    if (SMALLT) {  // lane = team: four waves, one output group each, no LDS traffic
+        if (NUTS) {  // the idle waves' shares of the leaf preparation (see LEAF_WAVE)
+            if (!small && wave >= 4) {
+                const int i = tid - 4 * 64;
+#pragma unroll
+                for (int k = 0; k < nd::LEAF_STAGE_LOADS; ++k)
+                    if (i < D) stg[k * D + i] = bigv[k];
+            }
+        }
+        tail_waves<NUTS, EXT>(A, chain, zoL, cL, zL, col, xs_staged ? xsL : nullptr, gradL, leaf1, stg);
+        DC_STAMP(10);
+        return;
+    }
+    tail_general<EXT>(A, chain, zoL, cL, zL, col, scratch);
+    DC_STAMP(10);
 }
 
 // ------------------------------------------------------------ per-lane fixture math
@@ -1366,6 +1598,20 @@ __device__ __forceinline__ float clamp0(float t) {  // max(t, 0) in one instruct
 __device__ __forceinline__ uint32_t zero_bytes(uint32_t v) {
     return ~(((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v | 0x7F7F7F7Fu);
 }
+// Score classes of four fixtures at once (bpl/_util.py:58-91 tests goals == 0 / == 1): bit 7 of
+// byte j of low7 is set when fixture j is a low score (both goals <= 1); x7 / y7 when in addition
+// the home / away side scored exactly one.
+struct ScoreMasks {
+    uint32_t low7, x7, y7;
+};
+__device__ __forceinline__ ScoreMasks score_masks(uint32_t x, uint32_t y) {
+    const uint32_t u = ((x | y) >> 1) & 0x7F7F7F7Fu;          // byte >> 1: zero <=> both goals <= 1
+    ScoreMasks m;
+    m.low7 = ~(u + 0x7F7F7F7Fu) & 0x80808080u;                // (no carry across bytes: u <= 0x7F)
+    m.x7 = (x << 7) & m.low7;                                 // bit 0 of byte j -> bit 7 of byte j
+    m.y7 = (y << 7) & m.low7;
+    return m;
+}
 // tau argument 1 + rho*c of one score class: log2 of its clip at 0, and dlogtau/drho
 __device__ __forceinline__ void class_terms(float rho, float c, float* l2, float* u) {
     const float t = fmaf(rho, c, 1.0f);
@@ -1399,44 +1645,61 @@ __device__ __forceinline__ LaneOut lane_uniform(const LaneData& Ld, float rho,
     class_terms(rho, -1.0f, &l11, &u11);
     float n00, n10, n01, n11, nall, sx, sy;  // (weighted) class counts, total, goal sums
     if (!WEIGHTED) {
-        const uint32_t one = 0x01010101u;
-        int c00 = 0, c10 = 0, c01 = 0, c11 = 0, nz = 0;
+        int c_low = 0, c_x1 = 0, c_y1 = 0, c11 = 0, nz = 0;
         uint32_t ax = 0, ay = 0;
 #pragma unroll
         for (int q = 0; q < XWORDS; ++q) {
             const uint32_t x = Ld.xw[q], y = Ld.yw[q];
-            c00 += __popc(zero_bytes(x | y));
-            c10 += __popc(zero_bytes((x ^ one) | y));
-            c01 += __popc(zero_bytes(x | (y ^ one)));
-            c11 += __popc(zero_bytes((x ^ one) | (y ^ one)));
-            ax = __builtin_amdgcn_sad_u8(x, 0u, ax);
-            ay = __builtin_amdgcn_sad_u8(y, 0u, ay);
+            const ScoreMasks m = score_masks(x, y);
+            c_low += __popc(m.low7);
+            c_x1 += __popc(m.x7);
+            c_y1 += __popc(m.y7);
+            c11 += __popc(m.x7 & m.y7);
+            if (CLIP) {
+                ax = __builtin_amdgcn_sad_u8(x, 0u, ax);
+                ay = __builtin_amdgcn_sad_u8(y, 0u, ay);
+            }
         }
         // null fixtures (goals (255, 255), never a low score) pad the end of a pair's run; the
         // lane's number of REAL fixtures rides in the second home-index halfword, which nothing
         // else reads (all fixtures of a lane share one pair)
         nz = LANE_FIX - (int)(Ld.hw[0] >> 16);
-        n00 = (float)c00; n10 = (float)c10; n01 = (float)c01; n11 = (float)c11;
+        n00 = (float)(c_low - c_x1 - c_y1 + c11);
+        n10 = (float)(c_x1 - c11);
+        n01 = (float)(c_y1 - c11);
+        n11 = (float)c11;
         nall = (float)(LANE_FIX - nz);
         sx = (float)((int)ax - 255 * nz);
         sy = (float)((int)ay - 255 * nz);
     } else {
+        // weights are streamed (4 B per fixture); the class of every fixture comes from the same
+        // SWAR masks, turned into 0 / 128 factors by v_cvt_f32_ubyteN: two instructions per
+        // (fixture, class) instead of a compare-select chain per fixture
         n00 = n10 = n01 = n11 = nall = sx = sy = 0.f;
 #pragma unroll
-        for (int j = 0; j < LANE_FIX; ++j) {
-            const uint32_t xj = (Ld.xw[j >> 2] >> (8 * (j & 3))) & 0xFFu;
-            const uint32_t yj = (Ld.yw[j >> 2] >> (8 * (j & 3))) & 0xFFu;
-            const float wv = Ld.wj[j];
-            n00 += (xj | yj) == 0 ? wv : 0.f;
-            n10 += (xj == 1 && yj == 0) ? wv : 0.f;
-            n01 += (xj == 0 && yj == 1) ? wv : 0.f;
-            n11 += (xj == 1 && yj == 1) ? wv : 0.f;
-            nall += wv;
-            if (CLIP) {
-                sx += wv * (float)xj;
-                sy += wv * (float)yj;
+        for (int q = 0; q < XWORDS; ++q) {
+            const uint32_t x = Ld.xw[q], y = Ld.yw[q];
+            const ScoreMasks m = score_masks(x, y);
+            const uint32_t m11 = m.x7 & m.y7, m10 = m.x7 & ~m.y7, m01 = m.y7 & ~m.x7,
+                           m00 = m.low7 & ~(m.x7 | m.y7);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float wv = Ld.wj[4 * q + j];
+                n00 = fmaf(wv, (float)((m00 >> (8 * j)) & 0xFFu), n00);
+                n10 = fmaf(wv, (float)((m10 >> (8 * j)) & 0xFFu), n10);
+                n01 = fmaf(wv, (float)((m01 >> (8 * j)) & 0xFFu), n01);
+                n11 = fmaf(wv, (float)((m11 >> (8 * j)) & 0xFFu), n11);
+                nall += wv;
+                if (CLIP) {
+                    sx = fmaf(wv, (float)((x >> (8 * j)) & 0xFFu), sx);
+                    sy = fmaf(wv, (float)((y >> (8 * j)) & 0xFFu), sy);
+                }
             }
         }
+        n00 *= 1.0f / 128.0f;  // (exact: the factors are 0 or 2^7)
+        n10 *= 1.0f / 128.0f;
+        n01 *= 1.0f / 128.0f;
+        n11 *= 1.0f / 128.0f;
     }
     LaneOut o;
     o.key = h | (a << 16);
@@ -1467,6 +1730,54 @@ __device__ __forceinline__ LaneOut lane_uniform(const LaneData& Ld, float rho,
 
 // ------------------------------------------------------------------------- dc_eval
 
+// The prior workgroup's wait for the `n_stream` streaming workgroups of its chain: lane g of one
+// wave polls group counter g (streaming workgroup w arrives at counter w % TK_GROUPS) with an
+// L1-bypassing load until every counter holds its member count, then re-arms them.  BOUNDED: the
+// streaming workgroups need nothing from this one, so they always finish; the limit (~0.1 s of
+// polling) only turns a fault elsewhere into NaN outputs instead of a hung kernel.
+constexpr int ARRIVE_SPIN_LIMIT = 1 << 18;
+__device__ __forceinline__ bool wait_arrivals(unsigned int* tk, int n_stream, int lane) {
+    const int g = lane < TK_GROUPS ? lane : TK_GROUPS - 1;
+    const unsigned int want = (unsigned int)((n_stream - g + TK_GROUPS - 1) / TK_GROUPS);
+    unsigned int* p = tk + (1 + g) * TK_STRIDE;
+    bool ok = false;
+    for (int spin = 0; spin < ARRIVE_SPIN_LIMIT; ++spin) {
+        const unsigned int v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ok = __ballot(v != want) == 0ull;
+        if (ok) break;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    if (lane < TK_GROUPS && want != 0u)
+        __hip_atomic_store(p, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return ok;
+}
+
+template <class T>
+__device__ __forceinline__ T* as_global(T* p) {
+    return (T*)(__attribute__((address_space(1))) T*)p;
+}
+// A fresh copy of the kernel's (single, by-value) argument from the kernarg segment.  The
+// pointer is made opaque so the scalar loads stay where the copy is taken.
+__device__ __forceinline__ EvalArgs reload_args() {
+    typedef const __attribute__((address_space(4))) uint32_t* kptr;
+    kptr src = (kptr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(src));
+    constexpr int NW = (int)(sizeof(EvalArgs) / 4);
+    static_assert(sizeof(EvalArgs) % 4 == 0, "EvalArgs is copied word by word");
+    uint32_t tmp[NW];
+#pragma unroll
+    for (int i = 0; i < NW; ++i) tmp[i] = src[i];
+    EvalArgs B;
+    __builtin_memcpy(&B, tmp, sizeof B);
+    // the copied pointers have lost their address space (flat loads): they are global memory
+#define DC_GLOBAL(f) B.f = as_global(B.f)
+    DC_GLOBAL(pairs); DC_GLOBAL(xs); DC_GLOBAL(xsf); DC_GLOBAL(cA); DC_GLOBAL(cD); DC_GLOBAL(cH);
+    DC_GLOBAL(hbuf); DC_GLOBAL(tickets); DC_GLOBAL(gacc); DC_GLOBAL(z); DC_GLOBAL(potential);
+    DC_GLOBAL(grad); DC_GLOBAL(aux); DC_GLOBAL(nuts); DC_GLOBAL(debug);
+#undef DC_GLOBAL
+    return B;
+}
+
 #ifdef DC_MIN_WAVES  // waves per SIMD the register allocation must allow (2 workgroups per CU = 4)
 #define DC_LAUNCH_BOUNDS __launch_bounds__(BLOCK, DC_MIN_WAVES)
 #else
@@ -1482,6 +1793,7 @@ __global__ DC_LAUNCH_BOUNDS void dc_eval(EvalArgs A) {
     const double* z = z_of(A, chain);
 #ifdef DC_STAMPS
     const unsigned long long t_entry = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long c_entry = __builtin_amdgcn_s_memtime();
 #endif
     // device-resident NUTS: the subtree this launch belonged to may already be complete
     const double nuts_done = NUTS ? nuts_of(A, chain)[nd::H_S_DONE] : 0.0;
@@ -1496,13 +1808,45 @@ __global__ DC_LAUNCH_BOUNDS void dc_eval(EvalArgs A) {
     double* acc = reinterpret_cast<double*>(tabA + tab_len(T));  // [3*T1]
     double* red = acc + 3 * T1 + ((3 * T1) & 1);               // [WAVES*4]
     float* redm = reinterpret_cast<float*>(red + WAVES * N_SCAL);  // [WAVES*4]
-    int* shflag = reinterpret_cast<int*>(redm + WAVES * 4);  // dynamic LDS only (G17)
 
     if (blockIdx.x == 0) {
+        // ---- the prior workgroup: z-only work beside the streaming, then it WAITS for the
+        // streaming workgroups' arrivals and runs the tail.  (It used to take a ticket like the
+        // others and hand its record over through memory; the last arriver -- two dependent
+        // returning atomics later -- ran the tail: ~0.5 us more on the critical path, and this
+        // workgroup's own drain + ticket, 1.1 us, made it the last arriver.)
         if (NUTS && nuts_done != 0.0) return;
-        prior_body<CLIP>(A, chain, smem);
+        const size_t tail_bytes = (acc_tail_lds_bytes(T, L.D, L.K, A.zo_stride, STAGED && NUTS) + 15) & ~(size_t)15;
+        prior_body<CLIP, true>(A, chain, smem + tail_bytes, reinterpret_cast<double*>(smem));
         DC_STAMP(4);
-    } else {
+        int* okflag = reinterpret_cast<int*>(smem + tail_bytes);  // (prior scratch: free after the barrier)
+        // The tail reads its arguments from the kernarg segment again (scalar loads behind an
+        // opaque pointer): kept live in SGPRs from the kernel entry they were spilled.
+        // (Twice: once for the preload, once more after the wait -- the second copy comes from
+        // the scalar cache, and nothing is held in SGPRs across the polling loop.)
+        TailPre pre;
+        nd::LeafState<1> leaf1{};            // D <= 64: the leaf's vectors in registers (waves 4, 5)
+        double bigv[nd::LEAF_STAGE_LOADS];   // D > 64: waves 4..7 stage one 64-element slice each
+        tail_preload<STAGED, NUTS>(reload_args(), chain, pre, leaf1, bigv);
+        __syncthreads();
+        DC_STAMP(5);
+        if (wave == 0) {
+            const bool ok = wait_arrivals(A.tickets + (size_t)chain * TK_WORDS, A.n_wg, lane);
+            if (lane == 0) *okflag = ok ? 1 : 0;
+        }
+        __syncthreads();
+        DC_STAMP(6);
+        if (*okflag == 0) {  // the streaming workgroups never arrived (bounded wait): poison the outputs
+            double* grad = grad_of(A, chain);
+            for (int i = tid; i < L.D; i += BLOCK) grad[i] = __builtin_nan("");
+            if (tid == 0) *pot_of(A, chain) = __builtin_nan("");
+            return;
+        }
+        const EvalArgs B = reload_args();
+        tail_acc<STAGED, NUTS, CLIP>(B, chain, smem, pre, leaf1, bigv);
+        return;
+    }
+    {
         const int wgi = blockIdx.x - 1;
         // ---- 0. every load the prologue needs, in the order the data is wanted: this thread's pair
         // and its entries of z (L2 hits) first, then the first tile (HBM), then the slab slots.
@@ -1528,7 +1872,7 @@ __global__ DC_LAUNCH_BOUNDS void dc_eval(EvalArgs A) {
         // (unconditional, index clamped: a load into a register that a branch also zeroes made the
         // compiler wait for it -- and, in order, for the whole tile -- right here)
         const int kq = min(o0 + tid, A.total_c - 1);
-        const int slot0 = A.wg_slots[kq], dst0 = A.wg_dst[kq];
+        const int slot0 = A.wg_slots[kq];
         // (uniform over the whole grid.  Checking this after the table loads are in flight
         // measured no gain: the flag's latency is not what delays z, z itself is cold.)
         if (NUTS && nuts_done != 0.0) return;
@@ -1550,26 +1894,21 @@ __global__ DC_LAUNCH_BOUNDS void dc_eval(EvalArgs A) {
 #endif
         // ---- 3. stream the fixtures
         double dSLAM = 0.0, dSLOG = 0.0, dSU = 0.0, dCLIP = 0.0;  // per lane
-        while (tile < tile_end) {
-            // prefetch the next tile: unconditional (the last iteration re-requests its own tile
-            // and drops it) -- behind a branch the compiler waits for the prefetch as well when it
-            // waits for the current tile
-            const LaneData pre = load_lane<WEIGHTED>(A, (size_t)min(tile + 1, tile_end - 1) * 64 + lane);
-            LaneData nxt = pre;
-            // One lane = LANE_FIX consecutive fixtures of ONE (home, away) pair (runs are padded
-            // with null fixtures): the two rates and the four score-class tau terms are computed
-            // once for the lane and each fixture is only classified.
+        // One lane = LANE_FIX consecutive fixtures of ONE (home, away) pair (runs are padded with
+        // null fixtures): the two rates and the four score-class tau terms are computed once for
+        // the lane and each fixture is only classified.
+        auto process = [&](const LaneData& ld) {
 #ifdef DC_STAMPS
-            if (cur.hw[0] == 0xFFFFFFFFu) rho_dbg += 1.0f;  // forces the loads to have landed
+            if (ld.hw[0] == 0xFFFFFFFFu) rho_dbg += 1.0f;  // forces the loads to have landed
             DC_STAMP(12);
 #endif
-            const LaneOut lo = lane_uniform<WEIGHTED, CLIP>(cur, rho, tabH, tabA);
-            // scalars: float32 over the lane's 8 fixtures only, float64 from there on
+            const LaneOut lo = lane_uniform<WEIGHTED, CLIP>(ld, rho, tabH, tabA);
+            // scalars: float32 over the lane's fixtures only, fixed point (q30) from there on
             // (a float32 sum over the whole wave-tile would cost ~1e-4 absolute in U)
-            dSLAM += (double)lo.slam;
-            dSLOG += (double)lo.slog;
-            dSU += (double)lo.su;
-            if (CLIP) dCLIP += (double)lo.sclip;
+            dSLAM += q30(lo.slam);
+            dSLOG += q30(lo.slog);
+            dSU += q30(lo.su);
+            if (CLIP) dCLIP += q30(lo.sclip);
             float rsh = lo.rsh, rsa = lo.rsa;
             const uint32_t key = lo.key;
 #ifdef DC_STAMPS
@@ -1583,7 +1922,7 @@ __global__ DC_LAUNCH_BOUNDS void dc_eval(EvalArgs A) {
             const int nruns = __popcll(heads);
             if (nruns == 1) {  // whole wave-tile on one pair (the common case: sorted)
                 wave_sum2_f32(rsh, rsa);
-                if (lane == 0) flush_run(acc, T1, key, rsh, rsa);
+                if (lane == 0) flush_run_q(acc, T1, key, rsh, rsa);
             } else if (nruns <= RUN_LOOP_MAX) {  // a few runs: one masked DPP sum per run
                 unsigned long long hd = heads;
                 while (hd) {
@@ -1594,18 +1933,28 @@ __global__ DC_LAUNCH_BOUNDS void dc_eval(EvalArgs A) {
                     const uint32_t kk = (uint32_t)__builtin_amdgcn_readlane((int)key, first);
                     float s0 = in ? rsh : 0.f, s1 = in ? rsa : 0.f;
                     wave_sum2_f32(s0, s1);
-                    if (lane == 0) flush_run(acc, T1, kk, s0, s1);
+                    if (lane == 0) flush_run_q(acc, T1, kk, s0, s1);
                 }
             } else {  // many short runs: every lane adds its own sums (LDS atomics)
-                flush_run(acc, T1, key, rsh, rsa);
+                flush_run_q(acc, T1, key, rsh, rsa);
             }
-
-            // The prefetched words must not be touched before this point: without the opaque
-            // redefinition the compiler hoists the next tile's first use (index masking) up to
-            // the loads, which turns the prefetch into a stall (measured: +20 % at N = 1e8).
-            asm volatile("" : "+v"(nxt.hw[0]), "+v"(nxt.aw[0]), "+v"(nxt.xw[0]), "+v"(nxt.yw[0]));
-            cur = nxt;
-            ++tile;
+        };
+        if (tile < tile_end) {  // (wave uniform; a wave without tiles skips the lot)
+            // every tile but the last is processed with the NEXT one in flight ...
+            while (tile + 1 < tile_end) {
+                LaneData nxt = load_lane<WEIGHTED>(A, (size_t)(tile + 1) * 64 + lane);
+                process(cur);
+                // The prefetched words must not be touched before this point: without the opaque
+                // redefinition the compiler hoists the next tile's first use (index masking) up to
+                // the loads, which turns the prefetch into a stall (measured: +20 % at N = 1e8).
+                asm volatile("" : "+v"(nxt.hw[0]), "+v"(nxt.aw[0]), "+v"(nxt.xw[0]), "+v"(nxt.yw[0]));
+                cur = nxt;
+                ++tile;
+            }
+            // ... and the last one (the ONLY one up to ~1e6 fixtures) with nothing in flight: the
+            // unconditional prefetch this replaces made a single-tile wave wait for a reload of its
+            // own tile, a whole memory round trip at the end of its critical path
+            process(cur);
         }
         DC_STAMP(3);
 #ifdef DC_STAMPS
@@ -1626,57 +1975,50 @@ __global__ DC_LAUNCH_BOUNDS void dc_eval(EvalArgs A) {
         DC_STAMP(15);
         __syncthreads();
         DC_STAMP(11);
-        {   // publish only the slots this workgroup's fixtures touch (static list)
-            double* cmpw = A.hbuf + (size_t)chain * A.hb_stride + A.zo_stride + A.n_wg * N_SCAL;
+        {   // add the slots this workgroup's fixtures touch (static list) and its four scalars
+            // into the chain's accumulator rows (integer atomics at agent scope, no return)
+            long long* ga = A.gacc + (size_t)chain * ga_rows(T) * GA_ROW;
+            unsigned int bad = 0u;
             for (int k = o0 + tid; k < o1; k += BLOCK) {
                 const int slot = k == o0 + tid ? slot0 : A.wg_slots[k];
                 const int which = slot / T, t = slot - which * T;
-                st_sc1(&cmpw[k == o0 + tid ? dst0 : A.wg_dst[k]], acc[which * T1 + t]);
+                ga_add(ga + (size_t)slot * GA_ROW, acc[which * T1 + t], &bad);
             }
-        }
-        if (tid < N_SCAL) {
-            double s = 0.0;
+            if (tid >= BLOCK - N_SCAL) {  // (the last wave: the slot lanes are the first ones)
+                const int k = tid - (BLOCK - N_SCAL);
+                double sv = 0.0;
 #pragma unroll
-            for (int wv = 0; wv < WAVES; ++wv) s += red[wv * N_SCAL + tid];
-            st_sc1(&A.hbuf[(size_t)chain * A.hb_stride + A.zo_stride + wgi * N_SCAL + tid], s);
+                for (int wv = 0; wv < WAVES; ++wv) sv += red[wv * N_SCAL + k];
+                ga_add(ga + (size_t)(3 * T + (wgi % GA_SHARDS) * N_SCAL + k) * GA_ROW, sv, &bad);
+            }
+            if (bad != 0u)
+                (void)__hip_atomic_fetch_or(
+                    reinterpret_cast<unsigned int*>(ga + (size_t)(3 * T + N_SCAL * GA_SHARDS) * GA_ROW),
+                    bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         DC_STAMP(4);
     }
 
-    // ---- 5. the last-arriving workgroup runs the tail.  Payloads were stored
-    // write-through (sc1); every storing wave drains, the workgroup barriers, one lane
-    // takes a ticket (relaxed, agent scope); the last arriver reads with sc1 loads.
-    // Tickets are two-level: ~250 same-address atomics arriving within a microsecond queue
-    // up at ~12 ns each (the last one returned 2.6 us after the burst began); with TK_GROUPS
-    // group counters on separate cache lines and one top counter the queues are 16 deep.
+    // ---- 5. arrive.  The sums were added with agent-scope atomics; every adding wave drains,
+    // the workgroup barriers, one lane adds to its group's arrival counter (no return value: the
+    // workgroup is done).  The prior workgroup polls the counters with L1-bypassing loads
+    // (MI355X_MICROARCH.md, hand-off table: "agent-scope atomic adds, one lane of each storing
+    // workgroup / a global_load sc1 poll of that counter / a workgroup barrier between that poll
+    // and every load of the bytes").  TK_GROUPS counters on separate lines: same-address
+    // atomics queue at ~12 ns each.
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     DC_STAMP(5);
     if (tid == 0) {
         unsigned int* tk = A.tickets + (size_t)chain * TK_WORDS;
-        const unsigned int g = blockIdx.x % TK_GROUPS;
-        const unsigned int members = (gridDim.x - g + TK_GROUPS - 1) / TK_GROUPS;  // blocks of group g
-        const unsigned int groups = gridDim.x < TK_GROUPS ? gridDim.x : TK_GROUPS; // non-empty groups
-        int last = 0;
-        unsigned int* tg = tk + (1 + g) * TK_STRIDE;
-        const unsigned int t1 =
-            __hip_atomic_fetch_add(tg, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (t1 == members - 1) {  // last of its group: re-arm it (stream ordered), go up
-            __hip_atomic_store(tg, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned int t2 =
-                __hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (t2 == groups - 1) {
-                __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                last = 1;
-            }
-        }
-        *shflag = last;
+        (void)__hip_atomic_fetch_add(tk + (1 + (blockIdx.x - 1) % TK_GROUPS) * TK_STRIDE, 1u,
+                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    __syncthreads();
     DC_STAMP(6);
-    if (*shflag == 0) return;
-    __syncthreads();
-    tail_body<STAGED, NUTS, CLIP>(A, chain, smem);
+#ifdef DC_STAMPS  // shader clock of this workgroup's life: cycles (s_memtime) per 10 ns tick
+    if (threadIdx.x == 0 && A.debug && blockIdx.y == 0)
+        A.debug[(size_t)blockIdx.x * 16 + 9] = __builtin_amdgcn_s_memtime() - c_entry;
+#endif
 }
 
 }  // namespace dc

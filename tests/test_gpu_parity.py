@@ -108,6 +108,36 @@ def test_full_size_1e6(hip_ctx):
             _check(model, fx, f"league_1e6/{pname} [vec]", z, Uv[i], gv[i], auxv[i])
 
 
+@pytest.mark.parametrize("model,name", [(O.MODEL_BASIC, "dummy"), (O.MODEL_BASIC, "league_1e5"),
+                                        (O.MODEL_EXTENDED, "dummy_cov"), (O.MODEL_EXTENDED, "leaguew_3e4")])
+def test_wild_region_matches_oracle(hip_ctx, model, name):
+    """init_to_uniform(radius=2) starts a chain at z ~ U(-2, 2)^D: rates up to e^30 (basic model;
+    the extended model clips them at 15), potentials of 1e15 and more.  The accumulator rows
+    carry such sums in their hi word (dc_kernels.hip.h, GA_ROW); the float32 tables limit the
+    agreement with the float64 oracle to ~1e-6 relative there."""
+    import torch
+
+    fx = cases.fixtures(name)
+    D = O.latent_dim(model, fx.n_teams, fx.k if model == O.MODEL_EXTENDED else 0)
+    zs = [np.random.RandomState(40 + i).uniform(-2.0, 2.0, D) for i in range(6)]
+    outs, (Ub, gb, _), (Uv, gv, _) = _run(hip_ctx, model, fx, zs)
+    big = 0.0
+    for i, (z, (U, g, aux)) in enumerate(zip(zs, outs)):
+        Uo, go, auxo = O.potential_and_grad(model, fx, z)
+        big = max(big, abs(Uo))
+        print(f"{name}/wild{i}: U={Uo:.6e} dU/U={(U - Uo) / abs(Uo):+.2e} "
+              f"dg/|g|={np.abs(g - go).max() / np.abs(go).max():.2e} rho={auxo['rho']:+.4f}")
+        assert np.isfinite(Uo) and np.isfinite(U)
+        assert abs(U - Uo) <= 5e-6 * abs(Uo)
+        assert np.abs(g - go).max() <= 2e-5 * np.abs(go).max()
+        # (exact fixed-point sums up to 2^53 units of 2^-30 per row, i.e. 8e6; beyond, float64
+        # rounding makes the grid.y batch's other partition differ in the last bits)
+        assert abs(U - Ub[i]) <= 1e-14 * abs(U) and np.abs(g - gb[i]).max() <= 1e-13 * np.abs(g).max()
+        assert abs(Uv[i] - Uo) <= 5e-6 * abs(Uo)
+    if model == O.MODEL_BASIC:
+        assert big > 1e6 * fx.n / 380.0  # beyond the accumulator rows' lo word (1.6e7 per row)
+
+
 @pytest.mark.parametrize("weighted", [False, True])
 def test_config3_extended_covariates_1e6(hip_ctx, weighted):
     """BASELINE.json configs[2] exactly as stated: extended model, 5 covariates
@@ -211,6 +241,38 @@ def test_graph_replay_matches_direct(hip_ctx):
     U = torch.zeros(8, dtype=torch.float64, device=hip_ctx.device)
     g = torch.zeros_like(z)
     hip_ctx.logp_grad_graph(16, z, U, g, replays=3)
+    torch.cuda.synchronize()
+    assert torch.equal(U, Ud) and torch.equal(g, gd)
+
+
+def test_graph_survives_slab_growth(hip_ctx):
+    """A cached hipGraph holds the hand-off slab / ticket pointers in its kernel arguments.  A
+    batched call with more chains than the slabs were sized for reallocates them, so the cached
+    graphs must be dropped and re-captured: graph, 8-chain batch, graph again == direct path."""
+    import torch
+
+    fx = cases.fixtures("league_1e5")
+    hip_ctx.set_fixtures(O.MODEL_BASIC, fx.home_idx.astype(np.uint16), fx.away_idx.astype(np.uint16),
+                         fx.home_goals.astype(np.uint8), fx.away_goals.astype(np.uint8), 20)
+    z = torch.tensor(np.random.RandomState(11).uniform(-0.5, 0.5, (8, 45)), dtype=torch.float64,
+                     device=hip_ctx.device)
+    direct = [hip_ctx.logp_grad(z[i].contiguous()) for i in range(8)]
+    Ud = torch.cat([d[0] for d in direct])
+    gd = torch.stack([d[1] for d in direct])
+    U = torch.zeros(8, dtype=torch.float64, device=hip_ctx.device)
+    g = torch.zeros_like(z)
+    hip_ctx.logp_grad_graph(8, z, U, g, replays=2)
+    torch.cuda.synchronize()
+    assert torch.equal(U, Ud) and torch.equal(g, gd)
+    hip_ctx.set_option("vec_min_chains", 0)
+    try:
+        Ub, gb, _ = hip_ctx.logp_grad(z)  # 8 chains as grid.y copies: the slabs grow
+    finally:
+        hip_ctx.set_option("vec_min_chains", 32)
+    assert torch.equal(Ub, Ud) and torch.equal(gb, gd)
+    U.zero_()
+    g.zero_()
+    hip_ctx.logp_grad_graph(8, z, U, g, replays=2)  # same key as before the growth
     torch.cuda.synchronize()
     assert torch.equal(U, Ud) and torch.equal(g, gd)
 

@@ -6,7 +6,7 @@ sys.path[:0] = [ROOT + "/bpl-next_amd", ROOT]
 import numpy as np, torch
 from bench import synthetic_league
 from bpl import _ffi
-_ffi._LIB_NAME = "libbplhip_stamps.so"
+_ffi._LIB_NAME = os.environ.get("STAMPS_LIB", "libbplhip_stamps.so")
 from bpl._ffi import HipContext, MODEL_BASIC, MODEL_EXTENDED
 
 TEAMS = int(os.environ.get('TEAMS', '20'))
@@ -35,6 +35,8 @@ def run(n, model=MODEL_BASIC, max_wg=255, k=0, weighted=False):
     for k in [0, 1, 2, 12, 13, 3, 15, 11, 4, 5, 6]:
         col = rel[1:, k][st[1:, k] > 0]
         if col.size: print(f"  {names[k]:10s} median {np.median(col):7.2f} us  min {col.min():7.2f}  max {col.max():7.2f}")
+    life = (st[1:, 6] - st[1:, 0]) * 10.0  # ns, entry -> arrival
+    print("  shader clock over the streaming workgroups' lives: median %.2f GHz" % np.median(st[1:, 9] / life))
     last = int(np.argmax(st[:, 10]))
     print("  tail WG", last, " ".join(f"{names[k]}={rel[last, k]:.2f}" for k in range(11)),
           f"epi:sums={rel[last, 11]:.2f} epi:puts={rel[last, 14]:.2f}")
@@ -70,6 +72,8 @@ def run_nuts(n=1_000_000):
 
 if len(sys.argv) > 1 and sys.argv[1] == "nuts":
     run_nuts()
+elif len(sys.argv) > 1 and sys.argv[1] == "basic":
+    run(1_000_000)
 else:
     for n in (1_000_000,):
         run(n)
