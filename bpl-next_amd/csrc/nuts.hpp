@@ -331,16 +331,21 @@ struct Sampler {
     }
 };
 
-// init_to_uniform(radius) with numpyro's seed-handler key plumbing (Appendix B.5):
-// per attempt  key, subkey = split(key);  per site (model order)  seed, k = split(seed);
-// k_u, _ = split(k);  z_site = Uniform(-r, r)(k_u).
-inline void draw_init(tf::Key subkey, const std::vector<Site>& sites, double radius, vec* z) {
-    tf::Key seed = subkey;
+// One attempt of init_to_uniform(radius) as numpyro's find_valid_initial_params runs it
+// (numpyro 0.13.2 infer/util.py: NUTS's default strategy with prototype parameters at hand takes
+// the branch that "doesn't require tracing the model"):
+//   key, subkey = split(key)
+//   for each latent site in model trace order:
+//       z_site = uniform(subkey, shape, -r, r);  key, subkey = split(key)
+// `key` is carried into the next attempt.  (Round 1 had restated the seed-handler branch -- one
+// key per site from handlers.seed, split again inside init_to_uniform -- which numpyro only takes
+// for strategies other than init_to_uniform; found by the independent oracle, oracle/nuts_oracle.py.)
+inline void draw_init(tf::Key* key, const std::vector<Site>& sites, double radius, vec* z) {
+    tf::Key sub;
+    tf::split2(*key, key, &sub);
     for (const Site& s : sites) {
-        tf::Key k_site, k_u, k_unused;
-        tf::split2(seed, &seed, &k_site);
-        tf::split2(k_site, &k_u, &k_unused);
-        tf::uniform(k_u, s.size, (float)-radius, (float)radius, z->data() + s.offset);
+        tf::uniform(sub, s.size, (float)-radius, (float)radius, z->data() + s.offset);
+        tf::split2(*key, key, &sub);
     }
 }
 
@@ -438,9 +443,7 @@ struct ChainDriver {
         } else {
             tf::Key k = key_init;
             for (int attempt = 0; attempt < 100 && !finite; ++attempt) {
-                tf::Key sub;
-                tf::split2(k, &k, &sub);
-                draw_init(sub, sites, cfg.init_radius, &z);
+                draw_init(&k, sites, cfg.init_radius, &z);
                 if (!set_state(z.data(), &pe, &finite)) return ST_EVAL_FAILED;
             }
             if (!finite) return ST_NO_FINITE_INIT;

@@ -96,7 +96,7 @@ def nuts_dc(cf: CFixtures, warm, samp, key, depth=10, thin=1, z0=None, step_size
     return rc, draws, stats, summ
 
 
-def nuts_gauss(sd, warm, samp, key, depth=10, thin=1, z0=None):
+def nuts_gauss(sd, warm, samp, key, depth=10, thin=1, z0=None, step_size=1.0):
     sd = np.ascontiguousarray(sd, dtype=np.float64)
     D = sd.size
     kept = samp // thin
@@ -107,7 +107,7 @@ def nuts_gauss(sd, warm, samp, key, depth=10, thin=1, z0=None):
     f = harness().harness_nuts_gauss
     f.restype = C.c_int
     f.argtypes = ([C.c_int, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p, C.c_uint32, C.c_uint32] +
-                  [C.c_void_p] * 3)
+                  [C.c_void_p] * 3 + [C.c_double])
     rc = f(D, _p(sd), warm, samp, depth, thin, _p(z0), key[0], key[1], _p(draws), _p(stats),
-           _p(summ))
+           _p(summ), float(step_size))
     return rc, draws, stats, summ

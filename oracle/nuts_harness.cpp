@@ -7,6 +7,7 @@
 #include <cstring>
 #include <vector>
 
+#include "../bpl-next_amd/csrc/dc_layout.h"
 #include "../bpl-next_amd/csrc/nuts.hpp"
 
 extern "C" int dco_potential_grad(int model, int64_t n, int T, int K, const uint16_t* h,
@@ -85,15 +86,29 @@ int harness_nuts_dc(int model, int64_t n, int T, int K, const uint16_t* h, const
     OraclePot pot{model, T, K, dco_latent_dim(model, T, K), n, h, a, x, y, w, xs};
     nuts::Config cfg;
     fill(&cfg, warm, samp, depth, thin, step_size > 0 ? step_size : 1.0);
+    // latent sites in model trace order, as the product binds them (bplhip.hip make_nuts_config)
+    const dc::Layout L = dc::make_layout(model, T, K);
+    if (model == dc::MODEL_BASIC) {
+        cfg.sites = {{L.o_ha, 1}, {L.o_md, 1}, {L.o_sa, 1}, {L.o_sd, 1}, {L.o_adec, T}, {L.o_ddec, T}, {L.o_corr, 1}};
+    } else {
+        cfg.sites = {{L.o_mha, 1}, {L.o_sh, 1}, {L.o_md, 1}, {L.o_sa, 1}, {L.o_sd, 1}};
+        if (K) {
+            cfg.sites.push_back({L.o_bA, K});
+            cfg.sites.push_back({L.o_bD, K});
+        }
+        for (auto st : {nuts::Site{L.o_u, 1}, nuts::Site{L.o_sat, T}, nuts::Site{L.o_sdt, T},
+                        nuts::Site{L.o_hadec, T}, nuts::Site{L.o_corr, 1}})
+            cfg.sites.push_back(st);
+    }
     return run(pot, cfg, z0, khi, klo, draws, stats, summary);
 }
 
 int harness_nuts_gauss(int D, const double* sd, int warm, int samp, int depth, int thin,
                        const double* z0, uint32_t khi, uint32_t klo, double* draws,
-                       double* stats, double* summary) {
+                       double* stats, double* summary, double step_size) {
     GaussPot pot{D, sd};
     nuts::Config cfg;
-    fill(&cfg, warm, samp, depth, thin);
+    fill(&cfg, warm, samp, depth, thin, step_size > 0 ? step_size : 1.0);
     return run(pot, cfg, z0, khi, klo, draws, stats, summary);
 }
 

@@ -21,9 +21,9 @@ split / bits / normal (tests/test_nuts_oracle.py).
 Only tests/ may import this module.
 
 Differences from numpyro that are deliberate and shared with the product: the chain state is
-float64 (numpyro: float32); random draws keep jax's float32 values (uniform's mantissa trick,
-normal = sqrt(2) * erfinv(u) evaluated in float64 here and rounded to float32 -- jax uses a
-float32 polynomial for erfinv, so a draw can differ from jax's in its last float32 bit).
+float64 (numpyro: float32); uniform draws are jax's float32 values exactly (mantissa trick);
+a normal draw is sqrt(2) * erfinv(u) of jax's float32 u evaluated in float64 -- jax evaluates a
+float32 polynomial for erfinv, so its draw equals this one up to the last float32 bit.
 """
 import math
 
@@ -97,11 +97,17 @@ def uniform(key, n, minval=0.0, maxval=1.0):
     return np.maximum(lo, f * np.float32(hi - lo) + lo).astype(np.float32)
 
 
-def normal(key, n):
-    """jax.random.normal(key, (n,), float32)."""
+def normal(key, n, float32_result=False):
+    """jax.random.normal(key, (n,), float32) = sqrt(2) * erfinv(u), u = uniform(key, (n,),
+    nextafter(-1, 0), 1) in float32.  Default: the float64 inverse of the float32 u (the chain
+    state is float64; jax itself evaluates a float32 polynomial, so its value is this one up to
+    the last float32 bit).  float32_result=True rounds like jax's output dtype."""
     lo = np.nextafter(np.float32(-1.0), np.float32(0.0))
     u = uniform(key, n, lo, 1.0)
-    return (np.float32(math.sqrt(2.0)) * erfinv(u.astype(np.float64)).astype(np.float32)).astype(np.float32)
+    v = math.sqrt(2.0) * erfinv(u.astype(np.float64))
+    if float32_result:
+        return (np.float32(math.sqrt(2.0)) * erfinv(u.astype(np.float64)).astype(np.float32)).astype(np.float32)
+    return v
 
 
 def bernoulli(key, p):
@@ -452,4 +458,23 @@ def run_chain(pot, key, num_warmup, num_samples, z0=None, site_shapes=None, step
     out["final_step_size"] = wa.step_size
     out["inverse_mass_matrix"] = wa.inv_mass.copy()
     out["z0"] = np.asarray(z0, dtype=np.float64)
+    return out
+
+
+# ------------------------------------------------------------------ the reference's models
+
+def site_shapes(model, n_teams, k=0):
+    """Latent sample sites in MODEL TRACE order (the order find_valid_initial_params walks them)
+    with their sizes.  basic: bpl/dixon_coles.py:46-78 (`attack` / `defence` are reparametrised:
+    the traced latent sites are `*_decentered`); extended: bpl/extended_dixon_coles.py:112-235."""
+    T = n_teams
+    if model == 0:
+        return [("home_advantage", 1), ("mean_defence", 1), ("std_attack", 1), ("std_defence", 1),
+                ("attack_decentered", T), ("defence_decentered", T), ("corr_coef_raw", 1)]
+    out = [("mean_home_advantage", 1), ("std_home_advantage", 1), ("mean_defence", 1),
+           ("std_attack", 1), ("std_defence", 1)]
+    if k:
+        out += [("attack_coefficients", k), ("defence_coefficients", k)]
+    out += [("u", 1), ("standardised_attack", T), ("standardised_defence", T),
+            ("home_advantage_decentered", T), ("corr_coef_raw", 1)]
     return out
