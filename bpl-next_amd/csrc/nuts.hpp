@@ -339,7 +339,7 @@ struct Sampler {
 //       z_site = uniform(subkey, shape, -r, r);  key, subkey = split(key)
 // `key` is carried into the next attempt.  (Round 1 had restated the seed-handler branch -- one
 // key per site from handlers.seed, split again inside init_to_uniform -- which numpyro only takes
-// for strategies other than init_to_uniform; found by the independent oracle, oracle/nuts_oracle.py.)
+// for strategies other than init_to_uniform; found by the independent restatement the tests hold.)
 inline void draw_init(tf::Key* key, const std::vector<Site>& sites, double radius, vec* z) {
     tf::Key sub;
     tf::split2(*key, key, &sub);
