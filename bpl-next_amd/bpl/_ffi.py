@@ -43,6 +43,7 @@ ABI_SYMBOLS = (
     "bplhip_constrain",
     "bplhip_predict_set_posterior",
     "bplhip_predict_score_proba",
+    "bplhip_predict_score_grid",
     "bplhip_threefry_split",
     "bplhip_threefry_bits",
 )
@@ -146,6 +147,8 @@ def load_library():
     lib.bplhip_predict_set_posterior.restype = C.c_int
     lib.bplhip_predict_score_proba.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp]
     lib.bplhip_predict_score_proba.restype = C.c_int
+    lib.bplhip_predict_score_grid.argtypes = [vp, i64, vp, vp, i32, vp, vp]
+    lib.bplhip_predict_score_grid.restype = C.c_int
     lib.bplhip_threefry_split.argtypes = [u32, u32, i32, C.POINTER(u32)]
     lib.bplhip_threefry_split.restype = None
     lib.bplhip_threefry_bits.argtypes = [u32, u32, i32, C.POINTER(u32)]
@@ -425,6 +428,19 @@ class HipContext:
         with self._torch.cuda.device(self.device):
             self._check(self._lib.bplhip_predict_score_proba(
                 self._h, m, _np_ptr(h), _np_ptr(a), _np_ptr(x), _np_ptr(y), _np_ptr(out), self._stream()))
+        return out
+
+    def predict_score_grid(self, home_idx, away_idx, max_goals: int) -> np.ndarray:
+        """[m, max_goals+1, max_goals+1] scoreline probabilities of the m fixtures."""
+        h = np.ascontiguousarray(home_idx, dtype=np.uint16)
+        a = np.ascontiguousarray(away_idx, dtype=np.uint16)
+        if h.size != a.size:
+            raise ValueError("home and away index arrays must have equal length")
+        g1 = int(max_goals) + 1
+        out = np.empty((h.size, g1, g1), dtype=np.float64)
+        with self._torch.cuda.device(self.device):
+            self._check(self._lib.bplhip_predict_score_grid(
+                self._h, h.size, _np_ptr(h), _np_ptr(a), int(max_goals), _np_ptr(out), self._stream()))
         return out
 
     # -- sampler

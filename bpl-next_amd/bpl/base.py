@@ -1,20 +1,21 @@
-"""Base class of the match predictors (host side).
-
-Mirrors the reference's bpl/base.py:25-348 method for method (same names, arguments,
-return shapes and error behaviour); arrays are numpy instead of jax.  Everything here
-is post-processing of posterior draws -- it runs once per predict_* call, not per
-leapfrog -- and stays on the host in this round.
+"""Predict side of the match predictors: everything the reference's BaseMatchPredictor offers
+(bpl/base.py:25-348 -- same method names, arguments, return shapes, error behaviour), built on
+ONE device primitive instead of re-tiling scoreline queries: the per-fixture scoreline grid
+`bplhip_predict_score_grid` (csrc/dc_predict.hip.h, one wave per fixture on the matrix cores).
+Outcome probabilities, n-goal marginals and the sampling methods are reductions of that grid;
+`predict_score_proba` for arbitrary scorelines uses the pointwise kernel.  Arrays are numpy
+(the reference returns jax arrays).  There is no host fallback: the predict path needs the HIP
+library and a GPU, like `fit`.
 """
 
 from __future__ import annotations
 
-from abc import abstractmethod
 from datetime import datetime
 from typing import Dict, Iterable, Optional, Tuple, Union
 
 import numpy as np
 
-from bpl._util import map_choice, str_to_list
+from bpl._util import map_choice
 
 MAX_GOALS = 15
 DTYPES = {
@@ -25,204 +26,157 @@ DTYPES = {
     "outcome": "uint8",
 }
 
+TeamArg = Union[str, int, Iterable[str], Iterable[int]]
+
 
 def _prng_key(seed: int):
+    """jax.random.PRNGKey(seed) as the (hi, lo) pair the library's threefry takes."""
     seed = int(seed) & 0xFFFFFFFFFFFFFFFF
     return (seed >> 32) & 0xFFFFFFFF, seed & 0xFFFFFFFF
 
 
+def _wall_clock_seed() -> int:
+    # the reference seeds from the clock when random_state is None (bpl/base.py:173-174)
+    return int(datetime.now().timestamp() * 100)
+
+
 class BaseMatchPredictor:
-    """Abstract class for models of football matches."""
+    """Common predict API of the team-level models.  A subclass provides `fit` and the four
+    posterior arrays (`attack`, `defence` [draws, teams]; `home_advantage` [draws] or
+    [draws, teams]; `corr_coef` [draws])."""
 
     def __init__(self):
-        # unique team names (sorted) and the name -> integer index map
-        self.teams = None
-        self._teams_dict = None
-        # True: predict_score_proba (and everything built on it) runs on the GPU through
-        # libbplhip's predict kernel instead of host numpy (same results to ~1e-13)
-        self.predict_on_device = False
-        self._predict_ctx = None
-        self._predict_key = None
+        self.teams = None          # sorted unique team names
+        self._teams_dict = None    # name -> index
+        self._predict_ctx = None   # bpl._ffi.HipContext holding the uploaded posterior
+        self._uploaded = None      # identity of the arrays last uploaded
 
-    def _device_score_proba(self, home_ind, away_ind, home_goals, away_goals) -> np.ndarray:
-        """predict_score_proba on the device for index arrays; scalars are broadcast."""
-        from bpl._ffi import HipContext
+    # ------------------------------------------------------------------ plumbing
+    def fit(self, training_data, **kwargs) -> "BaseMatchPredictor":
+        raise NotImplementedError("subclasses implement fit()")
 
-        m = len(home_ind)
-        hg = np.broadcast_to(np.asarray(home_goals), (m,)) if np.ndim(home_goals) == 0 else np.asarray(home_goals)
-        ag = np.broadcast_to(np.asarray(away_goals), (m,)) if np.ndim(away_goals) == 0 else np.asarray(away_goals)
+    def _team_indices(self, *team_args: TeamArg):
+        """Names (or ready indices), scalar or iterable -> uint16 index arrays.  Unknown names
+        raise KeyError, as the reference's dictionary lookup does."""
+        out = []
+        for arg in team_args:
+            items = [arg] if isinstance(arg, (str, int, np.integer)) else list(arg)
+            out.append(np.fromiter((self._teams_dict[t] if isinstance(t, str) else int(t) for t in items),
+                                   dtype=DTYPES["teams"], count=len(items)))
+        return out if len(out) > 1 else out[0]
+
+    # (name kept: the reference's helper of the same role, bpl/base.py:62-72)
+    def _parse_fixture_args(self, home_team: TeamArg, away_team: TeamArg):
+        return tuple(self._team_indices(home_team, away_team))
+
+    def _device(self):
+        """The context with this model's current posterior draws on the GPU."""
         if self._predict_ctx is None:
+            from bpl._ffi import HipContext
+
             self._predict_ctx = HipContext(0)
-        key = (id(self.attack), id(self.defence), id(self.home_advantage), id(self.corr_coef),
-               np.shape(self.attack))
-        if key != self._predict_key:
-            self._predict_ctx.predict_set_posterior(self.attack, self.defence,
-                                                    self.home_advantage, self.corr_coef)
-            self._predict_key = key
-        return self._predict_ctx.predict_score_proba(home_ind, away_ind, hg, ag)
+        arrays = (self.attack, self.defence, self.home_advantage, self.corr_coef)
+        stamp = tuple(id(a) for a in arrays) + (np.shape(self.attack),)
+        if stamp != self._uploaded:
+            self._predict_ctx.predict_set_posterior(*arrays)
+            self._uploaded = stamp
+        return self._predict_ctx
 
-    @abstractmethod
-    def fit(
-        self, training_data: Dict[str, Union[Iterable[str], Iterable[float]]], **kwargs
-    ) -> "BaseMatchPredictor":
-        """Fit the model to data and return self."""
+    def _grid(self, home_idx: np.ndarray, away_idx: np.ndarray, max_goals: int) -> np.ndarray:
+        """[fixtures, max_goals+1, max_goals+1]: P(home scores x, away scores y)."""
+        return self._device().predict_score_grid(home_idx, away_idx, int(max_goals))
 
-    @abstractmethod
-    def predict_score_proba(
-        self,
-        home_team: Union[str, Iterable[str]],
-        away_team: Union[str, Iterable[str]],
-        home_goals: Union[int, Iterable[int]],
-        away_goals: Union[int, Iterable[int]],
-    ) -> np.ndarray:
-        """Return the probability of a particular scoreline."""
+    def _calculate_expected_goals(self, home_team: TeamArg, away_team: TeamArg) -> Tuple[np.ndarray, np.ndarray]:
+        """Home and away scoring rates, [draws, fixtures] (bpl/dixon_coles.py:126-137,
+        bpl/extended_dixon_coles.py:335-358)."""
+        h, a = self._team_indices(home_team, away_team)
+        edge = self.home_advantage[:, None] if np.ndim(self.home_advantage) == 1 else self.home_advantage[:, h]
+        log_home = self.attack[:, h] - self.defence[:, a] + edge
+        log_away = self.attack[:, a] - self.defence[:, h]
+        return np.exp(log_home), np.exp(log_away)
 
-    def _parse_fixture_args(self, home_team, away_team):
-        home_team, away_team = str_to_list(home_team, away_team)
-        if isinstance(home_team[0], str):
-            home_team = np.array([self._teams_dict[t] for t in home_team], DTYPES["teams"])
-        if isinstance(away_team[0], str):
-            away_team = np.array([self._teams_dict[t] for t in away_team], DTYPES["teams"])
-        return home_team, away_team
+    # ------------------------------------------------------------------ probabilities
+    def predict_score_proba(self, home_team: TeamArg, away_team: TeamArg,
+                            home_goals: Union[int, Iterable[int]],
+                            away_goals: Union[int, Iterable[int]]) -> np.ndarray:
+        """Probability of each requested scoreline: posterior mean of tau * Poisson * Poisson
+        (bpl/dixon_coles.py:139-163)."""
+        h, a = self._team_indices(home_team, away_team)
+        x = np.broadcast_to(np.asarray(home_goals), h.shape)
+        y = np.broadcast_to(np.asarray(away_goals), h.shape)
+        return self._device().predict_score_proba(h, a, x, y)
 
-    def predict_score_grid_proba(
-        self,
-        home_team: Union[str, Iterable[str]],
-        away_team: Union[str, Iterable[str]],
-        max_goals: Optional[int] = MAX_GOALS,
-    ) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
-        """Scoreline probabilities on the (max_goals+1)^2 grid for each fixture."""
-        home_team, away_team = self._parse_fixture_args(home_team, away_team)
+    def predict_score_grid_proba(self, home_team: TeamArg, away_team: TeamArg,
+                                 max_goals: Optional[int] = MAX_GOALS,
+                                 ) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+        """(probabilities [fixtures, G+1, G+1], home-goal grid, away-goal grid)
+        (bpl/base.py:74-111)."""
+        h, a = self._team_indices(home_team, away_team)
+        counts = np.arange(max_goals + 1)
+        return (self._grid(h, a, max_goals),) + tuple(np.meshgrid(counts, counts, indexing="ij"))
 
-        n_goals = np.arange(0, max_goals + 1)
-        home_goals, away_goals = np.meshgrid(n_goals, n_goals, indexing="ij")
-        home_goals_flat = np.tile(home_goals.reshape((max_goals + 1) ** 2), len(home_team))
-        away_goals_flat = np.tile(away_goals.reshape((max_goals + 1) ** 2), len(home_team))
-        home_team_rep = np.repeat(home_team, (max_goals + 1) ** 2)
-        away_team_rep = np.repeat(away_team, (max_goals + 1) ** 2)
+    def predict_outcome_proba(self, home_team: TeamArg, away_team: TeamArg,
+                              max_goals: Optional[int] = MAX_GOALS) -> Dict[str, np.ndarray]:
+        """Home win / draw / away win (bpl/base.py:113-148): the strictly lower triangle, the
+        diagonal and the strictly upper triangle of the scoreline grid."""
+        h, a = self._team_indices(home_team, away_team)
+        grid = self._grid(h, a, max_goals)
+        return {
+            "home_win": np.tril(grid, -1).sum(axis=(1, 2)),
+            "draw": np.trace(grid, axis1=1, axis2=2),
+            "away_win": np.triu(grid, 1).sum(axis=(1, 2)),
+        }
 
-        probs = self.predict_score_proba(
-            home_team_rep, away_team_rep, home_goals_flat, away_goals_flat
-        ).reshape(len(home_team), max_goals + 1, max_goals + 1)
-        return probs, home_goals, away_goals
+    def _goal_marginal(self, n, team: TeamArg, opponent: TeamArg, team_is_home: bool,
+                       count_team_goals: bool, max_goals: int) -> np.ndarray:
+        """P(`team` scores [concedes] n) with the other side's goals summed over 0..max_goals:
+        a row or column sum of ONE fixture's grid."""
+        wanted = np.atleast_1d(np.asarray(n, dtype=np.int64))
+        t, o = self._team_indices(team, opponent)
+        depth = max(int(max_goals), int(wanted.max()))
+        grid = self._grid(*((t, o) if team_is_home else (o, t)), depth)[0]
+        # axis 0 counts the home side's goals: the team's when it is at home and we count its own
+        own_axis = 0 if team_is_home == count_team_goals else 1
+        other = np.take(grid, np.arange(max_goals + 1), axis=1 - own_axis)
+        return other.sum(axis=1 - own_axis)[wanted]
 
-    def predict_outcome_proba(
-        self,
-        home_team: Union[str, Iterable[str]],
-        away_team: Union[str, Iterable[str]],
-        max_goals: Optional[int] = MAX_GOALS,
-    ) -> Dict[str, np.ndarray]:
-        """Home win, draw and away win probabilities."""
-        home_team, away_team = self._parse_fixture_args(home_team, away_team)
-        probs, home_goals, away_goals = self.predict_score_grid_proba(
-            home_team, away_team, max_goals=max_goals
-        )
-        home_win = probs[:, home_goals > away_goals].sum(axis=-1)
-        draw = probs[:, home_goals == away_goals].sum(axis=-1)
-        away_win = probs[:, home_goals < away_goals].sum(axis=-1)
-        return {"home_win": home_win, "draw": draw, "away_win": away_win}
+    def predict_score_n_proba(self, n: Union[int, Iterable[int]], team: TeamArg, opponent: TeamArg,
+                              home: Optional[bool] = True,
+                              max_goals: Optional[int] = MAX_GOALS) -> np.ndarray:
+        """Probability that `team` scores n goals against `opponent` (bpl/base.py:248-297)."""
+        return self._goal_marginal(n, team, opponent, bool(home), True, max_goals)
 
-    def sample_score(
-        self,
-        home_team: Union[str, Iterable[str]],
-        away_team: Union[str, Iterable[str]],
-        num_samples: int = 1,
-        random_state: int = None,
-        max_goals: Optional[int] = MAX_GOALS,
-    ) -> Dict[str, np.ndarray]:
-        """Sample scorelines between two teams."""
-        home_team, away_team = self._parse_fixture_args(home_team, away_team)
-        if random_state is None:
-            random_state = int(datetime.now().timestamp() * 100)
+    def predict_concede_n_proba(self, n: Union[int, Iterable[int]], team: TeamArg, opponent: TeamArg,
+                                home: Optional[bool] = True,
+                                max_goals: Optional[int] = MAX_GOALS) -> np.ndarray:
+        """Probability that `team` concedes n goals against `opponent` (bpl/base.py:299-348)."""
+        return self._goal_marginal(n, team, opponent, bool(home), False, max_goals)
 
-        probs, home_goals, away_goals = self.predict_score_grid_proba(
-            home_team, away_team, max_goals=max_goals
-        )
-        home_goals = np.array(home_goals.flatten(), DTYPES["goals"])
-        away_goals = np.array(away_goals.flatten(), DTYPES["goals"])
+    # ------------------------------------------------------------------ sampling
+    def sample_score(self, home_team: TeamArg, away_team: TeamArg, num_samples: int = 1,
+                     random_state: int = None, max_goals: Optional[int] = MAX_GOALS,
+                     ) -> Dict[str, np.ndarray]:
+        """Scorelines drawn from each fixture's grid, [fixtures, num_samples] per side
+        (bpl/base.py:150-195): one categorical draw over the flattened grid, then
+        cell -> (row, column)."""
+        h, a = self._team_indices(home_team, away_team)
+        seed = _wall_clock_seed() if random_state is None else random_state
+        width = max_goals + 1
+        grid = self._grid(h, a, max_goals).reshape(len(h), width * width)
+        cell = map_choice(_prng_key(seed), np.arange(width * width, dtype="uint32"), num_samples, grid)
+        rows, cols = np.divmod(cell, width)
+        return {"home_score": rows.astype(DTYPES["goals"]), "away_score": cols.astype(DTYPES["goals"])}
 
-        sample_idx = map_choice(
-            _prng_key(random_state),
-            np.arange(len(home_goals), dtype="uint32"),
-            num_samples,
-            probs.reshape((len(home_team), -1)),
-        )
-        return {"home_score": home_goals[sample_idx], "away_score": away_goals[sample_idx]}
-
-    def sample_outcome(
-        self,
-        home_team: Union[str, Iterable[str]],
-        away_team: Union[str, Iterable[str]],
-        num_samples: int = 1,
-        random_state: int = None,
-        max_goals: Optional[int] = MAX_GOALS,
-    ) -> np.ndarray:
-        """Sample the winner ('Draw' for a draw) of matches between two teams."""
-        home_team, away_team = self._parse_fixture_args(home_team, away_team)
-        if random_state is None:
-            random_state = int(datetime.now().timestamp() * 100)
-
-        probs = self.predict_outcome_proba(home_team, away_team, max_goals=max_goals)
-        probs = np.array([probs["home_win"], probs["draw"], probs["away_win"]]).T
-
-        sample_idx = map_choice(
-            _prng_key(random_state), np.arange(probs.shape[1], dtype="uint32"), num_samples, probs
-        )
-
-        home_team = np.asarray(home_team)
-        away_team = np.asarray(away_team)
-        winner = np.empty((len(home_team), num_samples), dtype=DTYPES["teams"])
-        home_team_rep = home_team.repeat(num_samples).reshape((len(home_team), num_samples))
-        away_team_rep = away_team.repeat(num_samples).reshape((len(home_team), num_samples))
-        winner[sample_idx == 0] = home_team_rep[sample_idx == 0]
-        winner[sample_idx == 2] = away_team_rep[sample_idx == 2]
-        winner[sample_idx == 1] = len(self.teams)  # temporary index for 'Draw'
-
-        _teams_with_draw = np.append(self.teams, "Draw")
-        return _teams_with_draw[winner]
-
-    def predict_score_n_proba(
-        self,
-        n: Union[int, Iterable[int]],
-        team: Union[str, Iterable[str]],
-        opponent: Union[str, Iterable[str]],
-        home: Optional[bool] = True,
-        max_goals: Optional[int] = MAX_GOALS,
-    ) -> np.ndarray:
-        """Probability that `team` scores n goals against `opponent`."""
-        n = [n] if isinstance(n, (int, np.integer)) else n
-        team, opponent = self._parse_fixture_args(team, opponent)
-        team_rep = np.repeat(team, (max_goals + 1) * len(n))
-        opponent_rep = np.repeat(opponent, (max_goals + 1) * len(n))
-        n_rep = np.resize(n, (max_goals + 1) * len(n))
-        x_rep = np.repeat(np.arange(max_goals + 1), len(n))
-
-        probs = (
-            self.predict_score_proba(team_rep, opponent_rep, n_rep, x_rep)
-            if home
-            else self.predict_score_proba(opponent_rep, team_rep, x_rep, n_rep)
-        ).reshape(max_goals + 1, len(n))
-        return probs.sum(axis=0)
-
-    def predict_concede_n_proba(
-        self,
-        n: Union[int, Iterable[int]],
-        team: Union[str, Iterable[str]],
-        opponent: Union[str, Iterable[str]],
-        home: Optional[bool] = True,
-        max_goals: Optional[int] = MAX_GOALS,
-    ) -> np.ndarray:
-        """Probability that `team` concedes n goals against `opponent`."""
-        n = [n] if isinstance(n, (int, np.integer)) else n
-        team, opponent = self._parse_fixture_args(team, opponent)
-        team_rep = np.repeat(team, (max_goals + 1) * len(n))
-        opponent_rep = np.repeat(opponent, (max_goals + 1) * len(n))
-        n_rep = np.resize(n, (max_goals + 1) * len(n))
-        x_rep = np.repeat(np.arange(max_goals + 1), len(n))
-
-        probs = (
-            self.predict_score_proba(team_rep, opponent_rep, x_rep, n_rep)
-            if home
-            else self.predict_score_proba(opponent_rep, team_rep, n_rep, x_rep)
-        ).reshape(max_goals + 1, len(n))
-        return probs.sum(axis=0)
+    def sample_outcome(self, home_team: TeamArg, away_team: TeamArg, num_samples: int = 1,
+                       random_state: int = None, max_goals: Optional[int] = MAX_GOALS) -> np.ndarray:
+        """Winner's name, or 'Draw', [fixtures, num_samples] (bpl/base.py:197-246)."""
+        h, a = self._team_indices(home_team, away_team)
+        seed = _wall_clock_seed() if random_state is None else random_state
+        p = self.predict_outcome_proba(h, a, max_goals=max_goals)
+        table = np.column_stack([p["home_win"], p["draw"], p["away_win"]])
+        pick = map_choice(_prng_key(seed), np.arange(3, dtype="uint32"), num_samples, table)
+        labels = np.append(self.teams, "Draw")
+        draw_slot = len(self.teams)
+        # 0 -> the home side's name, 1 -> 'Draw', 2 -> the away side's
+        who = np.where(pick == 0, h[:, None], np.where(pick == 2, a[:, None], draw_slot))
+        return labels[who]

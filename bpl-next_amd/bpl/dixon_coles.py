@@ -1,98 +1,50 @@
-"""A simple team-level Dixon-Coles model -- drop-in for the reference's
-bpl/dixon_coles.py:26-163.  `fit()` keeps the reference signature; the model function
-(`_model`, bpl/dixon_coles.py:39-84) and numpyro's NUTS are replaced by the HIP path in
-libbplhip.so (dc_stream / dc_epilogue kernels + the C++ NUTS driver)."""
+"""The team-level Dixon-Coles model behind the reference's class name and `fit` signature
+(bpl/dixon_coles.py:26-163).  The model function (`_model`, :39-84) and numpyro's NUTS are
+replaced by libbplhip.so -- the `dc_eval` kernel evaluates the log-density and its gradient,
+the chain lives on the device -- and the predict methods come from `BaseMatchPredictor`
+(one device grid per fixture)."""
 
 from __future__ import annotations
 
-from typing import Any, Dict, Iterable, Optional, Tuple, Union
+from typing import Any, Dict, Iterable, Optional, Union
 
 import numpy as np
 
 from bpl._ffi import MODEL_BASIC
 from bpl._mcmc import run_mcmc
-from bpl._util import dixon_coles_correlation_term, parse_teams, poisson_log_prob
-from bpl.base import DTYPES, BaseMatchPredictor
+from bpl._util import parse_teams
+from bpl.base import BaseMatchPredictor, DTYPES
 
 __all__ = ["DixonColesMatchPredictor"]
+TrainingData = Dict[str, Union[Iterable[str], Iterable[float]]]
+
+# posterior sites the reference keeps as attributes after a fit (bpl/dixon_coles.py:118-122)
+_KEPT_SITES = ("attack", "defence", "home_advantage", "corr_coef")
 
 
 class DixonColesMatchPredictor(BaseMatchPredictor):
-    """A Dixon-Coles like model for predicting match outcomes."""
+    """Attack and defence ability per team, one home advantage, Dixon-Coles low-score
+    correlation."""
 
-    # pylint: disable=duplicate-code
     def __init__(self):
         super().__init__()
-        self.attack = None
-        self.defence = None
-        self.home_advantage = None
-        self.corr_coef = None
-        self.mcmc_info_ = None
+        for site in _KEPT_SITES:
+            setattr(self, site, None)
+        self.mcmc_info_ = None  # sampler statistics (no reference counterpart)
 
-    # pylint: disable=arguments-differ,too-many-arguments,duplicate-code
-    def fit(
-        self,
-        training_data: Dict[str, Union[Iterable[str], Iterable[float]]],
-        random_state: int = 42,
-        num_warmup: int = 500,
-        num_samples: int = 1000,
-        mcmc_kwargs: Optional[Dict[str, Any]] = None,
-        run_kwargs: Optional[Dict[str, Any]] = None,
-    ) -> "DixonColesMatchPredictor":
-        self.teams, self._teams_dict, home_ind, away_ind = parse_teams(
-            training_data["home_team"], training_data["away_team"], DTYPES["teams"]
+    # pylint: disable=arguments-differ,too-many-arguments
+    def fit(self, training_data: TrainingData, random_state: int = 42, num_warmup: int = 500,
+            num_samples: int = 1000, mcmc_kwargs: Optional[Dict[str, Any]] = None,
+            run_kwargs: Optional[Dict[str, Any]] = None) -> "DixonColesMatchPredictor":
+        """Same arguments and defaults as the reference's fit (bpl/dixon_coles.py:87-95)."""
+        names = parse_teams(training_data["home_team"], training_data["away_team"], DTYPES["teams"])
+        self.teams, self._teams_dict, home_idx, away_idx = names
+        goals = [np.array(training_data[side]) for side in ("home_goals", "away_goals")]
+        draws, self.mcmc_info_ = run_mcmc(
+            MODEL_BASIC, home_idx, away_idx, goals[0], goals[1], len(self.teams),
+            random_state=random_state, num_warmup=num_warmup, num_samples=num_samples,
+            mcmc_kwargs=mcmc_kwargs, run_kwargs=run_kwargs,
         )
-        samples, info = run_mcmc(
-            MODEL_BASIC,
-            home_ind,
-            away_ind,
-            np.array(training_data["home_goals"]),
-            np.array(training_data["away_goals"]),
-            len(self.teams),
-            random_state=random_state,
-            num_warmup=num_warmup,
-            num_samples=num_samples,
-            mcmc_kwargs=mcmc_kwargs,
-            run_kwargs=run_kwargs,
-        )
-        self.attack = samples["attack"]
-        self.defence = samples["defence"]
-        self.home_advantage = samples["home_advantage"]
-        self.corr_coef = samples["corr_coef"]
-        self.mcmc_info_ = info
+        for site in _KEPT_SITES:
+            setattr(self, site, draws[site])
         return self
-
-    def _calculate_expected_goals(
-        self, home_team: Union[str, Iterable[str]], away_team: Union[str, Iterable[str]]
-    ) -> Tuple[np.ndarray, np.ndarray]:
-        home_ind, away_ind = self._parse_fixture_args(home_team, away_team)
-
-        attack_home, defence_home = self.attack[:, home_ind], self.defence[:, home_ind]
-        attack_away, defence_away = self.attack[:, away_ind], self.defence[:, away_ind]
-
-        home_rate = np.exp(attack_home - defence_away + self.home_advantage[:, None])
-        away_rate = np.exp(attack_away - defence_home)
-        return home_rate, away_rate
-
-    def predict_score_proba(
-        self,
-        home_team: Union[str, Iterable[str]],
-        away_team: Union[str, Iterable[str]],
-        home_goals: Union[int, Iterable[int]],
-        away_goals: Union[int, Iterable[int]],
-    ) -> np.ndarray:
-        home_team, away_team = self._parse_fixture_args(home_team, away_team)
-        if self.predict_on_device:
-            return self._device_score_proba(home_team, away_team, home_goals, away_goals)
-
-        expected_home_goals, expected_away_goals = self._calculate_expected_goals(
-            home_team, away_team
-        )
-        corr_term = dixon_coles_correlation_term(
-            home_goals, away_goals, expected_home_goals, expected_away_goals, self.corr_coef
-        )
-        home_probs = np.exp(poisson_log_prob(expected_home_goals, home_goals))
-        away_probs = np.exp(poisson_log_prob(expected_away_goals, away_goals))
-
-        sampled_probs = np.exp(corr_term) * home_probs * away_probs
-        return sampled_probs.mean(axis=0)

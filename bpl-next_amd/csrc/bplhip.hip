@@ -115,6 +115,7 @@ struct bplhip_ctx {
     DevBuf d_nuts, d_ns;
     // posterior draws for the device predict path (dc_predict.hip.h)
     DevBuf dp_att, dp_def, dp_ha, dp_corr, dp_q;
+    DevBuf dp_att32, dp_def32, dp_ha32, dp_corr32;  // the same in float32 (grid kernel)
     int pred_S = 0, pred_T = 0, pred_ha_stride = 0;
     double* h_pinned = nullptr;
     size_t h_pinned_bytes = 0;
@@ -2060,9 +2061,64 @@ static int bplhip_predict_set_posterior_impl(bplhip_ctx* c, int32_t s, int32_t t
     HIP_TRY(c, hipMemcpy(c->dp_def.p, defence, st, hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(c->dp_ha.p, home_advantage, hb, hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(c->dp_corr.p, corr_coef, (size_t)s * 8, hipMemcpyHostToDevice));
+    // float32 copies for the grid kernel (the reference's own dtype)
+    auto up32 = [&](DevBuf& b, const double* src, size_t n) -> int {
+        std::vector<float> tmp(src, src + n);
+        HIP_TRY(c, b.ensure(n * 4));
+        HIP_TRY(c, hipMemcpy(b.p, tmp.data(), n * 4, hipMemcpyHostToDevice));
+        return BPLHIP_OK;
+    };
+    int rc = up32(c->dp_att32, attack, (size_t)s * t);
+    if (rc == BPLHIP_OK) rc = up32(c->dp_def32, defence, (size_t)s * t);
+    if (rc == BPLHIP_OK) rc = up32(c->dp_ha32, home_advantage, home_advantage_per_team ? (size_t)s * t : (size_t)s);
+    if (rc == BPLHIP_OK) rc = up32(c->dp_corr32, corr_coef, (size_t)s);
+    if (rc != BPLHIP_OK) return rc;
     c->pred_S = s;
     c->pred_T = t;
     c->pred_ha_stride = home_advantage_per_team ? t : 0;
+    return BPLHIP_OK;
+}
+
+static int bplhip_predict_score_grid_impl(bplhip_ctx* c, int64_t m, const uint16_t* home_idx,
+                                         const uint16_t* away_idx, int32_t max_goals, double* out,
+                                         void* stream) {
+    if (!c) return BPLHIP_EINVAL;
+    if (c->pred_S == 0) return fail(c, BPLHIP_ESTATE, "predict_score_grid: no posterior set");
+    if (max_goals < 0 || max_goals > dcp::GRID_MAX_GOALS)
+        return fail(c, BPLHIP_EINVAL, "predict_score_grid: max_goals=%d out of range [0,%d]", max_goals,
+                    dcp::GRID_MAX_GOALS);
+    if (m < 0 || m > 0x7FFFFFFF || (m > 0 && (!home_idx || !away_idx || !out)))
+        return fail(c, BPLHIP_EINVAL, "predict_score_grid: bad argument");
+    if (m == 0) return BPLHIP_OK;
+    for (int64_t i = 0; i < m; ++i)
+        if (home_idx[i] >= c->pred_T || away_idx[i] >= c->pred_T)
+            return fail(c, BPLHIP_EINVAL, "predict_score_grid: team index out of range at %lld", (long long)i);
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t cells = (size_t)m * (max_goals + 1) * (max_goals + 1);
+    const size_t idx_bytes = ((size_t)m * 4 + 7) & ~(size_t)7;
+    HIP_TRY(c, c->dp_q.ensure(idx_bytes + cells * 8));
+    uint16_t* q = c->dp_q.as<uint16_t>();
+    double* d_out = reinterpret_cast<double*>(c->dp_q.as<char>() + idx_bytes);
+    HIP_TRY(c, hipMemcpyAsync(q, home_idx, (size_t)m * 2, hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(q + m, away_idx, (size_t)m * 2, hipMemcpyHostToDevice, s));
+    dcp::GridArgs A{};
+    A.S = c->pred_S;
+    A.T = c->pred_T;
+    A.attack = c->dp_att32.as<const float>();
+    A.defence = c->dp_def32.as<const float>();
+    A.home_adv = c->dp_ha32.as<const float>();
+    A.ha_stride = c->pred_ha_stride;
+    A.corr = c->dp_corr32.as<const float>();
+    A.M = (int)m;
+    A.G = max_goals;
+    A.h = q;
+    A.a = q + m;
+    A.out = d_out;
+    hipLaunchKernelGGL(dcp::predict_score_grid, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, s, A);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(out, d_out, cells * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
     return BPLHIP_OK;
 }
 
@@ -2170,6 +2226,13 @@ extern "C" int bplhip_predict_set_posterior(bplhip_ctx* c, int32_t s, int32_t t,
                                             int32_t home_advantage_per_team,
                                             const double* corr_coef) {
     return guarded(c, "bplhip_predict_set_posterior", [&] { return bplhip_predict_set_posterior_impl(c, s, t, attack, defence, home_advantage, home_advantage_per_team, corr_coef); });
+}
+extern "C" int bplhip_predict_score_grid(bplhip_ctx* c, int64_t m, const uint16_t* home_idx,
+                                         const uint16_t* away_idx, int32_t max_goals, double* out,
+                                         void* stream) {
+    return guarded(c, "bplhip_predict_score_grid", [&] {
+        return bplhip_predict_score_grid_impl(c, m, home_idx, away_idx, max_goals, out, stream);
+    });
 }
 extern "C" int bplhip_predict_score_proba(bplhip_ctx* c, int64_t m, const uint16_t* home_idx,
                                           const uint16_t* away_idx, const uint16_t* home_goals,

@@ -277,6 +277,16 @@ int bplhip_predict_set_posterior(bplhip_ctx* ctx, int32_t s, int32_t t, const do
 int bplhip_predict_score_proba(bplhip_ctx* ctx, int64_t m, const uint16_t* home_idx,
                                const uint16_t* away_idx, const uint16_t* home_goals,
                                const uint16_t* away_goals, double* out, void* stream);
+/* `predict_score_grid_proba` (bpl/base.py:74-111): for each of the m fixtures the whole
+ * (max_goals+1) x (max_goals+1) grid of scoreline probabilities, out[i, x, y] = mean over draws of
+ * exp(tau term) * Poisson(x; home rate) * Poisson(y; away rate) -- the primitive the reference's
+ * predict_outcome_proba (:113-148), predict_score_n_proba / predict_concede_n_proba (:248-348)
+ * and sample_score / sample_outcome (:150-246) are reductions of.  One wave per fixture on the
+ * matrix cores (float32 pmf outer products, float64 accumulation across 64-draw blocks).
+ * HOST u16[m] in, HOST f64[m, max_goals+1, max_goals+1] out, max_goals <= 63, synchronous. */
+int bplhip_predict_score_grid(bplhip_ctx* ctx, int64_t m, const uint16_t* home_idx,
+                              const uint16_t* away_idx, int32_t max_goals, double* out,
+                              void* stream);
 
 /* threefry2x32 helpers with jax.random semantics (jax 0.4.24, non-partitionable
  * threefry): used by the Python host for key plumbing (random.split for multi-chain

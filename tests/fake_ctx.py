@@ -59,3 +59,42 @@ class FakeCtx:
 
     def close(self):
         pass
+
+
+class FakePredictCtx:
+    """TEST-ONLY numpy (float64) predict backend with bpl._ffi.HipContext's predict surface:
+    a literal restatement of the reference's predict_score_proba (bpl/dixon_coles.py:126-163,
+    bpl/_util.py:35-93).  The CPU API tests inject it as `model._predict_ctx`; the GPU tests use it
+    as the float64 comparator of the device kernels."""
+
+    def predict_set_posterior(self, attack, defence, home_advantage, corr_coef):
+        self.att, self.dfn = np.asarray(attack, float), np.asarray(defence, float)
+        self.ha, self.cc = np.asarray(home_advantage, float), np.asarray(corr_coef, float)
+
+    def predict_score_proba(self, h, a, x, y):
+        from scipy.special import gammaln
+
+        h, a = np.asarray(h, int), np.asarray(a, int)
+        x, y = np.asarray(x, int), np.asarray(y, int)
+        ha = self.ha[:, None] if self.ha.ndim == 1 else self.ha[:, h]
+        lh = np.exp(self.att[:, h] - self.dfn[:, a] + ha)
+        la = np.exp(self.att[:, a] - self.dfn[:, h])
+        rho = self.cc[:, None]
+        tau = np.ones_like(lh)
+        tau = np.where((x == 0) & (y == 0), np.clip(1 - rho * lh * la, 0, None), tau)
+        tau = np.where((x == 1) & (y == 0), np.clip(1 + rho * la, 0, None), tau)
+        tau = np.where((x == 0) & (y == 1), np.clip(1 + rho * lh, 0, None), tau)
+        tau = np.where((x == 1) & (y == 1), np.clip(1 - rho + 0 * lh, 0, None), tau)
+        ph = np.exp(np.log(lh) * x - gammaln(x + 1.0) - lh)
+        pa = np.exp(np.log(la) * y - gammaln(y + 1.0) - la)
+        return (tau * ph * pa).mean(axis=0)
+
+    def predict_score_grid(self, h, a, max_goals):
+        h, a = np.asarray(h, int), np.asarray(a, int)
+        g1 = max_goals + 1
+        xs, ys = np.meshgrid(np.arange(g1), np.arange(g1), indexing="ij")
+        out = np.empty((len(h), g1, g1))
+        for i in range(len(h)):
+            out[i] = self.predict_score_proba(np.full(g1 * g1, h[i]), np.full(g1 * g1, a[i]),
+                                              xs.ravel(), ys.ravel()).reshape(g1, g1)
+        return out

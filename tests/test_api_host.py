@@ -1,12 +1,14 @@
-"""Host-side mirror of the reference API (bpl/base.py, bpl/_util.py) on a synthetic
-posterior -- the reference's own property tests (tests/test_base_models.py:15-96) with the
-NUTS fit replaced by hand-made draws, so they run without a GPU."""
+"""Host logic of the predict API (bpl/base.py: argument handling, the reductions of the scoreline
+grid, sampling) on a synthetic posterior -- the reference's own property tests
+(tests/test_base_models.py:15-96) with the NUTS fit replaced by hand-made draws and the device
+kernels by a numpy stand-in (tests/fake_ctx.py), so they run without a GPU."""
 import numpy as np
 import pytest
 
 from bpl import DixonColesMatchPredictor, ExtendedDixonColesMatchPredictor
 from bpl._util import compute_corr_coef_bounds, dixon_coles_correlation_term, parse_teams
 from bpl.base import MAX_GOALS
+from fake_ctx import FakePredictCtx
 
 
 def _fake_fit(cls, dummy_data, S=64, seed=0):
@@ -21,6 +23,7 @@ def _fake_fit(cls, dummy_data, S=64, seed=0):
         m.home_advantage = rs.normal(0.25, 0.05, S)
     else:
         m.home_advantage = rs.normal(0.25, 0.05, (S, T))
+    m._predict_ctx = FakePredictCtx()  # (no GPU here: the numpy restatement stands in for the kernels)
     return m
 
 

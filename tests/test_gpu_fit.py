@@ -293,30 +293,46 @@ def test_fit_num_chains_lockstep_vs_sequential(dummy_data):
 
 
 @pytest.mark.parametrize("model_cls", MODELS)
-def test_device_predict_matches_host_predict(fitted, model_cls):
-    """Row f-2: predict_score_proba / outcome / n-goals through the HIP predict kernel equal
-    the host numpy path (float64 both; tolerance 1e-12)."""
+def test_device_predict_matches_float64_restatement(fitted, model_cls):
+    """Row f-2: the predict kernels (csrc/dc_predict.hip.h) against a float64 numpy restatement
+    of the reference's predict_score_proba (tests/fake_ctx.py) on a fitted posterior.
+    Tolerances: the pointwise kernel is float64 throughout (1e-12); the grid kernel computes the
+    Poisson pmfs in float32 (v_exp_f32 of an argument of magnitude <= ~40: 2e-6 relative) on
+    float32 posterior draws, accumulated on the matrix cores in blocks of 64 draws and in float64
+    across blocks: 3e-6 relative + 1e-12."""
+    from fake_ctx import FakePredictCtx
+
     models, dd = fitted
     model = models[model_cls]
-    host = {
-        "score": model.predict_score_proba(dd["home_team"], dd["away_team"], dd["home_goals"], dd["away_goals"]),
-        "single": model.predict_score_proba("0", "1", 1, 0),
-        "outcome": model.predict_outcome_proba(dd["home_team"][:40], dd["away_team"][:40]),
-        "n": model.predict_score_n_proba(np.arange(MAX_GOALS + 1), "0", "1"),
-    }
-    model.predict_on_device = True
-    try:
-        dev = {
-            "score": model.predict_score_proba(dd["home_team"], dd["away_team"], dd["home_goals"], dd["away_goals"]),
-            "single": model.predict_score_proba("0", "1", 1, 0),
-            "outcome": model.predict_outcome_proba(dd["home_team"][:40], dd["away_team"][:40]),
-            "n": model.predict_score_n_proba(np.arange(MAX_GOALS + 1), "0", "1"),
-        }
-    finally:
-        model.predict_on_device = False
-    assert np.abs(dev["score"] - host["score"]).max() < 1e-12
-    assert np.abs(dev["single"] - host["single"]).max() < 1e-12
-    assert np.abs(dev["n"] - host["n"]).max() < 1e-12
-    for k in ("home_win", "draw", "away_win"):
-        assert np.abs(dev["outcome"][k] - host["outcome"][k]).max() < 1e-12
-    assert np.allclose(dev["outcome"]["home_win"] + dev["outcome"]["draw"] + dev["outcome"]["away_win"], 1.0, atol=1e-5)
+    ref = FakePredictCtx()
+    ref.predict_set_posterior(model.attack, model.defence, model.home_advantage, model.corr_coef)
+    h, a = model._team_indices(dd["home_team"], dd["away_team"])
+    # pointwise
+    got = model.predict_score_proba(dd["home_team"], dd["away_team"], dd["home_goals"], dd["away_goals"])
+    want = ref.predict_score_proba(h, a, dd["home_goals"], dd["away_goals"])
+    assert np.abs(got - want).max() < 1e-12
+    assert abs(model.predict_score_proba("0", "1", 1, 0)[0] - ref.predict_score_proba([0], [1], [1], [0])[0]) < 1e-12
+    # the grid, default depth and a multi-tile one (max_goals = 20: 2 x 2 tiles of 16)
+    for depth in (MAX_GOALS, 20, 3):
+        grid, xs, ys = model.predict_score_grid_proba(dd["home_team"][:60], dd["away_team"][:60], max_goals=depth)
+        want = ref.predict_score_grid(h[:60], a[:60], depth)
+        assert grid.shape == (60, depth + 1, depth + 1) and xs.shape == (depth + 1, depth + 1)
+        assert xs[3, 0] == 3 and ys[0, 3] == 3
+        err = np.abs(grid - want)
+        assert (err <= 3e-6 * want + 1e-12).all(), (depth, err.max())
+    # the reductions of the grid
+    out = model.predict_outcome_proba(dd["home_team"][:40], dd["away_team"][:40])
+    g = ref.predict_score_grid(h[:40], a[:40], MAX_GOALS)
+    xs, ys = np.meshgrid(np.arange(MAX_GOALS + 1), np.arange(MAX_GOALS + 1), indexing="ij")
+    for key, mask in (("home_win", xs > ys), ("draw", xs == ys), ("away_win", xs < ys)):
+        assert np.abs(out[key] - g[:, mask].sum(axis=1)).max() < 3e-6
+    n = np.arange(MAX_GOALS + 1)
+    g01 = ref.predict_score_grid([0], [1], MAX_GOALS)[0]
+    g10 = ref.predict_score_grid([1], [0], MAX_GOALS)[0]
+    assert np.abs(model.predict_score_n_proba(n, "0", "1") - g01.sum(axis=1)).max() < 3e-6
+    assert np.abs(model.predict_score_n_proba(n, "0", "1", home=False) - g10.sum(axis=0)).max() < 3e-6
+    assert np.abs(model.predict_concede_n_proba(n, "0", "1") - g01.sum(axis=0)).max() < 3e-6
+    assert np.abs(model.predict_concede_n_proba(n, "0", "1", home=False) - g10.sum(axis=1)).max() < 3e-6
+    # n beyond max_goals: the other side is still summed over 0..max_goals only
+    deep = ref.predict_score_grid([0], [1], 18)[0]
+    assert abs(model.predict_score_n_proba(18, "0", "1")[0] - deep[18, :MAX_GOALS + 1].sum()) < 1e-9

@@ -24,3 +24,15 @@ th = time.perf_counter() - t0
 print(f"predict_score_proba: {h.size} entries x {S} draws: {t * 1e3:.2f} ms end to end (H2D + kernel + D2H), "
       f"{h.size * S / t / 1e9:.2f} G entry-draws/s; grids sum to {out.reshape(len(pairs), -1).sum(1).mean():.6f}; "
       f"(numpy: the two rate arrays alone take {th * 1e3:.0f} ms)")
+# the grid kernel (one wave per fixture on the matrix cores): the same season of grids
+g = c.predict_score_grid([p[0] for p in pairs], [p[1] for p in pairs], MG - 1)
+ts = []
+for _ in range(5):
+    t0 = time.perf_counter(); g = c.predict_score_grid([p[0] for p in pairs], [p[1] for p in pairs], MG - 1); ts.append(time.perf_counter() - t0)
+tg = float(np.median(ts))
+print(f"predict_score_grid: {len(pairs)} fixtures x {MG}x{MG} x {S} draws: {tg * 1e3:.2f} ms end to end; "
+      f"max |grid - pointwise| = {np.abs(g.reshape(-1) - out).max():.2e}")
+big = np.tile(np.array(pairs), (256, 1))  # 97 280 fixtures
+t0 = time.perf_counter(); gb = c.predict_score_grid(big[:, 0], big[:, 1], MG - 1); tb = time.perf_counter() - t0
+print(f"predict_score_grid: {len(big)} fixtures ({gb.size * 8 / 1e6:.0f} MB of grids): {tb * 1e3:.1f} ms end to end, "
+      f"{len(big) * MG * MG * S / tb / 1e12:.2f} T cell-draws/s")
