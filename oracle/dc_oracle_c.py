@@ -111,3 +111,54 @@ def nuts_gauss(sd, warm, samp, key, depth=10, thin=1, z0=None, step_size=1.0):
     rc = f(D, _p(sd), warm, samp, depth, thin, _p(z0), key[0], key[1], _p(draws), _p(stats),
            _p(summ), float(step_size))
     return rc, draws, stats, summ
+
+
+# ---------------------------------------------------------------- the timed CPU comparator
+_port = None
+
+
+def port_lib():
+    global _port
+    if _port is None:
+        p = os.path.join(_DIR, "_build", "libdccpuport.so")
+        if not os.path.exists(p):
+            _build()
+        _port = C.CDLL(p)
+        _port.dcp_create.restype = C.c_void_p
+        _port.dcp_create.argtypes = [C.c_int, C.c_int64, C.c_int, C.c_int] + [C.c_void_p] * 6 + [C.c_int]
+        _port.dcp_destroy.argtypes = [C.c_void_p]
+        _port.dcp_eval.argtypes = [C.c_void_p] * 5
+        _port.dcp_eval_many.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        _port.dcp_eval_many.restype = C.c_double
+        _port.dcp_threads.argtypes = [C.c_void_p]
+    return _port
+
+
+class CpuPort:
+    """oracle/dc_cpu_port.c: the HIP kernel's algorithm on host cores (float32 per-fixture
+    arithmetic, float64 accumulation, OpenMP, no allocation per evaluation)."""
+
+    def __init__(self, cf: CFixtures, nthreads=0):
+        self.cf = cf
+        self.w32 = None if cf.w is None else np.ascontiguousarray(cf.w, dtype=np.float32)
+        self.h = port_lib().dcp_create(cf.model, cf.n, cf.T, cf.K, _p(cf.h), _p(cf.a), _p(cf.x), _p(cf.y),
+                                       _p(self.w32), _p(cf.xs), int(nthreads))
+        assert self.h
+        self.threads = port_lib().dcp_threads(self.h)
+
+    def eval(self, z):
+        z = np.ascontiguousarray(z, dtype=np.float64)
+        U, g, aux = np.zeros(1), np.zeros(self.cf.D), np.zeros(4)
+        port_lib().dcp_eval(self.h, _p(z), _p(U), _p(g), _p(aux))
+        return float(U[0]), g, aux
+
+    def eval_many(self, zs, count):
+        zs = np.ascontiguousarray(zs, dtype=np.float64)
+        U, g = np.zeros(1), np.zeros(self.cf.D)
+        port_lib().dcp_eval_many(self.h, _p(zs), zs.shape[0], int(count), _p(U), _p(g))
+        return float(U[0]), g
+
+    def close(self):
+        if self.h:
+            port_lib().dcp_destroy(self.h)
+            self.h = None

@@ -138,3 +138,27 @@ def test_edge_cases_single_fixture_and_unused_teams():
     unused = [t for t in range(fx.n_teams) if t not in (fx.home_idx[0], fx.away_idx[0])]
     assert g[sl["attack_decentered"]][unused] == pytest.approx(z[sl["attack_decentered"]][unused])
     assert np.isfinite(U)
+
+
+def test_cpu_port_matches_the_float64_oracle():
+    """oracle/dc_cpu_port.c (the CPU comparator bench.py times beside the GPU: the HIP kernel's
+    algorithm on host cores, float32 per-fixture arithmetic) against the float64 oracle, every
+    case family and latent point, one and several threads: float32-table tolerances."""
+    import cases
+    import dc_oracle as O
+    import dc_oracle_c as OC
+
+    for model, name in [(O.MODEL_BASIC, "dummy"), (O.MODEL_BASIC, "ragged_777"), (O.MODEL_BASIC, "league_1e5"),
+                        (O.MODEL_EXTENDED, "dummy_cov"), (O.MODEL_EXTENDED, "dummy_w"),
+                        (O.MODEL_EXTENDED, "timed_w"), (O.MODEL_EXTENDED, "ragged_5000")]:
+        fx = cases.fixtures(name)
+        cf = OC.CFixtures(model, fx)
+        for nt in (1, 3):
+            port = OC.CpuPort(cf, nt)
+            for pname, z in cases.z_points(model, fx):
+                Uo, go, auxo = O.potential_and_grad(model, fx, z)
+                U, g, aux = port.eval(z)
+                assert abs(U - Uo) <= 2e-6 * abs(Uo), (name, pname, nt)
+                assert np.abs(g - go).max() <= 5e-6 * np.abs(go).max(), (name, pname, nt)
+                assert abs(aux[0] - auxo["rho"]) <= 1e-6
+            port.close()
