@@ -13,6 +13,8 @@ Like the reference, the class is importable from this module, not from `bpl`."""
 
 from __future__ import annotations
 
+import warnings
+
 from typing import Any, Dict, Iterable, Optional, Tuple, Union
 
 import numpy as np
@@ -95,8 +97,20 @@ class DynamicNeutralDixonColesMatchPredictor:
         random_walk: bool = True,
     ) -> "DynamicNeutralDixonColesMatchPredictor":
         """Fit the model.  training_data keys: home_team, away_team, home_goals,
-        away_goals, gameweek (0-based ints), neutral_venue (0/1), optional team_covariates."""
+        away_goals, gameweek (0-based ints), neutral_venue (0/1), optional team_covariates.
+
+        random_walk=True (default) fits the INTENDED model, attack[g] = attack[g-1] + increment;
+        the reference's code discards those updates (bpl/dynamic_dixon_coles.py:192-218 assign
+        `attack.at[j].set(...)` to nothing), so its posterior is that of random_walk=False.  A
+        warning says so once per fit; pass random_walk=False for the reference's behaviour."""
         from bpl._ffi import HipContext
+
+        if random_walk:
+            warnings.warn(
+                "DynamicNeutralDixonColesMatchPredictor.fit(random_walk=True) fits the intended "
+                "random-walk model; the upstream implementation discards the walk (its attack and "
+                "defence stay at zero). Results differ from upstream: pass random_walk=False to "
+                "reproduce it.", stacklevel=2)
 
         home_team = list(training_data["home_team"])
         away_team = list(training_data["away_team"])

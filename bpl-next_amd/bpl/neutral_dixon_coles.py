@@ -153,6 +153,12 @@ class NeutralDixonColesMatchPredictor:
             raise TypeError(f"MCMC.run got unexpected keyword argument(s) {sorted(bad)}")
         num_chains = int(mcmc_kwargs.get("num_chains", 1))
         thinning = int(mcmc_kwargs.get("thinning", 1))
+        chain_method = mcmc_kwargs.get("chain_method", "parallel")
+        if chain_method not in ("parallel", "sequential", "vectorized"):
+            raise ValueError("Only supporting the following methods to draw chains:"
+                             ' "sequential", "parallel", or "vectorized"')
+        if num_chains < 1 or thinning < 1:
+            raise ValueError("num_chains and thinning must be positive")
         rank, ws = _dist.world()
         ctx = HipContext(_dist.local_device_index() if ws > 1 else 0)
         try:
@@ -174,18 +180,30 @@ class NeutralDixonColesMatchPredictor:
             draws = np.empty((len(mine), kept, D))
             corr = np.empty((len(mine), kept))
             leap = np.zeros((len(mine), 3))
-            z0a = None if z0 is None else np.asarray(z0, np.float64)
+            # init_params: one point for every chain ([D]) or one per chain ([num_chains, D]),
+            # sliced per chain like bpl/_mcmc.py:run_mcmc does
+            z0a = None
+            if z0 is not None:
+                z0a = np.asarray(z0, np.float64)
+                if z0a.size == D:
+                    z0a = np.tile(z0a.reshape(1, D), (num_chains, 1))
+                elif z0a.size == num_chains * D:
+                    z0a = z0a.reshape(num_chains, D)
+                else:
+                    raise ValueError(f"init_params must have {D} or {num_chains}x{D} entries, got {z0a.size}")
             results = None
-            if len(mine) > 1 and mcmc_kwargs.get("chain_method", "parallel") != "sequential":
+            if len(mine) > 1 and chain_method != "sequential":
                 from bpl._ffi import BPLHIP_EUNSUPPORTED, BplHipError
 
                 try:  # chains of this rank run concurrently on the device
-                    results = ctx.nuts_run_chains(cfg, [keys[c] for c in mine], z0a)
+                    results = ctx.nuts_run_chains(cfg, [keys[c] for c in mine],
+                                                  None if z0a is None else z0a[list(mine)])
                 except BplHipError as e:
                     if e.code != BPLHIP_EUNSUPPORTED:
                         raise
             for j, c in enumerate(mine):
-                d, st = results[j] if results is not None else ctx.nuts_run(cfg, keys[c], z0a)
+                d, st = results[j] if results is not None else ctx.nuts_run(
+                    cfg, keys[c], None if z0a is None else z0a[c])
                 draws[j], corr[j] = d, st["corr_coef"]
                 leap[j] = (st["total_leapfrogs"], st["wall_seconds"], st["total_divergences"])
             draws = _dist.gather_chains(draws, num_chains, device=ctx.device)

@@ -1565,13 +1565,9 @@ __device__ __forceinline__ void load_words(const uint32_t* p, uint32_t (&d)[NW])
         d[0] = *p;
     }
 }
+// the lane's weights (time-weighted likelihood): 4 B per fixture, the bulk of a weighted tile
 template <bool WEIGHTED>
-__device__ __forceinline__ LaneData load_lane(const EvalArgs& A, size_t o /* tile*64 + lane */) {
-    LaneData L;
-    L.hw[0] = A.h[o];
-    L.aw[0] = A.a[o];
-    load_words<XWORDS>(A.x + o * XWORDS, L.xw);
-    load_words<XWORDS>(A.y + o * XWORDS, L.yw);
+__device__ __forceinline__ void load_lane_weights(const EvalArgs& A, size_t o, LaneData& L) {
     if (WEIGHTED) {
 #pragma unroll
         for (int q = 0; q < LANE_FIX / 4; ++q) {
@@ -1582,6 +1578,16 @@ __device__ __forceinline__ LaneData load_lane(const EvalArgs& A, size_t o /* til
 #pragma unroll
         for (int j = 0; j < LANE_FIX; ++j) L.wj[j] = 1.0f;
     }
+}
+// indices and goals only (WITH_WEIGHTS = false: the caller requests the weights later)
+template <bool WEIGHTED, bool WITH_WEIGHTS = true>
+__device__ __forceinline__ LaneData load_lane(const EvalArgs& A, size_t o /* tile*64 + lane */) {
+    LaneData L;
+    L.hw[0] = A.h[o];
+    L.aw[0] = A.a[o];
+    load_words<XWORDS>(A.x + o * XWORDS, L.xw);
+    load_words<XWORDS>(A.y + o * XWORDS, L.yw);
+    if (WITH_WEIGHTS) load_lane_weights<WEIGHTED>(A, o, L);
     return L;
 }
 
@@ -1867,7 +1873,11 @@ __global__ DC_LAUNCH_BOUNDS void dc_eval(EvalArgs A) {
         int tile = wave < A.active_waves ? gw * A.tiles_per_wave : A.n_tiles;
         const int tile_end = min(tile + A.tiles_per_wave, A.n_tiles);
         // (a wave without tiles loads the last one and never uses it)
-        LaneData cur = load_lane<WEIGHTED>(A, (size_t)min(tile, A.n_tiles - 1) * 64 + lane);
+        // (the weights of a time-weighted tile -- 8 KB per wave -- are requested AFTER the table
+        // loads: vector loads return in order, and behind them the covariate rows of the tables
+        // waited 1.7 us for HBM)
+        const size_t lane0 = (size_t)min(tile, A.n_tiles - 1) * 64 + lane;
+        LaneData cur = load_lane<WEIGHTED, false>(A, lane0);
         const int o0 = A.wg_off[wgi], o1 = A.wg_off[wgi + 1];  // static sparse-slab slots
         // (unconditional, index clamped: a load into a register that a branch also zeroes made the
         // compiler wait for it -- and, in order, for the whole tile -- right here)
@@ -1879,6 +1889,8 @@ __global__ DC_LAUNCH_BOUNDS void dc_eval(EvalArgs A) {
 
         // ---- 1. per-team tables (float32) + zero accumulators
         build_tables_f32<CLIP>(L, z, A.xsf, tabH, tabA, tid, tz0, fs);
+        if (WEIGHTED) asm volatile("" ::: "memory");  // (keeps the weight loads behind the table loads)
+        load_lane_weights<WEIGHTED>(A, lane0, cur);
         for (int i = tid; i < 3 * T1; i += BLOCK) acc[i] = 0.0;
         __syncthreads();
         DC_STAMP(1);
