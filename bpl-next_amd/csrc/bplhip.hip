@@ -130,6 +130,8 @@ struct bplhip_ctx {
     bool neutral = false;
     dcn::NeuLayout NL{};
     DevBuf dd_gw, dd_nv, dd_cells, dd_acc, dd_hyp, dd_hc, dd_ac;
+    DevBuf dd_gwoff, dd_tick;  // dynamic model: first fixture of each gameweek; arrival counters
+    bool dyn_attr_set = false;
     std::map<GraphKey, hipGraphExec_t> graphs;
     hipStream_t cap_stream = nullptr;
 
@@ -282,18 +284,25 @@ int launch_eval_dynamic(bplhip_ctx* c, int chains, const double* z, double* pot,
         const int nb2 = (int)((c->n + A.chunk - 1) / A.chunk);
         const int cell_blocks = (L.T + dcd::CELL_BLOCK / 64 - 1) / (dcd::CELL_BLOCK / 64);
         A.scratch_n = dcd::scratch_doubles(L.G, L.T, L.K);
-        hipLaunchKernelGGL(dcd::dyn_cells, dim3(cell_blocks), dim3(dcd::CELL_BLOCK), 0, s, A);
-        hipLaunchKernelGGL(dcd::dyn_pass1, dim3(nb), dim3(fb), 0, s, A);
-        if (!c->lds_attr_set) {
+        A.gw_off = c->dd_gwoff.as<const int>();
+        A.tickets = c->dd_tick.as<unsigned int>();
+        const int team_blocks = (L.T + dcd::BACK_BLOCK / 64 - 1) / (dcd::BACK_BLOCK / 64);
+        if (!c->dyn_attr_set) {
             HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(dcd::dyn_pass2),
                                            hipFuncAttributeMaxDynamicSharedMemorySize,
                                            dcd::PASS2_LDS_CELLS * dcd::A_N * 8));
+            HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(dcd::dyn_back),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)dcd::back_lds_bytes(dcd::BACK_LDS_G)));
+            c->dyn_attr_set = true;
             c->lds_attr_set = true;
         }
+        hipLaunchKernelGGL(dcd::dyn_cells, dim3(cell_blocks), dim3(dcd::CELL_BLOCK), 0, s, A);
+        hipLaunchKernelGGL(dcd::dyn_pass1, dim3(nb), dim3(fb), 0, s, A);
         hipLaunchKernelGGL(dcd::dyn_pass2, dim3(nb2), dim3(fb),
                            (size_t)dcd::PASS2_LDS_CELLS * dcd::A_N * 8, s, A);
-        hipLaunchKernelGGL(dcd::dyn_epi_cells, dim3(cell_blocks), dim3(dcd::CELL_BLOCK), 0, s, A);
-        hipLaunchKernelGGL(dcd::dyn_final, dim3(1), dim3(dcd::FINAL_BLOCK), 0, s, A);
+        hipLaunchKernelGGL(dcd::dyn_back, dim3(team_blocks), dim3(dcd::BACK_BLOCK),
+                           dcd::back_lds_bytes(L.G), s, A);
         HIP_TRY(c, hipGetLastError());
     }
     return BPLHIP_OK;
@@ -1051,6 +1060,16 @@ static int bplhip_set_fixtures_dynamic_impl(bplhip_ctx* c, int64_t n, int32_t n_
     HIP_TRY(c, c->dd_cells.ensure(GT * dcd::P_N * 8));
     HIP_TRY(c, c->dd_acc.ensure(dcd::scratch_doubles(n_gameweeks, n_teams, k) * 8));
     HIP_TRY(c, c->dd_hyp.ensure((size_t)6 * n_gameweeks * 8));
+    {   // first fixture of every gameweek (sorted), and the two arrival counters
+        std::vector<int> gw_off(n_gameweeks + 1, 0);
+        for (int64_t i = 0; i < n; ++i) gw_off[g[i] + 1] += 1;
+        for (int j = 0; j < n_gameweeks; ++j) gw_off[j + 1] += gw_off[j];
+        HIP_TRY(c, c->dd_gwoff.ensure(gw_off.size() * 4));
+        HIP_TRY(c, hipMemcpy(c->dd_gwoff.p, gw_off.data(), gw_off.size() * 4, hipMemcpyHostToDevice));
+        HIP_TRY(c, c->dd_tick.ensure(64));
+        HIP_TRY(c, hipMemset(c->dd_tick.p, 0, 64));
+        HIP_TRY(c, hipMemset(c->dd_acc.p, 0, dcd::scratch_doubles(n_gameweeks, n_teams, k) * 8));
+    }
     c->h_xs.clear();
     if (k > 0) {
         c->h_xs.assign(covariates, covariates + (size_t)n_teams * k);

@@ -5,19 +5,23 @@
 // the behaviour of the code as written (attack = defence = 0).
 //
 // BASELINE config 4 (T = 100, G = 50, D = 35 502).  float64 throughout; fixtures sorted by
-// gameweek; one memset + five launches per evaluation, every one parallel over its natural
-// axis (the 7 [G,T] latent tables make D large: the z-side work matters as much as the
-// fixtures):
+// gameweek; four launches per evaluation, every one parallel over its natural axis (the 7 [G,T]
+// latent tables make D large: the z-side work matters as much as the fixtures, 1.3 MB of
+// tables per evaluation).  (Tried in round 2 and measured slower: the cells on 16-team workgroups
+// with the LAST-ARRIVING workgroup running both fixture passes alone -- one launch instead of
+// three, 40 us instead of 18: one CU moves ~25 GB/s and its 2500 fixtures are dependent
+// load -> gather -> exp chains.)
 //   dyn_cells     one WAVE per team, lanes = gameweeks: the walk is a wave prefix sum
 //   dyn_pass1     fixtures (grid-stride): rates; maxima for the rho bounds, one atomicMax
 //                 per workgroup
 //   dyn_pass2     fixtures (contiguous chunk per workgroup): Poisson + tau value and adjoint
 //                 into the six per-cell accumulators -- LDS-private for the (few) gameweeks
 //                 the chunk spans, flushed with float64 atomics; arg-extremal fixtures
-//   dyn_epi_cells one wave per team: bounds adjoint, the walk's adjoint as a wave suffix
-//                 sum, priors + Jacobians and chain rule of the 7 cell tables, per-gameweek
-//                 sums by atomics
-//   dyn_final     per-gameweek hyper-parameters, covariate coefficients, scalars, potential
+//   dyn_back      one wave per team: bounds adjoint, the walk's adjoint as a wave suffix sum,
+//                 priors + Jacobians and chain rule of the 7 cell tables; the per-gameweek sums
+//                 reduced over the workgroup's teams in LDS, then ONE global atomic per entry;
+//                 the last-arriving workgroup (ticket) finishes the per-gameweek
+//                 hyper-parameters, coefficients, scalars and the potential
 // Roofline: HBM-bound stream of 9 B per fixture (u16,u16,u8,u8,u16,u8) + gathers from an
 // L2-resident cell table; at config-4 size (N = 2500) it is launch-latency bound.
 // Mathematics: SURVEY.md Appendix A.5 (+ Appendix A.1-A.3 for the shared pieces).
@@ -114,6 +118,8 @@ struct DynArgs {
     double* grad;
     double* aux;
     int random_walk;
+    const int* gw_off;       // [G + 1] first fixture of each gameweek (fixtures are sorted by it)
+    unsigned int* tickets;   // [2] arrival counters: dyn_front, dyn_back (zero between launches)
     DynLayout L;
 };
 
@@ -165,18 +171,17 @@ __device__ __forceinline__ double wave_suffix(double v, int lane) {
 constexpr int CELL_BLOCK = 256;   // 4 waves = 4 teams per workgroup
 constexpr int FIX_BLOCK = 1024;       // largest workgroup of the fixture passes (launches use 256 or 1024)
 
-// ---- per-(gameweek, team) constrained sites: one wave per team, lanes over gameweeks
-__global__ __launch_bounds__(CELL_BLOCK) void dyn_cells(DynArgs A) {
+// ---- per-(gameweek, team) constrained sites of team t: one wave, lanes over gameweeks.
+// WT: write-through (sc1) stores -- the cells are read by another workgroup of the same launch.
+template <bool WT>
+__device__ __forceinline__ void cells_of_team(const DynArgs& A, int t, int lane) {
     const DynLayout& L = A.L;
     const int G = L.G, T = L.T, K = L.K;
     const double* z = A.z;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int t = blockIdx.x * (CELL_BLOCK / 64) + wave;
-    // this launch also clears the evaluation's scratch (saves a separate fill launch)
-    for (size_t i = (size_t)blockIdx.x * CELL_BLOCK + threadIdx.x; i < A.scratch_n;
-         i += (size_t)gridDim.x * CELL_BLOCK)
-        A.acc[i] = 0.0;
-    if (t >= T) return;
+    auto put = [&](double* p, double v) {
+        if (WT) dc::st_sc1(p, v);
+        else *p = v;
+    };
     double att0 = 0.0, def0 = z[L.o_md];
     for (int k = 0; k < K; ++k) {
         const double xv = A.xs[(size_t)t * K + k];
@@ -221,16 +226,27 @@ __global__ __launch_bounds__(CELL_BLOCK) void dyn_cells(DynArgs A) {
             const double hdf = z_mhd + s[4] * z_hdf;
             const double adf = z_mad + s[5] * z_adf;
             double* P = A.cells + (size_t)c * P_N;
-            P[P_AH] = a_ + hat;
-            P[P_AA] = a_ + aat;
-            P[P_BH] = d_ + hdf;
-            P[P_BA] = d_ + adf;
-            P[P_ATT] = a_;
-            P[P_DEF] = d_;
+            put(&P[P_AH], a_ + hat);
+            put(&P[P_AA], a_ + aat);
+            put(&P[P_BH], d_ + hdf);
+            put(&P[P_BA], d_ + adf);
+            put(&P[P_ATT], a_);
+            put(&P[P_DEF], d_);
         }
     }
 }
+__global__ __launch_bounds__(CELL_BLOCK) void dyn_cells(DynArgs A) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int t = blockIdx.x * (CELL_BLOCK / 64) + wave;
+    // this launch also clears the evaluation's scratch (saves a separate fill launch)
+    for (size_t i = (size_t)blockIdx.x * CELL_BLOCK + threadIdx.x; i < A.scratch_n;
+         i += (size_t)gridDim.x * CELL_BLOCK)
+        A.acc[i] = 0.0;
+    if (t >= A.L.T) return;
+    cells_of_team<false>(A, t, lane);
+}
 
+template <bool SC1 = false>
 __device__ __forceinline__ void fixture_etas(const DynArgs& A, long long i, int* ch, int* ca,
                                              int* neutral, double* eh, double* ea) {
     const int T = A.L.T;
@@ -243,8 +259,10 @@ __device__ __forceinline__ void fixture_etas(const DynArgs& A, long long i, int*
     // (the four parameters by selected offsets, not by a branch: a divergent branch around loads
     // is two dependent round trips)
     const bool nvf = *neutral != 0;
-    const double ph_att = Ph[nvf ? P_ATT : P_AH], pa_def = Pa[nvf ? P_DEF : P_BA];
-    const double pa_att = Pa[nvf ? P_ATT : P_AA], ph_def = Ph[nvf ? P_DEF : P_BH];
+    // (SC1: the cells were stored write-through by other workgroups of this launch)
+    auto ld = [&](const double* p) { return SC1 ? dc::ld_sc1(p) : *p; };
+    const double ph_att = ld(&Ph[nvf ? P_ATT : P_AH]), pa_def = ld(&Pa[nvf ? P_DEF : P_BA]);
+    const double pa_att = ld(&Pa[nvf ? P_ATT : P_AA]), ph_def = ld(&Ph[nvf ? P_DEF : P_BH]);
     *eh = ph_att - pa_def;
     *ea = pa_att - ph_def;
     if (A.hc) {  // bpl/neutral_dixon_coles_WC.py:188-203
@@ -534,14 +552,31 @@ __device__ inline void build_coupling(const DynArgs& A, const Bounds& b, Couplin
     __syncthreads();
 }
 
-// ---- per-cell chain rule: one wave per team, lanes over gameweeks (from the last one)
-__global__ __launch_bounds__(CELL_BLOCK) void dyn_epi_cells(DynArgs A) {
+// ---- per-cell chain rule (one wave per team, lanes over gameweeks from the last one), then the
+// last-arriving workgroup finishes the per-gameweek hyper-parameters and the potential.
+// The ten per-gameweek sums are reduced over the workgroup's teams in LDS before ONE global
+// atomic per (sum, gameweek) and workgroup: they were ten global atomics per cell, 100 adders per
+// address at config 4.
+constexpr int BACK_BLOCK = 256;   // 4 waves = 4 teams per workgroup (25 workgroups at 100 teams:
+                                  // a 1024-thread variant on 7 CUs was 2x slower -- the tables are
+                                  // 0.5 MB per evaluation and one CU moves ~25 GB/s)
+constexpr int BACK_LDS_G = 1024;  // gameweeks whose sums fit the LDS pre-reduction (10 x G doubles)
+__host__ __device__ inline size_t back_lds_bytes(int G) { return G <= BACK_LDS_G ? (size_t)10 * G * 8 : 8; }
+__device__ void final_body(const DynArgs& A, double* shl);
+
+__global__ __launch_bounds__(BACK_BLOCK) void dyn_back(DynArgs A) {
+    extern __shared__ double lgs[];  // [10][G] when G <= BACK_LDS_G
+    __shared__ double shl[BACK_BLOCK / 64];
+    __shared__ int s_last;
     const DynLayout& L = A.L;
     const int G = L.G, T = L.T, K = L.K;
     const double* z = A.z;
     double* grad = A.grad;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int t = blockIdx.x * (CELL_BLOCK / 64) + wave;
+    const int t = blockIdx.x * (BACK_BLOCK / 64) + wave;
+    const bool lds_sums = G <= BACK_LDS_G;
+    if (lds_sums)
+        for (int k = threadIdx.x; k < 10 * G; k += BACK_BLOCK) lgs[k] = 0.0;
     const Bounds b = load_bounds(A);
     // adjoint of the bounds: built once per workgroup in LDS (a per-thread table would live in
     // scratch memory), read by every lane
@@ -555,9 +590,9 @@ __global__ __launch_bounds__(CELL_BLOCK) void dyn_epi_cells(DynArgs A) {
             if (C.cell[e] == cell && C.which[e] == which) v += C.val[e];
         return v;
     };
-    if (t >= T) return;  // (after the barrier)
+    double* gs = lds_sums ? lgs : A.gsum;  // (LDS atomics here, one global atomic per entry below)
     double carry_a = 0.0, carry_d = 0.0, Lloc = 0.0;
-    const int nchunk = (G + 63) / 64;
+    const int nchunk = t < T ? (G + 63) / 64 : 0;  // (a wave without a team only joins the barriers)
     for (int ck = nchunk - 1; ck >= 0; --ck) {
         const int g = ck * 64 + lane;
         const bool on = g < G;
@@ -613,16 +648,16 @@ __global__ __launch_bounds__(CELL_BLOCK) void dyn_epi_cells(DynArgs A) {
             grad[L.o_hdf + c] = -(s_hd * g_hdf - hdf);
             grad[L.o_adf + c] = -(s_ad * g_adf - adf);
             // per-gameweek sums: 0 sa*RA, 1 sd*RD, 2..5 sum G_x, 6..9 sum dec*G_x
-            atomicAdd(&A.gsum[0 * G + g], sa * RA);
-            atomicAdd(&A.gsum[1 * G + g], sd * RD);
-            atomicAdd(&A.gsum[2 * G + g], g_hat);
-            atomicAdd(&A.gsum[3 * G + g], g_aat);
-            atomicAdd(&A.gsum[4 * G + g], g_hdf);
-            atomicAdd(&A.gsum[5 * G + g], g_adf);
-            atomicAdd(&A.gsum[6 * G + g], hat * g_hat);
-            atomicAdd(&A.gsum[7 * G + g], aat * g_aat);
-            atomicAdd(&A.gsum[8 * G + g], hdf * g_hdf);
-            atomicAdd(&A.gsum[9 * G + g], adf * g_adf);
+            atomicAdd(&gs[0 * G + g], sa * RA);
+            atomicAdd(&gs[1 * G + g], sd * RD);
+            atomicAdd(&gs[2 * G + g], g_hat);
+            atomicAdd(&gs[3 * G + g], g_aat);
+            atomicAdd(&gs[4 * G + g], g_hdf);
+            atomicAdd(&gs[5 * G + g], g_adf);
+            atomicAdd(&gs[6 * G + g], hat * g_hat);
+            atomicAdd(&gs[7 * G + g], aat * g_aat);
+            atomicAdd(&gs[8 * G + g], hdf * g_hdf);
+            atomicAdd(&gs[9 * G + g], adf * g_adf);
             // priors of the cell sites
             Lloc += log_u + 3.0 * log_1mu + 2.995732273553991 - sp_z - sp_mz;
             Lloc += -0.5 * sa * sa - HALF_LOG_2PI - 0.5 * e * e * iv - 0.5 * log(vv) - HALF_LOG_2PI;
@@ -631,31 +666,50 @@ __global__ __launch_bounds__(CELL_BLOCK) void dyn_epi_cells(DynArgs A) {
     }
     // carry_a, carry_d hold the sums over all gameweeks: d/d(prior means of the walk)
     Lloc = wave_sum(Lloc);
-    if (lane == 0) {
-        atomicAdd(&A.red[R_MD], carry_d);
-        atomicAdd(&A.red[R_L], Lloc);
+    if (t < T) {
+        if (lane == 0) {
+            atomicAdd(&A.red[R_MD], carry_d);
+            atomicAdd(&A.red[R_L], Lloc);
+        }
+        for (int j = lane; j < 2 * K; j += 64) {
+            const int k = j < K ? j : j - K;
+            atomicAdd(&A.cov[j], A.xs[(size_t)t * K + k] * (j < K ? carry_a : carry_d));
+        }
     }
-    for (int j = lane; j < 2 * K; j += 64) {
-        const int k = j < K ? j : j - K;
-        atomicAdd(&A.cov[j], A.xs[(size_t)t * K + k] * (j < K ? carry_a : carry_d));
+    __syncthreads();
+    if (lds_sums)
+        for (int k = threadIdx.x; k < 10 * G; k += BACK_BLOCK) {
+            const double v = lgs[k];
+            if (v != 0.0) atomicAdd(&A.gsum[k], v);
+        }
+    // ---- arrive (atomics drained); the last workgroup runs the final part
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned int k = __hip_atomic_fetch_add(A.tickets + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = k == gridDim.x - 1;
+        if (s_last) __hip_atomic_store(A.tickets + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    __syncthreads();
+    if (!s_last) return;
+    final_body(A, shl);
 }
 
-// ---- per-gameweek hyper-parameters, coefficients, scalars
-constexpr int FINAL_BLOCK = 256;
-__global__ __launch_bounds__(FINAL_BLOCK) void dyn_final(DynArgs A) {
-    __shared__ double shl[FINAL_BLOCK / 64];
+// ---- per-gameweek hyper-parameters, coefficients, scalars (the last workgroup of dyn_back; the
+// sums were accumulated with agent-scope atomics by every workgroup: L1-bypassing loads)
+constexpr int FINAL_BLOCK = BACK_BLOCK;
+__device__ void final_body(const DynArgs& A, double* shl) {
     const DynLayout& L = A.L;
     const int G = L.G, K = L.K;
     const int tid = threadIdx.x;
     const double* z = A.z;
     double* grad = A.grad;
-    const double* gsum = A.gsum;
+    auto gsum = [&](int k) { return dc::ld_sc1(&A.gsum[k]); };
     double Lg = 0.0;
     for (int g = tid; g < G; g += FINAL_BLOCK) {
         const double s_att = A.hyp[g], s_def = A.hyp[G + g];
-        grad[L.o_s_att + g] = -(s_att * gsum[0 * G + g] + 1.0 - s_att * s_att);
-        grad[L.o_s_def + g] = -(s_def * gsum[1 * G + g] + 1.0 - s_def * s_def);
+        grad[L.o_s_att + g] = -(s_att * gsum(0 * G + g) + 1.0 - s_att * s_att);
+        grad[L.o_s_def + g] = -(s_def * gsum(1 * G + g) + 1.0 - s_def * s_def);
         Lg += -0.5 * s_att * s_att - HALF_LOG_2PI + LN2 + z[L.o_s_att + g];
         Lg += -0.5 * s_def * s_def - HALF_LOG_2PI + LN2 + z[L.o_s_def + g];
         const int o_mean[4] = {L.o_mha, L.o_maa, L.o_mhd, L.o_mad};
@@ -664,8 +718,8 @@ __global__ __launch_bounds__(FINAL_BLOCK) void dyn_final(DynArgs A) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const double s = A.hyp[(2 + j) * G + g], mean = z[o_mean[j] + g];
-            grad[o_mean[j] + g] = -(gsum[(2 + j) * G + g] - (mean - mu[j]) / 0.04);
-            grad[o_std[j] + g] = -(s * gsum[(6 + j) * G + g] + 1.0 - s * s);
+            grad[o_mean[j] + g] = -(gsum((2 + j) * G + g) - (mean - mu[j]) / 0.04);
+            grad[o_std[j] + g] = -(s * gsum((6 + j) * G + g) + 1.0 - s * s);
             const double r = (mean - mu[j]) / 0.2;
             Lg += -0.5 * r * r + 1.6094379124341003 - HALF_LOG_2PI;
             Lg += -0.5 * s * s - HALF_LOG_2PI + LN2 + z[o_std[j] + g];
@@ -673,7 +727,7 @@ __global__ __launch_bounds__(FINAL_BLOCK) void dyn_final(DynArgs A) {
     }
     for (int k = tid; k < 2 * K; k += FINAL_BLOCK) {
         const int o = k < K ? L.o_bA + k : L.o_bD + k - K;
-        grad[o] = -(A.cov[k] - z[o]);
+        grad[o] = -(dc::ld_sc1(&A.cov[k]) - z[o]);
         Lg += -0.5 * z[o] * z[o] - HALF_LOG_2PI;
     }
     Lg = wave_sum(Lg);
@@ -684,9 +738,9 @@ __global__ __launch_bounds__(FINAL_BLOCK) void dyn_final(DynArgs A) {
         for (int w = 0; w < FINAL_BLOCK / 64; ++w) Lsum += shl[w];
         const Bounds b = load_bounds(A);
         const double m = z[L.o_md], zc = z[L.o_corr];
-        grad[L.o_md] = -(A.red[R_MD] - m);
+        grad[L.o_md] = -(dc::ld_sc1(&A.red[R_MD]) - m);
         grad[L.o_corr] = -(b.G_rho * (b.UB - b.LB) * b.dq + (1.0 - 2.0 * b.sq));
-        double Ltot = Lsum + A.red[R_L] + A.sc[SC_U] - A.lgsum;
+        double Ltot = Lsum + dc::ld_sc1(&A.red[R_L]) + A.sc[SC_U] - A.lgsum;
         Ltot += -0.5 * m * m - HALF_LOG_2PI;
         Ltot += -softplus(zc) - softplus(-zc);  // Uniform(0,1): log_prob 0 + sigmoid Jacobian
         A.potential[0] = -Ltot;
