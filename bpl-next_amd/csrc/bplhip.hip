@@ -89,6 +89,9 @@ struct bplhip_ctx {
     // device buffers (library owned)
     DevBuf d_h, d_a, d_x, d_y, d_w, d_pairs, d_xs, d_cA, d_cD, d_cH, d_tickets, d_debug, d_xsf, d_hbuf;
     DevBuf d_gacc;  // accumulator rows of dc_eval's hand-off (dc::GA_ROW)
+    DevBuf d_zb;    // persistent evaluation kernel: the next position as tagged granules
+    unsigned int loop_tag = 0;  // tags handed out so far (a launch of k steps takes k + 1 of them)
+    int opt_persistent_kernel = 1;  // 1: a single chain's leapfrogs run inside one resident launch
     int slab_chains = 0;
     // tuning options (bplhip_set_option)
     int opt_device_nuts = 1;  // 1: tree builder on the device (nuts_dev.hip.h) when supported
@@ -427,6 +430,47 @@ int launch_eval(bplhip_ctx* c, int chains, const double* z, double* pot, double*
                                  : launch_eval_t<true, false>(c, A, chains, s);
     return clip ? launch_eval_t<false, true>(c, A, chains, s)
                 : launch_eval_t<false, false>(c, A, chains, s);
+}
+
+// ---- persistent evaluation kernel (dc_eval_loop): up to `steps` leapfrogs of ONE device-resident
+// chain in one launch.  Needs the leaf in the tail (basic / extended, <= 64 teams) and a grid that
+// is co-resident (one workgroup per CU).
+bool loop_ok(const bplhip_ctx* c) {
+    if (c->dynamic || c->neutral || !c->opt_persistent_kernel) return false;
+    const bplhip_ctx::EvalPart& ep = c->parts[0];
+    return ep.staged && ep.n_wg + 1 <= c->n_cu && ctx_lds_bytes(c, true) <= 64 * 1024;
+}
+template <bool W, bool C>
+int launch_loop_t(bplhip_ctx* c, const dc::EvalArgs& A, hipStream_t s) {
+    const size_t lds = ctx_lds_bytes(c, true);
+    if (lds > 48 * 1024)
+        HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(dc::dc_eval_loop<W, C>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((dc::dc_eval_loop<W, C>), dim3(c->ep->n_wg + 1, 1), dim3(dc::BLOCK), lds, s, A);
+    HIP_TRY(c, hipGetLastError());
+    return BPLHIP_OK;
+}
+int launch_eval_loop(bplhip_ctx* c, double* ns, int nuts_depth, const nd::Persist* persist, int steps,
+                     hipStream_t s) {
+    const int D = c->L.D;
+    select_part(c, 1);
+    if (c->d_zb.bytes < (size_t)D * 8 || c->loop_tag > 0xF0000000u) {  // fresh granules: tag 0 everywhere
+        HIP_TRY(c, c->d_zb.ensure((size_t)D * 8));
+        HIP_TRY(c, hipMemsetAsync(c->d_zb.p, 0, (size_t)D * 8, s));
+        c->loop_tag = 0;
+    }
+    dc::EvalArgs A = eval_args(c, 1, nd::vec(ns, D, nd::V_ZN), ns + nd::H_LEAF_PE, nd::vec(ns, D, nd::V_GRAD),
+                               ns + nd::H_LEAF_AUX0);
+    A.tag_base = c->loop_tag;
+    c->loop_tag += (unsigned int)steps + 2u;  // steps + the launch's own "finished" tag
+    A.nuts = ns;
+    A.nuts_max_depth = nuts_depth;
+    A.persist = persist;
+    A.persist_steps = steps;
+    A.zg = c->d_zb.as<unsigned long long>();
+    const bool clip = c->L.model == dc::MODEL_EXTENDED;
+    if (c->weighted) return clip ? launch_loop_t<true, true>(c, A, s) : launch_loop_t<true, false>(c, A, s);
+    return clip ? launch_loop_t<false, true>(c, A, s) : launch_loop_t<false, false>(c, A, s);
 }
 
 // ---- chain-vectorised evaluation (dc_vec.hip.h): stream launch + tail launch
@@ -849,6 +893,10 @@ int bplhip_set_option(bplhip_ctx* c, const char* name, int value) {
     }
     if (n == "persistent_nuts") {
         c->opt_persistent_nuts = value != 0;
+        return BPLHIP_OK;
+    }
+    if (n == "persistent_kernel") {  // 0: one launch per leapfrog even for a single resident chain
+        c->opt_persistent_kernel = value != 0;
         return BPLHIP_OK;
     }
     if (n == "gridy_max_chains") {
@@ -1634,7 +1682,8 @@ int run_chains_persistent(bplhip_ctx* c, hipStream_t s, const nuts::Config& nc, 
     else hipLaunchKernelGGL(nd::kp_start, dim3(C), dim3(64), 0, s, ns, stride, P);
     const nd::Persist* dP = d_desc.as<const nd::Persist>();
     std::vector<double> flags(C);
-    const int chunk = 256;
+    const bool looped = C == 1 && !generic && loop_ok(c);  // one resident launch per chunk
+    const int chunk = looped ? 1024 : 256;
     bool all_done = false;
     // every launch advances every unfinished chain by one leapfrog: an upper bound exists
     const double max_steps = (double)n_iter * (double)((1u << md) - 1) + 2.0 * chunk;
@@ -1647,6 +1696,10 @@ int run_chains_persistent(bplhip_ctx* c, hipStream_t s, const nuts::Config& nc, 
         if (const char* cap = getenv("BPLHIP_DEBUG_MAX_STEPS"))
             if (steps_done > atof(cap)) return fail(c, BPLHIP_EHIP, "debug: step cap reached");
 #endif
+        if (looped) {  // the whole chunk inside one resident launch
+            rc = launch_eval_loop(c, ns, md, dP, chunk, s);
+            if (rc != BPLHIP_OK) return rc;
+        } else
         for (int k = 0; k < chunk; ++k) {
             if (generic) {
                 for (int ch = 0; ch < C && rc == BPLHIP_OK; ++ch) {

@@ -155,6 +155,13 @@ struct EvalArgs {
     int nuts_stride;
     int nuts_max_depth;
     const nd::Persist* persist;  // persistent chains: doubling / transition advance in the tail
+    // persistent EVALUATION kernel (dc_eval_loop: one chain): the launch stays resident for up to
+    // `persist_steps` leapfrogs; the leaf's wave publishes the next position as data-tagged
+    // granules {float32 z_i, tag}, tag = tag_base + 1 + step (the host hands out tag ranges that
+    // never repeat, so a granule of an earlier launch can never look current)
+    int persist_steps;
+    unsigned int tag_base;
+    unsigned long long* zg;  // [chains][D] granules
     Layout L;
 };
 __device__ __forceinline__ const double* z_of(const EvalArgs& A, int c) { return A.z + (size_t)c * A.z_stride; }
@@ -429,23 +436,30 @@ struct F32Scalars {
 __device__ __forceinline__ float exp_f32(float x) {
     return __builtin_amdgcn_exp2f(x * 1.44269504088896341f);
 }
-template <bool EXT>
+// SC1: z is read with L1-bypassing vector loads (the persistent evaluation kernel: the position
+// was written by another CU of the SAME launch, and a uniform-address plain load would be a
+// scalar load through the non-coherent scalar cache)
+template <bool SC1>
+__device__ __forceinline__ double zld(const double* p) {
+    return SC1 ? ld_sc1(p) : *p;
+}
+template <bool EXT, bool SC1 = false>
 __device__ __forceinline__ F32Scalars f32_scalars(const Layout& L, const double* z) {
     F32Scalars s;
-    s.s_a = exp_f32((float)z[L.o_sa]);
-    s.s_d = exp_f32((float)z[L.o_sd]);
-    s.m = (float)z[L.o_md];
-    const float zc = (float)z[L.o_corr];
+    s.s_a = exp_f32((float)zld<SC1>(&z[L.o_sa]));
+    s.s_d = exp_f32((float)zld<SC1>(&z[L.o_sd]));
+    s.m = (float)zld<SC1>(&z[L.o_md]);
+    const float zc = (float)zld<SC1>(&z[L.o_corr]);
     float q = __builtin_amdgcn_rcpf(1.0f + exp_f32(-zc));
     s.q = fminf(fmaxf(q, (float)SIG_LO), (float)SIG_HI);
     if (!EXT) {
-        s.gam = (float)z[L.o_ha];
+        s.gam = (float)zld<SC1>(&z[L.o_ha]);
         s.s_h = 0.f;
         s.mha = 0.f;
     } else {
         s.gam = 0.f;
-        s.s_h = exp_f32((float)z[L.o_sh]);
-        s.mha = (float)z[L.o_mha];
+        s.s_h = exp_f32((float)zld<SC1>(&z[L.o_sh]));
+        s.mha = (float)zld<SC1>(&z[L.o_mha]);
     }
     return s;
 }
@@ -453,15 +467,15 @@ __device__ __forceinline__ F32Scalars f32_scalars(const Layout& L, const double*
 struct TeamZ {
     double a, d, h;
 };
-template <bool EXT>
+template <bool EXT, bool SC1 = false>
 __device__ __forceinline__ TeamZ load_team_z(const Layout& L, const double* z, int t) {
     TeamZ v;
-    v.a = z[(EXT ? L.o_sat : L.o_adec) + t];
-    v.d = z[(EXT ? L.o_sdt : L.o_ddec) + t];
-    v.h = EXT ? z[L.o_hadec + t] : 0.0;
+    v.a = zld<SC1>(&z[(EXT ? L.o_sat : L.o_adec) + t]);
+    v.d = zld<SC1>(&z[(EXT ? L.o_sdt : L.o_ddec) + t]);
+    v.h = EXT ? zld<SC1>(&z[L.o_hadec + t]) : 0.0;
     return v;
 }
-template <bool EXT>
+template <bool EXT, bool SC1 = false>
 __device__ __forceinline__ void f32_table_entry(const Layout& L, const F32Scalars& s,
                                                 const double* z, const float* xsf, int t,
                                                 const TeamZ& tz, float2* vh, float2* va) {
@@ -474,8 +488,8 @@ __device__ __forceinline__ void f32_table_entry(const Layout& L, const F32Scalar
         float apm = 0.f, dpm = s.m;
         for (int k = 0; k < L.K; ++k) {
             const float xv = xsf[(size_t)t * L.K + k];
-            apm += xv * (float)z[L.o_bA + k];
-            dpm += xv * (float)z[L.o_bD + k];
+            apm += xv * (float)zld<SC1>(&z[L.o_bA + k]);
+            dpm += xv * (float)zld<SC1>(&z[L.o_bD + k]);
         }
         att = apm + (float)tz.a * s.s_a;
         def = dpm + (float)tz.d * s.s_d;
@@ -487,13 +501,13 @@ __device__ __forceinline__ void f32_table_entry(const Layout& L, const F32Scalar
 }
 // `first`: team `tid`'s entries of z, loaded by the caller BEFORE its bulk loads -- vector loads
 // return in order, and behind a tile's worth of fixture loads they would wait for HBM
-template <bool EXT>
+template <bool EXT, bool SC1 = false>
 __device__ __forceinline__ void build_tables_f32(const Layout& L, const double* z,
                                                  const float* xsf, float2* tabH, float2* tabA,
                                                  int tid, const TeamZ& first, const F32Scalars& s) {
     for (int t = tid; t <= L.T; t += BLOCK) {
         float2 vh = make_float2(0.f, 0.f), va = vh;
-        if (t < L.T) f32_table_entry<EXT>(L, s, z, xsf, t, t == tid ? first : load_team_z<EXT>(L, z, t), &vh, &va);
+        if (t < L.T) f32_table_entry<EXT, SC1>(L, s, z, xsf, t, t == tid ? first : load_team_z<EXT, SC1>(L, z, t), &vh, &va);
         tabH[t] = vh;
         tabA[t] = va;
     }
@@ -914,6 +928,28 @@ __device__ void prior_body(const EvalArgs& A, int chain, char* smem, double* zo_
     }
 }
 
+// ---- the next position as data-tagged granules (persistent evaluation kernel).  One naturally
+// aligned 8-byte {float32 value, tag} per latent entry, written by ONE write-through store: the
+// reader needs no flag and no ordering (MI355X_MICROARCH.md, handoff-1to1).  float32 is what the
+// streaming workgroups build their tables from anyway; the tail workgroup keeps the float64 state.
+// (the "finished" tag is launch specific too -- tag_base + persist_steps + 1 -- or the FIN
+// granules of one launch would end the next one before its tail had published anything)
+__device__ __forceinline__ void st_granule(unsigned long long* g, float v, unsigned int tag) {
+    __hip_atomic_store(g, ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long ld_granule(const unsigned long long* g) {
+    return __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// one wave: z (this workgroup's own float64 stores, plain loads) -> granules
+__device__ __forceinline__ void publish_z(unsigned long long* zg, const double* z, int D, int lane,
+                                          unsigned int tag) {
+    for (int i = lane; i < D; i += 64) st_granule(&zg[i], (float)z[i], tag);
+}
+__device__ __forceinline__ void publish_fin(unsigned long long* zg, int D, int lane, unsigned int fin_tag) {
+    for (int i = lane; i < D; i += 64) st_granule(&zg[i], 0.f, fin_tag);
+}
+
 // Per-team epilogue for T <= 64: lane t owns team t, sums are DPP wave reductions, adds and
 // FMAs only.  A single wave issues a dependent instruction every ~5 cycles, so the work is
 // split by OUTPUT GROUP over four waves that never need each other's results:
@@ -925,7 +961,8 @@ __device__ void prior_body(const EvalArgs& A, int chain, char* smem, double* zo_
 template <bool NUTS, bool EXT>
 __device__ void tail_waves(const EvalArgs& A, int chain, const double* zoL, const double* cL,
                            const double* zL, const double* col, const double* xsL,
-                           double* gradL, const nd::LeafState<1>& leaf1, double* stg) {
+                           double* gradL, const nd::LeafState<1>& leaf1, double* stg,
+                           unsigned int pub_tag = 0u /* persistent kernel: tag of the NEXT step */) {
     const Layout& L = A.L;
     const int T = L.T, K = L.K, D = L.D;
     const int t = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1074,15 +1111,24 @@ __device__ void tail_waves(const EvalArgs& A, int chain, const double* zoL, cons
         DC_STAMP_LEAF(13);
         __syncthreads();
         DC_STAMP_LEAF(12);
-        if (wave != LEAF_WAVE && wave != RNG_WAVE) return;  // (barriers below: these two only)
-        // the two halves of the leaf (nuts_dev.hip.h), one wave each
+        // the two halves of the leaf (nuts_dev.hip.h), one wave each; the other waves only join
+        // the barriers (every wave reaches the end of this function: the persistent evaluation
+        // kernel goes on to the next leapfrog from here)
         if (wave == LEAF_WAVE) {
             const bool sub_done =
                 small ? nd::leaf_moves(ns, D, A.nuts_max_depth, t, gradL, lf1)
                       : nd::leaf_moves_staged(ns, D, A.nuts_max_depth, t, gradL, stg, lf1.hv);
             DC_STAMP_LEAF(11);
-            if (t == 0) gradL[D + 5] = sub_done ? 1.0 : 0.0;
-        } else {
+            if (t == 0) {
+                gradL[D + 5] = sub_done ? 1.0 : 0.0;
+                gradL[D + 6] = 0.0;  // (chain finished: set below)
+            }
+            // persistent kernel: the next position goes out NOW (the subtree goes on: V_ZN is final;
+            // this wave stored it, so its own loads see it) -- the streaming workgroups start the
+            // next leapfrog while the other half of the leaf is still being booked
+            if (pub_tag != 0u && !sub_done)
+                publish_z(A.zg + (size_t)chain * D, nd::vec(ns, D, nd::V_ZN), D, t, pub_tag);
+        } else if (wave == RNG_WAVE) {
             if (small) nd::leaf_weights(ns, D, t, gradL, lf1);
             else nd::leaf_weights_staged(ns, D, t, gradL, stg, lf1.hv, lf1.nhi, lf1.nlo, lf1.u_take);
             DC_STAMP_WAVE(RNG_WAVE, 15);
@@ -1091,10 +1137,21 @@ __device__ void tail_waves(const EvalArgs& A, int chain, const double* zoL, cons
         // persistent chains: a finished subtree (rare) is combined by the leaf wave, which must
         // then see the other half's stores -- release + barrier, acquire in persist_advance
         __syncthreads();
-        if (gradL[D + 5] == 0.0) return;
+        if (gradL[D + 5] == 0.0) return;  // (uniform)
         if (wave == RNG_WAVE) nd::wave_mem_sync();
         __syncthreads();
-        if (wave == LEAF_WAVE) nd::persist_advance(ns, *A.persist, chain, t);
+        if (wave == LEAF_WAVE) {
+            nd::persist_advance(ns, *A.persist, chain, t);
+            if (pub_tag != 0u) {  // a new doubling / transition starts somewhere else -- or nowhere
+                const bool fin = (ns + A.persist->pd_off)[nd::P_ALLDONE] != 0.0;
+                if (fin) {
+                    publish_fin(A.zg + (size_t)chain * D, D, t, A.tag_base + 1u + (unsigned int)A.persist_steps);
+                    if (t == 0) gradL[D + 6] = 1.0;
+                } else {
+                    publish_z(A.zg + (size_t)chain * D, nd::vec(ns, D, nd::V_ZN), D, t, pub_tag);
+                }
+            }
+        }
     }
 }
 
@@ -1449,7 +1506,8 @@ __device__ __forceinline__ void tail_preload(const EvalArgs& A, int chain, TailP
 template <bool SMALLT, bool NUTS, bool EXT>
 __device__ __forceinline__ void tail_acc(const EvalArgs& A, int chain, char* smem, const TailPre& P,
                                          const nd::LeafState<1>& leaf1,
-                                         const double (&bigv)[nd::LEAF_STAGE_LOADS]) {
+                                         const double (&bigv)[nd::LEAF_STAGE_LOADS],
+                                         unsigned int pub_tag = 0u) {
     const Layout& L = A.L;
     const int T = L.T, K = L.K, D = L.D;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1532,12 +1590,18 @@ __device__ __forceinline__ void tail_acc(const EvalArgs& A, int chain, char* sme
                     if (i < D) stg[k * D + i] = bigv[k];
             }
         }
-        tail_waves<NUTS, EXT>(A, chain, zoL, cL, zL, col, xs_staged ? xsL : nullptr, gradL, leaf1, stg);
+        tail_waves<NUTS, EXT>(A, chain, zoL, cL, zL, col, xs_staged ? xsL : nullptr, gradL, leaf1, stg, pub_tag);
         DC_STAMP(10);
         return;
     }
     tail_general<EXT>(A, chain, zoL, cL, zL, col, scratch);
     DC_STAMP(10);
+}
+// where tail_acc keeps its NUTS hand-over block gradL (grad | U | aux | sub_done | finished)
+__device__ __forceinline__ double* acc_tail_gradL(const EvalArgs& A, char* smem) {
+    const Layout& L = A.L;
+    return reinterpret_cast<double*>(smem) + A.zo_stride + 3 * L.T + L.D + (3 * L.T + N_SCAL + 4) + WAVES * 8 +
+           (size_t)L.T * xs_staged_k(L.K);
 }
 
 // ------------------------------------------------------------ per-lane fixture math
@@ -2031,6 +2095,286 @@ __global__ DC_LAUNCH_BOUNDS void dc_eval(EvalArgs A) {
     if (threadIdx.x == 0 && A.debug && blockIdx.y == 0)
         A.debug[(size_t)blockIdx.x * 16 + 9] = __builtin_amdgcn_s_memtime() - c_entry;
 #endif
+}
+
+// ------------------------------------------------------------------- dc_eval_loop
+// PERSISTENT evaluation kernel of a device-resident chain (one chain, <= 64 teams, the NUTS
+// leaf in the tail): the launch stays resident for up to `persist_steps` leapfrogs instead of
+// one launch per leapfrog.  What a dependent launch pays every time -- the dispatch ramp of the
+// grid (0.7-1.2 us first to last workgroup), the kernel boundary, the kernel-argument and
+// position loads from cold caches, the first tile from HBM/MALL (1.6 us after entry) -- is paid
+// once: a wave's tile of fixtures stays in its REGISTERS for the whole launch, and the next
+// position travels as data-tagged granules {float32 z_i, tag} that the leaf's wave stores the
+// moment it knows it (no flag, no drain, no barrier on the way):
+//   tail workgroup (block 0)   prior -> wait for the arrivals -> tail + leaf (+ chain advance);
+//        the leaf wave publishes the granules of the next step
+//   streaming workgroups       every thread polls the granules it needs (L1-bypassing loads,
+//        BOUNDED), tables -> rho -> the resident tile -> accumulator rows -> arrive
+// Every workgroup invalidates its scalar cache at the top of a step (the chain state is
+// rewritten by vector stores between steps; uniform-address loads go through that cache).
+// The grid must be co-resident (host: one workgroup per CU); a finished chain ends the launch
+// (FIN granules); every spin is bounded and a timeout ends the launch the same way.
+constexpr int GRANULE_SPIN_LIMIT = 1 << 21;
+
+// this thread's granules of step `want`: a lane's team entries + the scalar sites
+struct ZPolled {
+    float a, d, h;            // team entries (decentered / standardised sites)
+    float sa, sd, md, corr;   // std_attack, std_defence, mean_defence, corr_coef_raw
+    float e0, e1;             // basic: home_advantage, -; extended: std_home_advantage, mean_home_advantage
+    int state;                // 1 ok, 0 the chain finished, -1 timed out
+};
+template <bool EXT>
+__device__ __forceinline__ ZPolled poll_z(const unsigned long long* zg, const Layout& L, int t,
+                                          unsigned int want, unsigned int fin_tag) {
+    const int idx[9] = {(EXT ? L.o_sat : L.o_adec) + t, (EXT ? L.o_sdt : L.o_ddec) + t,
+                        EXT ? L.o_hadec + t : L.o_sa, L.o_sa, L.o_sd, L.o_md, L.o_corr,
+                        EXT ? L.o_sh : L.o_ha, EXT ? L.o_mha : L.o_sa};
+    unsigned long long v[9];
+    ZPolled r;
+    r.state = -1;
+    for (int spin = 0; spin < GRANULE_SPIN_LIMIT; ++spin) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) v[k] = ld_granule(&zg[idx[k]]);
+        bool ok = true, fin = false;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const unsigned int tg = (unsigned int)(v[k] >> 32);
+            ok = ok && tg == want;
+            fin = fin || tg == fin_tag;
+        }
+        if (__ballot(fin) != 0ull) { r.state = 0; break; }
+        if (__ballot(!ok) == 0ull) { r.state = 1; break; }
+        __builtin_amdgcn_s_sleep(1);
+    }
+    auto f = [&](int k) { return __uint_as_float((unsigned int)v[k]); };
+    r.a = f(0); r.d = f(1); r.h = f(2); r.sa = f(3); r.sd = f(4); r.md = f(5); r.corr = f(6);
+    r.e0 = f(7); r.e1 = f(8);
+    return r;
+}
+// one more granule (covariate coefficients), same protocol
+__device__ __forceinline__ float poll_one(const unsigned long long* g, unsigned int want, unsigned int fin_tag,
+                                          int* state) {
+    unsigned long long v = 0;
+    for (int spin = 0; spin < GRANULE_SPIN_LIMIT; ++spin) {
+        v = ld_granule(g);
+        const unsigned int tg = (unsigned int)(v >> 32);
+        if (tg == want) break;
+        if (tg == fin_tag) { *state = 0; break; }
+        if (spin + 1 == GRANULE_SPIN_LIMIT) *state = -1;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    return __uint_as_float((unsigned int)v);
+}
+
+template <bool WEIGHTED, bool CLIP>
+__global__ DC_LAUNCH_BOUNDS void dc_eval_loop(EvalArgs A) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr bool STAGED = true, NUTS = true;
+    const Layout& L = A.L;
+    const int T = L.T, T1 = T + 1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int chain = blockIdx.y;
+    if (nuts_of(A, chain)[nd::H_S_DONE] != 0.0) return;  // the chain had finished before this launch
+    const int steps = A.persist_steps;
+    unsigned long long* zg = A.zg + (size_t)chain * L.D;
+    const unsigned int fin_tag = A.tag_base + 1u + (unsigned int)steps;
+
+    if (blockIdx.x == 0) {
+        const size_t tail_bytes = (acc_tail_lds_bytes(T, L.D, L.K, A.zo_stride, true) + 15) & ~(size_t)15;
+        int* okflag = reinterpret_cast<int*>(smem + tail_bytes);
+        // step 0's position is where the previous launch (or the chain's start) left it
+        if (wave == LEAF_WAVE) publish_z(zg, nd::vec(nuts_of(A, chain), L.D, nd::V_ZN), L.D, lane, A.tag_base + 1u);
+        for (int s = 0; s < steps; ++s) {
+            DC_STAMP(0);
+            __builtin_amdgcn_s_dcache_inv();
+            prior_body<CLIP, true>(A, chain, smem + tail_bytes, reinterpret_cast<double*>(smem));
+            DC_STAMP(4);
+            TailPre pre;
+            nd::LeafState<1> leaf1{};
+            double bigv[nd::LEAF_STAGE_LOADS];
+            tail_preload<STAGED, NUTS>(reload_args(), chain, pre, leaf1, bigv);
+            __syncthreads();
+            if (wave == 0) {
+                const bool ok = wait_arrivals(A.tickets + (size_t)chain * TK_WORDS, A.n_wg, lane);
+                if (lane == 0) *okflag = ok ? 1 : 0;
+            }
+            __syncthreads();
+            DC_STAMP(6);
+            if (*okflag == 0) {  // bounded wait expired: end the launch for everybody, poison the outputs
+                if (wave == LEAF_WAVE) publish_fin(zg, L.D, lane, fin_tag);
+                if (tid == 0) *pot_of(A, chain) = __builtin_nan("");
+                return;
+            }
+            const bool last = s + 1 == steps;
+            {
+                const EvalArgs B = reload_args();
+                // (the last step of the launch publishes nothing: the next launch starts from V_ZN)
+                tail_acc<STAGED, NUTS, CLIP>(B, chain, smem, pre, leaf1, bigv, last ? 0u : A.tag_base + 2u + (unsigned int)s);
+            }
+            __syncthreads();  // (also: this step's LDS is dead, the next prior may overwrite it)
+            DC_STAMP(5);
+            if (acc_tail_gradL(A, smem)[L.D + 6] != 0.0) return;  // the chain finished (FIN is out)
+            if (last && ld_sc1(&(nuts_of(A, chain) + A.persist->pd_off)[nd::P_ALLDONE]) != 0.0) return;
+        }
+        return;
+    }
+
+    // ---- streaming workgroups
+    float2* tabH = reinterpret_cast<float2*>(smem);
+    float2* tabA = tabH + tab_len(T);
+    double* acc = reinterpret_cast<double*>(tabA + tab_len(T));
+    double* red = acc + 3 * T1 + ((3 * T1) & 1);
+    float* redm = reinterpret_cast<float*>(red + WAVES * N_SCAL);
+    int* flag = reinterpret_cast<int*>(redm + WAVES * 4);
+    const int wgi = blockIdx.x - 1;
+    uint32_t pr0 = 0;
+    if (tid < A.P) pr0 = A.pairs[tid];
+    const int gw = wgi * A.active_waves + wave;
+    const int tile0 = wave < A.active_waves ? gw * A.tiles_per_wave : A.n_tiles;
+    const int tile_end = min(tile0 + A.tiles_per_wave, A.n_tiles);
+    // the wave's (first) tile: loaded ONCE, resident in registers for every leapfrog of the launch
+    const LaneData res = load_lane<WEIGHTED>(A, (size_t)min(tile0, A.n_tiles - 1) * 64 + lane);
+    const int o0 = A.wg_off[wgi], o1 = A.wg_off[wgi + 1];
+    const int kq = min(o0 + tid, A.total_c - 1);
+    const int slot0 = A.wg_slots[kq];
+    long long* ga = A.gacc + (size_t)chain * ga_rows(T) * GA_ROW;
+    if (tid == 0) *flag = 1;
+
+    for (int s = 0; s < steps; ++s) {
+        const unsigned int want = A.tag_base + 1u + (unsigned int)s;
+        // ---- this thread's granules: one round trip brings the data and the "go"
+        ZPolled zp = poll_z<CLIP>(zg, L, min(tid, T - 1), want, fin_tag);
+        DC_STAMP(0);
+        F32Scalars fs;
+        fs.s_a = exp_f32(zp.sa);
+        fs.s_d = exp_f32(zp.sd);
+        fs.m = zp.md;
+        {
+            const float q = __builtin_amdgcn_rcpf(1.0f + exp_f32(-zp.corr));
+            fs.q = fminf(fmaxf(q, (float)SIG_LO), (float)SIG_HI);
+        }
+        fs.gam = CLIP ? 0.f : zp.e0;
+        fs.s_h = CLIP ? exp_f32(zp.e0) : 0.f;
+        fs.mha = CLIP ? zp.e1 : 0.f;
+        int state = zp.state;
+        for (int t = tid; t <= T; t += BLOCK) {  // the float32 tables, exactly as f32_table_entry builds them
+            float2 vh = make_float2(0.f, 0.f), va = vh;
+            if (t < T) {
+                float za = zp.a, zd = zp.d, zh = zp.h;
+                if (t != tid) {  // (more than 512 teams never get here: <= 64)
+                    za = poll_one(&zg[(CLIP ? L.o_sat : L.o_adec) + t], want, fin_tag, &state);
+                    zd = poll_one(&zg[(CLIP ? L.o_sdt : L.o_ddec) + t], want, fin_tag, &state);
+                    zh = CLIP ? poll_one(&zg[L.o_hadec + t], want, fin_tag, &state) : 0.f;
+                }
+                float att, def, ha;
+                if (!CLIP) {
+                    att = fs.s_a * za;
+                    def = fs.m + fs.s_d * zd;
+                    ha = fs.gam;
+                } else {
+                    float apm = 0.f, dpm = fs.m;
+                    for (int k = 0; k < L.K; ++k) {
+                        const float xv = A.xsf[(size_t)t * L.K + k];
+                        apm += xv * poll_one(&zg[L.o_bA + k], want, fin_tag, &state);
+                        dpm += xv * poll_one(&zg[L.o_bD + k], want, fin_tag, &state);
+                    }
+                    att = apm + za * fs.s_a;
+                    def = dpm + zd * fs.s_d;
+                    ha = fs.mha + fs.s_h * zh;
+                }
+                const float edn = exp_f32(-def);
+                vh = make_float2(exp_f32(att + ha), edn);
+                va = make_float2(exp_f32(att), edn);
+            }
+            tabH[t] = vh;
+            tabA[t] = va;
+        }
+        for (int i = tid; i < 3 * T1; i += BLOCK) acc[i] = 0.0;
+        if (state != 1) *flag = state;  // (any thread: the chain finished, or a bounded wait expired)
+        __syncthreads();
+        if (*flag != 1) return;
+        DC_STAMP(1);
+        float mP, mQ, mR;
+        pair_maxima_f32<CLIP>(A, tabH, tabA, pr0, redm, tid, &mP, &mQ, &mR);
+        const float rho = rho_f32(mP, mQ, mR, fs.q);
+        DC_STAMP(2);
+
+        double dSLAM = 0.0, dSLOG = 0.0, dSU = 0.0, dCLIP = 0.0;
+        auto process = [&](const LaneData& ld) {
+            const LaneOut lo = lane_uniform<WEIGHTED, CLIP>(ld, rho, tabH, tabA);
+            dSLAM += q30(lo.slam);
+            dSLOG += q30(lo.slog);
+            dSU += q30(lo.su);
+            if (CLIP) dCLIP += q30(lo.sclip);
+            float rsh = lo.rsh, rsa = lo.rsa;
+            const uint32_t key = lo.key;
+            const uint32_t kprev = prev_lane_u32(key, ~key);
+            const unsigned long long heads = __ballot(kprev != key);
+            const int nruns = __popcll(heads);
+            if (nruns == 1) {
+                wave_sum2_f32(rsh, rsa);
+                if (lane == 0) flush_run_q(acc, T1, key, rsh, rsa);
+            } else if (nruns <= RUN_LOOP_MAX) {
+                unsigned long long hd = heads;
+                while (hd) {
+                    const int first = __ffsll((long long)hd) - 1;
+                    hd &= hd - 1;
+                    const int stop = hd ? __ffsll((long long)hd) - 1 : 64;
+                    const bool in = lane >= first && lane < stop;
+                    const uint32_t kk = (uint32_t)__builtin_amdgcn_readlane((int)key, first);
+                    float s0 = in ? rsh : 0.f, s1 = in ? rsa : 0.f;
+                    wave_sum2_f32(s0, s1);
+                    if (lane == 0) flush_run_q(acc, T1, kk, s0, s1);
+                }
+            } else {
+                flush_run_q(acc, T1, key, rsh, rsa);
+            }
+        };
+        if (tile0 < tile_end) {
+            process(res);
+            for (int tile = tile0 + 1; tile < tile_end; ++tile)  // longer streams: the rest from L2 / HBM
+                process(load_lane<WEIGHTED>(A, (size_t)tile * 64 + lane));
+        }
+        DC_STAMP(3);
+        dSLAM = wave_sum_f64(dSLAM);
+        dSLOG = wave_sum_f64(dSLOG);
+        dSU = wave_sum_f64(dSU);
+        if (CLIP) dCLIP = wave_sum_f64(dCLIP);
+        if (lane == 0) {
+            red[wave * N_SCAL + 0] = dSLAM;
+            red[wave * N_SCAL + 1] = dSLOG;
+            red[wave * N_SCAL + 2] = dSU;
+            red[wave * N_SCAL + 3] = dCLIP;
+        }
+        __syncthreads();
+        {
+            unsigned int bad = 0u;
+            for (int k = o0 + tid; k < o1; k += BLOCK) {
+                const int slot = k == o0 + tid ? slot0 : A.wg_slots[k];
+                const int which = slot / T, t = slot - which * T;
+                ga_add(ga + (size_t)slot * GA_ROW, acc[which * T1 + t], &bad);
+            }
+            if (tid >= BLOCK - N_SCAL) {
+                const int k = tid - (BLOCK - N_SCAL);
+                double sv = 0.0;
+#pragma unroll
+                for (int wv = 0; wv < WAVES; ++wv) sv += red[wv * N_SCAL + k];
+                ga_add(ga + (size_t)(3 * T + (wgi % GA_SHARDS) * N_SCAL + k) * GA_ROW, sv, &bad);
+            }
+            if (bad != 0u)
+                (void)__hip_atomic_fetch_or(
+                    reinterpret_cast<unsigned int*>(ga + (size_t)(3 * T + N_SCAL * GA_SHARDS) * GA_ROW),
+                    bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        DC_STAMP(4);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        DC_STAMP(5);
+        if (tid == 0)
+            (void)__hip_atomic_fetch_add(A.tickets + (size_t)chain * TK_WORDS + (1 + wgi % TK_GROUPS) * TK_STRIDE,
+                                         1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        DC_STAMP(6);
+    }
 }
 
 }  // namespace dc

@@ -67,7 +67,8 @@ def run_nuts(n=1_000_000):
         col = rel[1:, k]
         print(f"  {nm:12s} median {np.median(col):7.2f} us  min {col.min():7.2f}  max {col.max():7.2f}")
     last = int(np.argmax(st[:, 10]))
-    print("  tail WG", last, " ".join(f"{nm}={rel[last, k]:.2f}" for k, nm in [(6, "ticket"), (7, "tail:start"), (8, "tail:loads"), (9, "tail:colsums"), (14, "outputs"), (13, "leaf:prepared"), (12, "leaf:start"), (11, "moves:end"), (15, "weights:end")]))
+    print("  tail WG", last, " ".join(f"{nm}={rel[last, k]:.2f}" for k, nm in [(6, "ticket"), (7, "tail:start"), (8, "tail:loads"), (9, "tail:colsums"), (14, "outputs"), (13, "leaf:prepared"), (12, "leaf:start"), (11, "moves:end"), (15, "weights:end"), (5, "published (persistent kernel)")]))
+    print("  (persistent kernel: a step's record; entry = the step's start in that workgroup; tail WG entry=%.2f)" % rel[0, 0])
     c.close()
 
 if len(sys.argv) > 1 and sys.argv[1] == "nuts":
