@@ -49,9 +49,10 @@ constexpr int WAVES = BLOCK / 64;
 // device-resident NUTS: waves 4..7 of the tail workgroup idle during the per-team epilogue, so
 // the leaf's preparation is spread over them and costs nothing on the serial path
 constexpr int PAIR_BATCH = 4;            // pairs requested per round of the rho-bound loops
-constexpr int LEAF_WAVE = 4;             // books the leaf
-constexpr int RNG_WAVE = 5;              // draws the leaf's random numbers (threefry)
-constexpr int COV_WAVE_A = 6, COV_WAVE_D = 7;  // covariate-coefficient gradients (any launch)
+constexpr int LEAF_WAVE = 6;             // books the leaf (waves k and k + 4 share a SIMD: 6 and 7 sit
+                                         // beside the two lightest epilogue groups, waves 2 and 3)
+constexpr int RNG_WAVE = 7;              // draws the leaf's random numbers (threefry)
+constexpr int COV_WAVE_A = 4, COV_WAVE_D = 5;  // covariate-coefficient gradients (any launch)
 // (Copying the whole checkpoint area into LDS on waves 6,7 -- so that a leaf closing several
 // subtrees needs no dependent load -- measured no gain for one chain and the larger LDS
 // footprint cost 20 % at 16 chains: not done.)
