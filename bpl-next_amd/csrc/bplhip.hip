@@ -92,6 +92,8 @@ struct bplhip_ctx {
     DevBuf d_zb;    // persistent evaluation kernel: the next position as tagged granules
     unsigned int loop_tag = 0;  // tags handed out so far (a launch of k steps takes k + 1 of them)
     int opt_persistent_kernel = 1;  // 1: a single chain's leapfrogs run inside one resident launch
+    int opt_fused_small = 1;        // 1: neutral / dynamic evaluations that fit one CU's LDS run as one launch
+    bool neu_attr_set = false;
     int slab_chains = 0;
     // tuning options (bplhip_set_option)
     int opt_device_nuts = 1;  // 1: tree builder on the device (nuts_dev.hip.h) when supported
@@ -133,6 +135,10 @@ struct bplhip_ctx {
     bool neutral = false;
     dcn::NeuLayout NL{};
     DevBuf dd_gw, dd_nv, dd_cells, dd_acc, dd_hyp, dd_hc, dd_ac;
+    DevBuf dd_fpack, dd_sched, dd_slot_off;  // single-launch neutral kernel (dcn::neu_fused)
+    bool neu_fusable = false;
+    int neu_slots = 0;
+    int opt_debug_stop = 0;         // diagnostic build only
     DevBuf dd_gwoff, dd_tick;  // dynamic model: first fixture of each gameweek; arrival counters
     bool dyn_attr_set = false;
     std::map<GraphKey, hipGraphExec_t> graphs;
@@ -314,7 +320,32 @@ int launch_eval_dynamic(bplhip_ctx* c, int chains, const double* z, double* pot,
 int launch_eval_neutral(bplhip_ctx* c, int chains, const double* z, double* pot, double* grad,
                         double* aux, hipStream_t s) {
     const dcn::NeuLayout& L = c->NL;
-    for (int ch = 0; ch < chains; ++ch) {  // chains run back to back
+    if (c->opt_fused_small && c->neu_fusable) {  // one workgroup per chain, one launch for all of them
+        dcn::FusedArgs A{};
+        A.L = L;
+        A.n = (int)c->n;
+        A.fx = c->dd_fpack.as<const dcn::FusedFixture>();
+        A.n_slots = c->neu_slots;
+        A.sched = c->dd_sched.as<const uint32_t>();
+        A.slot_off = c->dd_slot_off.as<const int>();
+        A.xs = L.K ? c->d_xs.as<const double>() : nullptr;
+        A.lgsum = c->lgsum;
+        A.z = z;
+        A.potential = pot;
+        A.grad = grad;
+        A.aux = aux;
+        A.stop_after = c->opt_debug_stop;
+        if (!c->neu_attr_set) {
+            HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(dcn::neu_fused),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT));
+            c->neu_attr_set = true;
+        }
+        hipLaunchKernelGGL(dcn::neu_fused, dim3(chains), dim3(dcn::FUSED_BLOCK),
+                           dcn::fused_lds_doubles(L, c->n, c->neu_slots) * 8, s, A);
+        HIP_TRY(c, hipGetLastError());
+        return BPLHIP_OK;
+    }
+    for (int ch = 0; ch < chains; ++ch) {  // multi-launch path: chains run back to back
         dcn::NeuArgs A{};
         dcd::DynArgs& F = A.F;
         F.h = c->d_h.as<const uint16_t>();
@@ -899,6 +930,17 @@ int bplhip_set_option(bplhip_ctx* c, const char* name, int value) {
         c->opt_persistent_kernel = value != 0;
         return BPLHIP_OK;
     }
+#ifdef DC_STAMPS
+    if (n == "debug_stop") {
+        c->opt_debug_stop = value;
+        drop_graphs(c);
+        return BPLHIP_OK;
+    }
+#endif
+    if (n == "fused_small") {  // 0: neutral / dynamic evaluations always take the multi-launch path
+        c->opt_fused_small = value != 0;
+        return BPLHIP_OK;
+    }
     if (n == "gridy_max_chains") {
         if (value < 1 || value > 4096) return fail(c, BPLHIP_EINVAL, "gridy_max_chains out of range");
         c->opt_gridy_max_chains = value;
@@ -1005,8 +1047,9 @@ static int bplhip_set_fixtures_neutral_impl(bplhip_ctx* c, int64_t n, int32_t n_
         HIP_TRY(c, c->d_w.ensure(n * 4));
         HIP_TRY(c, hipMemcpyAsync(c->d_w.p, w.data(), n * 4, hipMemcpyHostToDevice, s));
     }
+    std::vector<uint8_t> hcv, acv;
     if (n_conf > 0) {  // (device -> device: the library keeps its own copy)
-        std::vector<uint8_t> hcv(n), acv(n);
+        hcv.resize(n); acv.resize(n);
         HIP_TRY(c, hipMemcpy(hcv.data(), home_conf, n, hipMemcpyDeviceToHost));
         HIP_TRY(c, hipMemcpy(acv.data(), away_conf, n, hipMemcpyDeviceToHost));
         for (int64_t i = 0; i < n; ++i)
@@ -1022,6 +1065,60 @@ static int bplhip_set_fixtures_neutral_impl(bplhip_ctx* c, int64_t n, int32_t n_
         HIP_TRY(c, c->dd_ac.ensure(n));
         HIP_TRY(c, hipMemcpy(c->dd_hc.p, hcv.data(), n, hipMemcpyHostToDevice));
         HIP_TRY(c, hipMemcpy(c->dd_ac.p, acv.data(), n, hipMemcpyHostToDevice));
+    }
+    // single-launch kernel (dcn::neu_fused): packed fixtures and the schedule of its gather step
+    const dcn::NeuLayout NL = dcn::make_neu_layout(n_teams, k, n_conf);
+    c->neu_fusable = n <= dcn::FUSED_MAX_N && n_teams <= dcn::FUSED_MAX_T && n_conf <= dcn::FUSED_MAX_C;
+    if (c->neu_fusable) {
+        std::vector<dcn::FusedFixture> pack(n);
+        std::vector<int> off(n_teams + 1, 0);
+        for (int64_t i = 0; i < n; ++i) {
+            dcn::FusedFixture f{};
+            f.h = h[i]; f.a = a[i]; f.x = x[i]; f.y = y[i]; f.nv = nv[i];
+            f.hc = n_conf ? hcv[i] : 0;
+            f.ac = n_conf ? acv[i] : 0;
+            f.w = weights ? w[i] : 1.0f;
+            pack[i] = f;
+            ++off[h[i] + 1];
+            ++off[a[i] + 1];
+        }
+        for (int t = 0; t < n_teams; ++t) off[t + 1] += off[t];
+        // team-major incidence entries (fixture order within a team: the sums have a fixed order)
+        std::vector<uint32_t> inc(2 * n);
+        {
+            std::vector<int> fill(off.begin(), off.end() - 1);
+            for (int64_t i = 0; i < n; ++i) {
+                inc[fill[h[i]]++] = ((uint32_t)i << 2) | ((uint32_t)nv[i] << 1);
+                inc[fill[a[i]]++] = ((uint32_t)i << 2) | ((uint32_t)nv[i] << 1) | 1u;
+            }
+        }
+        // slots: <= 64 consecutive entries of one team, taken by one 16-lane row (lane `sub`
+        // holds entries sub, sub + 16, ...); row r of the workgroup takes slots r, r + 64, ...
+        constexpr int SLOT = 16 * dcn::FUSED_PRE;
+        std::vector<int> slot_off(n_teams + 1, 0);
+        for (int t = 0; t < n_teams; ++t) slot_off[t + 1] = slot_off[t] + (off[t + 1] - off[t] + SLOT - 1) / SLOT;
+        const int n_slots = slot_off[n_teams];
+        const int rounds = std::max(1, (n_slots + dcn::FUSED_ROWS - 1) / dcn::FUSED_ROWS);
+        std::vector<uint32_t> sched((size_t)rounds * dcn::FUSED_PRE * dcn::FUSED_BLOCK, dcn::INC_NONE);
+        for (int t = 0; t < n_teams; ++t)
+            for (int sl = slot_off[t]; sl < slot_off[t + 1]; ++sl) {
+                const int b0 = off[t] + (sl - slot_off[t]) * SLOT, b1 = std::min(b0 + SLOT, off[t + 1]);
+                const int round = sl / dcn::FUSED_ROWS, row = sl % dcn::FUSED_ROWS;
+                for (int e = b0; e < b1; ++e) {
+                    const int sub = (e - b0) % 16, r = (e - b0) / 16;
+                    sched[((size_t)round * dcn::FUSED_PRE + r) * dcn::FUSED_BLOCK + row * 16 + sub] = inc[e];
+                }
+            }
+        c->neu_slots = n_slots;
+        c->neu_fusable = dcn::fused_lds_doubles(NL, n, n_slots) * 8 <= LDS_LIMIT;
+        if (c->neu_fusable) {
+            HIP_TRY(c, c->dd_fpack.ensure(pack.size() * sizeof(dcn::FusedFixture)));
+            HIP_TRY(c, c->dd_sched.ensure(sched.size() * 4));
+            HIP_TRY(c, c->dd_slot_off.ensure(slot_off.size() * 4));
+            HIP_TRY(c, hipMemcpy(c->dd_fpack.p, pack.data(), pack.size() * sizeof(dcn::FusedFixture), hipMemcpyHostToDevice));
+            HIP_TRY(c, hipMemcpy(c->dd_sched.p, sched.data(), sched.size() * 4, hipMemcpyHostToDevice));
+            HIP_TRY(c, hipMemcpy(c->dd_slot_off.p, slot_off.data(), slot_off.size() * 4, hipMemcpyHostToDevice));
+        }
     }
     HIP_TRY(c, c->dd_cells.ensure((size_t)n_teams * dcd::P_N * 8));
     HIP_TRY(c, c->dd_acc.ensure(((size_t)n_teams * dcd::A_N + dcd::SC_N + n_conf) * 8));

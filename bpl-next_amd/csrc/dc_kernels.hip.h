@@ -277,6 +277,37 @@ __device__ __forceinline__ void wave_sum4_f64(double (&v)[4]) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) v[j] = readlane63_f64(v[j]);
 }
+// NV independent sums, interleaved step by step like wave_sum4_f64
+template <int NV>
+__device__ __forceinline__ void wave_sumN_f64(double (&v)[NV]) {
+#pragma unroll
+    for (int j = 0; j < NV; ++j) v[j] += dpp_f64<0xB1>(0.0, v[j]);
+#pragma unroll
+    for (int j = 0; j < NV; ++j) v[j] += dpp_f64<0x4E>(0.0, v[j]);
+#pragma unroll
+    for (int j = 0; j < NV; ++j) v[j] += dpp_f64<0x124>(0.0, v[j]);
+#pragma unroll
+    for (int j = 0; j < NV; ++j) v[j] += dpp_f64<0x128>(0.0, v[j]);
+#pragma unroll
+    for (int j = 0; j < NV; ++j) v[j] += dpp_f64<0x142, 0xA>(0.0, v[j]);
+#pragma unroll
+    for (int j = 0; j < NV; ++j) v[j] += dpp_f64<0x143, 0xC>(0.0, v[j]);
+#pragma unroll
+    for (int j = 0; j < NV; ++j) v[j] = readlane63_f64(v[j]);
+}
+// NV independent sums over each 16-lane ROW (every lane of a row gets its row's totals):
+// quad_perm, quad_perm, row_ror:4, row_ror:8 -- four steps, no cross-row traffic
+template <int NV>
+__device__ __forceinline__ void row_sum_f64(double (&v)[NV]) {
+#pragma unroll
+    for (int j = 0; j < NV; ++j) v[j] += dpp_f64<0xB1>(0.0, v[j]);
+#pragma unroll
+    for (int j = 0; j < NV; ++j) v[j] += dpp_f64<0x4E>(0.0, v[j]);
+#pragma unroll
+    for (int j = 0; j < NV; ++j) v[j] += dpp_f64<0x124>(0.0, v[j]);
+#pragma unroll
+    for (int j = 0; j < NV; ++j) v[j] += dpp_f64<0x128>(0.0, v[j]);
+}
 __device__ __forceinline__ double wave_max_f64(double v) {  // v >= 0
     v = fmax(v, dpp_f64<0xB1>(0.0, v));
     v = fmax(v, dpp_f64<0x4E>(0.0, v));

@@ -268,4 +268,543 @@ __global__ __launch_bounds__(NEU_EPI) void neu_epilogue(NeuArgs A) {
     }
 }
 
+
+// ---- the whole evaluation in ONE workgroup (one workgroup per chain), everything in LDS.
+// The four-launch path above is bound by its three kernel boundaries and by global round trips
+// between dependent steps (a 16 us epilogue that moves 23 KB).  At the sizes the neutral model
+// is usually fitted on (hundreds to a few thousand internationals) one CU holds all of it: z,
+// the cell records and the per-fixture adjoints live in LDS, six barriers replace the launches.
+// Wave 0 is the SCALAR wave (one scalar site per lane, every transcendental of the z side);
+// waves 1..15 are the 960 workers (teams, fixtures).
+//   A  workers: z -> LDS; cell records, one thread per team, straight from global z (each
+//      computes the six exp(std) itself: waiting for the scalar wave would cost a barrier)
+//      scalar wave: exp / sigmoid of its sites (what step D needs)
+//   C  workers: rates; maxima by DPP, one ds_max per wave
+//      scalar wave: the rest of its chain (log1p, log-density, constant gradient parts) -- off
+//      the critical path, it is needed from step F on
+//   D  bounds; value + adjoint (gh, ga) of every fixture -> LDS
+//   E  one 16-lane ROW per slot of (at most) 64 incidence entries of ONE team (host-built
+//      schedule, the first round's entries requested at kernel entry): gather the adjoints into
+//      six partial sums by four DPP steps inside the row; then fold each team's slots and add
+//      the bounds' adjoint.  No atomics (LDS float64 atomics retire about one lane per cycle: 8
+//      per fixture took 3 us of the first version's 11), and the sums have a fixed order.
+//   F  the sums over teams, one per wave
+//   G  team and scalar-site gradients, potential (every global store is after the last
+//      barrier: a barrier waits for the stores before it)
+// The arg-extremal fixtures travel as ONE packed word per bound (ds_max_u64 on
+// {~index, h, a, venue, confederations}): no second look at the fixture columns.
+constexpr int FUSED_BLOCK = 1024;
+constexpr int FUSED_WAVES = FUSED_BLOCK / 64;
+constexpr int FUSED_WORKERS = FUSED_BLOCK - 64;
+constexpr int FUSED_ROWS = FUSED_BLOCK / 16; // 16-lane rows: slots per round of step E
+constexpr int FUSED_MAX_N = 1 << 13;         // (LDS binds first for most shapes)
+constexpr int FUSED_MAX_T = 4095, FUSED_MAX_C = 255;
+constexpr int FUSED_PRE = 4;                 // incidence entries per lane and slot (64 per slot)
+constexpr int FUSED_CONF_COPIES = 8;         // private copies of the confederation accumulators
+constexpr int FUSED_SITES = 13;  // scalar sites: 6 stds, u, corr_coef_raw, 4 means, mean_defence
+// fixed LDS words
+enum {
+    FX_STD = 0,      // [6] exp(std sites): att, def, ha, aa, hd, ad
+    FX_Q = 6,        // corr_coef_raw site: clipped sigmoid
+    FX_RP = 7, FX_IVV, FX_LOGVV,   // rho' = 2u-1, 1/(1-rho'^2), log(1-rho'^2)
+    FX_LP = 10,      // log-density of the scalar sites, coefficients and confederation strengths
+    FX_MAX = 12,     // [3] maxima (bit patterns)
+    FX_KEY = 15,     // [3] packed arg-extremal fixtures
+    FX_MUL = 18,     // [13] gradient of scalar site l: -(mul[l] * dot_l + pre[l])
+    FX_PRE = 31,     // [13]
+    FX_WSUM = 44,    // [waves][2] per-wave sums over fixtures: value, d/d rho (added in wave order)
+    FX_SUMS = 44 + 2 * FUSED_WAVES,  // [NEU_SUMS + 2K]
+    FX_N = FX_SUMS
+};
+
+struct alignas(16) FusedFixture {  // one 16-byte load per fixture
+    uint16_t h, a;
+    uint8_t x, y, nv, hc, ac, pad[3];
+    float w;
+};
+static_assert(sizeof(FusedFixture) == 16, "FusedFixture is one dwordx4");
+// incidence entry of a team: fixture index << 2 | venue neutral << 1 | team is the away side
+constexpr uint32_t INC_NONE = 0xFFFFFFFFu;
+
+struct FusedArgs {
+    NeuLayout L;
+    int n;
+    int n_slots;                 // slots of step E (each: <= 64 incidence entries of one team)
+    const FusedFixture* fx;      // [n]
+    const uint32_t* sched;       // [rounds * FUSED_PRE][FUSED_BLOCK] entry of (round, k, thread) or INC_NONE
+    const int* slot_off;         // [T + 1] first slot of each team
+    const double* xs;            // [T, K] or nullptr
+    double lgsum;
+    const double* z;             // [chains, D]
+    double* potential;           // [chains]
+    double* grad;                // [chains, D]
+    double* aux;                 // [chains, 4] or nullptr
+    int stop_after;              // diagnostic build only: leave after this step (0: run to the end)
+};
+
+inline size_t fused_lds_doubles(const NeuLayout& L, long long n, int n_slots) {
+    return FX_N + NEU_SUMS + 2 * (size_t)L.K + L.D + (size_t)L.T * dcd::P_N + (size_t)L.T * dcd::A_N +
+           (size_t)(FUSED_CONF_COPIES + 1) * L.C + 2 * (size_t)n + (size_t)n_slots * dcd::A_N +
+           (L.T + 2) / 2;
+}
+
+__device__ __forceinline__ void wave_max3_f64(double& a, double& b, double& c) {  // all >= 0
+    using dc::dpp_f64;
+    a = fmax(a, dpp_f64<0xB1>(0.0, a)); b = fmax(b, dpp_f64<0xB1>(0.0, b)); c = fmax(c, dpp_f64<0xB1>(0.0, c));
+    a = fmax(a, dpp_f64<0x4E>(0.0, a)); b = fmax(b, dpp_f64<0x4E>(0.0, b)); c = fmax(c, dpp_f64<0x4E>(0.0, c));
+    a = fmax(a, dpp_f64<0x124>(0.0, a)); b = fmax(b, dpp_f64<0x124>(0.0, b)); c = fmax(c, dpp_f64<0x124>(0.0, c));
+    a = fmax(a, dpp_f64<0x128>(0.0, a)); b = fmax(b, dpp_f64<0x128>(0.0, b)); c = fmax(c, dpp_f64<0x128>(0.0, c));
+    a = fmax(a, dpp_f64<0x142, 0xA>(0.0, a)); b = fmax(b, dpp_f64<0x142, 0xA>(0.0, b)); c = fmax(c, dpp_f64<0x142, 0xA>(0.0, c));
+    a = fmax(a, dpp_f64<0x143, 0xC>(0.0, a)); b = fmax(b, dpp_f64<0x143, 0xC>(0.0, b)); c = fmax(c, dpp_f64<0x143, 0xC>(0.0, c));
+    a = dc::readlane63_f64(a); b = dc::readlane63_f64(b); c = dc::readlane63_f64(c);
+}
+
+#ifdef DC_STAMPS  // diagnostic build: the phase timeline (10 ns ticks since entry) replaces grad[0..9]
+#define NEU_STAMP_DECL unsigned long long stamp_[10] = {}
+#define NEU_STAMP(k)                                      \
+    do {                                                  \
+        stamp_[k] = __builtin_amdgcn_s_memrealtime();     \
+        if (A.stop_after == (k)) return;                  \
+    } while (0)
+#define NEU_STAMP_FLUSH for (int k_ = 0; k_ < 10; ++k_) grad[k_] = (double)(stamp_[k_] - stamp_[0])
+#else
+#define NEU_STAMP_DECL do { } while (0)
+#define NEU_STAMP(k) do { } while (0)
+#define NEU_STAMP_FLUSH do { } while (0)
+#endif
+
+__global__ __launch_bounds__(FUSED_BLOCK) void neu_fused(FusedArgs A) {
+    extern __shared__ double lds[];
+    NEU_STAMP_DECL;
+    NEU_STAMP(0);
+    const NeuLayout& L = A.L;
+    const int T = L.T, K = L.K, C = L.C, D = L.D, N = A.n;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wid = tid - 64;                          // worker index (waves 1..15), < 0 on the scalar wave
+    double* fixed = lds;
+    double* sums = fixed + FX_SUMS;                    // [NEU_SUMS + 2K]
+    double* zs = sums + NEU_SUMS + 2 * K;              // [D]
+    double* cells = zs + D;                            // [T][P_N]
+    double* accF = cells + T * dcd::P_N;               // [T][A_N] then [C]: adjoints, bounds included
+    double* cacc = accF + T * dcd::A_N + C;            // [FUSED_CONF_COPIES][C]
+    double* gb = cacc + FUSED_CONF_COPIES * C;         // [N][2] weighted (gh, ga)
+    double* part = gb + 2 * (size_t)N;                 // [n_slots][A_N] partial sums of step E
+    int* slot_off = reinterpret_cast<int*>(part + (size_t)A.n_slots * dcd::A_N);  // [T + 1]
+    unsigned long long* fixed_u = reinterpret_cast<unsigned long long*>(fixed);
+
+    const double* z = A.z + (size_t)blockIdx.x * D;
+    double* grad = A.grad + (size_t)blockIdx.x * D;
+
+    // ---- A
+    // every global word this thread needs before the first barrier is requested here
+    const FusedFixture first = A.fx[wid >= 0 && wid < N ? wid : 0];
+    uint32_t pre[FUSED_PRE];
+#pragma unroll
+    for (int r = 0; r < FUSED_PRE; ++r) pre[r] = A.sched[r * FUSED_BLOCK + tid];
+    // scalar wave: its site's latent value (kept across the first barrier)
+    //   0..5 stds | 6 u | 7 corr_coef_raw | 8..11 means (home attack, away attack, home defence,
+    //   away defence) | 12 mean_defence
+    double zv = 0.0, ez = 0.0, sg = 0.0, v_site = 0.0, dv_site = 0.0;
+    const bool sigm = lane == 6 || lane == 7;
+    if (wave == 0) {
+        const int o = lane == 0 ? L.o_s_att : lane == 1 ? L.o_s_def : lane == 2 ? L.o_s_ha
+                    : lane == 3 ? L.o_s_aa : lane == 4 ? L.o_s_hd : lane == 5 ? L.o_s_ad
+                    : lane == 6 ? L.o_u : lane == 7 ? L.o_corr : lane == 8 ? L.o_mha
+                    : lane == 9 ? L.o_maa : lane == 10 ? L.o_mhd : lane == 11 ? L.o_mad : L.o_md;
+        zv = z[lane < FUSED_SITES ? o : 0];
+        // one exp for lanes 0..7 TOGETHER (a float64 libm call is ~0.3 us of dependent
+        // instructions; on diverged lanes they would run one after another)
+        ez = exp(sigm ? -fabs(zv) : zv);
+        const double s_abs = 1.0 / (1.0 + ez);
+        sg = zv >= 0 ? s_abs : 1.0 - s_abs;
+        v_site = sg < dc::SIG_LO ? dc::SIG_LO : sg > dc::SIG_HI ? dc::SIG_HI : sg;
+        dv_site = (sg < dc::SIG_LO || sg > dc::SIG_HI) ? 0.0 : sg * (1.0 - sg);
+        if (lane < 6) fixed[FX_STD + lane] = ez;
+        if (lane == 7) fixed[FX_Q] = v_site;
+        if (lane >= 8 && lane < 14) fixed_u[FX_MAX + lane - 8] = 0ull;   // maxima and keys
+    } else {
+        for (int i = wid; i < D; i += FUSED_WORKERS) zs[i] = z[i];
+        for (int i = wid; i <= T; i += FUSED_WORKERS) slot_off[i] = A.slot_off[i];
+        for (int i = wid; i < FUSED_CONF_COPIES * C; i += FUSED_WORKERS) cacc[i] = 0.0;
+        // cell records from global z: the team's six values, the five means and the six stds in
+        // one round of loads
+        for (int t = wid; t < T; t += FUSED_WORKERS) {
+            const double sat = z[L.o_sat + t], sdt = z[L.o_sdt + t], zhat = z[L.o_hat + t],
+                         zaat = z[L.o_aat + t], zhdf = z[L.o_hdf + t], zadf = z[L.o_adf + t];
+            const double md = z[L.o_md], mha = z[L.o_mha], maa = z[L.o_maa], mhd = z[L.o_mhd], mad = z[L.o_mad];
+            const double l_att = z[L.o_s_att], l_def = z[L.o_s_def], l_ha = z[L.o_s_ha], l_aa = z[L.o_s_aa],
+                         l_hd = z[L.o_s_hd], l_ad = z[L.o_s_ad];
+            double att = 0.0, def = md;
+            for (int k = 0; k < K; ++k) {
+                const double xv = A.xs[(size_t)t * K + k];
+                att += xv * z[L.o_bA + k];
+                def += xv * z[L.o_bD + k];
+            }
+            att += sat * exp(l_att);
+            def += sdt * exp(l_def);
+            const double hat = mha + exp(l_ha) * zhat;
+            const double aat = maa + exp(l_aa) * zaat;
+            const double hdf = mhd + exp(l_hd) * zhdf;
+            const double adf = mad + exp(l_ad) * zadf;
+            double* P = cells + t * dcd::P_N;
+            P[dcd::P_AH] = att + hat;
+            P[dcd::P_AA] = att + aat;
+            P[dcd::P_BH] = def + hdf;
+            P[dcd::P_BA] = def + adf;
+            P[dcd::P_ATT] = att;
+            P[dcd::P_DEF] = def;
+        }
+    }
+    __syncthreads();
+    NEU_STAMP(1);
+    // ---- C
+    auto etas = [&](const FusedFixture& f, double* eh, double* ea) {
+        const double* Ph = cells + f.h * dcd::P_N;
+        const double* Pa = cells + f.a * dcd::P_N;
+        const bool nvf = f.nv != 0;
+        *eh = Ph[nvf ? dcd::P_ATT : dcd::P_AH] - Pa[nvf ? dcd::P_DEF : dcd::P_BA];
+        *ea = Pa[nvf ? dcd::P_ATT : dcd::P_AA] - Ph[nvf ? dcd::P_DEF : dcd::P_BH];
+        if (C) {  // bpl/neutral_dixon_coles_WC.py:188-203
+            const double d = zs[L.o_conf + f.hc] - zs[L.o_conf + f.ac];
+            *eh += d;
+            *ea -= d;
+        }
+    };
+    double eh0 = 0.0, ea0 = 0.0, lh0 = 0.0, la0 = 0.0;  // this worker's first fixture, kept for step D
+    if (wave == 0) {
+        // the rest of the scalar chain: one log1p for the two sigmoid sites, then per site its
+        // log-density and the constant part of its gradient
+        const double l1 = log1p(sigm ? ez : 0.0);
+        double Lp = 0.0;
+        // confederation strengths and coefficients ~ N(0,1): lanes stride over them
+        for (int k = lane; k < 2 * K + C; k += 64) {
+            const double v = zs[k < K ? L.o_bA + k : k < 2 * K ? L.o_bD + k - K : L.o_conf + k - 2 * K];
+            Lp += -0.5 * v * v - HALF_LOG_2PI;
+        }
+        double mul = 1.0, prec = 0.0;
+        if (lane < 6) {  // HalfNormal(scale) in log space: std_attack / std_defence scale 0.5, others 1
+            const double r = lane < 2 ? 2.0 * ez : ez;
+            Lp += LN2 - (lane < 2 ? -LN2 : 0.0) - HALF_LOG_2PI - 0.5 * r * r + zv;
+            mul = ez;
+            prec = 1.0 - r * r;
+        } else if (sigm) {
+            // log v, log(1-v), softplus(z) + softplus(-z) of the (clipped) sigmoid
+            const double az = fabs(zv), sp_pos = az + l1;
+            double log_v = zv >= 0 ? -l1 : -sp_pos, log_1mv = zv >= 0 ? -sp_pos : -l1;
+            if (dv_site == 0.0) {
+                log_v = log(v_site);
+                log_1mv = log1p(-v_site);
+            }
+            const double v = v_site;
+            if (lane == 6) {  // u ~ Beta(2,4); rho' = 2u - 1, 1 - rho'^2 = 4 u (1 - u)
+                const double rp = 2.0 * v - 1.0, vv = 1.0 - rp * rp;
+                fixed[FX_RP] = rp;
+                fixed[FX_IVV] = 1.0 / vv;
+                fixed[FX_LOGVV] = 2.0 * LN2 + log_v + log_1mv;
+                Lp += log_v + 3.0 * log_1mv + 2.995732273553991 - (sp_pos + l1);
+                mul = 2.0 * dv_site;
+                prec = (1.0 / v - 3.0 / (1.0 - v)) * dv_site + (1.0 - 2.0 * sg);
+            } else {          // corr_coef_raw ~ Beta(2,2)
+                Lp += log_v + log_1mv + 1.791759469228055 - (sp_pos + l1);
+                mul = dv_site;
+                prec = (1.0 / v - 1.0 / (1.0 - v)) * dv_site + (1.0 - 2.0 * sg);
+            }
+        } else if (lane < 12) {  // means ~ N(+-0.1, 0.2)
+            const double mu = (lane & 1) ? -0.1 : 0.1, r = (zv - mu) / 0.2;
+            Lp += -0.5 * r * r + 1.6094379124341003 - HALF_LOG_2PI;
+            prec = -(zv - mu) / 0.04;
+        } else if (lane == 12) {  // mean_defence ~ N(0,1)
+            Lp += -0.5 * zv * zv - HALF_LOG_2PI;
+            prec = -zv;
+        }
+        if (lane < FUSED_SITES) {
+            fixed[FX_MUL + lane] = mul;
+            fixed[FX_PRE + lane] = prec;
+        }
+        Lp = dc::wave_sum_f64(Lp);
+        if (lane == 0) {
+            fixed[FX_LP] = Lp;
+            fixed[FX_WSUM] = 0.0;        // (the scalar wave has no fixtures)
+            fixed[FX_WSUM + 1] = 0.0;
+        }
+    } else {
+        double mP = 0.0, mH = 0.0, mA = 0.0;
+        for (int i = wid; i < N; i += FUSED_WORKERS) {
+            FusedFixture f = first;
+            if (i != wid) f = A.fx[i];
+            double eh, ea;
+            etas(f, &eh, &ea);
+            const double lh = exp(eh), la = exp(ea);
+            if (i == wid) { eh0 = eh; ea0 = ea; lh0 = lh; la0 = la; }
+            mP = fmax(mP, lh * la);
+            mH = fmax(mH, lh);
+            mA = fmax(mA, la);
+        }
+        if (wid - lane < N) {  // (waves without fixtures: nothing to offer)
+            wave_max3_f64(mP, mH, mA);
+            // (positive doubles order like their bit patterns)
+            if (lane < 3)
+                atomicMax(&fixed_u[FX_MAX + lane],
+                          (unsigned long long)__double_as_longlong(lane == 0 ? mP : lane == 1 ? mH : mA));
+        }
+    }
+    __syncthreads();
+    NEU_STAMP(2);
+    // ---- D
+    // (the bounds cost two float64 divisions: only the waves that use them work them out -- four
+    // waves share a SIMD, and what all sixteen repeat is paid four times over)
+    auto bounds = [&]() {
+        dcd::Bounds r;
+        r.M = fixed[FX_MAX]; r.Lh = fixed[FX_MAX + 1]; r.La = fixed[FX_MAX + 2];
+        r.q = fixed[FX_Q];
+        r.UB = r.M > 1.0 ? 1.0 / r.M : 1.0;
+        r.LB = -1.0 / fmax(r.Lh, r.La);
+        r.rho = r.LB + r.q * (r.UB - r.LB);
+        r.G_rho = 0.0;
+        return r;
+    };
+    if (wave != 0 && wid - lane < N) {
+        const dcd::Bounds b = bounds();
+        double* cmine = cacc + (wave % FUSED_CONF_COPIES) * C;
+        double Ui = 0.0, ui = 0.0;
+        for (int i = wid; i < N; i += FUSED_WORKERS) {
+            FusedFixture f = first;
+            double eh = eh0, ea = ea0, lh = lh0, la = la0;
+            if (i != wid) {
+                f = A.fx[i];
+                etas(f, &eh, &ea);
+                lh = exp(eh);
+                la = exp(ea);
+            }
+            const double w = (double)f.w;
+            double Uf = f.x * eh - lh + f.y * ea - la;
+            double gh = f.x - lh, ga = f.y - la;
+            if (f.x <= 1 && f.y <= 1) {
+                const double c = f.x == 0 ? (f.y == 0 ? -lh * la : lh) : (f.y == 0 ? la : -1.0);
+                const double arg = 1.0 + b.rho * c;
+                if (arg > 0.0) {
+                    Uf += log(arg);
+                    const double u = c / arg;
+                    ui += w * u;
+                    if (f.x == 0) gh += b.rho * u;
+                    if (f.y == 0) ga += b.rho * u;
+                } else {
+                    Uf += log(0.0);  // -inf (tol = 0, bpl/_util.py:42)
+                }
+            }
+            Ui += w * Uf;
+            gh *= w;
+            ga *= w;
+            gb[2 * i] = gh;
+            gb[2 * i + 1] = ga;
+            // arg-extremal fixtures: the smallest index among those attaining a maximum wins
+            const unsigned long long key =
+                ((unsigned long long)(0x7FFFFF - i) << 41) | ((unsigned long long)f.h << 29) |
+                ((unsigned long long)f.a << 17) | ((unsigned long long)(f.nv != 0) << 16) |
+                ((unsigned long long)f.hc << 8) | (unsigned long long)f.ac;
+            if (lh * la == b.M) atomicMax(&fixed_u[FX_KEY], key);
+            if (lh == b.Lh) atomicMax(&fixed_u[FX_KEY + 1], key);
+            if (la == b.La) atomicMax(&fixed_u[FX_KEY + 2], key);
+            if (C) {
+                atomicAdd(&cmine[f.hc], gh - ga);
+                atomicAdd(&cmine[f.ac], ga - gh);
+            }
+        }
+        double both[2] = {Ui, ui};
+        dc::wave_sumN_f64(both);
+        if (lane == 0) {
+            fixed[FX_WSUM + 2 * wave] = both[0];
+            fixed[FX_WSUM + 2 * wave + 1] = both[1];
+        }
+    } else if (wave != 0 && lane == 0) {
+        fixed[FX_WSUM + 2 * wave] = 0.0;
+        fixed[FX_WSUM + 2 * wave + 1] = 0.0;
+    }
+    __syncthreads();
+    NEU_STAMP(3);
+    // ---- E
+    {
+        // gather: row `tid / 16` takes slots row, row + 64, ...; lane k-th entries 16 apart
+        const int sub = lane & 15, row = tid >> 4;
+        for (int slot = row, round = 0; slot < A.n_slots; slot += FUSED_ROWS, ++round) {
+            uint32_t e[FUSED_PRE];
+#pragma unroll
+            for (int r = 0; r < FUSED_PRE; ++r)
+                e[r] = round == 0 ? pre[r] : A.sched[(size_t)(round * FUSED_PRE + r) * FUSED_BLOCK + tid];
+            double s6[dcd::A_N];
+#pragma unroll
+            for (int j = 0; j < dcd::A_N; ++j) s6[j] = 0.0;
+#pragma unroll
+            for (int r = 0; r < FUSED_PRE; ++r) {
+                const bool have = e[r] != INC_NONE;
+                const int i = have ? (int)(e[r] >> 2) : 0;
+                const bool away = e[r] & 1, nvf = e[r] & 2;
+                const double gh = have ? gb[2 * i] : 0.0, ga = have ? gb[2 * i + 1] : 0.0;
+                const double up = away ? ga : gh, down = away ? gh : ga;  // own rate | the opponent's
+                const double upv = nvf ? 0.0 : up, downv = nvf ? 0.0 : down;
+                s6[dcd::A_ATT] += up;
+                s6[dcd::A_DEF] -= down;
+                s6[dcd::A_HATT] += away ? 0.0 : upv;
+                s6[dcd::A_AATT] += away ? upv : 0.0;
+                s6[dcd::A_ADEF] -= away ? downv : 0.0;
+                s6[dcd::A_HDEF] -= away ? 0.0 : downv;
+            }
+            dc::row_sum_f64(s6);
+            if (sub < dcd::A_N) {
+                double v = s6[0];
+#pragma unroll
+                for (int j = 1; j < dcd::A_N; ++j) v = sub == j ? s6[j] : v;
+                part[slot * dcd::A_N + sub] = v;
+            }
+        }
+    }
+    __syncthreads();
+    NEU_STAMP(4);
+    auto bounds_with_adjoint = [&]() {
+        dcd::Bounds r = bounds();
+#pragma unroll
+        for (int wv = 0; wv < FUSED_WAVES; ++wv) r.G_rho += fixed[FX_WSUM + 2 * wv + 1];
+        return r;
+    };
+    dcd::Bounds b{};  // (wave 0 always takes part here: it keeps its copy for step G)
+    if (tid - lane < T * dcd::A_N || tid - lane < C) {
+        b = bounds_with_adjoint();
+        // the bounds' adjoint reaches (at most) two fixtures: the one with the largest rate
+        // product (when it binds, M > 1) through both rates, the one with the largest single
+        // rate through that rate
+        const bool lb_home = b.Lh >= b.La;
+        const unsigned long long k0 = b.M > 1.0 ? fixed_u[FX_KEY] : 0ull;
+        const unsigned long long k1 = fixed_u[lb_home ? FX_KEY + 1 : FX_KEY + 2];
+        const double vP = b.G_rho * b.q * (-b.UB), vL = b.G_rho * (1.0 - b.q) * (-b.LB);
+        auto rate_adjoint = [&](unsigned long long key, bool home_rate, double v, int cell, int which) {
+            if (key == 0ull) return 0.0;
+            const int fh = (int)(key >> 29) & 0xFFF, fa = (int)(key >> 17) & 0xFFF;
+            const bool fnv = (key >> 16) & 1;
+            const int fhc = (int)(key >> 8) & 0xFF, fac = (int)key & 0xFF;
+            const int up = home_rate ? fh : fa, down = home_rate ? fa : fh;   // attack side / defence side
+            if (which == dcd::A_N) {
+                const int cu = home_rate ? fhc : fac, cd = home_rate ? fac : fhc;
+                return (cell == cu ? v : 0.0) - (cell == cd ? v : 0.0);
+            }
+            double r = 0.0;
+            if (which == dcd::A_ATT && cell == up) r += v;
+            if (which == dcd::A_DEF && cell == down) r -= v;
+            if (!fnv) {
+                if (which == (home_rate ? dcd::A_HATT : dcd::A_AATT) && cell == up) r += v;
+                if (which == (home_rate ? dcd::A_ADEF : dcd::A_HDEF) && cell == down) r -= v;
+            }
+            return r;
+        };
+        auto bounds_adjoint = [&](int cell, int which) {
+            return rate_adjoint(k0, true, vP, cell, which) + rate_adjoint(k0, false, vP, cell, which) +
+                   rate_adjoint(k1, lb_home, vL, cell, which);
+        };
+        for (int e = tid; e < T * dcd::A_N; e += FUSED_BLOCK) {  // fold each team's slots, in slot order
+            const int t = e / dcd::A_N, j = e - t * dcd::A_N;
+            double v = 0.0;
+            for (int sl = slot_off[t]; sl < slot_off[t + 1]; ++sl) v += part[sl * dcd::A_N + j];
+            accF[e] = v + bounds_adjoint(t, j);
+        }
+        for (int cf = tid; cf < C; cf += FUSED_BLOCK) {
+            double v = 0.0;
+            for (int cpy = 0; cpy < FUSED_CONF_COPIES; ++cpy) v += cacc[cpy * C + cf];
+            accF[T * dcd::A_N + cf] = v + bounds_adjoint(cf, dcd::A_N);
+        }
+    }
+    __syncthreads();
+    NEU_STAMP(5);
+    // ---- F: the NEU_SUMS + 2K sums over teams, one per wave
+    const double rp = fixed[FX_RP], ivv = fixed[FX_IVV];
+    {
+        const double log_vv = fixed[FX_LOGVV];
+        for (int s = wave; s < NEU_SUMS + 2 * K; s += FUSED_WAVES) {
+            double v = 0.0;
+            for (int t = lane; t < T; t += 64) {
+                const double* G6 = accF + t * dcd::A_N;
+                const double sa = zs[L.o_sat + t], sd = zs[L.o_sdt + t];
+                const double e = sd - rp * sa;
+                double term;
+                switch (s) {
+                    case 0: term = e * sa * ivv - rp * e * e * (ivv * ivv) + rp * ivv; break;
+                    case 1: term = sa * G6[dcd::A_ATT]; break;
+                    case 2: term = sd * G6[dcd::A_DEF]; break;
+                    case 3: term = G6[dcd::A_DEF]; break;
+                    case 4: term = G6[dcd::A_HATT]; break;
+                    case 5: term = G6[dcd::A_AATT]; break;
+                    case 6: term = G6[dcd::A_HDEF]; break;
+                    case 7: term = G6[dcd::A_ADEF]; break;
+                    case 8: term = zs[L.o_hat + t] * G6[dcd::A_HATT]; break;
+                    case 9: term = zs[L.o_aat + t] * G6[dcd::A_AATT]; break;
+                    case 10: term = zs[L.o_hdf + t] * G6[dcd::A_HDEF]; break;
+                    case 11: term = zs[L.o_adf + t] * G6[dcd::A_ADEF]; break;
+                    case 12: {
+                        const double hat = zs[L.o_hat + t], aat = zs[L.o_aat + t], hdf = zs[L.o_hdf + t],
+                                     adf = zs[L.o_adf + t];
+                        term = -0.5 * sa * sa - HALF_LOG_2PI - 0.5 * e * e * ivv - 0.5 * log_vv - HALF_LOG_2PI -
+                               0.5 * (hat * hat + aat * aat + hdf * hdf + adf * adf) - 4.0 * HALF_LOG_2PI;
+                        break;
+                    }
+                    default: {
+                        const int k = s - NEU_SUMS;
+                        term = k < K ? A.xs[(size_t)t * K + k] * G6[dcd::A_ATT]
+                                     : A.xs[(size_t)t * K + k - K] * G6[dcd::A_DEF];
+                    }
+                }
+                v += term;
+            }
+            v = dc::wave_sum_f64(v);
+            if (lane == 0) sums[s] = v;
+        }
+    }
+    __syncthreads();
+    NEU_STAMP(6);
+    // ---- G: gradients and the potential
+    if (wave != 0) {
+        const double s_att = fixed[FX_STD], s_def = fixed[FX_STD + 1], s_ha = fixed[FX_STD + 2],
+                     s_aa = fixed[FX_STD + 3], s_hd = fixed[FX_STD + 4], s_ad = fixed[FX_STD + 5];
+        for (int t = wid; t < T; t += FUSED_WORKERS) {
+            const double* G6 = accF + t * dcd::A_N;
+            const double sa = zs[L.o_sat + t], sd = zs[L.o_sdt + t];
+            const double e = sd - rp * sa;
+            grad[L.o_sat + t] = -(s_att * G6[dcd::A_ATT] - sa + rp * e * ivv);
+            grad[L.o_sdt + t] = -(s_def * G6[dcd::A_DEF] - e * ivv);
+            grad[L.o_hat + t] = -(s_ha * G6[dcd::A_HATT] - zs[L.o_hat + t]);
+            grad[L.o_aat + t] = -(s_aa * G6[dcd::A_AATT] - zs[L.o_aat + t]);
+            grad[L.o_hdf + t] = -(s_hd * G6[dcd::A_HDEF] - zs[L.o_hdf + t]);
+            grad[L.o_adf + t] = -(s_ad * G6[dcd::A_ADEF] - zs[L.o_adf + t]);
+        }
+        for (int k = wid; k < 2 * K; k += FUSED_WORKERS) {  // covariate coefficients ~ N(0,1)
+            const int o = k < K ? L.o_bA + k : L.o_bD + k - K;
+            grad[o] = -(sums[NEU_SUMS + k] - zs[o]);
+        }
+        for (int cf = wid; cf < C; cf += FUSED_WORKERS)  // confederation strengths ~ N(0,1)
+            grad[L.o_conf + cf] = -(accF[T * dcd::A_N + cf] - zs[L.o_conf + cf]);
+    } else if (lane < FUSED_SITES) {
+        // the sum each scalar site's gradient takes (sites in the lane order of step A)
+        const int o = lane == 0 ? L.o_s_att : lane == 1 ? L.o_s_def : lane == 2 ? L.o_s_ha
+                    : lane == 3 ? L.o_s_aa : lane == 4 ? L.o_s_hd : lane == 5 ? L.o_s_ad
+                    : lane == 6 ? L.o_u : lane == 7 ? L.o_corr : lane == 8 ? L.o_mha
+                    : lane == 9 ? L.o_maa : lane == 10 ? L.o_mhd : lane == 11 ? L.o_mad : L.o_md;
+        const int si = lane == 0 ? 1 : lane == 1 ? 2 : lane < 6 ? 6 + lane : lane == 6 ? 0
+                     : lane < 12 ? lane - 4 : 3;                        // (lane 7 takes G_rho instead)
+        const double dot = lane == 7 ? b.G_rho * (b.UB - b.LB) : sums[si];
+        grad[o] = -(fixed[FX_MUL + lane] * dot + fixed[FX_PRE + lane]);
+        if (lane == 0) {
+            double U = 0.0;
+#pragma unroll
+            for (int wv = 0; wv < FUSED_WAVES; ++wv) U += fixed[FX_WSUM + 2 * wv];
+            A.potential[blockIdx.x] = -(sums[12] + U - A.lgsum + fixed[FX_LP]);
+            NEU_STAMP(7);
+            NEU_STAMP_FLUSH;
+            if (A.aux) {
+                double* aux = A.aux + (size_t)blockIdx.x * 4;
+                aux[0] = b.rho;
+                aux[1] = b.LB;
+                aux[2] = b.UB;
+                aux[3] = b.q;
+            }
+        }
+    }
+}
+
 }  // namespace dcn

@@ -28,6 +28,7 @@ def _cases():
     yield "dummy_eps", NO.fixtures_from_data(dd, epsilon=0.3, rescale_weights=True)
     yield "dummy_cov", NO.fixtures_from_data(dd, epsilon=0.1,
                                              covariates=np.random.RandomState(0).normal(size=(20, 3)))
+    yield "synthetic_6e3", NO.synthetic_neutral(6_000, 150, k=3)   # several incidence rounds per wave
     yield "synthetic_3e4", NO.synthetic_neutral(30_000, 30, k=2)
     yield "synthetic_1e6", NO.synthetic_neutral(1_000_000, 20)
     # World-Cup variant: confederation strengths
@@ -43,17 +44,47 @@ def test_logp_grad_matches_oracle(hip_ctx, name, fx):
     fx.weights = fx.weights.astype(np.float32).astype(np.float64)  # what the device holds
     _bind(hip_ctx, fx)
     D = hip_ctx.dim
-    for seed, scale in ((1, 0.2), (2, 0.5), (3, 1.0)):
-        z = np.random.RandomState(seed).uniform(-scale, scale, D)
-        Uo, go, auxo = NO.potential_and_grad(fx, z)
-        U, g, aux = hip_ctx.logp_grad(torch.tensor(z, dtype=torch.float64, device=hip_ctx.device))
-        U, g, aux = float(U.cpu()[0]), g.cpu().numpy(), aux.cpu().numpy()[0]
-        print(f"{name:14s} N={fx.n:8d} U={Uo:.6f} dU={U - Uo:+.2e} dg={np.abs(g - go).max():.2e} "
-              f"|g|={np.abs(go).max():.2e}")
-        assert abs(U - Uo) <= 1e-11 * abs(Uo)
-        assert np.abs(g - go).max() <= 1e-10 * np.abs(go).max()
-        assert abs(aux[0] - auxo["rho"]) <= 1e-12
-        assert abs(aux[1] - auxo["LB"]) <= 1e-12 and abs(aux[2] - auxo["UB"]) <= 1e-12
+    # both evaluation paths: the single-launch kernel (small leagues) and the four-launch one
+    for fused in (1, 0):
+        hip_ctx.set_option("fused_small", fused)
+        for seed, scale in ((1, 0.2), (2, 0.5), (3, 1.0)):
+            z = np.random.RandomState(seed).uniform(-scale, scale, D)
+            Uo, go, auxo = NO.potential_and_grad(fx, z)
+            U, g, aux = hip_ctx.logp_grad(torch.tensor(z, dtype=torch.float64, device=hip_ctx.device))
+            U, g, aux = float(U.cpu()[0]), g.cpu().numpy(), aux.cpu().numpy()[0]
+            print(f"{name:14s} fused={fused} N={fx.n:8d} U={Uo:.6f} dU={U - Uo:+.2e} "
+                  f"dg={np.abs(g - go).max():.2e} |g|={np.abs(go).max():.2e}")
+            assert abs(U - Uo) <= 1e-11 * abs(Uo)
+            assert np.abs(g - go).max() <= 1e-10 * np.abs(go).max()
+            assert abs(aux[0] - auxo["rho"]) <= 1e-12
+            assert abs(aux[1] - auxo["LB"]) <= 1e-12 and abs(aux[2] - auxo["UB"]) <= 1e-12
+    hip_ctx.set_option("fused_small", 1)
+
+
+@pytest.mark.parametrize("n_conf", [0, 4])
+def test_batched_chains_match_single(hip_ctx, n_conf):
+    """Several chains in one call (one workgroup per chain in the single-launch kernel) give the
+    results of the chains evaluated one by one: bit for bit for the plain model (its sums have a
+    fixed order), to rounding with confederations (their adjoint is added with LDS atomics)."""
+    import torch
+
+    fx = NO.synthetic_neutral(5_000, 24, k=2, n_conf=n_conf)
+    fx.weights = fx.weights.astype(np.float32).astype(np.float64)
+    _bind(hip_ctx, fx)
+    z = torch.tensor(np.random.RandomState(5).uniform(-0.4, 0.4, (5, hip_ctx.dim)), dtype=torch.float64,
+                     device=hip_ctx.device)
+    Ub, gb, auxb = hip_ctx.logp_grad(z)
+    for c in range(z.shape[0]):
+        U, g, aux = hip_ctx.logp_grad(z[c].contiguous())
+        if n_conf == 0:
+            assert torch.equal(U[0], Ub[c]) and torch.equal(g.reshape(-1), gb[c])
+        else:
+            assert abs(float(U[0] - Ub[c])) <= 1e-13 * abs(float(U[0]))
+            assert float((g.reshape(-1) - gb[c]).abs().max()) <= 1e-12 * float(g.abs().max())
+        assert torch.equal(aux[0], auxb[c])
+        Uo, go, _ = NO.potential_and_grad(fx, z[c].cpu().numpy())
+        assert abs(float(U[0]) - Uo) <= 1e-11 * abs(Uo)
+        assert np.abs(g.cpu().numpy().reshape(-1) - go).max() <= 1e-10 * np.abs(go).max()
 
 
 @pytest.fixture(scope="module")
