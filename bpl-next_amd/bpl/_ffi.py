@@ -44,6 +44,7 @@ ABI_SYMBOLS = (
     "bplhip_predict_set_posterior",
     "bplhip_predict_score_proba",
     "bplhip_predict_score_grid",
+    "bplhip_selftest_math",
     "bplhip_threefry_split",
     "bplhip_threefry_bits",
 )
@@ -149,6 +150,8 @@ def load_library():
     lib.bplhip_predict_score_proba.restype = C.c_int
     lib.bplhip_predict_score_grid.argtypes = [vp, i64, vp, vp, i32, vp, vp]
     lib.bplhip_predict_score_grid.restype = C.c_int
+    lib.bplhip_selftest_math.argtypes = [vp, i32, i64, vp, vp]
+    lib.bplhip_selftest_math.restype = C.c_int
     lib.bplhip_threefry_split.argtypes = [u32, u32, i32, C.POINTER(u32)]
     lib.bplhip_threefry_split.restype = None
     lib.bplhip_threefry_bits.argtypes = [u32, u32, i32, C.POINTER(u32)]
@@ -441,6 +444,14 @@ class HipContext:
         with self._torch.cuda.device(self.device):
             self._check(self._lib.bplhip_predict_score_grid(
                 self._h, h.size, _np_ptr(h), _np_ptr(a), int(max_goals), _np_ptr(out), self._stream()))
+        return out
+
+    def selftest_math(self, which: int, x) -> np.ndarray:
+        """The library's short float64 device math on x: 0 exp, 1 log, 2 log1p (x >= 0), 3 1/x."""
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        out = np.empty_like(x)
+        with self._torch.cuda.device(self.device):
+            self._check(self._lib.bplhip_selftest_math(self._h, int(which), x.size, _np_ptr(x), _np_ptr(out)))
         return out
 
     # -- sampler

@@ -131,6 +131,7 @@ struct bplhip_ctx {
     bool dynamic = false;
     dcd::DynLayout DL{};
     int dyn_random_walk = 1;
+    bool dyn_scratch_clean = false;  // the single-launch kernel finds (and leaves) its scratch zeroed
     // neutral-venue model (dc_neutral.hip.h): the dynamic model's fixture passes + own z side
     bool neutral = false;
     dcn::NeuLayout NL{};
@@ -296,6 +297,18 @@ int launch_eval_dynamic(bplhip_ctx* c, int chains, const double* z, double* pot,
         A.gw_off = c->dd_gwoff.as<const int>();
         A.tickets = c->dd_tick.as<unsigned int>();
         const int team_blocks = (L.T + dcd::BACK_BLOCK / 64 - 1) / (dcd::BACK_BLOCK / 64);
+        // one launch when every workgroup is resident and a wave spans all gameweeks
+        // (and a workgroup's share of the fixtures is a few rounds of its threads)
+        if (c->opt_fused_small && L.G <= dcd::FUSED_DYN_MAX_G && L.T <= dcd::FUSED_DYN_MAX_T &&
+            c->n <= (long long)team_blocks * dcd::FUSED_DYN_BLOCK * 4) {
+            if (!c->dyn_scratch_clean) {  // (the four-launch path leaves its scratch as it ends)
+                HIP_TRY(c, hipMemsetAsync(A.acc, 0, A.scratch_n * 8, s));
+                c->dyn_scratch_clean = true;
+            }
+            hipLaunchKernelGGL(dcd::dyn_fused, dim3(team_blocks), dim3(dcd::FUSED_DYN_BLOCK), 0, s, A);
+            HIP_TRY(c, hipGetLastError());
+            continue;
+        }
         if (!c->dyn_attr_set) {
             HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(dcd::dyn_pass2),
                                            hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -306,6 +319,7 @@ int launch_eval_dynamic(bplhip_ctx* c, int chains, const double* z, double* pot,
             c->dyn_attr_set = true;
             c->lds_attr_set = true;
         }
+        c->dyn_scratch_clean = false;
         hipLaunchKernelGGL(dcd::dyn_cells, dim3(cell_blocks), dim3(dcd::CELL_BLOCK), 0, s, A);
         hipLaunchKernelGGL(dcd::dyn_pass1, dim3(nb), dim3(fb), 0, s, A);
         hipLaunchKernelGGL(dcd::dyn_pass2, dim3(nb2), dim3(fb),
@@ -939,6 +953,7 @@ int bplhip_set_option(bplhip_ctx* c, const char* name, int value) {
 #endif
     if (n == "fused_small") {  // 0: neutral / dynamic evaluations always take the multi-launch path
         c->opt_fused_small = value != 0;
+        drop_graphs(c);  // (captured launch sequences belong to the other path)
         return BPLHIP_OK;
     }
     if (n == "gridy_max_chains") {
@@ -1204,6 +1219,7 @@ static int bplhip_set_fixtures_dynamic_impl(bplhip_ctx* c, int64_t n, int32_t n_
     HIP_TRY(c, hipMemcpyAsync(c->dd_nv.p, nv.data(), n, hipMemcpyHostToDevice, s));
     HIP_TRY(c, c->dd_cells.ensure(GT * dcd::P_N * 8));
     HIP_TRY(c, c->dd_acc.ensure(dcd::scratch_doubles(n_gameweeks, n_teams, k) * 8));
+    c->dyn_scratch_clean = false;
     HIP_TRY(c, c->dd_hyp.ensure((size_t)6 * n_gameweeks * 8));
     {   // first fixture of every gameweek (sorted), and the two arrival counters
         std::vector<int> gw_off(n_gameweeks + 1, 0);
@@ -2401,6 +2417,28 @@ extern "C" int bplhip_predict_score_grid(bplhip_ctx* c, int64_t m, const uint16_
                                          void* stream) {
     return guarded(c, "bplhip_predict_score_grid", [&] {
         return bplhip_predict_score_grid_impl(c, m, home_idx, away_idx, max_goals, out, stream);
+    });
+}
+__global__ void selftest_math_kernel(int which, long long n, const double* in, double* out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double x = in[i];
+    out[i] = which == 0 ? dc::lean::exp(x) : which == 1 ? dc::lean::log(x)
+           : which == 2 ? dc::lean::log1p_pos(x) : dc::lean::rcp(x);
+}
+extern "C" int bplhip_selftest_math(bplhip_ctx* c, int32_t which, int64_t n, const double* in, double* out) {
+    return guarded(c, "bplhip_selftest_math", [&] {
+        if (!c || which < 0 || which > 3 || n < 1 || !in || !out) return c ? fail(c, BPLHIP_EINVAL, "selftest_math: bad arguments") : BPLHIP_EINVAL;
+        HIP_TRY(c, hipSetDevice(c->device));
+        DevBuf din, dout;
+        HIP_TRY(c, din.ensure((size_t)n * 8));
+        HIP_TRY(c, dout.ensure((size_t)n * 8));
+        HIP_TRY(c, hipMemcpy(din.p, in, (size_t)n * 8, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(selftest_math_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, which,
+                           (long long)n, din.as<const double>(), dout.as<double>());
+        HIP_TRY(c, hipGetLastError());
+        HIP_TRY(c, hipMemcpy(out, dout.p, (size_t)n * 8, hipMemcpyDeviceToHost));
+        return (int)BPLHIP_OK;
     });
 }
 extern "C" int bplhip_predict_score_proba(bplhip_ctx* c, int64_t m, const uint16_t* home_idx,

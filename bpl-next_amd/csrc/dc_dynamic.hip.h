@@ -562,7 +562,7 @@ constexpr int BACK_BLOCK = 256;   // 4 waves = 4 teams per workgroup (25 workgro
                                   // 0.5 MB per evaluation and one CU moves ~25 GB/s)
 constexpr int BACK_LDS_G = 1024;  // gameweeks whose sums fit the LDS pre-reduction (10 x G doubles)
 __host__ __device__ inline size_t back_lds_bytes(int G) { return G <= BACK_LDS_G ? (size_t)10 * G * 8 : 8; }
-__device__ void final_body(const DynArgs& A, double* shl);
+__device__ void final_body(const DynArgs& A, double* shl, const Bounds* known = nullptr);
 
 __global__ __launch_bounds__(BACK_BLOCK) void dyn_back(DynArgs A) {
     extern __shared__ double lgs[];  // [10][G] when G <= BACK_LDS_G
@@ -698,7 +698,7 @@ __global__ __launch_bounds__(BACK_BLOCK) void dyn_back(DynArgs A) {
 // ---- per-gameweek hyper-parameters, coefficients, scalars (the last workgroup of dyn_back; the
 // sums were accumulated with agent-scope atomics by every workgroup: L1-bypassing loads)
 constexpr int FINAL_BLOCK = BACK_BLOCK;
-__device__ void final_body(const DynArgs& A, double* shl) {
+__device__ void final_body(const DynArgs& A, double* shl, const Bounds* known) {
     const DynLayout& L = A.L;
     const int G = L.G, K = L.K;
     const int tid = threadIdx.x;
@@ -707,7 +707,8 @@ __device__ void final_body(const DynArgs& A, double* shl) {
     auto gsum = [&](int k) { return dc::ld_sc1(&A.gsum[k]); };
     double Lg = 0.0;
     for (int g = tid; g < G; g += FINAL_BLOCK) {
-        const double s_att = A.hyp[g], s_def = A.hyp[G + g];
+        // (hyp: written write-through by another workgroup -- of this launch, in dyn_fused)
+        const double s_att = dc::ld_sc1(&A.hyp[g]), s_def = dc::ld_sc1(&A.hyp[G + g]);
         grad[L.o_s_att + g] = -(s_att * gsum(0 * G + g) + 1.0 - s_att * s_att);
         grad[L.o_s_def + g] = -(s_def * gsum(1 * G + g) + 1.0 - s_def * s_def);
         Lg += -0.5 * s_att * s_att - HALF_LOG_2PI + LN2 + z[L.o_s_att + g];
@@ -717,7 +718,7 @@ __device__ void final_body(const DynArgs& A, double* shl) {
         const double mu[4] = {0.1, -0.1, 0.1, -0.1};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const double s = A.hyp[(2 + j) * G + g], mean = z[o_mean[j] + g];
+            const double s = dc::ld_sc1(&A.hyp[(2 + j) * G + g]), mean = z[o_mean[j] + g];
             grad[o_mean[j] + g] = -(gsum((2 + j) * G + g) - (mean - mu[j]) / 0.04);
             grad[o_std[j] + g] = -(s * gsum((6 + j) * G + g) + 1.0 - s * s);
             const double r = (mean - mu[j]) / 0.2;
@@ -736,11 +737,11 @@ __device__ void final_body(const DynArgs& A, double* shl) {
     if (tid == 0) {
         double Lsum = 0.0;
         for (int w = 0; w < FINAL_BLOCK / 64; ++w) Lsum += shl[w];
-        const Bounds b = load_bounds(A);
+        const Bounds b = known ? *known : load_bounds(A);
         const double m = z[L.o_md], zc = z[L.o_corr];
         grad[L.o_md] = -(dc::ld_sc1(&A.red[R_MD]) - m);
         grad[L.o_corr] = -(b.G_rho * (b.UB - b.LB) * b.dq + (1.0 - 2.0 * b.sq));
-        double Ltot = Lsum + dc::ld_sc1(&A.red[R_L]) + A.sc[SC_U] - A.lgsum;
+        double Ltot = Lsum + dc::ld_sc1(&A.red[R_L]) + dc::ld_sc1(&A.sc[SC_U]) - A.lgsum;
         Ltot += -0.5 * m * m - HALF_LOG_2PI;
         Ltot += -softplus(zc) - softplus(-zc);  // Uniform(0,1): log_prob 0 + sigmoid Jacobian
         A.potential[0] = -Ltot;
@@ -751,6 +752,498 @@ __device__ void final_body(const DynArgs& A, double* shl) {
             A.aux[3] = b.q;
         }
     }
+}
+
+
+// ---- the whole evaluation in ONE launch: dyn_cells, dyn_pass1, dyn_pass2 and dyn_back as
+// phases of one kernel with three grid barriers between them (all workgroups are resident: one
+// per four teams, at most 256).  A launch boundary costs ~2 us of drain + dispatch and the next
+// kernel starts cold; here each wave KEEPS its team's latent values, exp(std) and the u-site
+// transforms in registers from the first phase to the last, every fixture-independent
+// transcendental runs in the shadow of the first barrier, and each fixture thread keeps its
+// rates between the two fixture phases.  Single chunk of gameweeks per wave (G <= 64).
+//   1  wave per team, lane = gameweek: cells (walk = DPP prefix scan), write-through
+//   -- barrier 1 (in its shadow: u-site sigmoid / softplus / priors of this wave's cells)
+//   2  fixtures (a contiguous share per workgroup): rates; maxima, one atomicMax per workgroup
+//   -- barrier 2
+//   3  value + adjoint, float64 atomics straight into the L2-resident accumulators (a gameweek's
+//      fixtures touch distinct teams: no contention, no LDS staging); arg-extremal fixtures as
+//      ONE packed word each {~index, gameweek, h, a, venue}
+//   -- barrier 3
+//   4  wave per team again: bounds adjoint, walk adjoint (DPP suffix scan), chain rule, the ten
+//      per-gameweek sums transposed through LDS (no LDS atomics) and added with one global
+//      atomic per entry; the last workgroup to arrive runs final_body and re-zeroes the counters
+// Cross-workgroup data travels write-through / L1-bypassing (sc1); the barriers are an
+// agent-scope counter each, polled by one lane with a bounded spin.
+constexpr int FUSED_DYN_BLOCK = 256;
+constexpr int FUSED_DYN_MAX_G = 64, FUSED_DYN_MAX_T = 1024;
+constexpr unsigned int GRID_SPIN_LIMIT = 1u << 22;
+enum { TK_FINAL = 1, TK_B1 = 2, TK_B2 = 3, TK_B3 = 4, TK_FAIL = 5 };
+
+__device__ __forceinline__ void grid_arrive(unsigned int* ctr) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's stores and atomics are in L2
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// false: the other workgroups did not arrive within the spin limit, or an earlier launch gave up
+// (`failed`: the sticky TK_FAIL word as read at kernel entry).  A launch that gives up leaves the
+// counters in an unknown state: it sets TK_FAIL, and every later launch returns NaN until the
+// host re-zeroes the words (bplhip_set_fixtures_dynamic).
+__device__ __forceinline__ bool grid_wait(unsigned int* tickets, int which, unsigned int n, unsigned int failed,
+                                          int* s_ok) {
+    if (threadIdx.x == 0) {
+        unsigned int spins = 0;
+        bool ok = failed == 0;
+        while (ok && __hip_atomic_load(tickets + which, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < n) {
+            if (++spins >= GRID_SPIN_LIMIT) ok = false;
+            __builtin_amdgcn_s_sleep(1);
+        }
+        if (!ok) __hip_atomic_store(tickets + TK_FAIL, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *s_ok = ok;
+    }
+    __syncthreads();
+    return *s_ok != 0;
+}
+
+struct DynFx {
+    int g, h, a, x, y, nv;
+};
+
+// ---- final part of dyn_fused (the last workgroup to arrive; G <= 64: ONE wave, lane = gameweek).
+// Everything it reads was produced by other workgroups of this launch: L1-bypassing loads, all of
+// them requested before the first is used (a dependent chain of such loads is ~1 us each).
+// `jac_corr`: softplus(z_corr) + softplus(-z_corr), worked out long before.
+__device__ __forceinline__ void final_fused(const DynArgs& A, const Bounds& b, double jac_corr, int lane) {
+    const DynLayout& L = A.L;
+    const int G = L.G, K = L.K;
+    const double* z = A.z;
+    double* grad = A.grad;
+    const bool on = lane < G;
+    const int g = on ? lane : G - 1;
+    double hyp[6], gs[10], zmean[4], zstd[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) hyp[j] = dc::ld_sc1(&A.hyp[j * G + g]);
+#pragma unroll
+    for (int j = 0; j < 10; ++j) gs[j] = dc::ld_sc1(&A.gsum[j * G + g]);
+    const double r_md = dc::ld_sc1(&A.red[R_MD]), r_l = dc::ld_sc1(&A.red[R_L]), r_u = dc::ld_sc1(&A.sc[SC_U]);
+    const int o_mean[4] = {L.o_mha, L.o_maa, L.o_mhd, L.o_mad};
+    const int o_std[6] = {L.o_s_att, L.o_s_def, L.o_s_ha, L.o_s_aa, L.o_s_hd, L.o_s_ad};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) zmean[j] = z[o_mean[j] + g];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) zstd[j] = z[o_std[j] + g];
+    const double m = z[L.o_md];
+    double Lg = 0.0;
+    if (on) {
+        // HalfNormal(1) stds in log space; means ~ N(+-0.1, 0.2)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const double sv = hyp[j];
+            const double dot = j < 2 ? gs[j] : gs[4 + j];   // 0 sa*RA, 1 sd*RD, 6..9 dec*G_x
+            grad[o_std[j] + g] = -(sv * dot + 1.0 - sv * sv);
+            Lg += -0.5 * sv * sv - HALF_LOG_2PI + LN2 + zstd[j];
+        }
+        const double mu[4] = {0.1, -0.1, 0.1, -0.1};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            grad[o_mean[j] + g] = -(gs[2 + j] - (zmean[j] - mu[j]) / 0.04);
+            const double r = (zmean[j] - mu[j]) / 0.2;
+            Lg += -0.5 * r * r + 1.6094379124341003 - HALF_LOG_2PI;
+        }
+    }
+    for (int k = lane; k < 2 * K; k += 64) {
+        const int o = k < K ? L.o_bA + k : L.o_bD + k - K;
+        grad[o] = -(dc::ld_sc1(&A.cov[k]) - z[o]);
+        Lg += -0.5 * z[o] * z[o] - HALF_LOG_2PI;
+    }
+    // everything this launch accumulated is read: back to zero for the next evaluation
+    if (on) {
+#pragma unroll
+        for (int j = 0; j < 10; ++j) dc::st_sc1(&A.gsum[j * G + g], 0.0);
+    }
+    if (lane < SC_N) dc::st_sc1(&A.sc[lane], 0.0);
+    if (lane < R_N) dc::st_sc1(&A.red[lane], 0.0);
+    for (int k = lane; k < 2 * K; k += 64) dc::st_sc1(&A.cov[k], 0.0);
+    Lg = dc::wave_sum_f64(Lg);
+    if (lane == 0) {
+        grad[L.o_md] = -(r_md - m);
+        grad[L.o_corr] = -(b.G_rho * (b.UB - b.LB) * b.dq + (1.0 - 2.0 * b.sq));
+        double Ltot = Lg + r_l + r_u - A.lgsum;
+        Ltot += -0.5 * m * m - HALF_LOG_2PI;
+        Ltot += -jac_corr;  // Uniform(0,1): log_prob 0 + sigmoid Jacobian
+        A.potential[0] = -Ltot;
+        if (A.aux) {
+            A.aux[0] = b.rho;
+            A.aux[1] = b.LB;
+            A.aux[2] = b.UB;
+            A.aux[3] = b.q;
+        }
+    }
+}
+
+#ifdef DC_STAMPS  // diagnostic build: wave 0 of every workgroup overwrites the u-site gradient of its
+                  // first team, gameweeks 0..9, with the 100 MHz clock at ten points of the launch
+#define DYN_STAMP_DECL unsigned long long stamp_[10] = {}
+#define DYN_STAMP(k) stamp_[k] = __builtin_amdgcn_s_memrealtime()
+#define DYN_STAMP_FLUSH                                                                          \
+    do {                                                                                         \
+        if (tid == 0)                                                                            \
+            for (int k_ = 0; k_ < 10 && k_ < G; ++k_) grad[L.o_u + k_ * T + t] = (double)stamp_[k_]; \
+    } while (0)
+#else
+#define DYN_STAMP_DECL do { } while (0)
+#define DYN_STAMP(k) do { } while (0)
+#define DYN_STAMP_FLUSH do { } while (0)
+#endif
+__global__ __launch_bounds__(FUSED_DYN_BLOCK) void dyn_fused(DynArgs A) {
+    constexpr int WAVES = FUSED_DYN_BLOCK / 64;
+    __shared__ double lsum[WAVES][10][64];
+    __shared__ unsigned long long shm[3 * WAVES];
+    __shared__ double shr[2 * WAVES];
+    __shared__ int s_ok, s_last;
+    const DynLayout& L = A.L;
+    const int G = L.G, T = L.T, K = L.K;
+    const double* z = A.z;
+    double* grad = A.grad;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned int nb = gridDim.x;
+    const int t = blockIdx.x * WAVES + wave;
+    const bool on = t < T && lane < G;      // this lane owns cell (g = lane, t)
+    const int g = lane < G ? lane : G - 1, tc = t < T ? t : T - 1;
+    const int c = g * T + tc;
+    unsigned long long* scu = reinterpret_cast<unsigned long long*>(A.sc);
+    DYN_STAMP_DECL;
+    DYN_STAMP(0);
+    const unsigned int failed = __hip_atomic_load(A.tickets + TK_FAIL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    auto give_up = [&]() {
+        if (blockIdx.x == 0 && tid == 0) A.potential[0] = __builtin_nan("");
+    };
+
+    // ---- phase 1: every load first, unconditional with clamped indices
+    const long long share = (A.n + nb - 1) / nb;                     // fixtures per workgroup
+    const long long i_lo = (long long)blockIdx.x * share, i_hi = i_lo + share < A.n ? i_lo + share : A.n;
+    auto load_fx = [&](long long i) {
+        DynFx f;
+        f.g = A.gw[i]; f.h = A.h[i]; f.a = A.a[i]; f.x = A.x[i]; f.y = A.y[i]; f.nv = A.nv[i];
+        return f;
+    };
+    const long long i_first = i_lo + tid;
+    const DynFx first = load_fx(i_first < A.n ? i_first : A.n - 1);
+    const int o_std[6] = {L.o_s_att, L.o_s_def, L.o_s_ha, L.o_s_aa, L.o_s_hd, L.o_s_ad};
+    double zstd[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) zstd[j] = z[o_std[j] + g];
+    const double sa = z[L.o_sat + c], sd = z[L.o_sdt + c], zu = z[L.o_u + c];
+    const double z_mha = z[L.o_mha + g], z_maa = z[L.o_maa + g], z_mhd = z[L.o_mhd + g], z_mad = z[L.o_mad + g];
+    const double hat = z[L.o_hat + c], aat = z[L.o_aat + c], hdf = z[L.o_hdf + c], adf = z[L.o_adf + c];
+    const double z_corr = z[L.o_corr];
+    double att0 = 0.0, def0 = z[L.o_md];
+    for (int k = 0; k < K; ++k) {
+        const double xv = A.xs[(size_t)tc * K + k];
+        att0 += xv * z[L.o_bA + k];
+        def0 += xv * z[L.o_bD + k];
+    }
+    // (the scratch -- accumulators, maxima, sums -- is zero on entry: every word is put back to
+    // zero by the workgroup that consumes it, phase 4 and final_fused.  Clearing it here would put
+    // ~30 000 write-through stores in front of the first barrier.)
+    double s[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        s[j] = on ? dc::lean::exp(zstd[j]) : 0.0;
+        if (on && t == 0) dc::st_sc1(&A.hyp[j * G + g], s[j]);
+    }
+    {
+        double a_ = 0.0, d_ = 0.0;
+        if (A.random_walk) {
+            a_ = att0 + dc::wave_prefix_dpp_f64(on ? sa * s[0] : 0.0);
+            d_ = def0 + dc::wave_prefix_dpp_f64(on ? sd * s[1] : 0.0);
+        }
+        if (on) {
+            double* P = A.cells + (size_t)c * P_N;   // (48-byte records: three 16-byte stores)
+            static_assert(P_AH == 0 && P_AA == 1 && P_BH == 2 && P_BA == 3 && P_ATT == 4 && P_DEF == 5, "record order");
+            dc::st_sc1_x2(&P[P_AH], a_ + (z_mha + s[2] * hat), a_ + (z_maa + s[3] * aat));
+            dc::st_sc1_x2(&P[P_BH], d_ + (z_mhd + s[4] * hdf), d_ + (z_mad + s[5] * adf));
+            dc::st_sc1_x2(&P[P_ATT], a_, d_);
+        }
+    }
+    DYN_STAMP(1);
+    grid_arrive(A.tickets + TK_B1);
+    // In the barriers' shadows (a grid barrier is ~2 us of memory-side round trips after the last
+    // arrival): everything of the last phase that does not depend on the fixtures, a third each.
+    // Here: corr_coef_raw's sigmoid (phase 3 needs it).
+    const double ezc = dc::lean::exp(-fabs(z_corr)), l1c = dc::lean::log1p_pos(ezc);
+    const double sc_abs = dc::lean::rcp(1.0 + ezc);
+    const double sq = z_corr >= 0 ? sc_abs : 1.0 - sc_abs;             // sigmoid(corr_coef_raw)
+    const double q = sq < dc::SIG_LO ? dc::SIG_LO : sq > dc::SIG_HI ? dc::SIG_HI : sq;
+    const double dq = (sq < dc::SIG_LO || sq > dc::SIG_HI) ? 0.0 : sq * (1.0 - sq);
+    const double jac_corr = fabs(z_corr) + 2.0 * l1c;                   // softplus(z) + softplus(-z)
+    DYN_STAMP(2);
+    if (!grid_wait(A.tickets, TK_B1, nb, failed, &s_ok)) { give_up(); return; }
+    DYN_STAMP(3);
+
+    // ---- phase 2: rates of this workgroup's fixtures; maxima
+    double eh0 = 0.0, ea0 = 0.0, lh0 = 0.0, la0 = 0.0;  // this thread's first fixture, kept for phase 3
+    auto etas = [&](const DynFx& f, double* eh, double* ea) {
+        const double* Ph = A.cells + (size_t)(f.g * T + f.h) * P_N;
+        const double* Pa = A.cells + (size_t)(f.g * T + f.a) * P_N;
+        const bool nvf = f.nv != 0;
+        const double ph_att = dc::ld_sc1(&Ph[nvf ? P_ATT : P_AH]), pa_def = dc::ld_sc1(&Pa[nvf ? P_DEF : P_BA]);
+        const double pa_att = dc::ld_sc1(&Pa[nvf ? P_ATT : P_AA]), ph_def = dc::ld_sc1(&Ph[nvf ? P_DEF : P_BH]);
+        *eh = ph_att - pa_def;
+        *ea = pa_att - ph_def;
+    };
+    {
+        double mP = 0.0, mH = 0.0, mA = 0.0;
+        for (long long i = i_first; i < i_hi; i += FUSED_DYN_BLOCK) {
+            DynFx f = first;
+            if (i != i_first) f = load_fx(i);
+            double eh, ea;
+            etas(f, &eh, &ea);
+            const double lh = dc::lean::exp(eh), la = dc::lean::exp(ea);
+            if (i == i_first) { eh0 = eh; ea0 = ea; lh0 = lh; la0 = la; }
+            mP = fmax(mP, lh * la);
+            mH = fmax(mH, lh);
+            mA = fmax(mA, la);
+        }
+        dc::wave_max3_f64(mP, mH, mA);
+        if (lane == 0) {  // (positive doubles order like their bit patterns)
+            shm[wave * 3 + 0] = (unsigned long long)__double_as_longlong(mP);
+            shm[wave * 3 + 1] = (unsigned long long)__double_as_longlong(mH);
+            shm[wave * 3 + 2] = (unsigned long long)__double_as_longlong(mA);
+        }
+        __syncthreads();
+        if (tid < 3) {
+            unsigned long long m = 0;
+            for (int w = 0; w < WAVES; ++w) m = shm[w * 3 + tid] > m ? shm[w * 3 + tid] : m;
+            if (m) atomicMax(&scu[SC_MAXP + tid], m);
+        }
+    }
+    DYN_STAMP(4);
+    grid_arrive(A.tickets + TK_B2);
+    // (second shadow: the u site.  u = sigmoid(zu) ~ Beta(2,4): one exp + one log1p serve the
+    // value, its derivative, log u = -sp(-zu), log(1-u) = -sp(zu) and the Jacobian; then its part
+    // of the gradient)
+    const double az = fabs(zu), ez = dc::lean::exp(-az), l1 = dc::lean::log1p_pos(ez);
+    const double sp_pos = az + l1;                      // softplus(|zu|)
+    const double sp_z = zu >= 0 ? sp_pos : l1;          // softplus(zu)
+    const double sp_mz = zu >= 0 ? l1 : sp_pos;         // softplus(-zu)
+    const double s_abs = dc::lean::rcp(1.0 + ez);
+    const double su = zu >= 0 ? s_abs : 1.0 - s_abs;
+    double u = su, du = su * (1.0 - su), log_u = -sp_mz, log_1mu = -sp_z;
+    if (su < dc::SIG_LO || su > dc::SIG_HI) {           // clipped (|zu| > ~87)
+        u = su < dc::SIG_LO ? dc::SIG_LO : dc::SIG_HI;
+        du = 0.0;
+        log_u = log(u);
+        log_1mu = log1p(-u);
+    }
+    const double rp = 2.0 * u - 1.0, vv = 1.0 - rp * rp, iv = dc::lean::rcp(vv), e = sd - rp * sa;
+    const double dL_drp = e * sa * iv - rp * e * e * iv * iv + rp * iv;
+    const double g_u = -((dc::lean::rcp(u) - 3.0 * dc::lean::rcp(1.0 - u)) * du + 2.0 * dL_drp * du + (1.0 - 2.0 * su));
+    if (!grid_wait(A.tickets, TK_B2, nb, failed, &s_ok)) { give_up(); return; }
+    DYN_STAMP(5);
+
+    // ---- phase 3: value + adjoint
+    Bounds b;
+    b.M = dc::ld_sc1(&A.sc[SC_MAXP]); b.Lh = dc::ld_sc1(&A.sc[SC_MAXH]); b.La = dc::ld_sc1(&A.sc[SC_MAXA]);
+    b.q = q; b.dq = dq; b.sq = sq;
+    b.UB = b.M > 1.0 ? 1.0 / b.M : 1.0;
+    b.LB = -1.0 / fmax(b.Lh, b.La);
+    b.rho = b.LB + b.q * (b.UB - b.LB);
+    {
+        double Ui = 0.0, ui = 0.0;
+        for (long long i = i_first; i < i_hi; i += FUSED_DYN_BLOCK) {
+            DynFx f = first;
+            double eh = eh0, ea = ea0, lh = lh0, la = la0;
+            if (i != i_first) {
+                f = load_fx(i);
+                etas(f, &eh, &ea);
+                lh = dc::lean::exp(eh);
+                la = dc::lean::exp(ea);
+            }
+            double Uf = f.x * eh - lh + f.y * ea - la;
+            double gh = f.x - lh, ga = f.y - la;
+            if (f.x <= 1 && f.y <= 1) {
+                const double cc = f.x == 0 ? (f.y == 0 ? -lh * la : lh) : (f.y == 0 ? la : -1.0);
+                const double arg = 1.0 + b.rho * cc;
+                if (arg > 0.0) {
+                    Uf += dc::lean::log(arg);
+                    const double uu = cc / arg;
+                    ui += uu;
+                    if (f.x == 0) gh += b.rho * uu;
+                    if (f.y == 0) ga += b.rho * uu;
+                } else {
+                    Uf += log(0.0);  // -inf (tol = 0, bpl/_util.py:42)
+                }
+            }
+            Ui += Uf;
+            // arg-extremal fixtures: the smallest index among those attaining a maximum wins
+            const unsigned long long key =
+                ((unsigned long long)(0x1FFFFFFF - i) << 35) | ((unsigned long long)f.g << 25) |
+                ((unsigned long long)f.h << 13) | ((unsigned long long)f.a << 1) | (unsigned long long)(f.nv != 0);
+            if (lh * la == b.M) atomicMax(&scu[SC_IDXP], key);
+            if (lh == b.Lh) atomicMax(&scu[SC_IDXQ], key);
+            if (la == b.La) atomicMax(&scu[SC_IDXR], key);
+            double* Ah = A.acc + (size_t)(f.g * T + f.h) * A_N;
+            double* Aa = A.acc + (size_t)(f.g * T + f.a) * A_N;
+            atomicAdd(&Ah[A_ATT], gh);
+            atomicAdd(&Aa[A_DEF], -gh);
+            atomicAdd(&Aa[A_ATT], ga);
+            atomicAdd(&Ah[A_DEF], -ga);
+            if (!f.nv) {
+                atomicAdd(&Ah[A_HATT], gh);
+                atomicAdd(&Aa[A_ADEF], -gh);
+                atomicAdd(&Aa[A_AATT], ga);
+                atomicAdd(&Ah[A_HDEF], -ga);
+            }
+        }
+        double both[2] = {Ui, ui};
+        dc::wave_sumN_f64(both);
+        if (lane == 0) {
+            shr[wave * 2] = both[0];
+            shr[wave * 2 + 1] = both[1];
+        }
+        __syncthreads();
+        if (tid < 2) {
+            double v = 0.0;
+            for (int w = 0; w < WAVES; ++w) v += shr[w * 2 + tid];
+            if (v != 0.0) atomicAdd(&A.sc[tid == 0 ? SC_U : SC_GRHO], v);
+        }
+    }
+    DYN_STAMP(6);
+    grid_arrive(A.tickets + TK_B3);
+    // (third shadow: log-density of this wave's cell sites -- log(1 - rho'^2) = log(4 u (1-u)) --
+    // the Jacobian of corr_coef_raw's sigmoid came with the first shadow)
+    double Lloc = 0.0;
+    if (on) {
+        Lloc += log_u + 3.0 * log_1mu + 2.995732273553991 - sp_z - sp_mz;
+        Lloc += -0.5 * sa * sa - HALF_LOG_2PI - 0.5 * e * e * iv - 0.5 * (2.0 * LN2 + log_u + log_1mu) - HALF_LOG_2PI;
+        Lloc += -0.5 * (hat * hat + aat * aat + hdf * hdf + adf * adf) - 4.0 * HALF_LOG_2PI;
+    }
+    if (!grid_wait(A.tickets, TK_B3, nb, failed, &s_ok)) { give_up(); return; }
+    DYN_STAMP(7);
+
+    // ---- phase 4: this wave's team again
+    double G6[A_N];
+    {
+        const double* Ac = A.acc + (size_t)c * A_N;
+#pragma unroll
+        for (int j = 0; j < A_N; ++j) G6[j] = dc::ld_sc1(&Ac[j]);
+    }
+    b.G_rho = dc::ld_sc1(&A.sc[SC_GRHO]);
+    // (all three packed fixtures with the accumulators, in one round of loads: behind the
+    // comparisons that pick two of them each was a dependent round trip of its own)
+    const unsigned long long keyP = __hip_atomic_load(&scu[SC_IDXP], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long keyQ = __hip_atomic_load(&scu[SC_IDXQ], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long keyR = __hip_atomic_load(&scu[SC_IDXR], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    {
+        // the bounds' adjoint reaches (at most) two fixtures: the one with the largest rate
+        // product (when it binds, M > 1) through both rates, the one with the largest single
+        // rate through that rate
+        const bool lb_home = b.Lh >= b.La;
+        const unsigned long long kP = b.M > 1.0 ? keyP : 0ull;
+        const unsigned long long kL = lb_home ? keyQ : keyR;
+        const double vP = b.G_rho * b.q * (-b.UB), vL = b.G_rho * (1.0 - b.q) * (-b.LB);
+        auto add_rate = [&](unsigned long long key, bool home_rate, double v) {
+            if (key == 0ull) return;
+            const int fg = (int)(key >> 25) & 0x3FF, fh = (int)(key >> 13) & 0xFFF, fa = (int)(key >> 1) & 0xFFF;
+            const bool fnv = key & 1;
+            if (fg != g) return;
+            const int up = home_rate ? fh : fa, down = home_rate ? fa : fh;   // attack side / defence side
+            if (tc == up) {
+                G6[A_ATT] += v;
+                if (!fnv) G6[home_rate ? A_HATT : A_AATT] += v;
+            }
+            if (tc == down) {
+                G6[A_DEF] -= v;
+                if (!fnv) G6[home_rate ? A_ADEF : A_HDEF] -= v;
+            }
+        };
+        add_rate(kP, true, vP);
+        add_rate(kP, false, vP);
+        add_rate(kL, lb_home, vL);
+    }
+    if (!on) {
+#pragma unroll
+        for (int j = 0; j < A_N; ++j) G6[j] = 0.0;
+    }
+    // adjoint of the walk: gradient w.r.t. increment g = sum of cell gradients at g' >= g
+    const double RA = dc::wave_suffix_dpp_f64(A.random_walk ? G6[A_ATT] : 0.0, lane);
+    const double RD = dc::wave_suffix_dpp_f64(A.random_walk ? G6[A_DEF] : 0.0, lane);
+    const double tot_a = dc::readlane_f64(RA, 0), tot_d = dc::readlane_f64(RD, 0);
+    const double g_hat = G6[A_HATT], g_adf = G6[A_ADEF], g_aat = G6[A_AATT], g_hdf = G6[A_HDEF];
+    {
+        // per-gameweek sums over teams: 0 sa*RA, 1 sd*RD, 2..5 sum G_x, 6..9 sum dec*G_x --
+        // each wave's row in LDS, folded below
+        double (*mine)[64] = lsum[wave];
+        mine[0][lane] = on ? sa * RA : 0.0;
+        mine[1][lane] = on ? sd * RD : 0.0;
+        mine[2][lane] = g_hat;
+        mine[3][lane] = g_aat;
+        mine[4][lane] = g_hdf;
+        mine[5][lane] = g_adf;
+        mine[6][lane] = on ? hat * g_hat : 0.0;
+        mine[7][lane] = on ? aat * g_aat : 0.0;
+        mine[8][lane] = on ? hdf * g_hdf : 0.0;
+        mine[9][lane] = on ? adf * g_adf : 0.0;
+    }
+    Lloc = dc::wave_sum_f64(Lloc);
+    if (t < T) {
+        if (lane == 0) {
+            atomicAdd(&A.red[R_MD], tot_d);
+            atomicAdd(&A.red[R_L], Lloc);
+        }
+        for (int j = lane; j < 2 * K; j += 64) {
+            const int k = j < K ? j : j - K;
+            atomicAdd(&A.cov[j], A.xs[(size_t)t * K + k] * (j < K ? tot_a : tot_d));
+        }
+    }
+    __syncthreads();
+    for (int k = tid; k < 10 * G; k += FUSED_DYN_BLOCK) {
+        const int kk = k / G, gg = k - kk * G;
+        double v = 0.0;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) v += lsum[w][kk][gg];
+        if (v != 0.0) atomicAdd(&A.gsum[k], v);
+    }
+    // ---- arrive (atomics drained); the last workgroup runs the final part
+    DYN_STAMP(8);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned int k = __hip_atomic_fetch_add(A.tickets + TK_FINAL, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = k == nb - 1;
+        if (s_last) {  // everyone is past every barrier: the counters go back to zero for the next launch
+            __hip_atomic_store(A.tickets + TK_FINAL, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(A.tickets + TK_B1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(A.tickets + TK_B2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(A.tickets + TK_B3, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    // this wave's gradient entries, and its accumulators back to zero for the next evaluation
+    // (the scans above took them) -- AFTER the arrival: nobody waits for these stores, and in
+    // front of it the arrival would wait for their write-through
+    if (on) {
+        grad[L.o_sat + c] = -(s[0] * RA - sa + rp * e * iv);
+        grad[L.o_sdt + c] = -(s[1] * RD - e * iv);
+        grad[L.o_u + c] = g_u;
+        grad[L.o_hat + c] = -(s[2] * g_hat - hat);
+        grad[L.o_aat + c] = -(s[3] * g_aat - aat);
+        grad[L.o_hdf + c] = -(s[4] * g_hdf - hdf);
+        grad[L.o_adf + c] = -(s[5] * g_adf - adf);
+        double* Az = A.acc + (size_t)c * A_N;
+        static_assert(A_N == 6, "three 16-byte stores");
+        dc::st_sc1_x2(&Az[0], 0.0, 0.0);
+        dc::st_sc1_x2(&Az[2], 0.0, 0.0);
+        dc::st_sc1_x2(&Az[4], 0.0, 0.0);
+    }
+    __syncthreads();
+    if (!s_last) {
+        DYN_STAMP_FLUSH;
+        return;
+    }
+    if (wave == 0) final_fused(A, b, jac_corr, lane);
+    DYN_STAMP(9);
+    DYN_STAMP_FLUSH;
 }
 
 }  // namespace dcd

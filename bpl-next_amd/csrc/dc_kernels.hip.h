@@ -191,6 +191,80 @@ __device__ __forceinline__ double* nuts_of(const EvalArgs& A, int c) { return A.
 #define DC_STAMP_WAVE(w, k) do { } while (0)
 #endif
 
+// ------------------------------------------------------------------ lean float64 math
+// The z side of the float64 kernels is a handful of exp / log / log1p / 1/x per lane on the
+// critical path of a latency-bound launch, and the device library's versions are 100-250
+// dependent instructions each (~0.5-0.7 us measured: three of them were 2.9 us of one phase).
+// These are the textbook reductions with no extended-precision tail: ~1-2 ulp, 20-35
+// instructions.  (Checked against libm by bplhip_selftest_math, tests/test_gpu_lean_math.py.)
+namespace lean {
+// exp: x = k ln2 + r (Cody-Waite, ln2 split so that k*ln2_hi is exact), Taylor to r^13 on
+// |r| <= ln2/2 (truncation 4e-18), scaled by ldexp.  Clamped to +-750: exp -> inf / 0 there.
+__device__ __forceinline__ double exp(double x) {
+    x = x > 750.0 ? 750.0 : (x < -750.0 ? -750.0 : x);  // (a NaN passes both comparisons)
+    const double k = __builtin_rint(x * 1.4426950408889634);
+    double r = __builtin_fma(k, -6.93147180369123816490e-01, x);
+    r = __builtin_fma(k, -1.90821492927058770002e-10, r);
+    double p = 1.6059043836821613e-10;                   // 1/13!
+    p = __builtin_fma(p, r, 2.08767569878681e-09);       // 1/12!
+    p = __builtin_fma(p, r, 2.505210838544172e-08);      // 1/11!
+    p = __builtin_fma(p, r, 2.755731922398589e-07);      // 1/10!
+    p = __builtin_fma(p, r, 2.7557319223985893e-06);     // 1/9!
+    p = __builtin_fma(p, r, 2.48015873015873e-05);       // 1/8!
+    p = __builtin_fma(p, r, 1.984126984126984e-04);      // 1/7!
+    p = __builtin_fma(p, r, 1.388888888888889e-03);      // 1/6!
+    p = __builtin_fma(p, r, 8.333333333333333e-03);      // 1/5!
+    p = __builtin_fma(p, r, 4.1666666666666664e-02);     // 1/4!
+    p = __builtin_fma(p, r, 1.6666666666666666e-01);     // 1/3!
+    p = __builtin_fma(p, r, 0.5);
+    p = __builtin_fma(p, r, 1.0);
+    p = __builtin_fma(p, r, 1.0);
+    return __builtin_ldexp(p, (int)k);
+}
+// 1/x for a normal x that is neither 0 nor inf: hardware estimate + two Newton steps
+__device__ __forceinline__ double rcp(double x) {
+    double y = __builtin_amdgcn_rcp(x);
+    y = __builtin_fma(y, __builtin_fma(-x, y, 1.0), y);
+    y = __builtin_fma(y, __builtin_fma(-x, y, 1.0), y);
+    return y;
+}
+// log of m * 2^e with m in [sqrt(1/2), sqrt(2)): f = m - 1, s = f / (2 + f),
+// log(1 + f) = f - f^2/2 + s (f^2/2 + R(s^2)) with the classic degree-7 minimax R (fdlibm's
+// published coefficients, |error| < 2^-58).  0 -> -inf, negative or NaN -> NaN, inf -> inf.
+__device__ __forceinline__ double log(double a) {
+    double m = __builtin_amdgcn_frexp_mant(a);           // [0.5, 1)
+    int e = __builtin_amdgcn_frexp_exp(a);
+    const bool low = m < 0.7071067811865476;
+    m = low ? 2.0 * m : m;
+    e = low ? e - 1 : e;
+    const double f = m - 1.0;
+    const double s = f * rcp(2.0 + f);
+    const double z = s * s;
+    double R = 1.479819860511658591e-01;
+    R = __builtin_fma(R, z, 1.531383769920937332e-01);
+    R = __builtin_fma(R, z, 1.818357216161805012e-01);
+    R = __builtin_fma(R, z, 2.222219843214978396e-01);
+    R = __builtin_fma(R, z, 2.857142874366239149e-01);
+    R = __builtin_fma(R, z, 3.999999999940941908e-01);
+    R = __builtin_fma(R, z, 6.666666666666735130e-01);
+    R *= z;
+    const double hfsq = 0.5 * f * f;
+    const double de = (double)e;
+    const double lo = __builtin_fma(s, hfsq + R, de * 1.90821492927058770002e-10);
+    double r = __builtin_fma(de, 6.93147180369123816490e-01, f - (hfsq - lo));
+    r = a == 0.0 ? -__builtin_inf() : r;
+    r = a == __builtin_inf() ? a : r;
+    r = a >= 0.0 ? r : __builtin_nan("");
+    return r;
+}
+// log(1 + x) for x >= 0 (here x = exp(-|z|) <= 1): the rounding error of 1 + x is put back
+__device__ __forceinline__ double log1p_pos(double x) {
+    const double u = 1.0 + x;
+    const double c = x - (u - 1.0);
+    return log(u) + c * rcp(u);
+}
+}  // namespace lean
+
 // ------------------------------------------------------------------ wave helpers (DPP)
 
 template <int CTRL, int ROW_MASK = 0xF>
@@ -276,6 +350,45 @@ __device__ __forceinline__ void wave_sum4_f64(double (&v)[4]) {
     for (int j = 0; j < 4; ++j) v[j] += dpp_f64<0x143, 0xC>(0.0, v[j]);
 #pragma unroll
     for (int j = 0; j < 4; ++j) v[j] = readlane63_f64(v[j]);
+}
+// three maxima at once, interleaved step by step
+__device__ __forceinline__ void wave_max3_f64(double& a, double& b, double& c) {  // all >= 0
+    a = fmax(a, dpp_f64<0xB1>(0.0, a)); b = fmax(b, dpp_f64<0xB1>(0.0, b)); c = fmax(c, dpp_f64<0xB1>(0.0, c));
+    a = fmax(a, dpp_f64<0x4E>(0.0, a)); b = fmax(b, dpp_f64<0x4E>(0.0, b)); c = fmax(c, dpp_f64<0x4E>(0.0, c));
+    a = fmax(a, dpp_f64<0x124>(0.0, a)); b = fmax(b, dpp_f64<0x124>(0.0, b)); c = fmax(c, dpp_f64<0x124>(0.0, c));
+    a = fmax(a, dpp_f64<0x128>(0.0, a)); b = fmax(b, dpp_f64<0x128>(0.0, b)); c = fmax(c, dpp_f64<0x128>(0.0, c));
+    a = fmax(a, dpp_f64<0x142, 0xA>(0.0, a)); b = fmax(b, dpp_f64<0x142, 0xA>(0.0, b)); c = fmax(c, dpp_f64<0x142, 0xA>(0.0, c));
+    a = fmax(a, dpp_f64<0x143, 0xC>(0.0, a)); b = fmax(b, dpp_f64<0x143, 0xC>(0.0, b)); c = fmax(c, dpp_f64<0x143, 0xC>(0.0, c));
+    a = readlane63_f64(a); b = readlane63_f64(b); c = readlane63_f64(c);
+}
+
+// Inclusive scans over the 64 lanes without the LDS crossbar.  Prefix (lane 0 first): four
+// zero-filled row_shr steps give each 16-lane row its own prefix, row_bcast:15 / row_bcast:31 add
+// the totals of the rows below.  Suffix (lane 63 first): four row_shl steps, then the totals of
+// the rows above (lanes 16, 32, 48 hold them) by readlane -- there is no row_bcast downwards.
+__device__ __forceinline__ double wave_prefix_dpp_f64(double v) {
+    v += dpp_f64<0x111>(0.0, v);       // row_shr:1
+    v += dpp_f64<0x112>(0.0, v);       // row_shr:2
+    v += dpp_f64<0x114>(0.0, v);       // row_shr:4
+    v += dpp_f64<0x118>(0.0, v);       // row_shr:8
+    v += dpp_f64<0x142, 0xA>(0.0, v);  // row_bcast:15 into rows 1,3
+    v += dpp_f64<0x143, 0xC>(0.0, v);  // row_bcast:31 into rows 2,3
+    return v;
+}
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+    const long long x = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)x, l);
+    const int hi = __builtin_amdgcn_readlane((int)(x >> 32), l);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ double wave_suffix_dpp_f64(double v, int lane) {
+    v += dpp_f64<0x101>(0.0, v);       // row_shl:1
+    v += dpp_f64<0x102>(0.0, v);       // row_shl:2
+    v += dpp_f64<0x104>(0.0, v);       // row_shl:4
+    v += dpp_f64<0x108>(0.0, v);       // row_shl:8
+    const double t1 = readlane_f64(v, 16), t2 = readlane_f64(v, 32), t3 = readlane_f64(v, 48);
+    const double hi = t2 + t3;
+    return v + (lane < 16 ? t1 + hi : lane < 32 ? hi : lane < 48 ? t3 : 0.0);
 }
 // NV independent sums, interleaved step by step like wave_sum4_f64
 template <int NV>
@@ -383,6 +496,13 @@ __device__ __forceinline__ void st_sc1(double* p, double v) {
     __hip_atomic_store(reinterpret_cast<unsigned long long*>(p),
                        (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
                        __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// two doubles (16-byte aligned) in ONE write-through store
+typedef double double2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void st_sc1_x2(double* p, double a, double b) {
+    double2_t v = {a, b};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
 }
 
 // ---- accumulator rows (see GA_ROW): add one double, take (read and re-arm) one row

@@ -348,17 +348,6 @@ inline size_t fused_lds_doubles(const NeuLayout& L, long long n, int n_slots) {
            (L.T + 2) / 2;
 }
 
-__device__ __forceinline__ void wave_max3_f64(double& a, double& b, double& c) {  // all >= 0
-    using dc::dpp_f64;
-    a = fmax(a, dpp_f64<0xB1>(0.0, a)); b = fmax(b, dpp_f64<0xB1>(0.0, b)); c = fmax(c, dpp_f64<0xB1>(0.0, c));
-    a = fmax(a, dpp_f64<0x4E>(0.0, a)); b = fmax(b, dpp_f64<0x4E>(0.0, b)); c = fmax(c, dpp_f64<0x4E>(0.0, c));
-    a = fmax(a, dpp_f64<0x124>(0.0, a)); b = fmax(b, dpp_f64<0x124>(0.0, b)); c = fmax(c, dpp_f64<0x124>(0.0, c));
-    a = fmax(a, dpp_f64<0x128>(0.0, a)); b = fmax(b, dpp_f64<0x128>(0.0, b)); c = fmax(c, dpp_f64<0x128>(0.0, c));
-    a = fmax(a, dpp_f64<0x142, 0xA>(0.0, a)); b = fmax(b, dpp_f64<0x142, 0xA>(0.0, b)); c = fmax(c, dpp_f64<0x142, 0xA>(0.0, c));
-    a = fmax(a, dpp_f64<0x143, 0xC>(0.0, a)); b = fmax(b, dpp_f64<0x143, 0xC>(0.0, b)); c = fmax(c, dpp_f64<0x143, 0xC>(0.0, c));
-    a = dc::readlane63_f64(a); b = dc::readlane63_f64(b); c = dc::readlane63_f64(c);
-}
-
 #ifdef DC_STAMPS  // diagnostic build: the phase timeline (10 ns ticks since entry) replaces grad[0..9]
 #define NEU_STAMP_DECL unsigned long long stamp_[10] = {}
 #define NEU_STAMP(k)                                      \
@@ -414,8 +403,8 @@ __global__ __launch_bounds__(FUSED_BLOCK) void neu_fused(FusedArgs A) {
         zv = z[lane < FUSED_SITES ? o : 0];
         // one exp for lanes 0..7 TOGETHER (a float64 libm call is ~0.3 us of dependent
         // instructions; on diverged lanes they would run one after another)
-        ez = exp(sigm ? -fabs(zv) : zv);
-        const double s_abs = 1.0 / (1.0 + ez);
+        ez = dc::lean::exp(sigm ? -fabs(zv) : zv);
+        const double s_abs = dc::lean::rcp(1.0 + ez);
         sg = zv >= 0 ? s_abs : 1.0 - s_abs;
         v_site = sg < dc::SIG_LO ? dc::SIG_LO : sg > dc::SIG_HI ? dc::SIG_HI : sg;
         dv_site = (sg < dc::SIG_LO || sg > dc::SIG_HI) ? 0.0 : sg * (1.0 - sg);
@@ -440,12 +429,12 @@ __global__ __launch_bounds__(FUSED_BLOCK) void neu_fused(FusedArgs A) {
                 att += xv * z[L.o_bA + k];
                 def += xv * z[L.o_bD + k];
             }
-            att += sat * exp(l_att);
-            def += sdt * exp(l_def);
-            const double hat = mha + exp(l_ha) * zhat;
-            const double aat = maa + exp(l_aa) * zaat;
-            const double hdf = mhd + exp(l_hd) * zhdf;
-            const double adf = mad + exp(l_ad) * zadf;
+            att += sat * dc::lean::exp(l_att);
+            def += sdt * dc::lean::exp(l_def);
+            const double hat = mha + dc::lean::exp(l_ha) * zhat;
+            const double aat = maa + dc::lean::exp(l_aa) * zaat;
+            const double hdf = mhd + dc::lean::exp(l_hd) * zhdf;
+            const double adf = mad + dc::lean::exp(l_ad) * zadf;
             double* P = cells + t * dcd::P_N;
             P[dcd::P_AH] = att + hat;
             P[dcd::P_AA] = att + aat;
@@ -474,7 +463,7 @@ __global__ __launch_bounds__(FUSED_BLOCK) void neu_fused(FusedArgs A) {
     if (wave == 0) {
         // the rest of the scalar chain: one log1p for the two sigmoid sites, then per site its
         // log-density and the constant part of its gradient
-        const double l1 = log1p(sigm ? ez : 0.0);
+        const double l1 = dc::lean::log1p_pos(sigm ? ez : 0.0);
         double Lp = 0.0;
         // confederation strengths and coefficients ~ N(0,1): lanes stride over them
         for (int k = lane; k < 2 * K + C; k += 64) {
@@ -499,15 +488,15 @@ __global__ __launch_bounds__(FUSED_BLOCK) void neu_fused(FusedArgs A) {
             if (lane == 6) {  // u ~ Beta(2,4); rho' = 2u - 1, 1 - rho'^2 = 4 u (1 - u)
                 const double rp = 2.0 * v - 1.0, vv = 1.0 - rp * rp;
                 fixed[FX_RP] = rp;
-                fixed[FX_IVV] = 1.0 / vv;
+                fixed[FX_IVV] = dc::lean::rcp(vv);
                 fixed[FX_LOGVV] = 2.0 * LN2 + log_v + log_1mv;
                 Lp += log_v + 3.0 * log_1mv + 2.995732273553991 - (sp_pos + l1);
                 mul = 2.0 * dv_site;
-                prec = (1.0 / v - 3.0 / (1.0 - v)) * dv_site + (1.0 - 2.0 * sg);
+                prec = (dc::lean::rcp(v) - 3.0 * dc::lean::rcp(1.0 - v)) * dv_site + (1.0 - 2.0 * sg);
             } else {          // corr_coef_raw ~ Beta(2,2)
                 Lp += log_v + log_1mv + 1.791759469228055 - (sp_pos + l1);
                 mul = dv_site;
-                prec = (1.0 / v - 1.0 / (1.0 - v)) * dv_site + (1.0 - 2.0 * sg);
+                prec = (dc::lean::rcp(v) - dc::lean::rcp(1.0 - v)) * dv_site + (1.0 - 2.0 * sg);
             }
         } else if (lane < 12) {  // means ~ N(+-0.1, 0.2)
             const double mu = (lane & 1) ? -0.1 : 0.1, r = (zv - mu) / 0.2;
@@ -534,14 +523,14 @@ __global__ __launch_bounds__(FUSED_BLOCK) void neu_fused(FusedArgs A) {
             if (i != wid) f = A.fx[i];
             double eh, ea;
             etas(f, &eh, &ea);
-            const double lh = exp(eh), la = exp(ea);
+            const double lh = dc::lean::exp(eh), la = dc::lean::exp(ea);
             if (i == wid) { eh0 = eh; ea0 = ea; lh0 = lh; la0 = la; }
             mP = fmax(mP, lh * la);
             mH = fmax(mH, lh);
             mA = fmax(mA, la);
         }
         if (wid - lane < N) {  // (waves without fixtures: nothing to offer)
-            wave_max3_f64(mP, mH, mA);
+            dc::wave_max3_f64(mP, mH, mA);
             // (positive doubles order like their bit patterns)
             if (lane < 3)
                 atomicMax(&fixed_u[FX_MAX + lane],
@@ -573,8 +562,8 @@ __global__ __launch_bounds__(FUSED_BLOCK) void neu_fused(FusedArgs A) {
             if (i != wid) {
                 f = A.fx[i];
                 etas(f, &eh, &ea);
-                lh = exp(eh);
-                la = exp(ea);
+                lh = dc::lean::exp(eh);
+                la = dc::lean::exp(ea);
             }
             const double w = (double)f.w;
             double Uf = f.x * eh - lh + f.y * ea - la;
@@ -583,7 +572,7 @@ __global__ __launch_bounds__(FUSED_BLOCK) void neu_fused(FusedArgs A) {
                 const double c = f.x == 0 ? (f.y == 0 ? -lh * la : lh) : (f.y == 0 ? la : -1.0);
                 const double arg = 1.0 + b.rho * c;
                 if (arg > 0.0) {
-                    Uf += log(arg);
+                    Uf += dc::lean::log(arg);
                     const double u = c / arg;
                     ui += w * u;
                     if (f.x == 0) gh += b.rho * u;

@@ -288,6 +288,12 @@ int bplhip_predict_score_grid(bplhip_ctx* ctx, int64_t m, const uint16_t* home_i
                               const uint16_t* away_idx, int32_t max_goals, double* out,
                               void* stream);
 
+/* Self-test of the library's own float64 device math (csrc/dc_kernels.hip.h, namespace
+ * dc::lean -- the short exp / log / log1p / reciprocal the float64 kernels use on their critical
+ * paths; no reference counterpart).  which: 0 exp(x), 1 log(x), 2 log(1 + x) for x >= 0, 3 1/x for
+ * normal x.  HOST f64[n] in and out, synchronous. */
+int bplhip_selftest_math(bplhip_ctx* ctx, int32_t which, int64_t n, const double* in, double* out);
+
 /* threefry2x32 helpers with jax.random semantics (jax 0.4.24, non-partitionable
  * threefry): used by the Python host for key plumbing (random.split for multi-chain
  * runs, bpl/dixon_coles.py:107).  out has 2*n words: n keys (hi, lo). */

@@ -10,9 +10,10 @@ import dc_dynamic_oracle as DO
 pytestmark = pytest.mark.gpu
 
 
-def _eval(ctx, fx, z, random_walk=True):
+def _eval(ctx, fx, z, random_walk=True, fused=1):
     import torch
 
+    ctx.set_option("fused_small", fused)  # 1: one launch with grid barriers (small leagues); 0: four launches
     cov = None if fx.covariates is None else DO.standardise_covariates(fx.covariates)
     ctx.set_fixtures_dynamic(fx.home_idx, fx.away_idx, fx.home_goals, fx.away_goals, fx.gameweek,
                              fx.neutral, fx.n_teams, fx.n_gameweeks, covariates_std=cov,
@@ -22,12 +23,14 @@ def _eval(ctx, fx, z, random_walk=True):
     U, g, aux = ctx.logp_grad(zt)
     U2, g2, _ = ctx.logp_grad(zt)
     assert abs(float(U2[0]) - float(U[0])) <= 1e-12 * abs(float(U[0]))
+    ctx.set_option("fused_small", 1)
     return float(U.cpu()[0]), g.cpu().numpy(), aux.cpu().numpy()[0]
 
 
+@pytest.mark.parametrize("fused", [1, 0])
 @pytest.mark.parametrize("random_walk", [True, False])
 @pytest.mark.parametrize("case", ["small", "small_cov", "config4"])
-def test_dynamic_logp_grad_matches_oracle(hip_ctx, case, random_walk):
+def test_dynamic_logp_grad_matches_oracle(hip_ctx, case, random_walk, fused):
     fx = {"small": lambda: DO.small_recipe(), "small_cov": lambda: DO.small_recipe(k=3),
           "config4": DO.config4_recipe}[case]()
     D = DO.latent_dim(fx.n_gameweeks, fx.n_teams, fx.k)
@@ -37,8 +40,8 @@ def test_dynamic_logp_grad_matches_oracle(hip_ctx, case, random_walk):
         if seed == 2:
             z[sl["mean_home_attack"]] = 1.2
         Uo, go, auxo = DO.potential_and_grad(fx, z, random_walk)
-        U, g, aux = _eval(hip_ctx, fx, z, random_walk)
-        print(f"{case} rw={random_walk} seed={seed} D={D} U={Uo:.6f} dU={U - Uo:+.2e} "
+        U, g, aux = _eval(hip_ctx, fx, z, random_walk, fused)
+        print(f"{case} rw={random_walk} fused={fused} seed={seed} D={D} U={Uo:.6f} dU={U - Uo:+.2e} "
               f"dg={np.abs(g - go).max():.2e} / {np.abs(go).max():.2e}")
         assert abs(U - Uo) <= 1e-9 * abs(Uo)
         assert np.abs(g - go).max() <= 1e-9 * np.abs(go).max()
