@@ -340,6 +340,14 @@ def main():
                 "kernel": "dc_eval (one launch per evaluation: streaming + prior + tail)",
                 "us_per_eval_events": per_eval_us,
                 "algorithmic_bytes_per_eval": n_fix * BYTES_PER_FIXTURE,
+                # the same fraction on the bytes the kernel actually moves (PMC, profiles/traffic.json)
+                "frac_traffic": (traffic / per_eval_us / 1e3 / HBM_PEAK_GBS) if traffic else None,
+                "duration_note": "HIP events around the replayed graph divided by its evaluations: kernel "
+                                 "duration plus the dependent-launch gap; rocprofv3's per-kernel average "
+                                 "(profiles/r02/kernels.md) is the duration alone",
+                "regime": "latency bound at this size (an empty kernel in the same graph is 2.06 us of the "
+                          "~6.8 us launch); the same kernel reaches 66% of peak at N=1e7 and 195% "
+                          "(algorithmic) at N=1e8: profiles/r02/n_sweep.txt",
             },
         }
         out.update(extra)

@@ -156,6 +156,12 @@ int bplhip_set_fixtures_neutral(bplhip_ctx* ctx, int64_t n, int32_t n_teams,
  *   "persistent_nuts" 1 (default) = the whole chain on the device (adaptation included, the
  *            host only enqueues evaluations); 0 = device trees with host-side adaptation
  *            (models of the evaluation kernel's tail only).
+ *   "persistent_kernel" 1 (default) = one resident chain of the basic / extended model runs its
+ *            leapfrogs INSIDE one launch (the streaming workgroups poll the next position);
+ *            0 = one launch per leapfrog.
+ *   "fused_small" 1 (default) = neutral / dynamic evaluations small enough for it run as ONE
+ *            launch (neutral: one workgroup per chain, everything in LDS; dynamic: phases behind
+ *            grid barriers); 0 = always the multi-launch path.
  *   "max_wg" streaming workgroups per evaluation (default 255: with the prior workgroup
  *            one per CU); applies at the next bplhip_set_fixtures
  *   "active_waves" waves per workgroup that own tiles: 0 (default) = automatic -- short

@@ -1,0 +1,27 @@
+#!/bin/bash
+# Runs ON THE GPU BOX (via gpurun): the measurements quoted in DESIGN.md / profiles/README.md that
+# are not per-kernel rocprofv3 profiles (those: tools/profile_all.sh).
+set -u
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+TAG=${1:-r02}
+OUT=$ROOT/gpurun_out/$TAG
+mkdir -p $OUT
+cd $ROOT
+python bench.py > $OUT/bench_default.json 2> $OUT/bench.err
+python bench.py --steps 20 --warmup 5 > $OUT/bench_driver_style.json 2>> $OUT/bench.err
+python tools/stamps.py > $OUT/stamps_timeline.txt 2>&1
+python tools/stamps.py nuts >> $OUT/stamps_timeline.txt 2>&1
+python tools/dynamic_stamps.py > $OUT/dynamic_timeline.txt 2>&1
+python tools/neutral_phases.py > $OUT/neutral_phases.txt 2>&1
+python tools/n_sweep.py > $OUT/n_sweep.txt 2>&1
+python tools/batched_bench.py > $OUT/batched_chains_vec.txt 2>&1
+VEC=0 CHAINS=8,64 python tools/batched_bench.py > $OUT/batched_chains_gridy.txt 2>&1
+CHAINS=4,8,16,32,64 python tools/lockstep_bench.py > $OUT/lockstep_chains.txt 2>&1
+python tools/dynamic_bench.py > $OUT/dynamic_model.txt 2>&1
+python tools/predict_bench.py > $OUT/predict.txt 2>&1
+python tools/neutral_bench.py > $OUT/neutral_model.txt 2>&1
+python tools/small_n_bench.py > $OUT/small_n.txt 2>&1
+python tools/configs_bench.py > $OUT/configs.txt 2>&1
+python tools/teams_sweep.py > $OUT/teams_sweep.txt 2>&1
+./tools/micro/xcd_handoff > $OUT/xcd_handoff.txt 2>&1
+tail -n 4 $OUT/*.txt | head -150

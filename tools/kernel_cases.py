@@ -29,13 +29,14 @@ def evals(D, chains=1):
     torch.cuda.synchronize()
 
 
-def league(model, n=1_000_000, weighted=False, cov=False):
+def league(model, n=1_000_000, weighted=False, cov=False, T=T):
     h, a, x, y = synthetic_league(n, T)
     w = np.exp(-1.0 * np.linspace(5, 0, n)).astype(np.float32) if weighted else None
     cv = None
     if cov:
         cv = np.random.RandomState(0).normal(size=(T, 5)); cv = (cv - cv.mean(0)) / cv.std(0)
     c.set_fixtures(model, h, a, x, y, T, weights=w, covariates_std=cv)
+    meta["teams"] = T
     pad = 1.006  # pair runs padded to 32 fixtures, the whole to 2048
     meta.update(n=n, algorithmic_bytes_per_launch=n * (10 if weighted else 6),
                 library_copy_bytes_per_launch=int(n * pad * (6.25 if weighted else 2.25)))
@@ -43,6 +44,8 @@ def league(model, n=1_000_000, weighted=False, cov=False):
 
 if case == "basic":
     league(MODEL_BASIC); evals(c.dim)
+elif case in ("t100", "t200"):
+    league(MODEL_BASIC, T=int(case[1:])); evals(c.dim)
 elif case == "c3":
     league(MODEL_EXTENDED, cov=True); evals(c.dim)
 elif case == "c3w":
