@@ -92,6 +92,8 @@ struct bplhip_ctx {
     DevBuf d_zb;    // persistent evaluation kernel: the next position as tagged granules
     unsigned int loop_tag = 0;  // tags handed out so far (a launch of k steps takes k + 1 of them)
     int opt_persistent_kernel = 1;  // 1: a single chain's leapfrogs run inside one resident launch
+    int opt_dense_pairs = 1;        // 1: complete pair tables take the separable (O(teams)) bounds
+    bool pairs_complete = false;
     int opt_fused_small = 1;        // 1: neutral / dynamic evaluations that fit one CU's LDS run as one launch
     bool neu_attr_set = false;
     int slab_chains = 0;
@@ -425,6 +427,7 @@ dc::EvalArgs eval_args(bplhip_ctx* c, int chains, const double* z, double* pot, 
     A.tiles_per_wave = c->ep->tpw;
     A.pairs = c->d_pairs.as<const uint32_t>();
     A.P = c->P;
+    A.dense_pairs = c->opt_dense_pairs && c->pairs_complete && c->P >= dc::DENSE_MIN_PAIRS;
     A.xs = c->L.K ? c->d_xs.as<const double>() : nullptr;
     A.xsf = c->L.K ? c->d_xsf.as<const float>() : nullptr;
     A.cA = c->d_cA.as<const double>();
@@ -888,6 +891,9 @@ static int bplhip_set_fixtures_impl(bplhip_ctx* c, int model_kind, int64_t n, in
     c->weighted = weights != nullptr;
     c->P = (int)pairs.size();
     c->lgsum = lgsum;
+    // every ordered pair h != a present (and no team against itself): the bounds are separable
+    c->pairs_complete = T >= 2 && (long long)pairs.size() == (long long)T * (T - 1) &&
+                        std::none_of(pairs.begin(), pairs.end(), [](uint32_t pr) { return (pr & 0xFFFFu) == (pr >> 16); });
     c->h_pairs = std::move(pairs);
     c->slab_chains = 0;
     // staged <=> T <= 64: the tail's one-lane-per-team epilogue (and the device-resident NUTS)
@@ -951,6 +957,11 @@ int bplhip_set_option(bplhip_ctx* c, const char* name, int value) {
         return BPLHIP_OK;
     }
 #endif
+    if (n == "dense_pairs") {  // 0: the rho bounds always walk the pair table
+        c->opt_dense_pairs = value != 0;
+        drop_graphs(c);
+        return BPLHIP_OK;
+    }
     if (n == "fused_small") {  // 0: neutral / dynamic evaluations always take the multi-launch path
         c->opt_fused_small = value != 0;
         drop_graphs(c);  // (captured launch sequences belong to the other path)

@@ -116,6 +116,7 @@ struct EvalArgs {
     int tiles_per_wave;
     int active_waves;       // waves of a workgroup that own tiles (the first ones)
     const uint32_t* pairs;  // [P] unique (home | away<<16)
+    int dense_pairs;  // 1: every ordered pair h != a is present -- the maxima over pairs are separable (O(T))
     int P;
     const double* xs;       // [T,K] standardised covariates (float64) or nullptr
     const float* xsf;       // the same in float32 (streaming prologue)
@@ -670,6 +671,147 @@ __device__ __forceinline__ float rho_f32(float mP, float mQ, float mR, float q) 
     const float lb = -__builtin_amdgcn_rcpf(fmaxf(mQ, mR));
     return fmaf(q, ub - lb, lb);
 }
+// ---- maxima over a COMPLETE pair table (every ordered pair h != a present: a league where
+// everybody has hosted everybody): the rates are products of per-team table entries,
+// lh(h,a) = AH_h * BD_a, la(h,a) = AA_a * BD_h, and rounding is monotone, so
+//   max lh = the largest AH times the largest BD of a DIFFERENT team -- exact, from the top two of each;
+//   max lh*la: the pair of the largest P_h = AH_h*BD_h and the largest Q_a = AA_a*BD_a of a different
+//   team, evaluated with the per-pair expression (equal to the walk over all pairs unless two
+//   candidates tie within an ulp -- and every workgroup computes the same value either way).
+// O(T) instead of O(pairs) per workgroup: at T = 200 the walks were 6 us of every streaming workgroup
+// and 13.5 us (float64, with arg-pairs) of the prior workgroup.  Taken from DENSE_MIN_PAIRS pairs on
+// (more than 90 teams): below, a few pairs per thread are the cheaper walk (measured at 48 and 64 teams).
+constexpr int DENSE_MIN_PAIRS = 8192;
+template <int NV>
+__device__ __forceinline__ void wave_maxN_f32(float (&v)[NV]) {  // all >= 0; results wave-uniform
+#pragma unroll
+    for (int j = 0; j < NV; ++j) v[j] = fmaxf(v[j], dpp_f32<0xB1>(0.f, v[j]));
+#pragma unroll
+    for (int j = 0; j < NV; ++j) v[j] = fmaxf(v[j], dpp_f32<0x4E>(0.f, v[j]));
+#pragma unroll
+    for (int j = 0; j < NV; ++j) v[j] = fmaxf(v[j], dpp_f32<0x124>(0.f, v[j]));
+#pragma unroll
+    for (int j = 0; j < NV; ++j) v[j] = fmaxf(v[j], dpp_f32<0x128>(0.f, v[j]));
+#pragma unroll
+    for (int j = 0; j < NV; ++j) v[j] = fmaxf(v[j], dpp_f32<0x142, 0xA>(0.f, v[j]));
+#pragma unroll
+    for (int j = 0; j < NV; ++j) v[j] = fmaxf(v[j], dpp_f32<0x143, 0xC>(0.f, v[j]));
+#pragma unroll
+    for (int j = 0; j < NV; ++j) v[j] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v[j]), 63));
+}
+template <int NV>
+__device__ __forceinline__ void wave_maxN_f64(double (&v)[NV]) {  // all >= 0; results wave-uniform
+#pragma unroll
+    for (int j = 0; j < NV; ++j) v[j] = fmax(v[j], dpp_f64<0xB1>(0.0, v[j]));
+#pragma unroll
+    for (int j = 0; j < NV; ++j) v[j] = fmax(v[j], dpp_f64<0x4E>(0.0, v[j]));
+#pragma unroll
+    for (int j = 0; j < NV; ++j) v[j] = fmax(v[j], dpp_f64<0x124>(0.0, v[j]));
+#pragma unroll
+    for (int j = 0; j < NV; ++j) v[j] = fmax(v[j], dpp_f64<0x128>(0.0, v[j]));
+#pragma unroll
+    for (int j = 0; j < NV; ++j) v[j] = fmax(v[j], dpp_f64<0x142, 0xA>(0.0, v[j]));
+#pragma unroll
+    for (int j = 0; j < NV; ++j) v[j] = fmax(v[j], dpp_f64<0x143, 0xC>(0.0, v[j]));
+#pragma unroll
+    for (int j = 0; j < NV; ++j) v[j] = readlane63_f64(v[j]);
+}
+// the largest and the second largest entry (of a different team) of ONE per-team array, with
+// their teams: lanes stride over the teams, then two wave maxima.  get(t): team t's value (> 0).
+// Teams: -1 when there is none.  Results wave-uniform.
+template <class F>
+struct Top2 {
+    F m1, m2;
+    int i1, i2;
+};
+__device__ __forceinline__ float wave_max_pos(float v) { return wave_max_f32(v); }
+__device__ __forceinline__ double wave_max_pos(double v) { return wave_max_f64(v); }
+template <class F, class Get>
+__device__ __forceinline__ Top2<F> wave_top2(int T, int lane, Get get) {
+    F a1 = (F)0, a2 = (F)0;
+    int j1 = -1, j2 = -1;
+    for (int t = lane; t < T; t += 64) {
+        const F v = get(t);
+        const bool first = v > a1, second = !first && v > a2;
+        a2 = first ? a1 : second ? v : a2;
+        j2 = first ? j1 : second ? t : j2;
+        a1 = first ? v : a1;
+        j1 = first ? t : j1;
+    }
+    Top2<F> R;
+    R.m1 = wave_max_pos(a1);
+    const unsigned long long b1 = __ballot(a1 == R.m1 && j1 >= 0);
+    const int win = b1 ? __ffsll((long long)b1) - 1 : 0;
+    R.i1 = b1 ? __builtin_amdgcn_readlane(j1, win) : -1;
+    const F c = lane == win ? a2 : a1;
+    const int jc = lane == win ? j2 : j1;
+    R.m2 = wave_max_pos(c);
+    const unsigned long long b2 = __ballot(c == R.m2 && jc >= 0);
+    R.i2 = b2 ? __builtin_amdgcn_readlane(jc, b2 ? __ffsll((long long)b2) - 1 : 0) : -1;
+    R.m2 = b2 ? R.m2 : (F)0;
+    return R;
+}
+// max over h != a of x_h * y_a from the top two of x and of y; *ph, *pa: the pair (or -1)
+template <class F>
+__device__ __forceinline__ F dense_pair_max(F x1, int ix1, F x2, int ix2, F y1, int iy1, F y2, int iy2,
+                                            int* ph, int* pa) {
+    if (ix1 != iy1) { *ph = ix1; *pa = iy1; return x1 * y1; }
+    const F c12 = ix1 >= 0 && iy2 >= 0 ? x1 * y2 : (F)0, c21 = ix2 >= 0 && iy1 >= 0 ? x2 * y1 : (F)0;
+    if (c12 >= c21) { *ph = ix1; *pa = iy2; return c12; }
+    *ph = ix2; *pa = iy1;
+    return c21;
+}
+// the five per-team arrays whose top two decide the maxima: 0 AH = tabH.x | 1 AA = tabA.x |
+// 2 BD = tabH.y (= tabA.y) | 3 P = AH*BD | 4 Q = AA*BD
+constexpr int DENSE_ARRAYS = 5;
+// float32 maxima of a complete pair table: waves 0..4 take one array each (a wave's top two are two
+// DPP maxima; all five on one wave, or on every wave, were as slow as walking 10 000 pairs), one
+// LDS record each, one barrier, then every thread evaluates the three candidates.  false: a rate
+// reaches the clip -- the clipped product is not separable, the caller walks the pairs.
+// rec: 5 x 4 floats (m1, m2, i1, i2 as bit patterns).
+template <bool CLIP>
+__device__ __forceinline__ bool dense_maxima_f32(int T, const float2* tabH, const float2* tabA, float* rec,
+                                                 int tid, float* oP, float* oQ, float* oR) {
+    const int lane = tid & 63, wave = tid >> 6;
+    if (wave < DENSE_ARRAYS) {
+        const Top2<float> R = wave_top2<float>(T, lane, [&](int t) {
+            const float2 th = tabH[t], ta = tabA[t];
+            return wave == 0 ? th.x : wave == 1 ? ta.x : wave == 2 ? th.y : wave == 3 ? th.x * th.y : ta.x * ta.y;
+        });
+        if (lane == 0) {
+            rec[wave * 4 + 0] = R.m1;
+            rec[wave * 4 + 1] = R.m2;
+            rec[wave * 4 + 2] = __int_as_float(R.i1);
+            rec[wave * 4 + 3] = __int_as_float(R.i2);
+        }
+    }
+    __syncthreads();
+    auto m1 = [&](int k) { return rec[k * 4]; };
+    auto m2 = [&](int k) { return rec[k * 4 + 1]; };
+    auto i1 = [&](int k) { return __float_as_int(rec[k * 4 + 2]); };
+    auto i2 = [&](int k) { return __float_as_int(rec[k * 4 + 3]); };
+    int h, a;
+    const float mQ = dense_pair_max<float>(m1(0), i1(0), m2(0), i2(0), m1(2), i1(2), m2(2), i2(2), &h, &a);
+    // la(h,a) = AA_a * BD_h: x runs over the away side
+    const float mR = dense_pair_max<float>(m1(1), i1(1), m2(1), i2(1), m1(2), i1(2), m2(2), i2(2), &a, &h);
+    // (with a margin: the prior workgroup's float64 maxima must be below the clip too)
+    if (CLIP && (mQ > (float)RATE_CLIP * 0.99999f || mR > (float)RATE_CLIP * 0.99999f)) {
+        __syncthreads();  // (the walk writes the records' words)
+        return false;
+    }
+    // the product: candidates by P_h * Q_a, value by the per-pair expression
+    dense_pair_max<float>(m1(3), i1(3), m2(3), i2(3), m1(4), i1(4), m2(4), i2(4), &h, &a);
+    float mP = 0.f;
+    if (h >= 0 && a >= 0) {
+        const float2 th = tabH[h], ta = tabA[a];
+        mP = (th.x * ta.y) * (ta.x * th.y);
+    }
+    *oP = mP;
+    *oQ = mQ;
+    *oR = mR;
+    return true;
+}
+
 // workgroup maxima of the pair rates from the float32 tables
 template <bool CLIP>
 __device__ __forceinline__ void pair_maxima_f32(const EvalArgs& A, const float2* tabH,
@@ -760,7 +902,9 @@ __device__ __forceinline__ SigSite sig_site(double zc) {
 // TO_LDS: the record goes to `zo_lds` (dc_eval: the prior workgroup runs the tail itself and reads
 // it from LDS); otherwise to the chain's global hand-off buffer with write-through stores (dc_vec:
 // the tail is a separate launch).
-template <bool CLIP, bool TO_LDS = false>
+// DENSE: the instantiation carries the separable bounds of complete pair tables (leagues of more
+// than 64 teams only: the small-league kernels keep their code size)
+template <bool CLIP, bool TO_LDS = false, bool DENSE = false>
 __device__ void prior_body(const EvalArgs& A, int chain, char* smem, double* zo_lds = nullptr) {
     const Layout& L = A.L;
     const int T = L.T, K = L.K, D = L.D;
@@ -964,13 +1108,59 @@ __device__ void prior_body(const EvalArgs& A, int chain, char* smem, double* zo_
         if (valid && lh > mQ) { mQ = lh; aQ = pr; }
         if (valid && la > mR) { mR = la; aR = pr; }
     };
-    if (tid < A.P) take(pr0, true);
-    for (int p0 = tid + BLOCK; p0 < A.P; p0 += PAIR_BATCH * BLOCK) {  // (see pair_maxima_f32)
-        uint32_t q[PAIR_BATCH];
+    // complete pair table: the maxima are separable (dense_maxima_f32).  The float32 ones exactly as
+    // in the streaming workgroups (same value, same decision); for the float64 ones with their
+    // arg-pairs waves 0..4 take one array each as well, and wave 0 evaluates the candidates; the
+    // reductions below then see uniform values (zero from the other waves)
+    float dPf = 0.f, dQf = 0.f, dRf = 0.f;
+    double* rec64 = scratch;  // [5][4] (free until block_sum)
+    const bool dense_in = DENSE && A.dense_pairs;
+    if (dense_in && wave < DENSE_ARRAYS) {
+        const Top2<double> R = wave_top2<double>(T, lane, [&](int t) {
+            const double ah = tru[t], aa = tru[T + t], bd = tru[2 * T + t];
+            return wave == 0 ? ah : wave == 1 ? aa : wave == 2 ? bd : wave == 3 ? ah * bd : aa * bd;
+        });
+        if (lane == 0) {
+            rec64[wave * 4 + 0] = R.m1;
+            rec64[wave * 4 + 1] = R.m2;
+            rec64[wave * 4 + 2] = (double)R.i1;
+            rec64[wave * 4 + 3] = (double)R.i2;
+        }
+    }
+    const bool dense = dense_in && dense_maxima_f32<CLIP>(T, tabH, tabA, redm, tid, &dPf, &dQf, &dRf);  // (barrier inside)
+    if (dense) {
+        __syncthreads();  // (every thread has read the float32 records: redm is written again below)
+        mPf = dPf; mQf = dQf; mRf = dRf;
+        if (wave == 0) {
+            auto m1 = [&](int k) { return rec64[k * 4]; };
+            auto m2 = [&](int k) { return rec64[k * 4 + 1]; };
+            auto i1 = [&](int k) { return (int)rec64[k * 4 + 2]; };
+            auto i2 = [&](int k) { return (int)rec64[k * 4 + 3]; };
+            int h, a;
+            mQ = dense_pair_max<double>(m1(0), i1(0), m2(0), i2(0), m1(2), i1(2), m2(2), i2(2), &h, &a);
+            aQ = (uint32_t)h | ((uint32_t)a << 16);
+            mR = dense_pair_max<double>(m1(1), i1(1), m2(1), i2(1), m1(2), i1(2), m2(2), i2(2), &a, &h);
+            aR = (uint32_t)h | ((uint32_t)a << 16);
+            dense_pair_max<double>(m1(3), i1(3), m2(3), i2(3), m1(4), i1(4), m2(4), i2(4), &h, &a);
+            if (h >= 0 && a >= 0) {
+                double lh = tru[h] * tru[2 * T + a], la = tru[T + a] * tru[2 * T + h];
+                if (CLIP) {
+                    lh = fmin(lh, RATE_CLIP);
+                    la = fmin(la, RATE_CLIP);
+                }
+                mP = lh * la;
+                aP = (uint32_t)h | ((uint32_t)a << 16);
+            }
+        }
+    } else {
+        if (tid < A.P) take(pr0, true);
+        for (int p0 = tid + BLOCK; p0 < A.P; p0 += PAIR_BATCH * BLOCK) {  // (see pair_maxima_f32)
+            uint32_t q[PAIR_BATCH];
 #pragma unroll
-        for (int u = 0; u < PAIR_BATCH; ++u) q[u] = A.pairs[min(p0 + u * BLOCK, A.P - 1)];
+            for (int u = 0; u < PAIR_BATCH; ++u) q[u] = A.pairs[min(p0 + u * BLOCK, A.P - 1)];
 #pragma unroll
-        for (int u = 0; u < PAIR_BATCH; ++u) take(q[u], p0 + u * BLOCK < A.P);
+            for (int u = 0; u < PAIR_BATCH; ++u) take(q[u], p0 + u * BLOCK < A.P);
+        }
     }
     mPf = wave_max_f32(mPf);
     mQf = wave_max_f32(mQf);
@@ -2039,7 +2229,7 @@ __global__ DC_LAUNCH_BOUNDS void dc_eval(EvalArgs A) {
         // workgroup's own drain + ticket, 1.1 us, made it the last arriver.)
         if (NUTS && nuts_done != 0.0) return;
         const size_t tail_bytes = (acc_tail_lds_bytes(T, L.D, L.K, A.zo_stride, STAGED && NUTS) + 15) & ~(size_t)15;
-        prior_body<CLIP, true>(A, chain, smem + tail_bytes, reinterpret_cast<double*>(smem));
+        prior_body<CLIP, true, !STAGED>(A, chain, smem + tail_bytes, reinterpret_cast<double*>(smem));
         DC_STAMP(4);
         int* okflag = reinterpret_cast<int*>(smem + tail_bytes);  // (prior scratch: free after the barrier)
         // The tail reads its arguments from the kernarg segment again (scalar loads behind an
@@ -2113,7 +2303,8 @@ __global__ DC_LAUNCH_BOUNDS void dc_eval(EvalArgs A) {
 
         // ---- 2. rho bounds over the unique-pair table (bpl/_util.py:23-30): values only
         float mP, mQ, mR;
-        pair_maxima_f32<CLIP>(A, tabH, tabA, pr0, redm, tid, &mP, &mQ, &mR);
+        if (!(!STAGED && A.dense_pairs && dense_maxima_f32<CLIP>(T, tabH, tabA, redm, tid, &mP, &mQ, &mR)))
+            pair_maxima_f32<CLIP>(A, tabH, tabA, pr0, redm, tid, &mP, &mQ, &mR);
         const float rho = rho_f32(mP, mQ, mR, fs.q);
         DC_STAMP(2);
 

@@ -356,6 +356,41 @@ def test_reserved_scoreline_and_lane_padding(hip_ctx):
         _check(model, fx, "lane_padding/u", z, float(U.cpu()[0]), g.cpu().numpy(), aux.cpu().numpy()[0])
 
 
+@pytest.mark.parametrize("model", [O.MODEL_BASIC, O.MODEL_EXTENDED])
+@pytest.mark.parametrize("teams,n", [(20, 100_000), (91, 150_000), (100, 200_000), (200, 400_000)])
+def test_separable_bounds_equal_pair_walk(hip_ctx, model, teams, n):
+    """A league in which every ordered pair has met takes the O(teams) bounds (top two table
+    entries per role instead of a walk over all pairs, dc_kernels.hip.h dense_maxima_f32): same rho,
+    same bounds, same arg-extremal pairs -- hence the same U and gradient -- as the pair walk
+    (option dense_pairs = 0), at ordinary points and where the extended model's rate clip binds
+    (there the separable path must hand over to the walk by itself); and both agree with the oracle.
+    (Taken from 8192 pairs on: 20 teams walk their 380 pairs either way.)"""
+    import torch
+
+    h, a, x, y = O.synthetic_league(n, teams)
+    fx = O.Fixtures(h, a, x, y, teams)
+    assert len(set(zip(h.tolist(), a.tolist()))) == teams * (teams - 1)
+    D = O.latent_dim(model, teams, 0)
+    zs = [np.random.RandomState(70 + i).uniform(-s, s, D) for i, s in enumerate((0.3, 0.8, 2.0, 2.0))]
+    outs = {}
+    for dense in (1, 0):
+        hip_ctx.set_option("dense_pairs", dense)
+        hip_ctx.set_fixtures(model, h.astype(np.uint16), a.astype(np.uint16), x.astype(np.uint8), y.astype(np.uint8), teams)
+        outs[dense] = [tuple(t.cpu().numpy().copy() for t in hip_ctx.logp_grad(torch.tensor(z, dtype=torch.float64, device=hip_ctx.device)))
+                       for z in zs]
+    hip_ctx.set_option("dense_pairs", 1)
+    for i, z in enumerate(zs):
+        (U1, g1, a1), (U0, g0, a0) = outs[1][i], outs[0][i]
+        print(f"T={teams} model={model} point {i}: U={U1[0]:.6e} dU={U1[0] - U0[0]:+.2e} dg={np.abs(g1 - g0).max():.2e} "
+              f"rho {a1[0][0]:+.6f} / {a0[0][0]:+.6f}")
+        # (rho, LB, UB, q: the maximum of the rate product may come out one ulp apart -- the walk takes
+        # the largest ROUNDED product, the separable path the pair with the largest exact one)
+        assert np.abs(a1 - a0).max() <= 4e-16 * np.abs(a0).max(), "rho, LB, UB, q"
+        assert abs(U1[0] - U0[0]) <= 1e-9 * abs(U0[0]) and np.abs(g1 - g0).max() <= 1e-9 * np.abs(g0).max()
+        if i < 2 and n <= 200_000:
+            _check(model, fx, f"dense T={teams}/{i}", z, float(U1[0]), g1.reshape(-1), a1[0])
+
+
 def test_nuts_with_many_teams(hip_ctx):
     """T > 64: the leaf does not fit dc_eval's tail, so the chain still lives on the device but
     books its leaves in separate launches -- one wave per chain up to 256 latent entries
