@@ -945,7 +945,9 @@ __global__ __launch_bounds__(FUSED_DYN_BLOCK) void dyn_fused(DynArgs A) {
     }
     // (the scratch -- accumulators, maxima, sums -- is zero on entry: every word is put back to
     // zero by the workgroup that consumes it, phase 4 and final_fused.  Clearing it here would put
-    // ~30 000 write-through stores in front of the first barrier.)
+    // ~30 000 write-through stores in front of the first barrier; and clearing even the few hundred
+    // words of maxima and sums here, write-through, by one workgroup, gave sums that changed from
+    // launch to launch -- words that other XCDs' atomics update must not be written by this launch.)
     double s[6];
 #pragma unroll
     for (int j = 0; j < 6; ++j) {

@@ -319,6 +319,19 @@ __device__ __forceinline__ float wave_max_f32(float v) {  // v >= 0
     v = fmaxf(v, dpp_f32<0x143, 0xC>(0.f, v));
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
+// three maxima at once, interleaved step by step (a single wave issues a dependent DPP + max only
+// every ~20 cycles)
+__device__ __forceinline__ void wave_max3_f32(float& a, float& b, float& c) {  // all >= 0
+    a = fmaxf(a, dpp_f32<0xB1>(0.f, a)); b = fmaxf(b, dpp_f32<0xB1>(0.f, b)); c = fmaxf(c, dpp_f32<0xB1>(0.f, c));
+    a = fmaxf(a, dpp_f32<0x4E>(0.f, a)); b = fmaxf(b, dpp_f32<0x4E>(0.f, b)); c = fmaxf(c, dpp_f32<0x4E>(0.f, c));
+    a = fmaxf(a, dpp_f32<0x124>(0.f, a)); b = fmaxf(b, dpp_f32<0x124>(0.f, b)); c = fmaxf(c, dpp_f32<0x124>(0.f, c));
+    a = fmaxf(a, dpp_f32<0x128>(0.f, a)); b = fmaxf(b, dpp_f32<0x128>(0.f, b)); c = fmaxf(c, dpp_f32<0x128>(0.f, c));
+    a = fmaxf(a, dpp_f32<0x142, 0xA>(0.f, a)); b = fmaxf(b, dpp_f32<0x142, 0xA>(0.f, b)); c = fmaxf(c, dpp_f32<0x142, 0xA>(0.f, c));
+    a = fmaxf(a, dpp_f32<0x143, 0xC>(0.f, a)); b = fmaxf(b, dpp_f32<0x143, 0xC>(0.f, b)); c = fmaxf(c, dpp_f32<0x143, 0xC>(0.f, c));
+    a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a), 63));
+    b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b), 63));
+    c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c), 63));
+}
 __device__ __forceinline__ double readlane63_f64(double v) {
     const long long x = __double_as_longlong(v);
     const int lo = __builtin_amdgcn_readlane((int)x, 63);
@@ -841,9 +854,7 @@ __device__ __forceinline__ void pair_maxima_f32(const EvalArgs& A, const float2*
 #pragma unroll
         for (int u = 0; u < PAIR_BATCH; ++u) take(q[u]);
     }
-    mP = wave_max_f32(mP);
-    mQ = wave_max_f32(mQ);
-    mR = wave_max_f32(mR);
+    wave_max3_f32(mP, mQ, mR);
     if (lane == 0) {
         redm[wave * 4 + 0] = mP;
         redm[wave * 4 + 1] = mQ;
