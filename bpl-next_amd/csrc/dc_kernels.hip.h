@@ -695,40 +695,6 @@ __device__ __forceinline__ float rho_f32(float mP, float mQ, float mR, float q) 
 // and 13.5 us (float64, with arg-pairs) of the prior workgroup.  Taken from DENSE_MIN_PAIRS pairs on
 // (more than 90 teams): below, a few pairs per thread are the cheaper walk (measured at 48 and 64 teams).
 constexpr int DENSE_MIN_PAIRS = 8192;
-template <int NV>
-__device__ __forceinline__ void wave_maxN_f32(float (&v)[NV]) {  // all >= 0; results wave-uniform
-#pragma unroll
-    for (int j = 0; j < NV; ++j) v[j] = fmaxf(v[j], dpp_f32<0xB1>(0.f, v[j]));
-#pragma unroll
-    for (int j = 0; j < NV; ++j) v[j] = fmaxf(v[j], dpp_f32<0x4E>(0.f, v[j]));
-#pragma unroll
-    for (int j = 0; j < NV; ++j) v[j] = fmaxf(v[j], dpp_f32<0x124>(0.f, v[j]));
-#pragma unroll
-    for (int j = 0; j < NV; ++j) v[j] = fmaxf(v[j], dpp_f32<0x128>(0.f, v[j]));
-#pragma unroll
-    for (int j = 0; j < NV; ++j) v[j] = fmaxf(v[j], dpp_f32<0x142, 0xA>(0.f, v[j]));
-#pragma unroll
-    for (int j = 0; j < NV; ++j) v[j] = fmaxf(v[j], dpp_f32<0x143, 0xC>(0.f, v[j]));
-#pragma unroll
-    for (int j = 0; j < NV; ++j) v[j] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v[j]), 63));
-}
-template <int NV>
-__device__ __forceinline__ void wave_maxN_f64(double (&v)[NV]) {  // all >= 0; results wave-uniform
-#pragma unroll
-    for (int j = 0; j < NV; ++j) v[j] = fmax(v[j], dpp_f64<0xB1>(0.0, v[j]));
-#pragma unroll
-    for (int j = 0; j < NV; ++j) v[j] = fmax(v[j], dpp_f64<0x4E>(0.0, v[j]));
-#pragma unroll
-    for (int j = 0; j < NV; ++j) v[j] = fmax(v[j], dpp_f64<0x124>(0.0, v[j]));
-#pragma unroll
-    for (int j = 0; j < NV; ++j) v[j] = fmax(v[j], dpp_f64<0x128>(0.0, v[j]));
-#pragma unroll
-    for (int j = 0; j < NV; ++j) v[j] = fmax(v[j], dpp_f64<0x142, 0xA>(0.0, v[j]));
-#pragma unroll
-    for (int j = 0; j < NV; ++j) v[j] = fmax(v[j], dpp_f64<0x143, 0xC>(0.0, v[j]));
-#pragma unroll
-    for (int j = 0; j < NV; ++j) v[j] = readlane63_f64(v[j]);
-}
 // the largest and the second largest entry (of a different team) of ONE per-team array, with
 // their teams: lanes stride over the teams, then two wave maxima.  get(t): team t's value (> 0).
 // Teams: -1 when there is none.  Results wave-uniform.

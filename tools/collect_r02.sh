@@ -13,6 +13,8 @@ python tools/stamps.py > $OUT/stamps_timeline.txt 2>&1
 python tools/stamps.py nuts >> $OUT/stamps_timeline.txt 2>&1
 python tools/dynamic_stamps.py > $OUT/dynamic_timeline.txt 2>&1
 python tools/neutral_phases.py > $OUT/neutral_phases.txt 2>&1
+TEAMS=100 python tools/stamps.py basic > $OUT/stamps_teams100.txt 2>&1
+TEAMS=200 python tools/stamps.py basic > $OUT/stamps_teams200.txt 2>&1
 python tools/n_sweep.py > $OUT/n_sweep.txt 2>&1
 python tools/batched_bench.py > $OUT/batched_chains_vec.txt 2>&1
 VEC=0 CHAINS=8,64 python tools/batched_bench.py > $OUT/batched_chains_gridy.txt 2>&1
@@ -23,5 +25,5 @@ python tools/neutral_bench.py > $OUT/neutral_model.txt 2>&1
 python tools/small_n_bench.py > $OUT/small_n.txt 2>&1
 python tools/configs_bench.py > $OUT/configs.txt 2>&1
 python tools/teams_sweep.py > $OUT/teams_sweep.txt 2>&1
-./tools/micro/xcd_handoff > $OUT/xcd_handoff.txt 2>&1
+hipcc -O3 --offload-arch=gfx950 -munsafe-fp-atomics -o /tmp/xcd_handoff tools/micro/xcd_handoff.hip 2>/dev/null && /tmp/xcd_handoff > $OUT/xcd_handoff.txt 2>&1
 tail -n 4 $OUT/*.txt | head -150
