@@ -303,8 +303,10 @@ int launch_eval_dynamic(bplhip_ctx* c, int chains, const double* z, double* pot,
         // (and a workgroup's share of the fixtures is a few rounds of its threads)
         if (c->opt_fused_small && L.G <= dcd::FUSED_DYN_MAX_G && L.T <= dcd::FUSED_DYN_MAX_T &&
             c->n <= (long long)team_blocks * dcd::FUSED_DYN_BLOCK * 4) {
-            if (!c->dyn_scratch_clean) {  // (the four-launch path leaves its scratch as it ends)
+            if (!c->dyn_scratch_clean) {  // (the four-launch path leaves its scratch and its cells as it ends)
                 HIP_TRY(c, hipMemsetAsync(A.acc, 0, A.scratch_n * 8, s));
+                HIP_TRY(c, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(A.cells), (int)dcd::CELL_EMPTY_WORD,
+                                             GT * dcd::P_N * 2, s));
                 c->dyn_scratch_clean = true;
             }
             hipLaunchKernelGGL(dcd::dyn_fused, dim3(team_blocks), dim3(dcd::FUSED_DYN_BLOCK), 0, s, A);

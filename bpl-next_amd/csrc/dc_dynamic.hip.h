@@ -763,7 +763,10 @@ __device__ void final_body(const DynArgs& A, double* shl, const Bounds* known) {
 // transcendental runs in the shadow of the first barrier, and each fixture thread keeps its
 // rates between the two fixture phases.  Single chunk of gameweeks per wave (G <= 64).
 //   1  wave per team, lane = gameweek: cells (walk = DPP prefix scan), write-through
-//   -- barrier 1 (in its shadow: u-site sigmoid / softplus / priors of this wave's cells)
+//   -- NO barrier: the cell records are their own flags.  They are armed with a NaN pattern no
+//      arithmetic produces (CELL_EMPTY; re-armed by their owner at the end of the launch), and a
+//      fixture thread simply re-reads its four entries until none of them is that pattern -- one
+//      cross-XCD hop (~0.6 us after the store) instead of drain + arrival + poll (3 us here)
 //   2  fixtures (a contiguous share per workgroup): rates; maxima, one atomicMax per workgroup
 //   -- barrier 2
 //   3  value + adjoint, float64 atomics straight into the L2-resident accumulators (a gameweek's
@@ -778,6 +781,11 @@ __device__ void final_body(const DynArgs& A, double* shl, const Bounds* known) {
 constexpr int FUSED_DYN_BLOCK = 256;
 constexpr int FUSED_DYN_MAX_G = 64, FUSED_DYN_MAX_T = 1024;
 constexpr unsigned int GRID_SPIN_LIMIT = 1u << 22;
+// "not written yet" in a cell record: a quiet NaN no arithmetic produces (computed NaNs are stored as
+// the canonical one).  Both words equal, so a 32-bit fill arms the table (bplhip.hip).
+constexpr unsigned long long CELL_EMPTY = 0x7FF800017FF80001ull;
+constexpr unsigned int CELL_EMPTY_WORD = 0x7FF80001u;
+constexpr unsigned int CELL_SPIN_LIMIT = 1u << 20;
 enum { TK_FINAL = 1, TK_B1 = 2, TK_B2 = 3, TK_B3 = 4, TK_FAIL = 5 };
 
 __device__ __forceinline__ void grid_arrive(unsigned int* ctr) {
@@ -900,7 +908,7 @@ __global__ __launch_bounds__(FUSED_DYN_BLOCK) void dyn_fused(DynArgs A) {
     __shared__ double lsum[WAVES][10][64];
     __shared__ unsigned long long shm[3 * WAVES];
     __shared__ double shr[2 * WAVES];
-    __shared__ int s_ok, s_last;
+    __shared__ int s_ok, s_last, s_bad;
     const DynLayout& L = A.L;
     const int G = L.G, T = L.T, K = L.K;
     const double* z = A.z;
@@ -937,6 +945,8 @@ __global__ __launch_bounds__(FUSED_DYN_BLOCK) void dyn_fused(DynArgs A) {
     const double z_mha = z[L.o_mha + g], z_maa = z[L.o_maa + g], z_mhd = z[L.o_mhd + g], z_mad = z[L.o_mad + g];
     const double hat = z[L.o_hat + c], aat = z[L.o_aat + c], hdf = z[L.o_hdf + c], adf = z[L.o_adf + c];
     const double z_corr = z[L.o_corr];
+    if (tid == 0) s_bad = 0;
+    __syncthreads();  // (the loads above are in flight; s_bad is set by whoever gives up waiting for a cell)
     double att0 = 0.0, def0 = z[L.o_md];
     for (int k = 0; k < K; ++k) {
         const double xv = A.xs[(size_t)tc * K + k];
@@ -963,16 +973,21 @@ __global__ __launch_bounds__(FUSED_DYN_BLOCK) void dyn_fused(DynArgs A) {
         if (on) {
             double* P = A.cells + (size_t)c * P_N;   // (48-byte records: three 16-byte stores)
             static_assert(P_AH == 0 && P_AA == 1 && P_BH == 2 && P_BA == 3 && P_ATT == 4 && P_DEF == 5, "record order");
-            dc::st_sc1_x2(&P[P_AH], a_ + (z_mha + s[2] * hat), a_ + (z_maa + s[3] * aat));
-            dc::st_sc1_x2(&P[P_BH], d_ + (z_mhd + s[4] * hdf), d_ + (z_mad + s[5] * adf));
-            dc::st_sc1_x2(&P[P_ATT], a_, d_);
+            // (a value must never look like CELL_EMPTY: compared as bits -- a floating-point
+            // `v != v` select here changed the stored values)
+            auto canon = [](double v) {
+                const long long u = __double_as_longlong(v);
+                return __longlong_as_double(u == (long long)CELL_EMPTY ? 0x7FF8000000000000ll : u);
+            };
+            dc::st_sc1_x2(&P[P_AH], canon(a_ + (z_mha + s[2] * hat)), canon(a_ + (z_maa + s[3] * aat)));
+            dc::st_sc1_x2(&P[P_BH], canon(d_ + (z_mhd + s[4] * hdf)), canon(d_ + (z_mad + s[5] * adf)));
+            dc::st_sc1_x2(&P[P_ATT], canon(a_), canon(d_));
         }
     }
     DYN_STAMP(1);
-    grid_arrive(A.tickets + TK_B1);
-    // In the barriers' shadows (a grid barrier is ~2 us of memory-side round trips after the last
-    // arrival): everything of the last phase that does not depend on the fixtures, a third each.
-    // Here: corr_coef_raw's sigmoid (phase 3 needs it).
+    // corr_coef_raw's sigmoid (phase 3 needs it) -- while the other workgroups' cells travel.  The
+    // rest of what does not depend on the fixtures runs in the barriers' shadows (a grid barrier is
+    // ~2 us of memory-side round trips after the last arrival).
     const double ezc = dc::lean::exp(-fabs(z_corr)), l1c = dc::lean::log1p_pos(ezc);
     const double sc_abs = dc::lean::rcp(1.0 + ezc);
     const double sq = z_corr >= 0 ? sc_abs : 1.0 - sc_abs;             // sigmoid(corr_coef_raw)
@@ -980,7 +995,6 @@ __global__ __launch_bounds__(FUSED_DYN_BLOCK) void dyn_fused(DynArgs A) {
     const double dq = (sq < dc::SIG_LO || sq > dc::SIG_HI) ? 0.0 : sq * (1.0 - sq);
     const double jac_corr = fabs(z_corr) + 2.0 * l1c;                   // softplus(z) + softplus(-z)
     DYN_STAMP(2);
-    if (!grid_wait(A.tickets, TK_B1, nb, failed, &s_ok)) { give_up(); return; }
     DYN_STAMP(3);
 
     // ---- phase 2: rates of this workgroup's fixtures; maxima
@@ -994,13 +1008,39 @@ __global__ __launch_bounds__(FUSED_DYN_BLOCK) void dyn_fused(DynArgs A) {
         *eh = ph_att - pa_def;
         *ea = pa_att - ph_def;
     };
+    // the same, waiting for the four entries to be written (phase 2 only: by phase 3 they all are)
+    auto etas_wait = [&](const DynFx& f, double* eh, double* ea) {
+        const double* Ph = A.cells + (size_t)(f.g * T + f.h) * P_N;
+        const double* Pa = A.cells + (size_t)(f.g * T + f.a) * P_N;
+        const bool nvf = f.nv != 0;
+        const double* p0 = &Ph[nvf ? P_ATT : P_AH];
+        const double* p1 = &Pa[nvf ? P_DEF : P_BA];
+        const double* p2 = &Pa[nvf ? P_ATT : P_AA];
+        const double* p3 = &Ph[nvf ? P_DEF : P_BH];
+        auto ldu = [](const double* p) {
+            return __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        };
+        unsigned long long u0, u1, u2, u3;
+        unsigned int spins = 0;
+        for (;;) {
+            u0 = ldu(p0); u1 = ldu(p1); u2 = ldu(p2); u3 = ldu(p3);
+            if (u0 != CELL_EMPTY && u1 != CELL_EMPTY && u2 != CELL_EMPTY && u3 != CELL_EMPTY) break;
+            if (++spins >= CELL_SPIN_LIMIT) {
+                s_bad = 1;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        *eh = __longlong_as_double((long long)u0) - __longlong_as_double((long long)u1);
+        *ea = __longlong_as_double((long long)u2) - __longlong_as_double((long long)u3);
+    };
     {
         double mP = 0.0, mH = 0.0, mA = 0.0;
         for (long long i = i_first; i < i_hi; i += FUSED_DYN_BLOCK) {
             DynFx f = first;
             if (i != i_first) f = load_fx(i);
             double eh, ea;
-            etas(f, &eh, &ea);
+            etas_wait(f, &eh, &ea);
             const double lh = dc::lean::exp(eh), la = dc::lean::exp(ea);
             if (i == i_first) { eh0 = eh; ea0 = ea; lh0 = lh; la0 = la; }
             mP = fmax(mP, lh * la);
@@ -1014,6 +1054,11 @@ __global__ __launch_bounds__(FUSED_DYN_BLOCK) void dyn_fused(DynArgs A) {
             shm[wave * 3 + 2] = (unsigned long long)__double_as_longlong(mA);
         }
         __syncthreads();
+        if (s_bad) {  // a cell never arrived: the launch gives up (sticky, like a barrier that times out)
+            if (tid == 0) __hip_atomic_store(A.tickets + TK_FAIL, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            give_up();
+            return;
+        }
         if (tid < 3) {
             unsigned long long m = 0;
             for (int w = 0; w < WAVES; ++w) m = shm[w * 3 + tid] > m ? shm[w * 3 + tid] : m;
@@ -1232,11 +1277,17 @@ __global__ __launch_bounds__(FUSED_DYN_BLOCK) void dyn_fused(DynArgs A) {
         grad[L.o_aat + c] = -(s[3] * g_aat - aat);
         grad[L.o_hdf + c] = -(s[4] * g_hdf - hdf);
         grad[L.o_adf + c] = -(s[5] * g_adf - adf);
-        double* Az = A.acc + (size_t)c * A_N;
-        static_assert(A_N == 6, "three 16-byte stores");
-        dc::st_sc1_x2(&Az[0], 0.0, 0.0);
-        dc::st_sc1_x2(&Az[2], 0.0, 0.0);
-        dc::st_sc1_x2(&Az[4], 0.0, 0.0);
+        // (plain stores: these words are next touched by the NEXT launch, and a kernel boundary
+        // writes them back; write-through stores here were waited for by the kernel's completion)
+        static_assert(A_N == 6 && P_N == 6, "three 16-byte stores each");
+        dc::double2_t* Az = reinterpret_cast<dc::double2_t*>(A.acc + (size_t)c * A_N);
+        const dc::double2_t zero2 = {0.0, 0.0};
+        Az[0] = zero2; Az[1] = zero2; Az[2] = zero2;
+        // ... and its cell record armed again (every reader is past phase 3: barrier 3)
+        const double empty = __longlong_as_double((long long)CELL_EMPTY);
+        dc::double2_t* P2 = reinterpret_cast<dc::double2_t*>(A.cells + (size_t)c * P_N);
+        const dc::double2_t empty2 = {empty, empty};
+        P2[0] = empty2; P2[1] = empty2; P2[2] = empty2;
     }
     __syncthreads();
     if (!s_last) {

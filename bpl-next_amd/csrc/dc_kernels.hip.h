@@ -512,11 +512,15 @@ __device__ __forceinline__ void st_sc1(double* p, double v) {
                        __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// two doubles (16-byte aligned) in ONE write-through store
+// two doubles (16-byte aligned) in ONE write-through store.  The s_nop is the hazard the compiler
+// would cover for its own stores and cannot see inside the asm: a store of more than 64 bits
+// reads its data registers a few cycles after issue, and the next VALU write to them (the
+// allocator reuses them at once) would change what is stored -- found as cell records that
+// depended on how the stored expression was written.
 typedef double double2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void st_sc1_x2(double* p, double a, double b) {
     double2_t v = {a, b};
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 2" ::"v"(p), "v"(v) : "memory");
 }
 
 // ---- accumulator rows (see GA_ROW): add one double, take (read and re-arm) one row
