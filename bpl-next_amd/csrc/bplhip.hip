@@ -758,6 +758,7 @@ static int bplhip_set_fixtures_impl(bplhip_ctx* c, int model_kind, int64_t n, in
     // array is padded to the tile size with the sentinel team T (zero table entries).
     std::vector<uint16_t> hs, as;
     std::vector<uint8_t> xs8, ys8;
+    std::vector<uint8_t> is_null;  // padding fixtures (any scoreline is a legal REAL one, 255-255 included)
     std::vector<float> ws;
     hs.reserve(n + n / 8 + dc::TILE); as.reserve(hs.capacity());
     xs8.reserve(hs.capacity()); ys8.reserve(hs.capacity());
@@ -771,13 +772,12 @@ static int bplhip_set_fixtures_impl(bplhip_ctx* c, int model_kind, int64_t n, in
             as.push_back(as.back());
             xs8.push_back(255);
             ys8.push_back(255);
+            is_null.push_back(1);
             if (weights) ws.push_back(0.0f);
         }
     };
     for (int64_t r = 0; r < n; ++r) {
         const uint32_t i = (uint32_t)order[r];
-        if (x[i] == 255 && y[i] == 255)
-            return fail(c, BPLHIP_EINVAL, "set_fixtures: the scoreline 255-255 is reserved (fixture %u)", i);
         const uint32_t pk = (uint32_t)h[i] | ((uint32_t)a[i] << 16);
         if (pairs.empty() || pairs.back() != pk) {
             if (!pairs.empty()) pad_run();
@@ -787,6 +787,7 @@ static int bplhip_set_fixtures_impl(bplhip_ctx* c, int model_kind, int64_t n, in
         as.push_back(a[i]);
         xs8.push_back(x[i]);
         ys8.push_back(y[i]);
+        is_null.push_back(0);
         const double wi = weights ? (double)w[i] : 1.0;
         if (weights) ws.push_back(w[i]);
         cA[h[i]] += wi * x[i];
@@ -826,7 +827,7 @@ static int bplhip_set_fixtures_impl(bplhip_ctx* c, int model_kind, int64_t n, in
         uint32_t cnt = 0;
         for (int j = 0; j < dc::LANE_FIX; ++j) {
             const int64_t r = l * dc::LANE_FIX + j;
-            cnt += r < n_lanefix && !(xs8[r] == 255 && ys8[r] == 255);
+            cnt += r < n_lanefix && !is_null[r];
         }
         h_lane[l] = (uint32_t)hs[l * dc::LANE_FIX] | (cnt << 16);
         a_lane[l] = (uint32_t)as[l * dc::LANE_FIX];

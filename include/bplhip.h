@@ -92,7 +92,8 @@ const char* bplhip_last_error(const bplhip_ctx* ctx);
  * The arrays are read once (synchronously on `stream`) and re-laid-out into a library
  * owned SoA copy (sorted by (home,away) pair, every pair's run padded to the lane width,
  * the whole padded to the tile size); the caller's buffers are not referenced after the
- * call returns.  The scoreline 255-255 is reserved for that padding (BPLHIP_EINVAL). */
+ * call returns.  (The padding fixtures carry goals 255-255 and weight 0; a real 255-255 fixture is
+ * legal -- which fixtures of a lane are real is recorded separately.) */
 int bplhip_set_fixtures(bplhip_ctx* ctx, int model_kind, int64_t n, int32_t n_teams,
                         const uint16_t* home_idx, const uint16_t* away_idx,
                         const uint8_t* home_goals, const uint8_t* away_goals,

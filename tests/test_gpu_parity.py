@@ -330,15 +330,11 @@ def test_bad_arguments_raise(hip_ctx):
 
 
 def test_reserved_scoreline_and_lane_padding(hip_ctx):
-    """Pair runs are padded to the lane width with null fixtures (goals 255-255): that scoreline is
-    rejected as input, and run lengths 1..17 (every padding amount) agree with the oracle."""
+    """Pair runs are padded to the lane width with null fixtures (goals 255-255, weight 0).  A REAL
+    255-255 fixture is legal all the same (the reference accepts any goals): run lengths 1..17
+    (every padding amount), with extreme scorelines among them, agree with the oracle."""
     import torch
-    from bpl._ffi import BplHipError
 
-    h = np.array([0, 1], np.uint16)
-    a = np.array([1, 0], np.uint16)
-    with pytest.raises(BplHipError):
-        hip_ctx.set_fixtures(O.MODEL_BASIC, h, a, np.array([255, 1], np.uint8), np.array([255, 0], np.uint8), 2)
     rs = np.random.RandomState(5)
     hh, aa = [], []
     for k, (p, q) in enumerate([(i, j) for i in range(5) for j in range(5) if i != j][:17]):
@@ -346,7 +342,9 @@ def test_reserved_scoreline_and_lane_padding(hip_ctx):
         aa += [q] * (k + 1)
     hh, aa = np.array(hh), np.array(aa)
     x, y = rs.poisson(1.5, hh.size), rs.poisson(1.2, hh.size)
-    x[3], y[3] = 255, 0  # a legal extreme
+    x[3], y[3] = 255, 0      # extremes, one of them the padding's own scoreline
+    x[40], y[40] = 255, 255
+    x[41], y[41] = 0, 255
     fx = O.Fixtures(hh, aa, x, y, 5)
     for model in (O.MODEL_BASIC, O.MODEL_EXTENDED):
         hip_ctx.set_fixtures(model, hh.astype(np.uint16), aa.astype(np.uint16), x.astype(np.uint8),
