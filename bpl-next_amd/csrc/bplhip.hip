@@ -335,8 +335,14 @@ int launch_eval_dynamic(bplhip_ctx* c, int chains, const double* z, double* pot,
     return BPLHIP_OK;
 }
 
+// the neutral model's single-launch kernel can take the NUTS leaf with it (nuts_state != nullptr)
+bool neutral_leaf_fusable(const bplhip_ctx* c) {
+    return c->neutral && c->opt_fused_small && c->neu_fusable && c->NL.D <= 64 * nd::LEAF_NE_MAX &&
+           (dcn::fused_lds_doubles(c->NL, c->n, c->neu_slots) + dcn::fused_leaf_doubles(c->NL)) * 8 <= LDS_LIMIT;
+}
 int launch_eval_neutral(bplhip_ctx* c, int chains, const double* z, double* pot, double* grad,
-                        double* aux, hipStream_t s) {
+                        double* aux, hipStream_t s, double* nuts_state = nullptr, size_t nuts_stride = 0,
+                        int nuts_depth = 0, const nd::Persist* persist = nullptr) {
     const dcn::NeuLayout& L = c->NL;
     if (c->opt_fused_small && c->neu_fusable) {  // one workgroup per chain, one launch for all of them
         dcn::FusedArgs A{};
@@ -354,11 +360,23 @@ int launch_eval_neutral(bplhip_ctx* c, int chains, const double* z, double* pot,
         A.aux = aux;
         A.stop_after = c->opt_debug_stop;
         if (!c->neu_attr_set) {
-            HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(dcn::neu_fused),
+            HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(dcn::neu_fused<false>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT));
+            HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(dcn::neu_fused<true>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT));
             c->neu_attr_set = true;
         }
-        hipLaunchKernelGGL(dcn::neu_fused, dim3(chains), dim3(dcn::FUSED_BLOCK),
+        if (nuts_state) {  // persistent chains: one launch evaluates AND books the leapfrog of every chain
+            A.nuts = nuts_state;
+            A.nuts_stride = nuts_stride;
+            A.max_depth = nuts_depth;
+            A.persist = *persist;
+            hipLaunchKernelGGL(dcn::neu_fused<true>, dim3(chains), dim3(dcn::FUSED_BLOCK),
+                               (dcn::fused_lds_doubles(L, c->n, c->neu_slots) + dcn::fused_leaf_doubles(L)) * 8, s, A);
+            HIP_TRY(c, hipGetLastError());
+            return BPLHIP_OK;
+        }
+        hipLaunchKernelGGL(dcn::neu_fused<false>, dim3(chains), dim3(dcn::FUSED_BLOCK),
                            dcn::fused_lds_doubles(L, c->n, c->neu_slots) * 8, s, A);
         HIP_TRY(c, hipGetLastError());
         return BPLHIP_OK;
@@ -1828,6 +1846,11 @@ int run_chains_persistent(bplhip_ctx* c, hipStream_t s, const nuts::Config& nc, 
             if (rc != BPLHIP_OK) return rc;
         } else
         for (int k = 0; k < chunk; ++k) {
+            if (generic && neutral_leaf_fusable(c)) {  // evaluation + leaf of every chain in ONE launch
+                rc = launch_eval_neutral(c, C, nullptr, nullptr, nullptr, nullptr, s, ns, stride, md, &P);
+                if (rc != BPLHIP_OK) return rc;
+                continue;
+            }
             if (generic) {
                 for (int ch = 0; ch < C && rc == BPLHIP_OK; ++ch) {
                     double* nsc = ns + (size_t)ch * stride;

@@ -340,9 +340,16 @@ struct FusedArgs {
     double* grad;                // [chains, D]
     double* aux;                 // [chains, 4] or nullptr
     int stop_after;              // diagnostic build only: leave after this step (0: run to the end)
+    // NUTS-aware instantiation (one persistent chain per workgroup): z, potential, gradient and aux
+    // live in the chain's state block; the scalar wave books the leaf after the gradient
+    double* nuts;                // [chains][nuts_stride] or nullptr
+    size_t nuts_stride;
+    int max_depth;
+    nd::Persist persist;
 };
 
-inline size_t fused_lds_doubles(const NeuLayout& L, long long n, int n_slots) {
+__host__ __device__ inline size_t fused_leaf_doubles(const NeuLayout& L) { return (size_t)L.D + 8; }  // grad | potential | aux
+__host__ __device__ inline size_t fused_lds_doubles(const NeuLayout& L, long long n, int n_slots) {
     return FX_N + NEU_SUMS + 2 * (size_t)L.K + L.D + (size_t)L.T * dcd::P_N + (size_t)L.T * dcd::A_N +
            (size_t)(FUSED_CONF_COPIES + 1) * L.C + 2 * (size_t)n + (size_t)n_slots * dcd::A_N +
            (L.T + 2) / 2;
@@ -362,6 +369,7 @@ inline size_t fused_lds_doubles(const NeuLayout& L, long long n, int n_slots) {
 #define NEU_STAMP_FLUSH do { } while (0)
 #endif
 
+template <bool NUTS>
 __global__ __launch_bounds__(FUSED_BLOCK) void neu_fused(FusedArgs A) {
     extern __shared__ double lds[];
     NEU_STAMP_DECL;
@@ -381,8 +389,10 @@ __global__ __launch_bounds__(FUSED_BLOCK) void neu_fused(FusedArgs A) {
     int* slot_off = reinterpret_cast<int*>(part + (size_t)A.n_slots * dcd::A_N);  // [T + 1]
     unsigned long long* fixed_u = reinterpret_cast<unsigned long long*>(fixed);
 
-    const double* z = A.z + (size_t)blockIdx.x * D;
-    double* grad = A.grad + (size_t)blockIdx.x * D;
+    double* ns = NUTS ? A.nuts + (size_t)blockIdx.x * A.nuts_stride : nullptr;
+    if (NUTS && ns[nd::H_S_DONE] != 0.0) return;  // chain finished (uniform over the workgroup)
+    const double* z = NUTS ? nd::vec(ns, D, nd::V_ZN) : A.z + (size_t)blockIdx.x * D;
+    double* grad = NUTS ? nd::vec(ns, D, nd::V_GRAD) : A.grad + (size_t)blockIdx.x * D;
 
     // ---- A
     // every global word this thread needs before the first barrier is requested here
@@ -782,16 +792,44 @@ __global__ __launch_bounds__(FUSED_BLOCK) void neu_fused(FusedArgs A) {
             double U = 0.0;
 #pragma unroll
             for (int wv = 0; wv < FUSED_WAVES; ++wv) U += fixed[FX_WSUM + 2 * wv];
-            A.potential[blockIdx.x] = -(sums[12] + U - A.lgsum + fixed[FX_LP]);
+            const double pot = -(sums[12] + U - A.lgsum + fixed[FX_LP]);
+            if (NUTS) {
+                ns[nd::H_LEAF_PE] = pot;
+                ns[nd::H_LEAF_AUX0] = b.rho; ns[nd::H_LEAF_AUX1] = b.LB;
+                ns[nd::H_LEAF_AUX2] = b.UB;  ns[nd::H_LEAF_AUX3] = b.q;
+            } else {
+                A.potential[blockIdx.x] = pot;
+            }
             NEU_STAMP(7);
             NEU_STAMP_FLUSH;
-            if (A.aux) {
+            if (!NUTS && A.aux) {
                 double* aux = A.aux + (size_t)blockIdx.x * 4;
                 aux[0] = b.rho;
                 aux[1] = b.LB;
                 aux[2] = b.UB;
                 aux[3] = b.q;
             }
+        }
+    }
+    if (NUTS) {
+        // ---- the leapfrog's bookkeeping (nuts_dev.hip.h: what kp_leaf does as a launch of its own),
+        // on the scalar wave, once every wave's gradient entries are stored (a barrier waits for the
+        // stores before it; the state block is read through L2: this CU has not cached those lines)
+        __syncthreads();
+        if (wave == 0) {
+            double* gL = lds + fused_lds_doubles(L, N, A.n_slots);   // grad[D] | potential | aux[4]
+            nd::LeafState<nd::LEAF_NE_MAX> leaf = nd::leaf_prefetch<nd::LEAF_NE_MAX>(ns, D, A.max_depth, lane);
+            const double* gr = nd::vec(ns, D, nd::V_GRAD);
+            for (int i = lane; i < D; i += 64) gL[i] = dc::ld_sc1(&gr[i]);
+            if (lane == 0) {
+                gL[D] = dc::ld_sc1(&ns[nd::H_LEAF_PE]);
+                gL[D + 1] = dc::ld_sc1(&ns[nd::H_LEAF_AUX0]); gL[D + 2] = dc::ld_sc1(&ns[nd::H_LEAF_AUX1]);
+                gL[D + 3] = dc::ld_sc1(&ns[nd::H_LEAF_AUX2]); gL[D + 4] = dc::ld_sc1(&ns[nd::H_LEAF_AUX3]);
+            }
+            nd::leaf_prepare<true>(leaf);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (one wave: its LDS writes before its reads)
+            const bool sub_done = nd::nuts_leaf(ns, D, A.max_depth, lane, gL, leaf);
+            if (sub_done) nd::persist_advance(ns, A.persist, blockIdx.x, lane);
         }
     }
 }
