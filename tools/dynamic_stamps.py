@@ -16,7 +16,7 @@ c.set_fixtures_dynamic(np.array(h), np.array(a), rs.poisson(1.5, n), rs.poisson(
                        np.zeros(n, np.uint8), Tn, G)
 D = c.dim
 o_u = D - G * Tn
-names = "entry cells-done shadow-done B1 rates-done B2 adjoint-done B3 back-done final-done".split()
+names = "entry cells-stored sigmoid-done (same) rates-done barrier-2 adjoint-done barrier-3 back-done final-done".split()
 z = torch.tensor(np.random.RandomState(7).uniform(-.3, .3, (8, D)), dtype=torch.float64, device=c.device)
 U = torch.zeros(8, dtype=torch.float64, device=c.device); gbuf = torch.zeros_like(z)
 rows, ends = [], []
