@@ -671,10 +671,23 @@ __device__ __forceinline__ void f32_table_entry(const Layout& L, const F32Scalar
 }
 // `first`: team `tid`'s entries of z, loaded by the caller BEFORE its bulk loads -- vector loads
 // return in order, and behind a tile's worth of fixture loads they would wait for HBM
-template <bool EXT, bool SC1 = false>
+// SMALLT (at most 64 teams, fewer than threads): a thread builds at most ONE entry, from `first` --
+// no load inside the loop.  With the loop, the entry's z values are a phi of `first` and an in-loop
+// load, and the compiler waits for EVERY outstanding load (the first tile's among them) before it
+// uses them.
+template <bool EXT, bool SC1 = false, bool SMALLT = false>
 __device__ __forceinline__ void build_tables_f32(const Layout& L, const double* z,
                                                  const float* xsf, float2* tabH, float2* tabA,
                                                  int tid, const TeamZ& first, const F32Scalars& s) {
+    if (SMALLT) {
+        if (tid <= L.T) {
+            float2 vh = make_float2(0.f, 0.f), va = vh;
+            if (tid < L.T) f32_table_entry<EXT, SC1>(L, s, z, xsf, tid, first, &vh, &va);
+            tabH[tid] = vh;
+            tabA[tid] = va;
+        }
+        return;
+    }
     for (int t = tid; t <= L.T; t += BLOCK) {
         float2 vh = make_float2(0.f, 0.f), va = vh;
         if (t < L.T) f32_table_entry<EXT, SC1>(L, s, z, xsf, t, t == tid ? first : load_team_z<EXT, SC1>(L, z, t), &vh, &va);
@@ -2275,7 +2288,7 @@ __global__ DC_LAUNCH_BOUNDS void dc_eval(EvalArgs A) {
         if (NUTS && nuts_done != 0.0) return;
 
         // ---- 1. per-team tables (float32) + zero accumulators
-        build_tables_f32<CLIP>(L, z, A.xsf, tabH, tabA, tid, tz0, fs);
+        build_tables_f32<CLIP, false, STAGED>(L, z, A.xsf, tabH, tabA, tid, tz0, fs);
         for (int i = tid; i < 3 * T1; i += BLOCK) acc[i] = 0.0;
         __syncthreads();
         DC_STAMP(1);
