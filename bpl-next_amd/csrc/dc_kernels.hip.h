@@ -863,11 +863,13 @@ struct SigSite {
     double v, dv, log_v, log_1mv, jac, sig;  // jac = -sp(z) - sp(-z); sig = unclipped
 };
 __device__ __forceinline__ SigSite sig_site(double zc) {
+    // (lean:: -- the short float64 routines: this chain is on the critical path of every leapfrog
+    // inside the persistent kernel, and of the extended model's plain evaluation)
     const double az = fabs(zc);
-    const double e = exp(-az);
-    const double l = log1p(e);            // sp(-|z|)
-    const double sp_pos = az + l;         // sp(|z|)
-    const double s_abs = 1.0 / (1.0 + e); // sigmoid(|z|)
+    const double e = lean::exp(-az);
+    const double l = lean::log1p_pos(e);            // sp(-|z|)
+    const double sp_pos = az + l;                   // sp(|z|)
+    const double s_abs = lean::rcp(1.0 + e);        // sigmoid(|z|)
     const double s = zc >= 0 ? s_abs : 1.0 - s_abs;
     SigSite r;
     r.sig = s;
@@ -937,9 +939,9 @@ __device__ void prior_body(const EvalArgs& A, int chain, char* smem, double* zo_
 
     // ---- z-only scalars, one transcendental chain per wave, in parallel
     //   0 s_a  1 s_d  2 s_h  3..8 corr site  9..14 u site
-    if (tid == 0) sc[0] = exp(z[L.o_sa]);
-    if (tid == 64) sc[1] = exp(z[L.o_sd]);
-    if (tid == 128) sc[2] = CLIP ? exp(z[L.o_sh]) : 0.0;
+    if (tid == 0) sc[0] = lean::exp(z[L.o_sa]);
+    if (tid == 64) sc[1] = lean::exp(z[L.o_sd]);
+    if (tid == 128) sc[2] = CLIP ? lean::exp(z[L.o_sh]) : 0.0;
     if (tid == 192) {
         const SigSite s = sig_site(z[L.o_corr]);
         sc[3] = s.v; sc[4] = s.dv; sc[5] = s.log_v; sc[6] = s.log_1mv; sc[7] = s.jac;
@@ -1012,7 +1014,7 @@ __device__ void prior_body(const EvalArgs& A, int chain, char* smem, double* zo_
         }
         const double arg = j == 0 ? att + ha : (j == 1 ? att : -def);
         const float tabv = j == 0 ? tabH[t].x : (j == 1 ? tabA[t].x : tabH[t].y);
-        const double tv = exp(arg);
+        const double tv = lean::exp(arg);
         tru[j * T + t] = tv;
         // eps = log(true/table) = log1p(r), r = (true - table)/table, |r| ~ 1e-7
         const double r = (tv - (double)tabv) / (double)tabv;
@@ -1046,8 +1048,8 @@ __device__ void prior_body(const EvalArgs& A, int chain, char* smem, double* zo_
     if (CLIP && (!sums_on_wave || wave == WAVES - 1)) {
         rp = 2.0 * sc[9] - 1.0;
         const double vv = 1.0 - rp * rp;
-        log_vv = log(vv);
-        ivv = 1.0 / vv;  // one division instead of six per team
+        log_vv = lean::log(vv);
+        ivv = lean::rcp(vv);  // one division instead of six per team
     }
     auto team_term = [&](int t, double cAt, double cDt, double cHt, double z0, double z1, double z2) {
         const double att = par[t], def = par[T + t], ha = par[2 * T + t];
@@ -1156,16 +1158,15 @@ __device__ void prior_body(const EvalArgs& A, int chain, char* smem, double* zo_
             for (int u = 0; u < PAIR_BATCH; ++u) take(q[u], p0 + u * BLOCK < A.P);
         }
     }
-    mPf = wave_max_f32(mPf);
-    mQf = wave_max_f32(mQf);
-    mRf = wave_max_f32(mRf);
+    wave_max3_f32(mPf, mQf, mRf);
     if (lane == 0) {
         redm[wave * 4 + 0] = mPf;
         redm[wave * 4 + 1] = mQf;
         redm[wave * 4 + 2] = mRf;
     }
     {
-        const double wP = wave_max_f64(mP), wQ = wave_max_f64(mQ), wR = wave_max_f64(mR);
+        double wP = mP, wQ = mQ, wR = mR;
+        wave_max3_f64(wP, wQ, wR);
         // first lane holding the wave maximum (no cross-lane min-reduction, no reload)
         const unsigned long long bP = __ballot(mP == wP), bQ = __ballot(mQ == wQ),
                                  bR = __ballot(mR == wR);
@@ -1209,9 +1210,8 @@ __device__ void prior_body(const EvalArgs& A, int chain, char* smem, double* zo_
                      a2 = src ? amx[lane * 8 + 2] : 0.0;
         const uint32_t q0 = src ? (uint32_t)amx[lane * 8 + 3] : 0u, q1 = src ? (uint32_t)amx[lane * 8 + 4] : 0u,
                        q2 = src ? (uint32_t)amx[lane * 8 + 5] : 0u;
-        M = wave_max_f64(a0);
-        Lh = wave_max_f64(a1);
-        La = wave_max_f64(a2);
+        M = a0; Lh = a1; La = a2;
+        wave_max3_f64(M, Lh, La);
         const unsigned long long bP = __ballot(src && a0 == M), bQ = __ballot(src && a1 == Lh),
                                  bR = __ballot(src && a2 == La);
         pP = (uint32_t)__builtin_amdgcn_readlane((int)q0, bP ? __ffsll((long long)bP) - 1 : 0);
@@ -2460,23 +2460,32 @@ struct ZPolled {
     float a, d, h;            // team entries (decentered / standardised sites)
     float sa, sd, md, corr;   // std_attack, std_defence, mean_defence, corr_coef_raw
     float e0, e1;             // basic: home_advantage, -; extended: std_home_advantage, mean_home_advantage
+    float coef;               // extended with covariates: lane k < K holds attack coefficient k, lane K + k defence k
     int state;                // 1 ok, 0 the chain finished, -1 timed out
 };
+// covariate coefficients that travel with the lanes' own granules (one per lane, fetched in the SAME
+// round of loads and handed round by readlane): polled one after the other inside the table build they
+// were 2K dependent round trips per leapfrog
+constexpr int LOOP_COEF_MAX_K = 32;
 template <bool EXT>
 __device__ __forceinline__ ZPolled poll_z(const unsigned long long* zg, const Layout& L, int t,
-                                          unsigned int want, unsigned int fin_tag) {
-    const int idx[9] = {(EXT ? L.o_sat : L.o_adec) + t, (EXT ? L.o_sdt : L.o_ddec) + t,
-                        EXT ? L.o_hadec + t : L.o_sa, L.o_sa, L.o_sd, L.o_md, L.o_corr,
-                        EXT ? L.o_sh : L.o_ha, EXT ? L.o_mha : L.o_sa};
-    unsigned long long v[9];
+                                          unsigned int want, unsigned int fin_tag, int lane) {
+    const int K = EXT ? L.K : 0;
+    const int o_coef = K > 0 && K <= LOOP_COEF_MAX_K ? (lane < K ? L.o_bA + lane : lane < 2 * K ? L.o_bD + lane - K : L.o_bA)
+                                                    : L.o_sa;
+    constexpr int NG = EXT ? 10 : 9;   // (the basic model has no coefficients: its batch stays at nine)
+    const int idx[10] = {(EXT ? L.o_sat : L.o_adec) + t, (EXT ? L.o_sdt : L.o_ddec) + t,
+                         EXT ? L.o_hadec + t : L.o_sa, L.o_sa, L.o_sd, L.o_md, L.o_corr,
+                         EXT ? L.o_sh : L.o_ha, EXT ? L.o_mha : L.o_sa, o_coef};
+    unsigned long long v[10] = {};
     ZPolled r;
     r.state = -1;
     for (int spin = 0; spin < GRANULE_SPIN_LIMIT; ++spin) {
 #pragma unroll
-        for (int k = 0; k < 9; ++k) v[k] = ld_granule(&zg[idx[k]]);
+        for (int k = 0; k < NG; ++k) v[k] = ld_granule(&zg[idx[k]]);
         bool ok = true, fin = false;
 #pragma unroll
-        for (int k = 0; k < 9; ++k) {
+        for (int k = 0; k < NG; ++k) {
             const unsigned int tg = (unsigned int)(v[k] >> 32);
             ok = ok && tg == want;
             fin = fin || tg == fin_tag;
@@ -2488,6 +2497,7 @@ __device__ __forceinline__ ZPolled poll_z(const unsigned long long* zg, const La
     auto f = [&](int k) { return __uint_as_float((unsigned int)v[k]); };
     r.a = f(0); r.d = f(1); r.h = f(2); r.sa = f(3); r.sd = f(4); r.md = f(5); r.corr = f(6);
     r.e0 = f(7); r.e1 = f(8);
+    r.coef = f(9);
     return r;
 }
 // one more granule (covariate coefficients), same protocol
@@ -2578,11 +2588,18 @@ __global__ DC_LAUNCH_BOUNDS void dc_eval_loop(EvalArgs A) {
     const int slot0 = A.wg_slots[kq];
     long long* ga = A.gacc + (size_t)chain * ga_rows(T) * GA_ROW;
     if (tid == 0) *flag = 1;
+    // this thread's row of the standardised covariates: data, resident for the whole launch
+    constexpr int KREG = 8;
+    const bool coef_fast = CLIP && L.K > 0 && L.K <= KREG;
+    float xs_reg[KREG];
+#pragma unroll
+    for (int k = 0; k < KREG; ++k)
+        xs_reg[k] = coef_fast && k < L.K ? A.xsf[(size_t)min(tid, T - 1) * L.K + k] : 0.f;
 
     for (int s = 0; s < steps; ++s) {
         const unsigned int want = A.tag_base + 1u + (unsigned int)s;
         // ---- this thread's granules: one round trip brings the data and the "go"
-        ZPolled zp = poll_z<CLIP>(zg, L, min(tid, T - 1), want, fin_tag);
+        ZPolled zp = poll_z<CLIP>(zg, L, min(tid, T - 1), want, fin_tag, lane);
         DC_STAMP(0);
         F32Scalars fs;
         fs.s_a = exp_f32(zp.sa);
@@ -2612,6 +2629,15 @@ __global__ DC_LAUNCH_BOUNDS void dc_eval_loop(EvalArgs A) {
                     ha = fs.gam;
                 } else {
                     float apm = 0.f, dpm = fs.m;
+                    if (coef_fast && t == tid) {   // (the usual case: coefficients came with zp, the row is resident)
+#pragma unroll
+                        for (int k = 0; k < KREG; ++k) {
+                            const float bA = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(zp.coef), k < L.K ? k : 0));
+                            const float bD = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(zp.coef), k < L.K ? L.K + k : 0));
+                            apm += k < L.K ? xs_reg[k] * bA : 0.f;
+                            dpm += k < L.K ? xs_reg[k] * bD : 0.f;
+                        }
+                    } else
                     for (int k = 0; k < L.K; ++k) {
                         const float xv = A.xsf[(size_t)t * L.K + k];
                         apm += xv * poll_one(&zg[L.o_bA + k], want, fin_tag, &state);
