@@ -1251,7 +1251,12 @@ static int bplhip_set_fixtures_dynamic_impl(bplhip_ctx* c, int64_t n, int32_t n_
     HIP_TRY(c, hipMemcpyAsync(c->dd_nv.p, nv.data(), n, hipMemcpyHostToDevice, s));
     HIP_TRY(c, c->dd_cells.ensure(GT * dcd::P_N * 8));
     HIP_TRY(c, c->dd_acc.ensure(dcd::scratch_doubles(n_gameweeks, n_teams, k) * 8));
-    c->dyn_scratch_clean = false;
+    // the single-launch kernel finds its scratch zeroed and its cell records armed (and leaves them so):
+    // done here, so that a launch sequence captured right after this call holds no fills
+    HIP_TRY(c, hipMemsetAsync(c->dd_acc.p, 0, dcd::scratch_doubles(n_gameweeks, n_teams, k) * 8, s));
+    HIP_TRY(c, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(c->dd_cells.p), (int)dcd::CELL_EMPTY_WORD,
+                                 GT * dcd::P_N * 2, s));
+    c->dyn_scratch_clean = true;
     HIP_TRY(c, c->dd_hyp.ensure((size_t)6 * n_gameweeks * 8));
     {   // first fixture of every gameweek (sorted), and the two arrival counters
         std::vector<int> gw_off(n_gameweeks + 1, 0);
