@@ -163,6 +163,9 @@ int bplhip_set_fixtures_neutral(bplhip_ctx* ctx, int64_t n, int32_t n_teams,
  *   "fused_small" 1 (default) = neutral / dynamic evaluations small enough for it run as ONE
  *            launch (neutral: one workgroup per chain, everything in LDS; dynamic: phases behind
  *            grid barriers); 0 = always the multi-launch path.
+ *   "dense_pairs" 1 (default) = a complete pair table (every ordered pair h != a present) of 8192
+ *            pairs or more takes the rho bounds from the top two table entries per role
+ *            (O(teams)); 0 = always walk the pair table.
  *   "max_wg" streaming workgroups per evaluation (default 255: with the prior workgroup
  *            one per CU); applies at the next bplhip_set_fixtures
  *   "active_waves" waves per workgroup that own tiles: 0 (default) = automatic -- short
