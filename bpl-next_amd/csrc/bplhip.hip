@@ -2288,17 +2288,20 @@ static int bplhip_predict_set_posterior_impl(bplhip_ctx* c, int32_t s, int32_t t
     HIP_TRY(c, hipMemcpy(c->dp_def.p, defence, st, hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(c->dp_ha.p, home_advantage, hb, hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(c->dp_corr.p, corr_coef, (size_t)s * 8, hipMemcpyHostToDevice));
-    // float32 copies for the grid kernel (the reference's own dtype)
-    auto up32 = [&](DevBuf& b, const double* src, size_t n) -> int {
-        std::vector<float> tmp(src, src + n);
-        HIP_TRY(c, b.ensure(n * 4));
-        HIP_TRY(c, hipMemcpy(b.p, tmp.data(), n * 4, hipMemcpyHostToDevice));
+    // float32 copies for the grid kernel (the reference's own dtype), TEAM-major: a team's draws are
+    // contiguous, a block of draws is one coalesced load (dc_predict.hip.h)
+    auto up32 = [&](DevBuf& b, const double* src, size_t rows, size_t cols) -> int {  // src [rows, cols] -> [cols, rows]
+        std::vector<float> tmp(rows * cols);
+        for (size_t r = 0; r < rows; ++r)
+            for (size_t q = 0; q < cols; ++q) tmp[q * rows + r] = (float)src[r * cols + q];
+        HIP_TRY(c, b.ensure(tmp.size() * 4));
+        HIP_TRY(c, hipMemcpy(b.p, tmp.data(), tmp.size() * 4, hipMemcpyHostToDevice));
         return BPLHIP_OK;
     };
-    int rc = up32(c->dp_att32, attack, (size_t)s * t);
-    if (rc == BPLHIP_OK) rc = up32(c->dp_def32, defence, (size_t)s * t);
-    if (rc == BPLHIP_OK) rc = up32(c->dp_ha32, home_advantage, home_advantage_per_team ? (size_t)s * t : (size_t)s);
-    if (rc == BPLHIP_OK) rc = up32(c->dp_corr32, corr_coef, (size_t)s);
+    int rc = up32(c->dp_att32, attack, (size_t)s, (size_t)t);
+    if (rc == BPLHIP_OK) rc = up32(c->dp_def32, defence, (size_t)s, (size_t)t);
+    if (rc == BPLHIP_OK) rc = up32(c->dp_ha32, home_advantage, (size_t)s, home_advantage_per_team ? (size_t)t : 1);
+    if (rc == BPLHIP_OK) rc = up32(c->dp_corr32, corr_coef, (size_t)s, 1);
     if (rc != BPLHIP_OK) return rc;
     c->pred_S = s;
     c->pred_T = t;
@@ -2342,7 +2345,8 @@ static int bplhip_predict_score_grid_impl(bplhip_ctx* c, int64_t m, const uint16
     A.h = q;
     A.a = q + m;
     A.out = d_out;
-    hipLaunchKernelGGL(dcp::predict_score_grid, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, s, A);
+    hipLaunchKernelGGL(dcp::predict_score_grid, dim3((unsigned)((m + dcp::GRID_WAVES - 1) / dcp::GRID_WAVES)),
+                       dim3(64 * dcp::GRID_WAVES), 0, s, A);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(out, d_out, cells * 8, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));

@@ -66,11 +66,26 @@ __global__ __launch_bounds__(256) void predict_score_proba(PredictArgs A) {
 }
 
 // ---- the grid kernel
+// One WAVE per fixture, blocks of 64 posterior draws.
+//   lane = draw:  the posterior's float32 copies are TEAM-major ([T][S]: a team's draws are
+//     contiguous), so a block is one coalesced round of loads (the next block's are in flight while
+//     this one is worked on).  Each lane works out its draw's two Poisson pmf vectors for the tile's
+//     16 goal counts -- one exp, then pmf(k+1) = pmf(k) rate / (k+1) -- and parks them in a
+//     wave-private LDS strip [draw][goal]; the four tau corrections of the low scorelines are plain
+//     per-draw products here as well.
+//   lane = (goal, draw % 4):  per group of four draws the two pmf vectors are the A and B operands of
+//     v_mfma_f32_16x16x4_f32 -- the grid is a sum over draws of OUTER PRODUCTS, a genuine rank-4
+//     update per instruction -- two LDS reads and one MFMA per step, float32 for 64 draws, then
+//     folded into float64.
+// History (24 320 fixtures x 1000 draws x 16 x 16, profiles/r02/): gathers attack[s, h] ... per group
+// of four draws inside the loop, pmf entries by one exp each, tau corrections in float64 on every
+// step: 1010 us; coalesced blocks + prefetch: 624 us; pmf by recurrence in the draw layout and the
+// corrections once per draw: see profiles/r02/kernels.md.
 struct GridArgs {
     int S, T;
-    const float* attack;     // [S,T] float32
-    const float* defence;    // [S,T]
-    const float* home_adv;   // [S] (ha_stride = 0) or [S,T] (ha_stride = T)
+    const float* attack;     // [T,S] float32, team-major
+    const float* defence;    // [T,S]
+    const float* home_adv;   // [S] (ha_stride = 0) or [T,S] (ha_stride != 0)
     int ha_stride;
     const float* corr;       // [S]
     int M, G;                // fixtures, max_goals
@@ -79,78 +94,98 @@ struct GridArgs {
     double* out;             // [M, G+1, G+1]
 };
 constexpr int GRID_MAX_GOALS = 63;
+constexpr int GRID_WAVES = 4;
+constexpr int GRID_ROW = 17;   // floats per draw in the strip (16 goal counts + 1: conflict-free both ways)
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-__global__ __launch_bounds__(256) void predict_score_grid(GridArgs A) {
-    __shared__ float lg[GRID_MAX_GOALS + 1];  // lgamma(k + 1)
-    for (int k = threadIdx.x; k <= GRID_MAX_GOALS; k += blockDim.x) lg[k] = (float)lgamma((double)k + 1.0);
+__global__ __launch_bounds__(64 * GRID_WAVES) void predict_score_grid(GridArgs A) {
+    __shared__ float lg[GRID_MAX_GOALS + 2];          // lgamma(k + 1)
+    __shared__ float rk[GRID_MAX_GOALS + 2];          // 1 / (k + 1)
+    __shared__ float strip[GRID_WAVES][2][64 * GRID_ROW];  // per wave: pmf_home, pmf_away of a block [draw][goal]
+    for (int k = threadIdx.x; k <= GRID_MAX_GOALS + 1; k += blockDim.x) {
+        lg[k] = (float)lgamma((double)k + 1.0);
+        rk[k] = (float)(1.0 / ((double)k + 1.0));
+    }
     __syncthreads();
-    const int lane = threadIdx.x & 63, d = lane >> 4, i = lane & 15;
-    const int f = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, d = lane >> 4, i = lane & 15;
+    const int f = blockIdx.x * GRID_WAVES + wave;
     if (f >= A.M) return;  // (wave uniform)
-    const int h = A.h[f], a = A.a[f], G = A.G, S = A.S, T = A.T;
+    const int h = A.h[f], a = A.a[f], G = A.G, S = A.S;
     const int G1 = G + 1, nt = (G + 16) / 16;
     double* out = A.out + (size_t)f * G1 * G1;
     const double inv_s = 1.0 / (double)S;
+    const float* att_h = A.attack + (size_t)h * S;
+    const float* att_a = A.attack + (size_t)a * S;
+    const float* def_h = A.defence + (size_t)h * S;
+    const float* def_a = A.defence + (size_t)a * S;
+    const float* ha_p = A.ha_stride ? A.home_adv + (size_t)h * S : A.home_adv;
+    float* pmH = strip[wave][0];
+    float* pmA = strip[wave][1];
+    // a block's raw values for this lane's draw (clamped index: the loads are unconditional)
+    struct Raw { float ah, aa, dh, da, ha, rho; };
+    auto load_raw = [&](int s0) {
+        const int s = min(s0 + lane, S - 1);
+        Raw r;
+        r.ah = att_h[s]; r.aa = att_a[s]; r.dh = def_h[s]; r.da = def_a[s]; r.ha = ha_p[s]; r.rho = A.corr[s];
+        return r;
+    };
     for (int tx = 0; tx < nt; ++tx)
         for (int ty = 0; ty < nt; ++ty) {
-            const int x = 16 * tx + i, y = 16 * ty + i;
-            const float fx = (float)x, fy = (float)y;
-            const float lgx = lg[min(x, GRID_MAX_GOALS)], lgy = lg[min(y, GRID_MAX_GOALS)];
+            const int x0 = 16 * tx, y0 = 16 * ty;
             const bool low_tile = tx == 0 && ty == 0;
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
             double accd[4] = {0.0, 0.0, 0.0, 0.0};
-            double c_a = 0.0, c_b = 0.0;  // lane i = 0: cells (0,0), (0,1); lane i = 1: (1,0), (1,1)
-            int fold = 0;
-            for (int s0 = 0; s0 < S; s0 += 4) {
-                const int sdr = s0 + d;
-                const bool valid = sdr < S;
-                const int s = valid ? sdr : S - 1;
-                const size_t r = (size_t)s * T;
-                const float ha = A.ha_stride ? A.home_adv[r + h] : A.home_adv[s];
-                const float eh = A.attack[r + h] - A.defence[r + a] + ha;
-                const float ea = A.attack[r + a] - A.defence[r + h];
-                const float lh = __expf(eh), la = __expf(ea);
-                // exp(Poisson.log_prob(k)) = exp(k log(rate) - rate - lgamma(k + 1))
-                const float pa = valid && x <= G ? __expf(fmaf(fx, eh, -lh) - lgx) : 0.f;
-                const float pb = valid && y <= G ? __expf(fmaf(fy, ea, -la) - lgy) : 0.f;
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(pa, pb, acc, 0, 0, 0);
-                if (low_tile && i < 2 && valid) {
-                    // exp(log(clip(1 + rho c, 0))) - 1 for the lane's two cells (bpl/_util.py:58-91)
-                    const float rho = A.corr[s];
-                    if (i == 0) {  // pa = pmf_h(0), pb = pmf_a(0); pmf_a(1) = pb * la
-                        c_a += (double)(pa * pb) * ((double)fmaxf(1.f - rho * lh * la, 0.f) - 1.0);
-                        c_b += (double)(pa * pb * la) * ((double)fmaxf(1.f + rho * lh, 0.f) - 1.0);
-                    } else {       // pa = pmf_h(1), pb = pmf_a(1); pmf_a(0) = exp(-la)
-                        c_a += (double)(pa * __expf(-la)) * ((double)fmaxf(1.f + rho * la, 0.f) - 1.0);
-                        c_b += (double)(pa * pb) * ((double)fmaxf(1.f - rho, 0.f) - 1.0);
+            double c00 = 0.0, c01 = 0.0, c10 = 0.0, c11 = 0.0;  // this lane's draws: tau corrections
+            Raw nxt = load_raw(0);
+            for (int s0 = 0; s0 < S; s0 += 64) {
+                const Raw cur = nxt;
+                if (s0 + 64 < S) nxt = load_raw(s0 + 64);     // in flight while this block is worked on
+                {   // lane = draw: the tile's 16 entries of both pmf vectors
+                    const bool valid = s0 + lane < S;
+                    const float eh = cur.ah - cur.da + cur.ha, ea = cur.aa - cur.dh;
+                    const float lh = __expf(eh), la = __expf(ea);
+                    // exp(Poisson.log_prob(k)) = exp(k log(rate) - rate - lgamma(k + 1)) at the tile's first
+                    // count, then pmf(k + 1) = pmf(k) rate / (k + 1)
+                    float ph = valid ? __expf(fmaf((float)x0, eh, -lh) - lg[x0]) : 0.f;
+                    float pa = valid ? __expf(fmaf((float)y0, ea, -la) - lg[y0]) : 0.f;
+                    if (low_tile) {
+                        // exp(log(clip(1 + rho c, 0))) - 1 for the four low scorelines (bpl/_util.py:58-91)
+                        const float rho = cur.rho, p1h = ph * lh, p1a = pa * la;
+                        c00 += (double)((ph * pa) * (fmaxf(1.f - rho * lh * la, 0.f) - 1.f));
+                        c01 += (double)((ph * p1a) * (fmaxf(1.f + rho * lh, 0.f) - 1.f));
+                        c10 += (double)((p1h * pa) * (fmaxf(1.f + rho * la, 0.f) - 1.f));
+                        c11 += (double)((p1h * p1a) * (fmaxf(1.f - rho, 0.f) - 1.f));
+                    }
+                    float* rowH = pmH + lane * GRID_ROW;
+                    float* rowA = pmA + lane * GRID_ROW;
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) {
+                        rowH[k] = x0 + k <= G ? ph : 0.f;
+                        rowA[k] = y0 + k <= G ? pa : 0.f;
+                        ph *= lh * rk[x0 + k];
+                        pa *= la * rk[y0 + k];
                     }
                 }
-                if (++fold == 16) {  // 64 draws per float32 accumulation
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) accd[j] += (double)acc[j];
-                    acc = f32x4{0.f, 0.f, 0.f, 0.f};
-                    fold = 0;
+                for (int g = 0; g < 16; ++g) {   // lane = (goal count i, draw 4 g + d)
+                    const int sl = 4 * g + d;
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(pmH[sl * GRID_ROW + i], pmA[sl * GRID_ROW + i], acc, 0, 0, 0);
                 }
-            }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) accd[j] += (double)acc[j];
-            if (low_tile) {  // the four corrections: sum over the four draw groups d
-                c_a += __shfl_xor(c_a, 16);
-                c_b += __shfl_xor(c_b, 16);
-                c_a += __shfl_xor(c_a, 32);
-                c_b += __shfl_xor(c_b, 32);
+                for (int j = 0; j < 4; ++j) accd[j] += (double)acc[j];   // 64 draws per float32 accumulation
+            }
+            if (low_tile) {
+                double c4[4] = {c00, c01, c10, c11};
+                dc::wave_sum4_f64(c4);
                 // cell (x, y) lives on lane (d = x / 4, i = y), register j = x % 4: (0,0) and (1,0)
                 // on lane 0 (j = 0, 1), (0,1) and (1,1) on lane 1
-                const double c00 = __shfl(c_a, 0), c01 = __shfl(c_b, 0), c10 = __shfl(c_a, 1),
-                             c11 = __shfl(c_b, 1);
-                if (lane == 0) { accd[0] += c00; accd[1] += c10; }
-                if (lane == 1) { accd[0] += c01; accd[1] += c11; }
+                if (lane == 0) { accd[0] += c4[0]; accd[1] += c4[2]; }
+                if (lane == 1) { accd[0] += c4[1]; accd[1] += c4[3]; }
             }
             // D[row = 4 (lane >> 4) + j][col = lane & 15]
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int xo = 16 * tx + 4 * d + j;
+                const int xo = 16 * tx + 4 * d + j, y = y0 + i;
                 if (xo <= G && y <= G) out[(size_t)xo * G1 + y] = accd[j] * inv_s;
             }
         }
