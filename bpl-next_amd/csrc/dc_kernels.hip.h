@@ -1125,8 +1125,8 @@ __device__ void prior_body(const EvalArgs& A, int chain, char* smem, double* zo_
     }
     const bool dense = dense_in && dense_maxima_f32<CLIP>(T, tabH, tabA, redm, tid, &dPf, &dQf, &dRf);  // (barrier inside)
     if (dense) {
-        __syncthreads();  // (every thread has read the float32 records: redm is written again below)
-        mPf = dPf; mQf = dQf; mRf = dRf;
+        // (the values are wave-uniform already: no reductions, nothing written over the records; wave 0
+        // files the float64 maxima and their arg-pairs for the combine below, zeros for the other waves)
         if (wave == 0) {
             auto m1 = [&](int k) { return rec64[k * 4]; };
             auto m2 = [&](int k) { return rec64[k * 4 + 1]; };
@@ -1147,6 +1147,12 @@ __device__ void prior_body(const EvalArgs& A, int chain, char* smem, double* zo_
                 mP = lh * la;
                 aP = (uint32_t)h | ((uint32_t)a << 16);
             }
+            if (lane < WAVES) {
+                const bool me = lane == 0;
+                amx[lane * 8 + 0] = me ? mP : 0.0; amx[lane * 8 + 1] = me ? mQ : 0.0; amx[lane * 8 + 2] = me ? mR : 0.0;
+                amx[lane * 8 + 3] = me ? (double)aP : 0.0; amx[lane * 8 + 4] = me ? (double)aQ : 0.0;
+                amx[lane * 8 + 5] = me ? (double)aR : 0.0;
+            }
         }
     } else {
         if (tid < A.P) take(pr0, true);
@@ -1158,6 +1164,7 @@ __device__ void prior_body(const EvalArgs& A, int chain, char* smem, double* zo_
             for (int u = 0; u < PAIR_BATCH; ++u) take(q[u], p0 + u * BLOCK < A.P);
         }
     }
+    if (!dense) {
     wave_max3_f32(mPf, mQf, mRf);
     if (lane == 0) {
         redm[wave * 4 + 0] = mPf;
@@ -1178,6 +1185,7 @@ __device__ void prior_body(const EvalArgs& A, int chain, char* smem, double* zo_
             amx[wave * 8 + 3] = (double)pP; amx[wave * 8 + 4] = (double)pQ;
             amx[wave * 8 + 5] = (double)pR;
         }
+    }
     }
     __syncthreads();
     DC_STAMP(3);
@@ -1231,12 +1239,15 @@ __device__ void prior_body(const EvalArgs& A, int chain, char* smem, double* zo_
         const double LB = -1.0 / fmax(Lh, La);
         const double rho = LB + q * (UB - LB);
         // the float32 rho every streaming workgroup computed (bit for bit)
-        float fP = 0.f, fQ = 0.f, fR = 0.f;
+        float fP = dPf, fQ = dQf, fR = dRf;   // (separable bounds: already the workgroup's maxima)
+        if (!dense) {
+            fP = fQ = fR = 0.f;
 #pragma unroll
-        for (int wv = 0; wv < WAVES; ++wv) {
-            fP = fmaxf(fP, redm[wv * 4 + 0]);
-            fQ = fmaxf(fQ, redm[wv * 4 + 1]);
-            fR = fmaxf(fR, redm[wv * 4 + 2]);
+            for (int wv = 0; wv < WAVES; ++wv) {
+                fP = fmaxf(fP, redm[wv * 4 + 0]);
+                fQ = fmaxf(fQ, redm[wv * 4 + 1]);
+                fR = fmaxf(fR, redm[wv * 4 + 2]);
+            }
         }
         const float rho_f = rho_f32(fP, fQ, fR, fs.q);
         DC_STAMP(15);
