@@ -756,7 +756,7 @@ __device__ void final_body(const DynArgs& A, double* shl, const Bounds* known) {
 
 
 // ---- the whole evaluation in ONE launch: dyn_cells, dyn_pass1, dyn_pass2 and dyn_back as
-// phases of one kernel with three grid barriers between them (all workgroups are resident: one
+// phases of one kernel with a data-flagged hand-off and two grid barriers between them (all workgroups are resident: one
 // per four teams, at most 256).  A launch boundary costs ~2 us of drain + dispatch and the next
 // kernel starts cold; here each wave KEEPS its team's latent values, exp(std) and the u-site
 // transforms in registers from the first phase to the last, every fixture-independent
