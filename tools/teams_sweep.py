@@ -5,7 +5,11 @@ import numpy as np, torch
 from bench import synthetic_league
 from bpl._ffi import HipContext, MODEL_BASIC
 c = HipContext(0)
-for T in (20, 32, 48, 64, 100, 200):
+if "ACTIVE_WAVES" in os.environ:   # experiment: a fixed partition (8 = all waves own tiles, half the workgroups)
+    c.set_option("active_waves", int(os.environ["ACTIVE_WAVES"]))
+if "MAX_WG" in os.environ:
+    c.set_option("max_wg", int(os.environ["MAX_WG"]))
+for T in [int(t) for t in os.environ.get("TEAMS_LIST", "20,32,48,64,100,200").split(",")]:
     h, a, x, y = synthetic_league(1_000_000, T)
     c.set_fixtures(MODEL_BASIC, h, a, x, y, T)
     D = c.dim
