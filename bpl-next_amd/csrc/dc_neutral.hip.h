@@ -757,7 +757,16 @@ __global__ __launch_bounds__(FUSED_BLOCK) void neu_fused(FusedArgs A) {
     }
     __syncthreads();
     NEU_STAMP(6);
-    // ---- G: gradients and the potential
+    // ---- G: gradients and the potential.  NUTS: every entry also goes to the leaf's LDS strip (the leaf
+    // would otherwise read the gradient back through L2), and the scalar wave requests the chain's
+    // state before its own entries (the loads are in flight while the gradient is written)
+    double* gL = lds + fused_lds_doubles(L, N, A.n_slots);   // NUTS: grad[D] | potential | aux[4]
+    auto put = [&](int o, double v) {
+        grad[o] = v;
+        if (NUTS) gL[o] = v;
+    };
+    nd::LeafState<nd::LEAF_NE_MAX> leaf{};
+    if (NUTS && wave == 0) leaf = nd::leaf_prefetch<nd::LEAF_NE_MAX>(ns, D, A.max_depth, lane);
     if (wave != 0) {
         const double s_att = fixed[FX_STD], s_def = fixed[FX_STD + 1], s_ha = fixed[FX_STD + 2],
                      s_aa = fixed[FX_STD + 3], s_hd = fixed[FX_STD + 4], s_ad = fixed[FX_STD + 5];
@@ -765,19 +774,19 @@ __global__ __launch_bounds__(FUSED_BLOCK) void neu_fused(FusedArgs A) {
             const double* G6 = accF + t * dcd::A_N;
             const double sa = zs[L.o_sat + t], sd = zs[L.o_sdt + t];
             const double e = sd - rp * sa;
-            grad[L.o_sat + t] = -(s_att * G6[dcd::A_ATT] - sa + rp * e * ivv);
-            grad[L.o_sdt + t] = -(s_def * G6[dcd::A_DEF] - e * ivv);
-            grad[L.o_hat + t] = -(s_ha * G6[dcd::A_HATT] - zs[L.o_hat + t]);
-            grad[L.o_aat + t] = -(s_aa * G6[dcd::A_AATT] - zs[L.o_aat + t]);
-            grad[L.o_hdf + t] = -(s_hd * G6[dcd::A_HDEF] - zs[L.o_hdf + t]);
-            grad[L.o_adf + t] = -(s_ad * G6[dcd::A_ADEF] - zs[L.o_adf + t]);
+            put(L.o_sat + t, -(s_att * G6[dcd::A_ATT] - sa + rp * e * ivv));
+            put(L.o_sdt + t, -(s_def * G6[dcd::A_DEF] - e * ivv));
+            put(L.o_hat + t, -(s_ha * G6[dcd::A_HATT] - zs[L.o_hat + t]));
+            put(L.o_aat + t, -(s_aa * G6[dcd::A_AATT] - zs[L.o_aat + t]));
+            put(L.o_hdf + t, -(s_hd * G6[dcd::A_HDEF] - zs[L.o_hdf + t]));
+            put(L.o_adf + t, -(s_ad * G6[dcd::A_ADEF] - zs[L.o_adf + t]));
         }
         for (int k = wid; k < 2 * K; k += FUSED_WORKERS) {  // covariate coefficients ~ N(0,1)
             const int o = k < K ? L.o_bA + k : L.o_bD + k - K;
-            grad[o] = -(sums[NEU_SUMS + k] - zs[o]);
+            put(o, -(sums[NEU_SUMS + k] - zs[o]));
         }
         for (int cf = wid; cf < C; cf += FUSED_WORKERS)  // confederation strengths ~ N(0,1)
-            grad[L.o_conf + cf] = -(accF[T * dcd::A_N + cf] - zs[L.o_conf + cf]);
+            put(L.o_conf + cf, -(accF[T * dcd::A_N + cf] - zs[L.o_conf + cf]));
     } else if (lane < FUSED_SITES) {
         // the sum each scalar site's gradient takes (sites in the lane order of step A)
         const int o = lane == 0 ? L.o_s_att : lane == 1 ? L.o_s_def : lane == 2 ? L.o_s_ha
@@ -787,7 +796,7 @@ __global__ __launch_bounds__(FUSED_BLOCK) void neu_fused(FusedArgs A) {
         const int si = lane == 0 ? 1 : lane == 1 ? 2 : lane < 6 ? 6 + lane : lane == 6 ? 0
                      : lane < 12 ? lane - 4 : 3;                        // (lane 7 takes G_rho instead)
         const double dot = lane == 7 ? b.G_rho * (b.UB - b.LB) : sums[si];
-        grad[o] = -(fixed[FX_MUL + lane] * dot + fixed[FX_PRE + lane]);
+        put(o, -(fixed[FX_MUL + lane] * dot + fixed[FX_PRE + lane]));
         if (lane == 0) {
             double U = 0.0;
 #pragma unroll
@@ -797,6 +806,8 @@ __global__ __launch_bounds__(FUSED_BLOCK) void neu_fused(FusedArgs A) {
                 ns[nd::H_LEAF_PE] = pot;
                 ns[nd::H_LEAF_AUX0] = b.rho; ns[nd::H_LEAF_AUX1] = b.LB;
                 ns[nd::H_LEAF_AUX2] = b.UB;  ns[nd::H_LEAF_AUX3] = b.q;
+                gL[D] = pot;
+                gL[D + 1] = b.rho; gL[D + 2] = b.LB; gL[D + 3] = b.UB; gL[D + 4] = b.q;
             } else {
                 A.potential[blockIdx.x] = pot;
             }
@@ -813,21 +824,11 @@ __global__ __launch_bounds__(FUSED_BLOCK) void neu_fused(FusedArgs A) {
     }
     if (NUTS) {
         // ---- the leapfrog's bookkeeping (nuts_dev.hip.h: what kp_leaf does as a launch of its own),
-        // on the scalar wave, once every wave's gradient entries are stored (a barrier waits for the
-        // stores before it; the state block is read through L2: this CU has not cached those lines)
+        // on the scalar wave, from the LDS strip, once every wave has written its entries (the barrier
+        // also waits for the global stores: the chain's next steps read the gradient from its state block)
         __syncthreads();
         if (wave == 0) {
-            double* gL = lds + fused_lds_doubles(L, N, A.n_slots);   // grad[D] | potential | aux[4]
-            nd::LeafState<nd::LEAF_NE_MAX> leaf = nd::leaf_prefetch<nd::LEAF_NE_MAX>(ns, D, A.max_depth, lane);
-            const double* gr = nd::vec(ns, D, nd::V_GRAD);
-            for (int i = lane; i < D; i += 64) gL[i] = dc::ld_sc1(&gr[i]);
-            if (lane == 0) {
-                gL[D] = dc::ld_sc1(&ns[nd::H_LEAF_PE]);
-                gL[D + 1] = dc::ld_sc1(&ns[nd::H_LEAF_AUX0]); gL[D + 2] = dc::ld_sc1(&ns[nd::H_LEAF_AUX1]);
-                gL[D + 3] = dc::ld_sc1(&ns[nd::H_LEAF_AUX2]); gL[D + 4] = dc::ld_sc1(&ns[nd::H_LEAF_AUX3]);
-            }
             nd::leaf_prepare<true>(leaf);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (one wave: its LDS writes before its reads)
             const bool sub_done = nd::nuts_leaf(ns, D, A.max_depth, lane, gL, leaf);
             if (sub_done) nd::persist_advance(ns, A.persist, blockIdx.x, lane);
         }
