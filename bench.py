@@ -346,7 +346,7 @@ def main():
                                  "duration plus the dependent-launch gap; rocprofv3's per-kernel average "
                                  "(profiles/r02/kernels.md) is the duration alone",
                 "regime": "latency bound at this size (an empty kernel in the same graph is 2.06 us of the "
-                          "~6.8 us launch); the same kernel reaches 66% of peak at N=1e7 and 195% "
+                          "~6.8 us launch); the same kernel reaches 79% of peak at N=1e7 and ~197% "
                           "(algorithmic) at N=1e8: profiles/r02/n_sweep.txt",
             },
         }
