@@ -17,7 +17,8 @@ MODEL_BASIC = 0
 MODEL_EXTENDED = 1
 MODEL_DYNAMIC = 2
 MODEL_NEUTRAL = 3
-BPLHIP_EUNSUPPORTED = -5  # include/bplhip.h
+# error codes of include/bplhip.h
+BPLHIP_EINVAL, BPLHIP_ESTATE, BPLHIP_EHIP, BPLHIP_ENOMEM, BPLHIP_EUNSUPPORTED, BPLHIP_ENUMERIC = -1, -2, -3, -4, -5, -6
 
 _LIB_NAME = os.environ.get("BPLHIP_LIB", "libbplhip.so")  # override: diagnostic builds only
 _lib = None
@@ -44,6 +45,9 @@ ABI_SYMBOLS = (
     "bplhip_predict_set_posterior",
     "bplhip_predict_score_proba",
     "bplhip_predict_score_grid",
+    "bplhip_predict_set_posterior_venue",
+    "bplhip_predict_score_proba_venue",
+    "bplhip_predict_score_grid_venue",
     "bplhip_selftest_math",
     "bplhip_threefry_split",
     "bplhip_threefry_bits",
@@ -150,6 +154,12 @@ def load_library():
     lib.bplhip_predict_score_proba.restype = C.c_int
     lib.bplhip_predict_score_grid.argtypes = [vp, i64, vp, vp, i32, vp, vp]
     lib.bplhip_predict_score_grid.restype = C.c_int
+    lib.bplhip_predict_set_posterior_venue.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp, vp, i32, vp, vp]
+    lib.bplhip_predict_set_posterior_venue.restype = C.c_int
+    lib.bplhip_predict_score_proba_venue.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.bplhip_predict_score_proba_venue.restype = C.c_int
+    lib.bplhip_predict_score_grid_venue.argtypes = [vp, i64, vp, vp, vp, vp, vp, i32, vp, vp]
+    lib.bplhip_predict_score_grid_venue.restype = C.c_int
     lib.bplhip_selftest_math.argtypes = [vp, i32, i64, vp, vp]
     lib.bplhip_selftest_math.restype = C.c_int
     lib.bplhip_threefry_split.argtypes = [u32, u32, i32, C.POINTER(u32)]
@@ -419,7 +429,40 @@ class HipContext:
             self._check(self._lib.bplhip_predict_set_posterior(
                 self._h, s, t, _np_ptr(att), _np_ptr(dfn), _np_ptr(ha), int(ha.ndim == 2), _np_ptr(cc)))
 
-    def predict_score_proba(self, home_idx, away_idx, home_goals, away_goals) -> np.ndarray:
+    def predict_set_posterior_venue(self, attack, defence, home_attack, away_attack, home_defence,
+                                    away_defence, corr_coef, confederation_strength=None):
+        """Posterior of the neutral-venue family (six [draws, teams] tables, optional
+        [draws, confederations] strengths); queries then take `neutral` (and `conf`)."""
+        tabs = [np.ascontiguousarray(t, dtype=np.float64)
+                for t in (attack, defence, home_attack, away_attack, home_defence, away_defence)]
+        cc = np.ascontiguousarray(corr_coef, dtype=np.float64)
+        s, t = tabs[0].shape
+        if any(x.shape != (s, t) for x in tabs) or cc.shape != (s,):
+            raise ValueError("posterior arrays have inconsistent shapes")
+        conf = None
+        if confederation_strength is not None:
+            conf = np.ascontiguousarray(confederation_strength, dtype=np.float64)
+            if conf.ndim != 2 or conf.shape[0] != s:
+                raise ValueError("confederation_strength must be [draws, confederations]")
+        with self._torch.cuda.device(self.device):
+            self._check(self._lib.bplhip_predict_set_posterior_venue(
+                self._h, s, t, *(_np_ptr(x) for x in tabs), 0 if conf is None else conf.shape[1],
+                None if conf is None else _np_ptr(conf), _np_ptr(cc)))
+
+    @staticmethod
+    def _venue_args(m, neutral, conf):
+        nv = np.ascontiguousarray(np.broadcast_to(np.asarray(neutral), (m,)), dtype=np.uint8)
+        if conf is None:
+            return nv, None, None
+        hc = np.ascontiguousarray(np.broadcast_to(np.asarray(conf[0]), (m,)), dtype=np.uint16)
+        ac = np.ascontiguousarray(np.broadcast_to(np.asarray(conf[1]), (m,)), dtype=np.uint16)
+        return nv, hc, ac
+
+    def predict_score_proba(self, home_idx, away_idx, home_goals, away_goals, neutral=None,
+                            conf=None) -> np.ndarray:
+        """Mean over the draws of tau * Poisson * Poisson per query.  `neutral` (0/1 per query) and
+        `conf` = (home, away confederation indices) select the venue-aware rates and must be given
+        exactly when the posterior was set with predict_set_posterior_venue."""
         h = np.ascontiguousarray(home_idx, dtype=np.uint16)
         a = np.ascontiguousarray(away_idx, dtype=np.uint16)
         x = np.ascontiguousarray(home_goals, dtype=np.uint16)
@@ -429,11 +472,18 @@ class HipContext:
             raise ValueError("query arrays must have equal length")
         out = np.empty(m, dtype=np.float64)
         with self._torch.cuda.device(self.device):
-            self._check(self._lib.bplhip_predict_score_proba(
-                self._h, m, _np_ptr(h), _np_ptr(a), _np_ptr(x), _np_ptr(y), _np_ptr(out), self._stream()))
+            if neutral is None:
+                self._check(self._lib.bplhip_predict_score_proba(
+                    self._h, m, _np_ptr(h), _np_ptr(a), _np_ptr(x), _np_ptr(y), _np_ptr(out), self._stream()))
+            else:
+                nv, hc, ac = self._venue_args(m, neutral, conf)
+                self._check(self._lib.bplhip_predict_score_proba_venue(
+                    self._h, m, _np_ptr(h), _np_ptr(a), _np_ptr(x), _np_ptr(y), _np_ptr(nv),
+                    None if hc is None else _np_ptr(hc), None if ac is None else _np_ptr(ac),
+                    _np_ptr(out), self._stream()))
         return out
 
-    def predict_score_grid(self, home_idx, away_idx, max_goals: int) -> np.ndarray:
+    def predict_score_grid(self, home_idx, away_idx, max_goals: int, neutral=None, conf=None) -> np.ndarray:
         """[m, max_goals+1, max_goals+1] scoreline probabilities of the m fixtures."""
         h = np.ascontiguousarray(home_idx, dtype=np.uint16)
         a = np.ascontiguousarray(away_idx, dtype=np.uint16)
@@ -442,8 +492,15 @@ class HipContext:
         g1 = int(max_goals) + 1
         out = np.empty((h.size, g1, g1), dtype=np.float64)
         with self._torch.cuda.device(self.device):
-            self._check(self._lib.bplhip_predict_score_grid(
-                self._h, h.size, _np_ptr(h), _np_ptr(a), int(max_goals), _np_ptr(out), self._stream()))
+            if neutral is None:
+                self._check(self._lib.bplhip_predict_score_grid(
+                    self._h, h.size, _np_ptr(h), _np_ptr(a), int(max_goals), _np_ptr(out), self._stream()))
+            else:
+                nv, hc, ac = self._venue_args(h.size, neutral, conf)
+                self._check(self._lib.bplhip_predict_score_grid_venue(
+                    self._h, h.size, _np_ptr(h), _np_ptr(a), _np_ptr(nv),
+                    None if hc is None else _np_ptr(hc), None if ac is None else _np_ptr(ac),
+                    int(max_goals), _np_ptr(out), self._stream()))
         return out
 
     def selftest_math(self, which: int, x) -> np.ndarray:

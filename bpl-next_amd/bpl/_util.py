@@ -1,77 +1,20 @@
-"""Private utility functions (host side, numpy).
+"""Host-side helpers of the predictors (numpy).
 
-Mirrors the reference's bpl/_util.py: same names, argument meaning and broadcasting.
-The training-time use of compute_corr_coef_bounds / dixon_coles_correlation_term
-(bpl/dixon_coles.py:79-84) runs inside the HIP kernel; the functions here serve the
-predict path (posterior post-processing), which is host numpy in this round.
+What the reference's bpl/_util.py holds for the MODEL -- `compute_corr_coef_bounds` (:17-31) and
+`dixon_coles_correlation_term` (:35-93) -- lives in the HIP kernels here (csrc/dc_kernels.hip.h for
+`fit`, csrc/dc_predict.hip.h for the predict methods); this module keeps only the argument
+plumbing: team-name parsing and the categorical sampling behind `sample_score` / `sample_outcome`.
 """
 
-from typing import Iterable, Optional, Tuple, Union
+from typing import Iterable, Tuple
 
 import numpy as np
 
 
 def str_to_list(*args):
-    """convert all elements of a list into strings.  (bpl/_util.py:10-14)"""
-    return ([x] if isinstance(x, str) else x for x in args)
-
-
-def compute_corr_coef_bounds(
-    expected_home_goals: np.ndarray, expected_away_goals: np.ndarray
-) -> Tuple[float, float]:
-    """Bounds of the correlation coefficient from the Dixon & Coles paper
-    (bpl/_util.py:17-31)."""
-    UB = np.min(np.array([np.min(1.0 / (expected_home_goals * expected_away_goals)), 1]))
-    LB = np.max(
-        np.array([np.max(-1.0 / expected_home_goals), np.max(-1.0 / expected_away_goals)])
-    )
-    return LB, UB
-
-
-# pylint: disable=too-many-arguments
-def dixon_coles_correlation_term(
-    home_goals: Union[int, Iterable[int]],
-    away_goals: Union[int, Iterable[int]],
-    home_rate: np.ndarray,
-    away_rate: np.ndarray,
-    corr_coef: np.ndarray,
-    weights: Optional[np.ndarray] = None,
-    tol: Optional[float] = 0,
-) -> np.ndarray:
-    """Correlation (tau) term of the Dixon & Coles paper (bpl/_util.py:35-93)."""
-    if isinstance(home_goals, (int, np.integer)):
-        home_goals = np.array(home_goals).reshape((1,))
-    if isinstance(away_goals, (int, np.integer)):
-        away_goals = np.array(away_goals).reshape((1,))
-    home_goals = np.asarray(home_goals)
-    away_goals = np.asarray(away_goals)
-    home_rate = np.asarray(home_rate, dtype=np.float64)
-    away_rate = np.asarray(away_rate, dtype=np.float64)
-    corr_coef = np.asarray(corr_coef, dtype=np.float64)
-    if weights is None:
-        weights = np.ones(len(home_goals))
-    weights = np.asarray(weights, dtype=np.float64)
-
-    corr_term = np.zeros_like(home_rate)
-    cc = corr_coef[..., None]
-    with np.errstate(divide="ignore", invalid="ignore"):
-        nil_nil = (home_goals == 0) & (away_goals == 0)
-        corr_term[..., nil_nil] = weights[..., nil_nil] * np.log(
-            np.clip(1.0 - cc * home_rate[..., nil_nil] * away_rate[..., nil_nil], tol, None)
-        )
-        one_nil = (home_goals == 1) & (away_goals == 0)
-        corr_term[..., one_nil] = weights[..., one_nil] * np.log(
-            np.clip(1.0 + cc * away_rate[..., one_nil], tol, None)
-        )
-        nil_one = (home_goals == 0) & (away_goals == 1)
-        corr_term[..., nil_one] = weights[..., nil_one] * np.log(
-            np.clip(1.0 + cc * home_rate[..., nil_one], tol, None)
-        )
-        one_one = (home_goals == 1) & (away_goals == 1)
-        corr_term[..., one_one] = weights[..., one_one] * np.log(
-            np.clip(1.0 - cc + 0.0 * home_rate[..., one_one], tol, None)
-        )
-    return corr_term
+    """A bare string stands for a one-element list; anything else passes through
+    (role of bpl/_util.py:10-14)."""
+    return tuple([arg] if isinstance(arg, str) else arg for arg in args)
 
 
 def map_choice(key, a, num_samples, p):
@@ -97,24 +40,12 @@ def map_choice(key, a, num_samples, p):
     return out
 
 
-def poisson_log_prob(rate, k):
-    """numpyro Poisson.log_prob: log(rate)*k - gammaln(k+1) - rate."""
-    from scipy.special import gammaln
-
-    k = np.asarray(k, dtype=np.float64)
-    with np.errstate(divide="ignore", invalid="ignore"):
-        return np.log(rate) * k - gammaln(k + 1.0) - rate
-
-
 def parse_teams(
     home_team: Iterable[str], away_team: Iterable[str], dtype: str
 ) -> Tuple[np.ndarray, dict, np.ndarray, np.ndarray]:
-    """Unique team names (string-sorted), name->index map and the per-fixture indices
-    (bpl/_util.py:115-135)."""
-    home_team = list(home_team)
-    away_team = list(away_team)
-    teams = np.array(sorted(set(home_team) | set(away_team)))
-    teams_dict = {t: i for i, t in enumerate(teams)}
-    home_ind = np.array([teams_dict[t] for t in home_team], dtype)
-    away_ind = np.array([teams_dict[t] for t in away_team], dtype)
-    return teams, teams_dict, home_ind, away_ind
+    """(team names in string-sorted order, name -> index, home indices, away indices), the
+    contract of bpl/_util.py:115-135: with teams "0".."19" team "2" has index 12."""
+    home, away = np.asarray(list(home_team)), np.asarray(list(away_team))
+    names = np.unique(np.concatenate([home, away]))  # sorted by code point, like sorted(set(...))
+    lookup = {str(name): index for index, name in enumerate(names)}
+    return names, lookup, np.searchsorted(names, home).astype(dtype), np.searchsorted(names, away).astype(dtype)

@@ -18,6 +18,7 @@ import numpy as np
 from bpl._util import map_choice
 
 MAX_GOALS = 15
+GRID_MAX_GOALS = 63  # depth of the device grid kernel (csrc/dc_predict.hip.h); deeper grids go pointwise
 DTYPES = {
     "goals": "uint8",
     "teams": "uint16",
@@ -40,7 +41,87 @@ def _wall_clock_seed() -> int:
     return int(datetime.now().timestamp() * 100)
 
 
-class BaseMatchPredictor:
+def _fingerprint(arrays) -> tuple:
+    """Cheap identity of a set of posterior arrays: object, shape, the sum and a strided sample of
+    the values -- an in-place edit (`model.attack[:, j] = ...`) changes it, a recycled `id` does
+    not fake it."""
+    out = []
+    for a in arrays:
+        if a is None:
+            out.append(None)
+            continue
+        a = np.asarray(a)
+        flat = a.reshape(-1)
+        out.append((id(a), a.shape, float(flat.sum()), flat[:: max(1, flat.size // 1024)].tobytes()))
+    return tuple(out)
+
+
+class PosteriorOnDevice:
+    """The posterior draws of a fitted model, resident on one GPU for the predict kernels.  A mixin:
+    the class says which arrays make up its posterior (`_posterior_arrays`) and how a context takes
+    them (`_upload_posterior`).  The device context is created on first use, re-fed whenever the
+    arrays change (assignment, `add_new_team`, in-place edits: `_fingerprint`), and is NOT part of the
+    model's state: a fitted model pickles and deep-copies like the reference's (plain arrays), the
+    copy re-creating its context on its first predict call."""
+
+    #: GPU index for the predict path; None = this rank's GPU (bpl._dist) / GPU 0 on one process
+    predict_device: Optional[int] = None
+    _predict_ctx = None   # bpl._ffi.HipContext holding the uploaded posterior
+    _uploaded = None      # fingerprint of the arrays last uploaded
+
+    def _posterior_arrays(self) -> tuple:
+        raise NotImplementedError
+
+    def _upload_posterior(self, ctx) -> None:
+        raise NotImplementedError
+
+    def invalidate_predict_cache(self) -> None:
+        """Force the next predict call to upload the posterior again."""
+        self._uploaded = None
+
+    def _device(self):
+        """The context with this model's current posterior draws on the GPU."""
+        if self._predict_ctx is None:
+            from bpl import _dist
+            from bpl._ffi import HipContext
+
+            index = self.predict_device
+            if index is None:
+                index = _dist.local_device_index() if _dist.world()[1] > 1 else 0
+            self._predict_ctx = HipContext(int(index))
+            self._uploaded = None
+        stamp = _fingerprint(self._posterior_arrays())
+        if stamp != self._uploaded:
+            self._upload_posterior(self._predict_ctx)
+            self._uploaded = stamp
+        return self._predict_ctx
+
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        state.pop("_predict_ctx", None)
+        state.pop("_uploaded", None)
+        return state
+
+    def __deepcopy__(self, memo):
+        import copy
+
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        for key, value in self.__getstate__().items():
+            setattr(new, key, copy.deepcopy(value, memo))
+        return new
+
+
+def grid_from_pointwise(score_proba, n_fixtures: int, max_goals: int) -> np.ndarray:
+    """A scoreline grid deeper than the grid kernel goes (max_goals > GRID_MAX_GOALS) through the
+    pointwise kernel: `score_proba(fixture_index, x, y)` over every cell."""
+    width = max_goals + 1
+    x, y = np.divmod(np.arange(width * width), width)
+    which = np.repeat(np.arange(n_fixtures), width * width)
+    return score_proba(which, np.tile(x, n_fixtures), np.tile(y, n_fixtures)).reshape(n_fixtures, width, width)
+
+
+class BaseMatchPredictor(PosteriorOnDevice):
     """Common predict API of the team-level models.  A subclass provides `fit` and the four
     posterior arrays (`attack`, `defence` [draws, teams]; `home_advantage` [draws] or
     [draws, teams]; `corr_coef` [draws])."""
@@ -48,8 +129,6 @@ class BaseMatchPredictor:
     def __init__(self):
         self.teams = None          # sorted unique team names
         self._teams_dict = None    # name -> index
-        self._predict_ctx = None   # bpl._ffi.HipContext holding the uploaded posterior
-        self._uploaded = None      # identity of the arrays last uploaded
 
     # ------------------------------------------------------------------ plumbing
     def fit(self, training_data, **kwargs) -> "BaseMatchPredictor":
@@ -69,22 +148,22 @@ class BaseMatchPredictor:
     def _parse_fixture_args(self, home_team: TeamArg, away_team: TeamArg):
         return tuple(self._team_indices(home_team, away_team))
 
-    def _device(self):
-        """The context with this model's current posterior draws on the GPU."""
-        if self._predict_ctx is None:
-            from bpl._ffi import HipContext
+    def _posterior_arrays(self):
+        return (self.attack, self.defence, self.home_advantage, self.corr_coef)
 
-            self._predict_ctx = HipContext(0)
-        arrays = (self.attack, self.defence, self.home_advantage, self.corr_coef)
-        stamp = tuple(id(a) for a in arrays) + (np.shape(self.attack),)
-        if stamp != self._uploaded:
-            self._predict_ctx.predict_set_posterior(*arrays)
-            self._uploaded = stamp
-        return self._predict_ctx
+    def _upload_posterior(self, ctx):
+        ctx.predict_set_posterior(self.attack, self.defence, self.home_advantage, self.corr_coef)
 
     def _grid(self, home_idx: np.ndarray, away_idx: np.ndarray, max_goals: int) -> np.ndarray:
         """[fixtures, max_goals+1, max_goals+1]: P(home scores x, away scores y)."""
-        return self._device().predict_score_grid(home_idx, away_idx, int(max_goals))
+        max_goals = int(max_goals)
+        if max_goals < 0:
+            raise ValueError("max_goals must be >= 0")
+        dev = self._device()
+        if max_goals <= GRID_MAX_GOALS:
+            return dev.predict_score_grid(home_idx, away_idx, max_goals)
+        return grid_from_pointwise(lambda f, x, y: dev.predict_score_proba(home_idx[f], away_idx[f], x, y),
+                                   len(home_idx), max_goals)
 
     def _calculate_expected_goals(self, home_team: TeamArg, away_team: TeamArg) -> Tuple[np.ndarray, np.ndarray]:
         """Home and away scoring rates, [draws, fixtures] (bpl/dixon_coles.py:126-137,
@@ -132,6 +211,8 @@ class BaseMatchPredictor:
         """P(`team` scores [concedes] n) with the other side's goals summed over 0..max_goals:
         a row or column sum of ONE fixture's grid."""
         wanted = np.atleast_1d(np.asarray(n, dtype=np.int64))
+        if wanted.size and wanted.min() < 0:
+            raise ValueError("n must be >= 0")
         t, o = self._team_indices(team, opponent)
         depth = max(int(max_goals), int(wanted.max()))
         grid = self._grid(*((t, o) if team_is_home else (o, t)), depth)[0]

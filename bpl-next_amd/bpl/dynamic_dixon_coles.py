@@ -21,8 +21,7 @@ import numpy as np
 
 from bpl import _dist
 from bpl._ffi import default_nuts_cfg, prng_key, threefry_split
-from bpl._util import dixon_coles_correlation_term, poisson_log_prob
-from bpl.base import MAX_GOALS
+from bpl.base import MAX_GOALS, PosteriorOnDevice
 
 __all__ = ["DynamicNeutralDixonColesMatchPredictor"]
 
@@ -50,7 +49,7 @@ def latent_sites(G: int, T: int, K: int):
 
 
 # pylint: disable=too-many-instance-attributes
-class DynamicNeutralDixonColesMatchPredictor:
+class DynamicNeutralDixonColesMatchPredictor(PosteriorOnDevice):
     """Dixon-Coles with neutral venues, separate home/away attack/defence offsets and a
     random walk of the team strengths over gameweeks."""
 
@@ -206,44 +205,57 @@ class DynamicNeutralDixonColesMatchPredictor:
                            "wall_seconds": float(leap[:, 1].max())}
         return self
 
+    # ---- predict side: the tables of ONE gameweek through the venue-aware device kernels
+    # (csrc/dc_predict.hip.h, the same entry points the neutral-venue classes use)
+    _VENUE_TABLES = ("attack", "defence", "home_attack", "away_attack", "home_defence", "away_defence")
+    _predict_gameweek = None
+
+    def _posterior_arrays(self):
+        return tuple(getattr(self, nm) for nm in self._VENUE_TABLES) + (self.corr_coef, np.asarray(self._predict_gameweek))
+
+    def _upload_posterior(self, ctx):
+        g = self._predict_gameweek
+        ctx.predict_set_posterior_venue(*(getattr(self, nm)[:, g, :] for nm in self._VENUE_TABLES), self.corr_coef)
+
+    def _week(self, gameweek: Optional[int]) -> int:
+        g = self.num_gameweeks - 1 if gameweek is None else int(gameweek)
+        if not 0 <= g < self.num_gameweeks:
+            raise IndexError(f"gameweek {g} outside 0..{self.num_gameweeks - 1}")
+        return g
+
+    def _fixture_indices(self, home_team, away_team):
+        home_team = [home_team] if isinstance(home_team, str) else list(home_team)
+        away_team = [away_team] if isinstance(away_team, str) else list(away_team)
+        return (np.array([self.teams.index(t) for t in home_team], dtype=np.uint16),
+                np.array([self.teams.index(t) for t in away_team], dtype=np.uint16))
+
     def _calculate_expected_goals(self, home_team, away_team, neutral_venue,
                                   gameweek: Optional[int] = None) -> Tuple[np.ndarray, np.ndarray]:
-        g = self.num_gameweeks - 1 if gameweek is None else int(gameweek)
-        home_ind = np.array([self.teams.index(t) for t in home_team])
-        away_ind = np.array([self.teams.index(t) for t in away_team])
-        nn = 1 - np.asarray(neutral_venue)
+        g = self._week(gameweek)
+        h, a = self._fixture_indices(home_team, away_team)
+        at_home = 1.0 - np.asarray(neutral_venue, dtype=np.float64)
         # signs as in `_model` (bpl/dynamic_dixon_coles.py:220-231)
-        home_rate = np.exp(self.attack[:, g, home_ind] - self.defence[:, g, away_ind]
-                           + nn * self.home_attack[:, g, home_ind]
-                           - nn * self.away_defence[:, g, away_ind])
-        away_rate = np.exp(self.attack[:, g, away_ind] - self.defence[:, g, home_ind]
-                           + nn * self.away_attack[:, g, away_ind]
-                           - nn * self.home_defence[:, g, home_ind])
-        return home_rate, away_rate
+        log_home = (self.attack[:, g, h] - self.defence[:, g, a]
+                    + at_home * self.home_attack[:, g, h] - at_home * self.away_defence[:, g, a])
+        log_away = (self.attack[:, g, a] - self.defence[:, g, h]
+                    + at_home * self.away_attack[:, g, a] - at_home * self.home_defence[:, g, h])
+        return np.exp(log_home), np.exp(log_away)
 
     def predict_score_proba(self, home_team, away_team, home_goals, away_goals, neutral_venue,
                             gameweek: Optional[int] = None) -> np.ndarray:
         """Probabilities of the given scorelines (mean over posterior draws)."""
-        home_team = [home_team] if isinstance(home_team, str) else list(home_team)
-        away_team = [away_team] if isinstance(away_team, str) else list(away_team)
-        ehg, eag = self._calculate_expected_goals(home_team, away_team, neutral_venue, gameweek)
-        corr_term = dixon_coles_correlation_term(home_goals, away_goals, ehg, eag, self.corr_coef)
-        home_probs = np.exp(poisson_log_prob(ehg, home_goals))
-        away_probs = np.exp(poisson_log_prob(eag, away_goals))
-        return (np.exp(corr_term) * home_probs * away_probs).mean(axis=0)
+        self._predict_gameweek = self._week(gameweek)
+        h, a = self._fixture_indices(home_team, away_team)
+        m = max(len(h), np.size(home_goals), np.size(away_goals))
+        spread = lambda v: np.broadcast_to(np.asarray(v), (m,))
+        return self._device().predict_score_proba(spread(h), spread(a), spread(home_goals), spread(away_goals),
+                                                  neutral=spread(neutral_venue))
 
     def predict_outcome_proba(self, home_team, away_team, neutral_venue,
                               gameweek: Optional[int] = None) -> Dict[str, np.ndarray]:
-        """Home win, draw and away win probabilities."""
-        home_team = [home_team] if isinstance(home_team, str) else list(home_team)
-        away_team = [away_team] if isinstance(away_team, str) else list(away_team)
-        nvv = np.broadcast_to(np.asarray(neutral_venue), (len(home_team),))
-        n_goals = np.arange(0, MAX_GOALS + 1)
-        x, y = np.meshgrid(n_goals, n_goals, indexing="ij")
-        k = (MAX_GOALS + 1) ** 2
-        probs = self.predict_score_proba(
-            np.repeat(home_team, k), np.repeat(away_team, k), np.tile(x.reshape(k), len(home_team)),
-            np.tile(y.reshape(k), len(home_team)), np.repeat(nvv, k), gameweek,
-        ).reshape(len(home_team), MAX_GOALS + 1, MAX_GOALS + 1)
-        return {"home_win": probs[:, x > y].sum(axis=-1), "draw": probs[:, x == y].sum(axis=-1),
-                "away_win": probs[:, x < y].sum(axis=-1)}
+        """Home win, draw and away win probabilities: the triangles of each fixture's scoreline grid."""
+        self._predict_gameweek = self._week(gameweek)
+        h, a = self._fixture_indices(home_team, away_team)
+        grid = self._device().predict_score_grid(h, a, MAX_GOALS, neutral=np.broadcast_to(np.asarray(neutral_venue), (len(h),)))
+        return {"home_win": np.tril(grid, -1).sum(axis=(1, 2)), "draw": np.trace(grid, axis1=1, axis2=2),
+                "away_win": np.triu(grid, 1).sum(axis=(1, 2))}

@@ -3,26 +3,22 @@
 Mirrors the reference's bpl/neutral_dixon_coles.py:30-902 (`NeutralDixonColesMatchPredictor`)
 method for method: same names, arguments, return shapes and error behaviour; arrays are
 numpy instead of jax.  `fit` drives libbplhip (bplhip_set_fixtures_neutral + bplhip_nuts_run);
-the predict methods are post-processing of posterior draws on the host.
+the predict methods run on the device like the league models' (bpl/base.py here): ONE primitive,
+the per-fixture scoreline grid of `bplhip_predict_score_grid_venue` (csrc/dc_predict.hip.h, the
+venue-aware rate form), of which outcomes, n-goal marginals and the sampling methods are
+reductions; arbitrary scorelines go through the pointwise kernel.  No host fallback.
 """
 
 from __future__ import annotations
 
 import warnings
-from datetime import datetime
 from typing import Any, Dict, Iterable, Optional, Tuple, Union
 
 import numpy as np
 
 from bpl import _dist
-from bpl._util import (
-    dixon_coles_correlation_term,
-    map_choice,
-    parse_teams,
-    poisson_log_prob,
-    str_to_list,
-)
-from bpl.base import DTYPES, MAX_GOALS, _prng_key
+from bpl._util import map_choice, parse_teams, str_to_list
+from bpl.base import DTYPES, GRID_MAX_GOALS, MAX_GOALS, PosteriorOnDevice, _prng_key, _wall_clock_seed, grid_from_pointwise
 
 __all__ = ["NeutralDixonColesMatchPredictor"]
 
@@ -67,7 +63,7 @@ def make_weights(n, time_diff, epsilon, game_weights, rescale_weights):
 
 
 # pylint: disable=too-many-instance-attributes
-class NeutralDixonColesMatchPredictor:
+class NeutralDixonColesMatchPredictor(PosteriorOnDevice):
     """Dixon-Coles with rho-correlated attack/defence, optional covariates, separate home and
     away attack/defence offsets per team that vanish at neutral venues, time decay and
     per-game weights (see bpl/neutral_dixon_coles.py:30-52)."""
@@ -264,97 +260,103 @@ class NeutralDixonColesMatchPredictor:
         return np.asarray(home_team), np.asarray(away_team), neutral_venue
 
     # ---- internals on index arrays; `conf` = None or (home_conf_idx, away_conf_idx)
+    _VENUE_TABLES = ("attack", "defence", "home_attack", "away_attack", "home_defence", "away_defence")
+
+    def _posterior_arrays(self):
+        return tuple(getattr(self, nm) for nm in self._VENUE_TABLES) + (self.corr_coef, self.confederation_strength)
+
+    def _upload_posterior(self, ctx):
+        ctx.predict_set_posterior_venue(*(getattr(self, nm) for nm in self._VENUE_TABLES), self.corr_coef,
+                                        confederation_strength=self.confederation_strength)
+
     def _rates(self, home_team, away_team, neutral_venue, conf=None):
-        on = 1 - np.asarray(neutral_venue).astype(np.float64)
-        eh = (self.attack[:, home_team] - self.defence[:, away_team]
-              + on * self.home_attack[:, home_team] - on * self.away_defence[:, away_team])
-        ea = (self.attack[:, away_team] - self.defence[:, home_team]
-              + on * self.away_attack[:, away_team] - on * self.home_defence[:, home_team])
+        """Scoring rates [draws, fixtures]: the venue offsets count only away from neutral ground."""
+        at_home = 1.0 - np.asarray(neutral_venue, dtype=np.float64)
+        log_home = (self.attack[:, home_team] - self.defence[:, away_team]
+                    + at_home * self.home_attack[:, home_team] - at_home * self.away_defence[:, away_team])
+        log_away = (self.attack[:, away_team] - self.defence[:, home_team]
+                    + at_home * self.away_attack[:, away_team] - at_home * self.home_defence[:, home_team])
         if conf is not None:
-            d = self.confederation_strength[:, conf[0]] - self.confederation_strength[:, conf[1]]
-            eh, ea = eh + d, ea - d
-        return np.exp(eh), np.exp(ea)
+            edge = self.confederation_strength[:, conf[0]] - self.confederation_strength[:, conf[1]]
+            log_home, log_away = log_home + edge, log_away - edge
+        return np.exp(log_home), np.exp(log_away)
 
     def _score_proba(self, home_team, away_team, home_goals, away_goals, neutral_venue, conf=None):
-        ehg, eag = self._rates(home_team, away_team, neutral_venue, conf)
-        corr_term = dixon_coles_correlation_term(home_goals, away_goals, ehg, eag, self.corr_coef)
-        home_probs = poisson_log_prob(ehg, home_goals)
-        away_probs = poisson_log_prob(eag, away_goals)
-        return np.exp(corr_term + home_probs + away_probs).mean(axis=0)
+        """Posterior-mean probability of each (fixture, scoreline) query: the pointwise kernel."""
+        home_team, away_team = np.atleast_1d(home_team), np.atleast_1d(away_team)
+        m = max(len(home_team), np.size(home_goals), np.size(away_goals))
+        spread = lambda v: np.broadcast_to(np.asarray(v), (m,))
+        return self._device().predict_score_proba(
+            spread(home_team), spread(away_team), spread(home_goals), spread(away_goals),
+            neutral=spread(neutral_venue), conf=None if conf is None else (spread(conf[0]), spread(conf[1])))
+
+    def _grid_probs(self, home_team, away_team, neutral_venue, conf, max_goals) -> np.ndarray:
+        """[fixtures, max_goals+1, max_goals+1]: P(home scores x, away scores y)."""
+        max_goals = int(max_goals)
+        if max_goals < 0:
+            raise ValueError("max_goals must be >= 0")
+        m = len(home_team)
+        nv = np.broadcast_to(np.asarray(neutral_venue), (m,))
+        dev = self._device()
+        if max_goals <= GRID_MAX_GOALS:
+            return dev.predict_score_grid(home_team, away_team, max_goals, neutral=nv, conf=conf)
+        pick = (lambda f: None) if conf is None else (lambda f: (np.asarray(conf[0])[f], np.asarray(conf[1])[f]))
+        return grid_from_pointwise(
+            lambda f, x, y: dev.predict_score_proba(home_team[f], away_team[f], x, y, neutral=nv[f], conf=pick(f)),
+            m, max_goals)
 
     def _grid(self, home_team, away_team, neutral_venue, conf, max_goals):
-        m = len(home_team)
-        neutral_venue = np.broadcast_to(neutral_venue, (m,))
-        n_goals = np.arange(0, max_goals + 1)
-        home_goals, away_goals = np.meshgrid(n_goals, n_goals, indexing="ij")
-        k = (max_goals + 1) ** 2
-        conf_rep = None if conf is None else (np.repeat(conf[0], k), np.repeat(conf[1], k))
-        probs = self._score_proba(
-            np.repeat(home_team, k), np.repeat(away_team, k), np.tile(home_goals.reshape(k), m),
-            np.tile(away_goals.reshape(k), m), np.repeat(neutral_venue, k), conf_rep,
-        ).reshape(m, max_goals + 1, max_goals + 1)
-        return probs, home_goals, away_goals
+        counts = np.arange(max_goals + 1)
+        return (self._grid_probs(home_team, away_team, neutral_venue, conf, max_goals),
+                *np.meshgrid(counts, counts, indexing="ij"))
 
     def _outcome(self, home_team, away_team, neutral_venue, conf, knockout, max_goals):
-        probs, home_goals, away_goals = self._grid(home_team, away_team, neutral_venue, conf, max_goals)
-        home_win = probs[:, home_goals > away_goals].sum(axis=-1)
-        draw = probs[:, home_goals == away_goals].sum(axis=-1)
-        away_win = probs[:, home_goals < away_goals].sum(axis=-1)
-        if knockout:
-            # don't consider draws (renormalise with home win and away win only)
-            norm = home_win + away_win
-            return {"home_win": home_win / norm, "away_win": away_win / norm}
-        return {"home_win": home_win, "draw": draw, "away_win": away_win}
+        grid = self._grid_probs(home_team, away_team, neutral_venue, conf, max_goals)
+        home_win = np.tril(grid, -1).sum(axis=(1, 2))   # home goals (axis 1) > away goals (axis 2)
+        away_win = np.triu(grid, 1).sum(axis=(1, 2))
+        if knockout:  # no draws: the two wins renormalised
+            decided = home_win + away_win
+            return {"home_win": home_win / decided, "away_win": away_win / decided}
+        return {"home_win": home_win, "draw": np.trace(grid, axis1=1, axis2=2), "away_win": away_win}
 
     def _sample_score(self, home_team, away_team, neutral_venue, conf, num_samples, random_state,
                       max_goals):
-        if random_state is None:
-            random_state = int(datetime.now().timestamp() * 100)
-        probs, home_goals, away_goals = self._grid(home_team, away_team, neutral_venue, conf, max_goals)
-        home_goals = np.array(home_goals.flatten(), DTYPES["goals"])
-        away_goals = np.array(away_goals.flatten(), DTYPES["goals"])
-        sample_idx = map_choice(_prng_key(random_state), np.arange(len(home_goals), dtype="uint32"),
-                                num_samples, probs.reshape((len(home_team), -1)))
-        return {"home_score": home_goals[sample_idx], "away_score": away_goals[sample_idx]}
+        seed = _wall_clock_seed() if random_state is None else random_state
+        width = max_goals + 1
+        flat = self._grid_probs(home_team, away_team, neutral_venue, conf, max_goals).reshape(len(home_team), width * width)
+        cell = map_choice(_prng_key(seed), np.arange(width * width, dtype="uint32"), num_samples, flat)
+        rows, cols = np.divmod(cell, width)
+        return {"home_score": rows.astype(DTYPES["goals"]), "away_score": cols.astype(DTYPES["goals"])}
 
     def _sample_outcome(self, home_team, away_team, neutral_venue, conf, knockout, num_samples,
                         random_state, max_goals):
-        if random_state is None:
-            random_state = int(datetime.now().timestamp() * 100)
-        probs = self._outcome(home_team, away_team, neutral_venue, conf, knockout, max_goals)
-        if knockout:
-            probs = np.array([probs["home_win"], probs["away_win"]]).T
-        else:
-            probs = np.array([probs["home_win"], probs["draw"], probs["away_win"]]).T
-        sample_idx = map_choice(_prng_key(random_state), np.arange(probs.shape[1], dtype="uint32"),
-                                num_samples, probs)
-        winner = np.empty((len(home_team), num_samples), dtype=DTYPES["teams"])
-        home_team_rep = home_team.repeat(num_samples).reshape((len(home_team), num_samples))
-        away_team_rep = away_team.repeat(num_samples).reshape((len(home_team), num_samples))
-        winner[sample_idx == 0] = home_team_rep[sample_idx == 0]
-        if knockout:
-            winner[sample_idx == 1] = away_team_rep[sample_idx == 1]
-        else:
-            winner[sample_idx == 2] = away_team_rep[sample_idx == 2]
-            winner[sample_idx == 1] = len(self.teams)  # temporary index for 'Draw'
-        return np.append(self.teams, "Draw")[winner]
+        seed = _wall_clock_seed() if random_state is None else random_state
+        p = self._outcome(home_team, away_team, neutral_venue, conf, knockout, max_goals)
+        order = ("home_win", "away_win") if knockout else ("home_win", "draw", "away_win")
+        table = np.column_stack([p[k] for k in order])
+        pick = map_choice(_prng_key(seed), np.arange(len(order), dtype="uint32"), num_samples, table)
+        labels = np.append(self.teams, "Draw")
+        home_col, away_col = np.asarray(home_team)[:, None], np.asarray(away_team)[:, None]
+        who = np.where(pick == 0, home_col, np.where(pick == len(order) - 1, away_col, len(self.teams)))
+        return labels[who]
 
     def _n_proba(self, n, team, opponent, conf, home, neutral_venue, max_goals, scored: bool):
-        n = [n] if isinstance(n, (int, np.integer)) else n
-        reps = (max_goals + 1) * len(n)
-        team_rep = np.repeat(team, reps)
-        opponent_rep = np.repeat(opponent, reps)
-        n_rep = np.resize(n, reps)
-        x_rep = np.repeat(np.arange(max_goals + 1), len(n))
-        nv_rep = np.repeat(neutral_venue, reps)
-        mine, theirs = (n_rep, x_rep) if scored else (x_rep, n_rep)
+        """P(`team` scores [concedes] n), the other side's goals summed over 0..max_goals: a row or
+        column sum of ONE fixture's grid (the reference sums predict_score_proba over the same cells,
+        bpl/neutral_dixon_coles.py:782-902)."""
+        wanted = np.atleast_1d(np.asarray(n, dtype=np.int64))
+        if wanted.size and wanted.min() < 0:
+            raise ValueError("n must be >= 0")
+        depth = max(int(max_goals), int(wanted.max()))
+        nv = np.atleast_1d(np.asarray(neutral_venue))[:1]
         if home:
-            c = None if conf is None else (np.repeat(conf[0], reps), np.repeat(conf[1], reps))
-            probs = self._score_proba(team_rep, opponent_rep, mine, theirs, nv_rep, c)
+            grid = self._grid_probs(team[:1], opponent[:1], nv, conf, depth)[0]
         else:
-            c = None if conf is None else (np.repeat(conf[1], reps), np.repeat(conf[0], reps))
-            probs = self._score_proba(opponent_rep, team_rep, theirs, mine, nv_rep, c)
-        return probs.reshape(max_goals + 1, len(n)).sum(axis=0)
+            grid = self._grid_probs(opponent[:1], team[:1], nv, None if conf is None else (conf[1], conf[0]), depth)[0]
+        # axis 0 counts the home side's goals: the team's when it is at home and we count its own
+        own_axis = 0 if bool(home) == scored else 1
+        other = np.take(grid, np.arange(max_goals + 1), axis=1 - own_axis)
+        return other.sum(axis=1 - own_axis)[wanted]
 
     def _new_team_draws(self, team_name: str, team_covariates):
         """Parameters of a new team drawn from the fitted priors

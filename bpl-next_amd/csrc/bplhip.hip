@@ -121,9 +121,12 @@ struct bplhip_ctx {
     // NUTS scratch (device): z, potential, grad, aux + pinned host mirror
     DevBuf d_nuts, d_ns;
     // posterior draws for the device predict path (dc_predict.hip.h)
-    DevBuf dp_att, dp_def, dp_ha, dp_corr, dp_q;
-    DevBuf dp_att32, dp_def32, dp_ha32, dp_corr32;  // the same in float32 (grid kernel)
-    int pred_S = 0, pred_T = 0, pred_ha_stride = 0;
+    // (tables 0..7: attack, defence, home_advantage | home_attack, away_attack, home_defence,
+    // away_defence, confederation_strength; float64 [S, cols] for the pointwise kernel and float32
+    // team-major [cols, S] for the grid kernel)
+    DevBuf dp_tab[8], dp_tab32[8], dp_corr, dp_corr32, dp_q, dp_fact;
+    int pred_S = 0, pred_T = 0, pred_C = 0, pred_ha_stride = 0;
+    bool pred_venue = false;
     double* h_pinned = nullptr;
     size_t h_pinned_bytes = 0;
     // host copies needed by bplhip_constrain (rho bounds over the unique pairs)
@@ -2269,7 +2272,29 @@ static int bplhip_constrain_dynamic_impl(bplhip_ctx* c, const double* z_draws, i
     return BPLHIP_OK;
 }
 
-// ---- predict path on the device (row f-2)
+// ---- predict path on the device (rows f-2, f-4)
+enum { PT_ATT = 0, PT_DEF, PT_HA, PT_HAT, PT_AAT, PT_HDF, PT_ADF, PT_CONF };
+// one posterior table: float64 as given + float32 transposed (a column's draws contiguous)
+static int predict_upload(bplhip_ctx* c, int which, const double* src, size_t rows, size_t cols) {
+    HIP_TRY(c, c->dp_tab[which].ensure(rows * cols * 8));
+    HIP_TRY(c, hipMemcpy(c->dp_tab[which].p, src, rows * cols * 8, hipMemcpyHostToDevice));
+    std::vector<float> tmp(rows * cols);
+    for (size_t r = 0; r < rows; ++r)
+        for (size_t q = 0; q < cols; ++q) tmp[q * rows + r] = (float)src[r * cols + q];
+    HIP_TRY(c, c->dp_tab32[which].ensure(tmp.size() * 4));
+    HIP_TRY(c, hipMemcpy(c->dp_tab32[which].p, tmp.data(), tmp.size() * 4, hipMemcpyHostToDevice));
+    return BPLHIP_OK;
+}
+static int predict_upload_corr(bplhip_ctx* c, const double* corr_coef, size_t s) {
+    HIP_TRY(c, c->dp_corr.ensure(s * 8));
+    HIP_TRY(c, hipMemcpy(c->dp_corr.p, corr_coef, s * 8, hipMemcpyHostToDevice));
+    std::vector<float> tmp(s);
+    for (size_t r = 0; r < s; ++r) tmp[r] = (float)corr_coef[r];
+    HIP_TRY(c, c->dp_corr32.ensure(s * 4));
+    HIP_TRY(c, hipMemcpy(c->dp_corr32.p, tmp.data(), s * 4, hipMemcpyHostToDevice));
+    return BPLHIP_OK;
+}
+
 static int bplhip_predict_set_posterior_impl(bplhip_ctx* c, int32_t s, int32_t t,
                                             const double* attack, const double* defence,
                                             const double* home_advantage,
@@ -2279,116 +2304,198 @@ static int bplhip_predict_set_posterior_impl(bplhip_ctx* c, int32_t s, int32_t t
     if (s < 1 || t < 1 || !attack || !defence || !home_advantage || !corr_coef)
         return fail(c, BPLHIP_EINVAL, "predict_set_posterior: bad argument");
     HIP_TRY(c, hipSetDevice(c->device));
-    const size_t st = (size_t)s * t * 8, hb = home_advantage_per_team ? st : (size_t)s * 8;
-    HIP_TRY(c, c->dp_att.ensure(st));
-    HIP_TRY(c, c->dp_def.ensure(st));
-    HIP_TRY(c, c->dp_ha.ensure(hb));
-    HIP_TRY(c, c->dp_corr.ensure((size_t)s * 8));
-    HIP_TRY(c, hipMemcpy(c->dp_att.p, attack, st, hipMemcpyHostToDevice));
-    HIP_TRY(c, hipMemcpy(c->dp_def.p, defence, st, hipMemcpyHostToDevice));
-    HIP_TRY(c, hipMemcpy(c->dp_ha.p, home_advantage, hb, hipMemcpyHostToDevice));
-    HIP_TRY(c, hipMemcpy(c->dp_corr.p, corr_coef, (size_t)s * 8, hipMemcpyHostToDevice));
-    // float32 copies for the grid kernel (the reference's own dtype), TEAM-major: a team's draws are
-    // contiguous, a block of draws is one coalesced load (dc_predict.hip.h)
-    auto up32 = [&](DevBuf& b, const double* src, size_t rows, size_t cols) -> int {  // src [rows, cols] -> [cols, rows]
-        std::vector<float> tmp(rows * cols);
-        for (size_t r = 0; r < rows; ++r)
-            for (size_t q = 0; q < cols; ++q) tmp[q * rows + r] = (float)src[r * cols + q];
-        HIP_TRY(c, b.ensure(tmp.size() * 4));
-        HIP_TRY(c, hipMemcpy(b.p, tmp.data(), tmp.size() * 4, hipMemcpyHostToDevice));
-        return BPLHIP_OK;
-    };
-    int rc = up32(c->dp_att32, attack, (size_t)s, (size_t)t);
-    if (rc == BPLHIP_OK) rc = up32(c->dp_def32, defence, (size_t)s, (size_t)t);
-    if (rc == BPLHIP_OK) rc = up32(c->dp_ha32, home_advantage, (size_t)s, home_advantage_per_team ? (size_t)t : 1);
-    if (rc == BPLHIP_OK) rc = up32(c->dp_corr32, corr_coef, (size_t)s, 1);
+    c->pred_S = 0;
+    int rc = predict_upload(c, PT_ATT, attack, (size_t)s, (size_t)t);
+    if (rc == BPLHIP_OK) rc = predict_upload(c, PT_DEF, defence, (size_t)s, (size_t)t);
+    if (rc == BPLHIP_OK) rc = predict_upload(c, PT_HA, home_advantage, (size_t)s, home_advantage_per_team ? (size_t)t : 1);
+    if (rc == BPLHIP_OK) rc = predict_upload_corr(c, corr_coef, (size_t)s);
     if (rc != BPLHIP_OK) return rc;
     c->pred_S = s;
     c->pred_T = t;
+    c->pred_C = 0;
     c->pred_ha_stride = home_advantage_per_team ? t : 0;
+    c->pred_venue = false;
     return BPLHIP_OK;
 }
 
-static int bplhip_predict_score_grid_impl(bplhip_ctx* c, int64_t m, const uint16_t* home_idx,
-                                         const uint16_t* away_idx, int32_t max_goals, double* out,
-                                         void* stream) {
+static int bplhip_predict_set_posterior_venue_impl(bplhip_ctx* c, int32_t s, int32_t t, const double* attack,
+                                                  const double* defence, const double* home_attack,
+                                                  const double* away_attack, const double* home_defence,
+                                                  const double* away_defence, int32_t n_conf,
+                                                  const double* confederation_strength,
+                                                  const double* corr_coef) {
     if (!c) return BPLHIP_EINVAL;
-    if (c->pred_S == 0) return fail(c, BPLHIP_ESTATE, "predict_score_grid: no posterior set");
-    if (max_goals < 0 || max_goals > dcp::GRID_MAX_GOALS)
-        return fail(c, BPLHIP_EINVAL, "predict_score_grid: max_goals=%d out of range [0,%d]", max_goals,
-                    dcp::GRID_MAX_GOALS);
-    if (m < 0 || m > 0x7FFFFFFF || (m > 0 && (!home_idx || !away_idx || !out)))
-        return fail(c, BPLHIP_EINVAL, "predict_score_grid: bad argument");
-    if (m == 0) return BPLHIP_OK;
-    for (int64_t i = 0; i < m; ++i)
+    if (s < 1 || t < 1 || !attack || !defence || !home_attack || !away_attack || !home_defence ||
+        !away_defence || !corr_coef || n_conf < 0 || (n_conf > 0) != (confederation_strength != nullptr))
+        return fail(c, BPLHIP_EINVAL, "predict_set_posterior_venue: bad argument");
+    HIP_TRY(c, hipSetDevice(c->device));
+    c->pred_S = 0;
+    const double* src[6] = {attack, defence, home_attack, away_attack, home_defence, away_defence};
+    const int slot[6] = {PT_ATT, PT_DEF, PT_HAT, PT_AAT, PT_HDF, PT_ADF};
+    for (int i = 0; i < 6; ++i) {
+        const int rc = predict_upload(c, slot[i], src[i], (size_t)s, (size_t)t);
+        if (rc != BPLHIP_OK) return rc;
+    }
+    if (n_conf) {
+        const int rc = predict_upload(c, PT_CONF, confederation_strength, (size_t)s, (size_t)n_conf);
+        if (rc != BPLHIP_OK) return rc;
+    }
+    const int rc = predict_upload_corr(c, corr_coef, (size_t)s);
+    if (rc != BPLHIP_OK) return rc;
+    c->pred_S = s;
+    c->pred_T = t;
+    c->pred_C = n_conf;
+    c->pred_ha_stride = 0;
+    c->pred_venue = true;
+    return BPLHIP_OK;
+}
+
+// argument checks shared by the four query entry points; venue = the caller is a *_venue entry
+static int predict_check_query(bplhip_ctx* c, const char* what, bool venue, int64_t m, const uint16_t* home_idx,
+                               const uint16_t* away_idx, const uint8_t* neutral, const uint16_t* home_conf,
+                               const uint16_t* away_conf) {
+    if (c->pred_S == 0) return fail(c, BPLHIP_ESTATE, "%s: no posterior set", what);
+    if (venue != c->pred_venue)
+        return fail(c, BPLHIP_ESTATE, "%s: the posterior was set with predict_set_posterior%s", what,
+                    c->pred_venue ? "_venue" : "");
+    if (m < 0 || m > 0x7FFFFFFF || (m > 0 && (!home_idx || !away_idx)))
+        return fail(c, BPLHIP_EINVAL, "%s: bad argument", what);
+    if (venue && m > 0 && (!neutral || (c->pred_C > 0) != (home_conf != nullptr) || (home_conf != nullptr) != (away_conf != nullptr)))
+        return fail(c, BPLHIP_EINVAL, "%s: neutral_venue is required, confederations exactly when the posterior has them", what);
+    for (int64_t i = 0; i < m; ++i) {
         if (home_idx[i] >= c->pred_T || away_idx[i] >= c->pred_T)
-            return fail(c, BPLHIP_EINVAL, "predict_score_grid: team index out of range at %lld", (long long)i);
+            return fail(c, BPLHIP_EINVAL, "%s: team index out of range at %lld", what, (long long)i);
+        if (venue && home_conf && (home_conf[i] >= c->pred_C || away_conf[i] >= c->pred_C))
+            return fail(c, BPLHIP_EINVAL, "%s: confederation index out of range at %lld", what, (long long)i);
+    }
+    return BPLHIP_OK;
+}
+
+static int predict_score_grid_any(bplhip_ctx* c, const char* what, bool venue, int64_t m, const uint16_t* home_idx,
+                                  const uint16_t* away_idx, const uint8_t* neutral, const uint16_t* home_conf,
+                                  const uint16_t* away_conf, int32_t max_goals, double* out, void* stream) {
+    if (!c) return BPLHIP_EINVAL;
+    if (max_goals < 0 || max_goals > dcp::GRID_MAX_GOALS)
+        return fail(c, BPLHIP_EINVAL, "%s: max_goals=%d out of range [0,%d]", what, max_goals, dcp::GRID_MAX_GOALS);
+    int rc = predict_check_query(c, what, venue, m, home_idx, away_idx, neutral, home_conf, away_conf);
+    if (rc != BPLHIP_OK) return rc;
+    if (m > 0 && !out) return fail(c, BPLHIP_EINVAL, "%s: bad argument", what);
+    if (m == 0) return BPLHIP_OK;
     HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t s = static_cast<hipStream_t>(stream);
     const size_t cells = (size_t)m * (max_goals + 1) * (max_goals + 1);
-    const size_t idx_bytes = ((size_t)m * 4 + 7) & ~(size_t)7;
+    // u16 h, a, hc, ac then u8 neutral, rounded up to 8 bytes
+    const size_t idx_bytes = ((size_t)m * 9 + 7) & ~(size_t)7;
     HIP_TRY(c, c->dp_q.ensure(idx_bytes + cells * 8));
     uint16_t* q = c->dp_q.as<uint16_t>();
+    uint8_t* qn = reinterpret_cast<uint8_t*>(q + 4 * m);
     double* d_out = reinterpret_cast<double*>(c->dp_q.as<char>() + idx_bytes);
     HIP_TRY(c, hipMemcpyAsync(q, home_idx, (size_t)m * 2, hipMemcpyHostToDevice, s));
     HIP_TRY(c, hipMemcpyAsync(q + m, away_idx, (size_t)m * 2, hipMemcpyHostToDevice, s));
+    if (venue) {
+        HIP_TRY(c, hipMemcpyAsync(qn, neutral, (size_t)m, hipMemcpyHostToDevice, s));
+        if (home_conf) {
+            HIP_TRY(c, hipMemcpyAsync(q + 2 * m, home_conf, (size_t)m * 2, hipMemcpyHostToDevice, s));
+            HIP_TRY(c, hipMemcpyAsync(q + 3 * m, away_conf, (size_t)m * 2, hipMemcpyHostToDevice, s));
+        }
+    }
+    if (!c->dp_fact.p) {  // c_k = rint(log2 k!) and 2^c_k / k! (dc_predict.hip.h), k = 0..63
+        struct { double scale[64]; float cexp[64]; } f;
+        for (int k = 0; k < 64; ++k) {
+            const double l2 = std::lgamma((double)k + 1.0) * 1.4426950408889634074;
+            const double ck = std::nearbyint(l2);
+            f.cexp[k] = (float)ck;
+            f.scale[k] = std::exp2(ck - l2);
+        }
+        HIP_TRY(c, c->dp_fact.ensure(sizeof f));
+        HIP_TRY(c, hipMemcpy(c->dp_fact.p, &f, sizeof f, hipMemcpyHostToDevice));
+    }
     dcp::GridArgs A{};
+    A.scale = c->dp_fact.as<const double>();
+    A.cexp = reinterpret_cast<const float*>(c->dp_fact.as<const double>() + 64);
     A.S = c->pred_S;
     A.T = c->pred_T;
-    A.attack = c->dp_att32.as<const float>();
-    A.defence = c->dp_def32.as<const float>();
-    A.home_adv = c->dp_ha32.as<const float>();
+    A.attack = c->dp_tab32[PT_ATT].as<const float>();
+    A.defence = c->dp_tab32[PT_DEF].as<const float>();
+    A.home_adv = c->dp_tab32[PT_HA].as<const float>();
     A.ha_stride = c->pred_ha_stride;
+    A.home_attack = c->dp_tab32[PT_HAT].as<const float>();
+    A.away_attack = c->dp_tab32[PT_AAT].as<const float>();
+    A.home_defence = c->dp_tab32[PT_HDF].as<const float>();
+    A.away_defence = c->dp_tab32[PT_ADF].as<const float>();
+    A.conf = c->pred_C ? c->dp_tab32[PT_CONF].as<const float>() : nullptr;
     A.corr = c->dp_corr32.as<const float>();
     A.M = (int)m;
     A.G = max_goals;
     A.h = q;
     A.a = q + m;
+    A.hc = q + 2 * m;
+    A.ac = q + 3 * m;
+    A.neutral = qn;
     A.out = d_out;
-    hipLaunchKernelGGL(dcp::predict_score_grid, dim3((unsigned)((m + dcp::GRID_WAVES - 1) / dcp::GRID_WAVES)),
-                       dim3(64 * dcp::GRID_WAVES), 0, s, A);
+    const dim3 grid((unsigned)((m + dcp::GRID_WAVES - 1) / dcp::GRID_WAVES)), block(64 * dcp::GRID_WAVES);
+    if (venue) hipLaunchKernelGGL(dcp::predict_score_grid<true>, grid, block, 0, s, A);
+    else hipLaunchKernelGGL(dcp::predict_score_grid<false>, grid, block, 0, s, A);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(out, d_out, cells * 8, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
     return BPLHIP_OK;
 }
 
-static int bplhip_predict_score_proba_impl(bplhip_ctx* c, int64_t m, const uint16_t* home_idx,
-                                          const uint16_t* away_idx, const uint16_t* home_goals,
-                                          const uint16_t* away_goals, double* out, void* stream) {
+static int predict_score_proba_any(bplhip_ctx* c, const char* what, bool venue, int64_t m, const uint16_t* home_idx,
+                                   const uint16_t* away_idx, const uint16_t* home_goals, const uint16_t* away_goals,
+                                   const uint8_t* neutral, const uint16_t* home_conf, const uint16_t* away_conf,
+                                   double* out, void* stream) {
     if (!c) return BPLHIP_EINVAL;
-    if (c->pred_S == 0) return fail(c, BPLHIP_ESTATE, "predict_score_proba: no posterior set");
-    if (m < 0 || (m > 0 && (!home_idx || !away_idx || !home_goals || !away_goals || !out)))
-        return fail(c, BPLHIP_EINVAL, "predict_score_proba: bad argument");
+    int rc = predict_check_query(c, what, venue, m, home_idx, away_idx, neutral, home_conf, away_conf);
+    if (rc != BPLHIP_OK) return rc;
+    if (m > 0 && (!home_goals || !away_goals || !out)) return fail(c, BPLHIP_EINVAL, "%s: bad argument", what);
     if (m == 0) return BPLHIP_OK;
-    for (int64_t i = 0; i < m; ++i)
-        if (home_idx[i] >= c->pred_T || away_idx[i] >= c->pred_T)
-            return fail(c, BPLHIP_EINVAL, "predict_score_proba: team index out of range at %lld",
-                        (long long)i);
     HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t s = static_cast<hipStream_t>(stream);
-    HIP_TRY(c, c->dp_q.ensure((size_t)m * (4 * 2 + 8)));
+    // u16 h, a, x, y, hc, ac then u8 neutral, rounded up to 8 bytes; then the f64 results
+    const size_t idx_bytes = ((size_t)m * 13 + 7) & ~(size_t)7;
+    HIP_TRY(c, c->dp_q.ensure(idx_bytes + (size_t)m * 8));
     uint16_t* q = c->dp_q.as<uint16_t>();
-    double* d_out = reinterpret_cast<double*>(c->dp_q.as<char>() + (((size_t)m * 8 + 7) & ~(size_t)7));
+    uint8_t* qn = reinterpret_cast<uint8_t*>(q + 6 * m);
+    double* d_out = reinterpret_cast<double*>(c->dp_q.as<char>() + idx_bytes);
     HIP_TRY(c, hipMemcpyAsync(q, home_idx, (size_t)m * 2, hipMemcpyHostToDevice, s));
     HIP_TRY(c, hipMemcpyAsync(q + m, away_idx, (size_t)m * 2, hipMemcpyHostToDevice, s));
     HIP_TRY(c, hipMemcpyAsync(q + 2 * m, home_goals, (size_t)m * 2, hipMemcpyHostToDevice, s));
     HIP_TRY(c, hipMemcpyAsync(q + 3 * m, away_goals, (size_t)m * 2, hipMemcpyHostToDevice, s));
+    if (venue) {
+        HIP_TRY(c, hipMemcpyAsync(qn, neutral, (size_t)m, hipMemcpyHostToDevice, s));
+        if (home_conf) {
+            HIP_TRY(c, hipMemcpyAsync(q + 4 * m, home_conf, (size_t)m * 2, hipMemcpyHostToDevice, s));
+            HIP_TRY(c, hipMemcpyAsync(q + 5 * m, away_conf, (size_t)m * 2, hipMemcpyHostToDevice, s));
+        }
+    }
     dcp::PredictArgs A{};
     A.S = c->pred_S;
     A.T = c->pred_T;
-    A.attack = c->dp_att.as<const double>();
-    A.defence = c->dp_def.as<const double>();
-    A.home_adv = c->dp_ha.as<const double>();
+    A.C = c->pred_C;
+    A.attack = c->dp_tab[PT_ATT].as<const double>();
+    A.defence = c->dp_tab[PT_DEF].as<const double>();
+    A.home_adv = c->dp_tab[PT_HA].as<const double>();
     A.ha_stride = c->pred_ha_stride;
+    A.home_attack = c->dp_tab[PT_HAT].as<const double>();
+    A.away_attack = c->dp_tab[PT_AAT].as<const double>();
+    A.home_defence = c->dp_tab[PT_HDF].as<const double>();
+    A.away_defence = c->dp_tab[PT_ADF].as<const double>();
+    A.conf = c->pred_C ? c->dp_tab[PT_CONF].as<const double>() : nullptr;
     A.corr = c->dp_corr.as<const double>();
     A.M = m;
     A.h = q;
     A.a = q + m;
     A.x = q + 2 * m;
     A.y = q + 3 * m;
+    A.hc = q + 4 * m;
+    A.ac = q + 5 * m;
+    A.neutral = qn;
     A.out = d_out;
-    hipLaunchKernelGGL(dcp::predict_score_proba, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, A);
+    const dim3 grid((unsigned)((m + 255) / 256)), block(256);
+    if (venue) hipLaunchKernelGGL(dcp::predict_score_proba<true>, grid, block, 0, s, A);
+    else hipLaunchKernelGGL(dcp::predict_score_proba<false>, grid, block, 0, s, A);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(out, d_out, (size_t)m * 8, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
@@ -2462,7 +2569,35 @@ extern "C" int bplhip_predict_score_grid(bplhip_ctx* c, int64_t m, const uint16_
                                          const uint16_t* away_idx, int32_t max_goals, double* out,
                                          void* stream) {
     return guarded(c, "bplhip_predict_score_grid", [&] {
-        return bplhip_predict_score_grid_impl(c, m, home_idx, away_idx, max_goals, out, stream);
+        return predict_score_grid_any(c, "predict_score_grid", false, m, home_idx, away_idx, nullptr, nullptr, nullptr, max_goals, out, stream);
+    });
+}
+extern "C" int bplhip_predict_set_posterior_venue(bplhip_ctx* c, int32_t s, int32_t t, const double* attack,
+                                                  const double* defence, const double* home_attack,
+                                                  const double* away_attack, const double* home_defence,
+                                                  const double* away_defence, int32_t n_conf,
+                                                  const double* confederation_strength,
+                                                  const double* corr_coef) {
+    return guarded(c, "bplhip_predict_set_posterior_venue", [&] {
+        return bplhip_predict_set_posterior_venue_impl(c, s, t, attack, defence, home_attack, away_attack, home_defence,
+                                                       away_defence, n_conf, confederation_strength, corr_coef);
+    });
+}
+extern "C" int bplhip_predict_score_grid_venue(bplhip_ctx* c, int64_t m, const uint16_t* home_idx,
+                                               const uint16_t* away_idx, const uint8_t* neutral_venue,
+                                               const uint16_t* home_conf, const uint16_t* away_conf,
+                                               int32_t max_goals, double* out, void* stream) {
+    return guarded(c, "bplhip_predict_score_grid_venue", [&] {
+        return predict_score_grid_any(c, "predict_score_grid_venue", true, m, home_idx, away_idx, neutral_venue, home_conf, away_conf, max_goals, out, stream);
+    });
+}
+extern "C" int bplhip_predict_score_proba_venue(bplhip_ctx* c, int64_t m, const uint16_t* home_idx,
+                                                const uint16_t* away_idx, const uint16_t* home_goals,
+                                                const uint16_t* away_goals, const uint8_t* neutral_venue,
+                                                const uint16_t* home_conf, const uint16_t* away_conf,
+                                                double* out, void* stream) {
+    return guarded(c, "bplhip_predict_score_proba_venue", [&] {
+        return predict_score_proba_any(c, "predict_score_proba_venue", true, m, home_idx, away_idx, home_goals, away_goals, neutral_venue, home_conf, away_conf, out, stream);
     });
 }
 __global__ void selftest_math_kernel(int which, long long n, const double* in, double* out) {
@@ -2490,5 +2625,5 @@ extern "C" int bplhip_selftest_math(bplhip_ctx* c, int32_t which, int64_t n, con
 extern "C" int bplhip_predict_score_proba(bplhip_ctx* c, int64_t m, const uint16_t* home_idx,
                                           const uint16_t* away_idx, const uint16_t* home_goals,
                                           const uint16_t* away_goals, double* out, void* stream) {
-    return guarded(c, "bplhip_predict_score_proba", [&] { return bplhip_predict_score_proba_impl(c, m, home_idx, away_idx, home_goals, away_goals, out, stream); });
+    return guarded(c, "bplhip_predict_score_proba", [&] { return predict_score_proba_any(c, "predict_score_proba", false, m, home_idx, away_idx, home_goals, away_goals, nullptr, nullptr, nullptr, out, stream); });
 }

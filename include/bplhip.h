@@ -298,6 +298,34 @@ int bplhip_predict_score_grid(bplhip_ctx* ctx, int64_t m, const uint16_t* home_i
                               const uint16_t* away_idx, int32_t max_goals, double* out,
                               void* stream);
 
+/* The same three entry points for the venue-aware rate form of the neutral-venue family:
+ * `_calculate_expected_goals` of bpl/neutral_dixon_coles.py:399-423 (four per-team offsets that
+ * are switched off at neutral venues), bpl/neutral_dixon_coles_WC.py:385-424 (plus the difference
+ * of the two sides' confederation strengths) and bpl/dynamic_dixon_coles.py:336-361 (the tables of
+ * one gameweek):
+ *   on = 1 - neutral_venue,  dc = confederation_strength[home_conf] - confederation_strength[away_conf]
+ *   log home rate = attack[h] - defence[a] + on (home_attack[h] - away_defence[a]) + dc
+ *   log away rate = attack[a] - defence[h] + on (away_attack[a] - home_defence[h]) - dc
+ * set_posterior_venue: six HOST f64[s,t] tables, confederation_strength HOST f64[s,n_conf] or NULL
+ * with n_conf = 0, corr_coef f64[s].  Queries: neutral_venue HOST u8[m] (required), home_conf /
+ * away_conf HOST u16[m] exactly when the posterior has confederations (else NULL).  A context holds
+ * ONE posterior: the plain and the venue entry points cannot be mixed (BPLHIP_ESTATE). */
+int bplhip_predict_set_posterior_venue(bplhip_ctx* ctx, int32_t s, int32_t t, const double* attack,
+                                       const double* defence, const double* home_attack,
+                                       const double* away_attack, const double* home_defence,
+                                       const double* away_defence, int32_t n_conf,
+                                       const double* confederation_strength,
+                                       const double* corr_coef);
+int bplhip_predict_score_proba_venue(bplhip_ctx* ctx, int64_t m, const uint16_t* home_idx,
+                                     const uint16_t* away_idx, const uint16_t* home_goals,
+                                     const uint16_t* away_goals, const uint8_t* neutral_venue,
+                                     const uint16_t* home_conf, const uint16_t* away_conf,
+                                     double* out, void* stream);
+int bplhip_predict_score_grid_venue(bplhip_ctx* ctx, int64_t m, const uint16_t* home_idx,
+                                    const uint16_t* away_idx, const uint8_t* neutral_venue,
+                                    const uint16_t* home_conf, const uint16_t* away_conf,
+                                    int32_t max_goals, double* out, void* stream);
+
 /* Self-test of the library's own float64 device math (csrc/dc_kernels.hip.h, namespace
  * dc::lean -- the short exp / log / log1p / reciprocal the float64 kernels use on their critical
  * paths; no reference counterpart).  which: 0 exp(x), 1 log(x), 2 log(1 + x) for x >= 0, 3 1/x for

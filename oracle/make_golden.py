@@ -38,7 +38,7 @@ def main():
     for model, name in GOLDEN_CASES:
         fx = cases.fixtures(name)
         pts = cases.z_points(model, fx)
-        zs, Us, gs, rhos, lbs, ubs = [], [], [], [], [], []
+        zs, Us, gs, rhos, lbs, ubs, atts, dfns, has = [], [], [], [], [], [], [], [], []
         for _, z in pts:
             U, g, aux = O.potential_and_grad(model, fx, z)
             zs.append(z)
@@ -47,6 +47,9 @@ def main():
             rhos.append(aux["rho"])
             lbs.append(aux["LB"])
             ubs.append(aux["UB"])
+            atts.append(aux["attack"])
+            dfns.append(aux["defence"])
+            has.append(np.broadcast_to(aux["home_advantage"], (fx.n_teams,)))
         np.savez_compressed(
             os.path.join(OUT, f"m{model}_{name}.npz"),
             model=model,
@@ -64,6 +67,11 @@ def main():
             rho=np.array(rhos),
             LB=np.array(lbs),
             UB=np.array(ubs),
+            # deterministic sites at each point (also what the stated tolerance of U is built from,
+            # tests/cases.py u_tolerance)
+            attack=np.stack(atts),
+            defence=np.stack(dfns),
+            home_advantage=np.stack(has),
         )
         print(f"wrote m{model}_{name}.npz  ({len(pts)} points, N={fx.n})")
     neutral_golden()

@@ -63,38 +63,68 @@ class FakeCtx:
 
 class FakePredictCtx:
     """TEST-ONLY numpy (float64) predict backend with bpl._ffi.HipContext's predict surface:
-    a literal restatement of the reference's predict_score_proba (bpl/dixon_coles.py:126-163,
-    bpl/_util.py:35-93).  The CPU API tests inject it as `model._predict_ctx`; the GPU tests use it
-    as the float64 comparator of the device kernels."""
+    a restatement of the reference's predict_score_proba -- bpl/dixon_coles.py:126-163 for the
+    league models, bpl/neutral_dixon_coles.py:399-488 / bpl/neutral_dixon_coles_WC.py:363-470 for the
+    venue-aware family -- with the tau term of bpl/_util.py:35-93.  The CPU API tests inject it as
+    `model._predict_ctx`; the GPU tests use it as the float64 comparator of the device kernels."""
 
     def predict_set_posterior(self, attack, defence, home_advantage, corr_coef):
         self.att, self.dfn = np.asarray(attack, float), np.asarray(defence, float)
         self.ha, self.cc = np.asarray(home_advantage, float), np.asarray(corr_coef, float)
+        self.venue = None
 
-    def predict_score_proba(self, h, a, x, y):
+    def predict_set_posterior_venue(self, attack, defence, home_attack, away_attack, home_defence,
+                                    away_defence, corr_coef, confederation_strength=None):
+        self.att, self.dfn = np.asarray(attack, float), np.asarray(defence, float)
+        self.venue = [np.asarray(t, float) for t in (home_attack, away_attack, home_defence, away_defence)]
+        self.conf = None if confederation_strength is None else np.asarray(confederation_strength, float)
+        self.cc = np.asarray(corr_coef, float)
+
+    def _log_rates(self, h, a, neutral, conf):
+        eh = self.att[:, h] - self.dfn[:, a]
+        ea = self.att[:, a] - self.dfn[:, h]
+        if self.venue is None:
+            assert neutral is None and conf is None
+            return eh + (self.ha[:, None] if self.ha.ndim == 1 else self.ha[:, h]), ea
+        assert neutral is not None and (conf is None) == (self.conf is None)
+        hat, aat, hdf, adf = self.venue
+        on = 1.0 - np.broadcast_to(np.asarray(neutral, float), h.shape)
+        eh = eh + on * hat[:, h] - on * adf[:, a]
+        ea = ea + on * aat[:, a] - on * hdf[:, h]
+        if conf is not None:
+            hc = np.broadcast_to(np.asarray(conf[0], int), h.shape)
+            ac = np.broadcast_to(np.asarray(conf[1], int), h.shape)
+            d = self.conf[:, hc] - self.conf[:, ac]
+            eh, ea = eh + d, ea - d
+        return eh, ea
+
+    def predict_score_proba(self, h, a, x, y, neutral=None, conf=None):
         from scipy.special import gammaln
 
         h, a = np.asarray(h, int), np.asarray(a, int)
         x, y = np.asarray(x, int), np.asarray(y, int)
-        ha = self.ha[:, None] if self.ha.ndim == 1 else self.ha[:, h]
-        lh = np.exp(self.att[:, h] - self.dfn[:, a] + ha)
-        la = np.exp(self.att[:, a] - self.dfn[:, h])
+        eh, ea = self._log_rates(h, a, neutral, conf)
+        lh, la = np.exp(eh), np.exp(ea)
         rho = self.cc[:, None]
         tau = np.ones_like(lh)
         tau = np.where((x == 0) & (y == 0), np.clip(1 - rho * lh * la, 0, None), tau)
         tau = np.where((x == 1) & (y == 0), np.clip(1 + rho * la, 0, None), tau)
         tau = np.where((x == 0) & (y == 1), np.clip(1 + rho * lh, 0, None), tau)
         tau = np.where((x == 1) & (y == 1), np.clip(1 - rho + 0 * lh, 0, None), tau)
-        ph = np.exp(np.log(lh) * x - gammaln(x + 1.0) - lh)
-        pa = np.exp(np.log(la) * y - gammaln(y + 1.0) - la)
+        ph = np.exp(eh * x - gammaln(x + 1.0) - lh)
+        pa = np.exp(ea * y - gammaln(y + 1.0) - la)
         return (tau * ph * pa).mean(axis=0)
 
-    def predict_score_grid(self, h, a, max_goals):
+    def predict_score_grid(self, h, a, max_goals, neutral=None, conf=None):
         h, a = np.asarray(h, int), np.asarray(a, int)
         g1 = max_goals + 1
         xs, ys = np.meshgrid(np.arange(g1), np.arange(g1), indexing="ij")
         out = np.empty((len(h), g1, g1))
+        nv = None if neutral is None else np.broadcast_to(np.asarray(neutral), h.shape)
         for i in range(len(h)):
+            ci = None if conf is None else (np.broadcast_to(np.asarray(conf[0]), h.shape)[i],
+                                            np.broadcast_to(np.asarray(conf[1]), h.shape)[i])
             out[i] = self.predict_score_proba(np.full(g1 * g1, h[i]), np.full(g1 * g1, a[i]),
-                                              xs.ravel(), ys.ravel()).reshape(g1, g1)
+                                              xs.ravel(), ys.ravel(),
+                                              None if nv is None else nv[i], ci).reshape(g1, g1)
         return out

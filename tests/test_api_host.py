@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 from bpl import DixonColesMatchPredictor, ExtendedDixonColesMatchPredictor
-from bpl._util import compute_corr_coef_bounds, dixon_coles_correlation_term, parse_teams
+from bpl._util import parse_teams, str_to_list
 from bpl.base import MAX_GOALS
 from fake_ctx import FakePredictCtx
 
@@ -36,22 +36,56 @@ def test_parse_teams_string_sorted(dummy_data):
     assert h.dtype == np.uint16 and list(a[:3]) == [1, 12, 13]
 
 
-def test_corr_term_and_bounds_semantics():
-    lh, la = np.array([1.5, 0.8, 2.0, 1.1, 0.7]), np.array([1.1, 1.3, 0.4, 0.9, 2.5])
-    LB, UB = compute_corr_coef_bounds(lh, la)
-    assert UB == pytest.approx(1 / (0.7 * 2.5)) and LB == pytest.approx(-1 / 2.5)
-    x, y = np.array([0, 1, 0, 1, 3]), np.array([0, 0, 1, 1, 0])
-    rho = np.array([0.1, -0.2])
-    t = dixon_coles_correlation_term(x, y, np.tile(lh, (2, 1)), np.tile(la, (2, 1)), rho)
-    assert t.shape == (2, 5)
-    assert t[0, 0] == pytest.approx(np.log(1 - 0.1 * 1.5 * 1.1))
-    assert t[1, 1] == pytest.approx(np.log(1 - 0.2 * 1.3))
-    assert t[0, 2] == pytest.approx(np.log(1 + 0.1 * 2.0))
-    assert t[1, 3] == pytest.approx(np.log(1 + 0.2))
-    assert np.all(t[:, 4] == 0)
-    # tol = 0: clipped argument -> -inf, like the reference
-    t = dixon_coles_correlation_term(0, 0, np.array([[3.0]]), np.array([[3.0]]), np.array([0.5]))
-    assert np.isneginf(t[0, 0])
+def test_str_to_list():
+    a, b = str_to_list("x", ["y", "z"])
+    assert a == ["x"] and b == ["y", "z"]
+
+
+@pytest.mark.parametrize("model_cls", MODELS)
+def test_fitted_model_pickles_and_copies_after_predict(dummy_data, model_cls):
+    """The reference's fitted models are plain arrays and pickle; the device context a predict call
+    creates must not change that (it is dropped from the state and re-created lazily)."""
+    import copy
+    import pickle
+
+    model = _fake_fit(model_cls, dummy_data)
+    before = model.predict_outcome_proba("0", "1")
+    blob = pickle.dumps(model)
+    clone = pickle.loads(blob)
+    twin = copy.deepcopy(model)
+    for other in (clone, twin):
+        assert other._predict_ctx is None and np.array_equal(other.attack, model.attack)
+        other._predict_ctx = FakePredictCtx()
+        after = other.predict_outcome_proba("0", "1")
+        assert after["home_win"][0] == pytest.approx(before["home_win"][0], abs=1e-12)
+    twin.attack[:, 0] += 1.0  # (a deep copy owns its arrays)
+    assert not np.array_equal(twin.attack, model.attack)
+
+
+def test_in_place_edit_reaches_the_device(dummy_data):
+    """An in-place edit of a posterior array keeps its `id`: the upload cache must notice anyway."""
+    model = _fake_fit(DixonColesMatchPredictor, dummy_data)
+    p0 = model.predict_outcome_proba("0", "1")["home_win"][0]
+    model.attack[:, model._teams_dict["0"]] += 0.7
+    p1 = model.predict_outcome_proba("0", "1")["home_win"][0]
+    assert p1 > p0 + 0.05
+    model.attack = model.attack - 0.0  # reassignment
+    assert model.predict_outcome_proba("0", "1")["home_win"][0] == pytest.approx(p1, abs=1e-12)
+    model.invalidate_predict_cache()
+    assert model._uploaded is None
+
+
+def test_deep_grids_and_bad_n(dummy_data):
+    """max_goals beyond the grid kernel's depth (63) goes through the pointwise kernel; negative
+    goal counts are an error, not a wrapped index."""
+    model = _fake_fit(DixonColesMatchPredictor, dummy_data)
+    deep, xs, ys = model.predict_score_grid_proba(["0"], ["1"], max_goals=70)
+    shallow, _, _ = model.predict_score_grid_proba(["0"], ["1"], max_goals=20)
+    assert deep.shape == (1, 71, 71) and xs[70, 0] == 70 and ys[0, 70] == 70
+    assert np.abs(deep[0, :21, :21] - shallow[0]).max() < 1e-12
+    assert model.predict_score_n_proba(66, "0", "1", max_goals=66)[0] >= 0.0
+    with pytest.raises(ValueError):
+        model.predict_score_n_proba(-1, "0", "1")
 
 
 @pytest.mark.parametrize("model_cls", MODELS)

@@ -6,6 +6,7 @@ import pytest
 
 from bpl import NeutralDixonColesMatchPredictor, NeutralDixonColesMatchPredictorWC
 from bpl.neutral_dixon_coles import latent_sites, make_weights
+from fake_ctx import FakePredictCtx
 
 MAX_GOALS = 15
 TOL = 1e-2
@@ -34,6 +35,7 @@ def _posterior(cls, S=200, T=6, C=0, seed=0):
         m.conferences = np.array([str(i) for i in range(C)])
         m._conferences_dict = {c: i for i, c in enumerate(m.conferences)}
         m.confederation_strength = rs.normal(0, 0.2, (S, C))
+    m._predict_ctx = FakePredictCtx()  # (no GPU here: the numpy restatement stands in for the kernels)
     return m
 
 

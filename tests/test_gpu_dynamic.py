@@ -88,6 +88,22 @@ def test_dynamic_fit_smoke(hip_ctx):
     p = m.predict_outcome_proba(["t0", "t1"], ["t2", "t3"], [0, 1])
     assert np.allclose(p["home_win"] + p["draw"] + p["away_win"], 1.0, atol=1e-5)
     assert m.predict_score_proba("t0", "t1", 1, 0, 0).shape == (1,)
+    # the predict methods run on the device (venue-aware kernels on ONE gameweek's tables):
+    # against the float64 restatement, for the default (last) gameweek and an earlier one
+    from fake_ctx import FakePredictCtx
+
+    for week in (None, 1):
+        g = G - 1 if week is None else week
+        ref = FakePredictCtx()
+        ref.predict_set_posterior_venue(*(getattr(m, nm)[:, g, :] for nm in m._VENUE_TABLES), m.corr_coef)
+        h, a, nv = np.array([0, 1, 4]), np.array([2, 3, 5]), np.array([0, 1, 0])
+        got = m.predict_score_proba(["t0", "t1", "t4"], ["t2", "t3", "t5"], [1, 0, 2], [0, 0, 1], nv, gameweek=week)
+        assert np.abs(got - ref.predict_score_proba(h, a, [1, 0, 2], [0, 0, 1], nv)).max() < 1e-12
+        out = m.predict_outcome_proba(["t0", "t1", "t4"], ["t2", "t3", "t5"], nv, gameweek=week)
+        grid = ref.predict_score_grid(h, a, 15, nv)
+        assert np.abs(out["draw"] - np.trace(grid, axis1=1, axis2=2)).max() < 3e-6
+        lh, la = m._calculate_expected_goals(["t0"], ["t2"], [0], gameweek=week)
+        assert lh.shape == (40, 1) and np.all(lh > 0)
 
 
 def test_dynamic_chain_on_device_matches_host_tree(hip_ctx):

@@ -218,3 +218,69 @@ def test_wc_fit_and_predict(model_wc):
     assert s["home_score"].shape == (1, 20)
     w = m.sample_outcome(["0"], ["5"], ["0"], ["1"], [1], knockout=True, num_samples=20, random_state=3)
     assert set(np.unique(w)) <= {"0", "5"}
+
+
+# ---- device predict path of the venue-aware family (csrc/dc_predict.hip.h, VENUE = 1)
+def _venue_check(m, h, a, nv, conf, x, y):
+    """Device kernels against tests/fake_ctx.FakePredictCtx (float64 numpy restatement of the
+    reference's predict_score_proba).  Tolerances as for the league models (tests/test_gpu_fit.py):
+    pointwise kernel float64 throughout -> 1e-12; grid kernel float32 pmfs on float32 draws, float64
+    across 64-draw blocks -> 3e-6 relative + 1e-12."""
+    from fake_ctx import FakePredictCtx
+
+    ref = FakePredictCtx()
+    ref.predict_set_posterior_venue(m.attack, m.defence, m.home_attack, m.away_attack, m.home_defence,
+                                    m.away_defence, m.corr_coef, confederation_strength=m.confederation_strength)
+    got = m._score_proba(h, a, x, y, nv, conf)
+    want = ref.predict_score_proba(h, a, x, y, nv, conf)
+    assert np.abs(got - want).max() < 1e-12
+    for depth in (MAX_GOALS, 20, 3):
+        grid = m._grid_probs(h[:40], a[:40], nv[:40], None if conf is None else (conf[0][:40], conf[1][:40]), depth)
+        want = ref.predict_score_grid(h[:40], a[:40], depth, nv[:40],
+                                      None if conf is None else (conf[0][:40], conf[1][:40]))
+        err = np.abs(grid - want)
+        assert (err <= 3e-6 * want + 1e-12).all(), (depth, err.max(), (err / (want + 1e-300)).max())
+    return ref
+
+
+def test_device_predict_matches_float64_restatement(model):
+    m, dd = model
+    h, a, nv = m._parse_fixture_args(dd["home_team"], dd["away_team"], dd["neutral_venue"])
+    assert nv.min() == 0 and nv.max() == 1
+    ref = _venue_check(m, h, a, nv, None, np.asarray(dd["home_goals"]), np.asarray(dd["away_goals"]))
+    # the reductions of the grid, through the public API
+    out = m.predict_outcome_proba(dd["home_team"][:30], dd["away_team"][:30], dd["neutral_venue"][:30])
+    g = ref.predict_score_grid(h[:30], a[:30], MAX_GOALS, nv[:30])
+    xs, ys = np.meshgrid(np.arange(MAX_GOALS + 1), np.arange(MAX_GOALS + 1), indexing="ij")
+    for key, mask in (("home_win", xs > ys), ("draw", xs == ys), ("away_win", xs < ys)):
+        assert np.abs(out[key] - g[:, mask].sum(axis=1)).max() < 3e-6
+    n = np.arange(MAX_GOALS + 1)
+    t0, t1 = m._teams_dict["0"], m._teams_dict["1"]
+    for venue in (0, 1):
+        g01 = ref.predict_score_grid([t0], [t1], MAX_GOALS, [venue])[0]
+        g10 = ref.predict_score_grid([t1], [t0], MAX_GOALS, [venue])[0]
+        assert np.abs(m.predict_score_n_proba(n, "0", "1", neutral_venue=venue) - g01.sum(axis=1)).max() < 3e-6
+        assert np.abs(m.predict_score_n_proba(n, "0", "1", home=False, neutral_venue=venue) - g10.sum(axis=0)).max() < 3e-6
+        assert np.abs(m.predict_concede_n_proba(n, "0", "1", neutral_venue=venue) - g01.sum(axis=0)).max() < 3e-6
+    # a fitted model pickles after predicting (the device context is not part of its state)
+    import pickle
+
+    clone = pickle.loads(pickle.dumps(m))
+    assert clone._predict_ctx is None
+    assert np.array_equal(clone.predict_score_proba("0", "1", 1, 0, 0), m.predict_score_proba("0", "1", 1, 0, 0))
+
+
+def test_wc_device_predict_matches_float64_restatement(model_wc):
+    m, dd = model_wc
+    h, a, hc, ac, nv = m._parse_fixture_args(dd["home_team"], dd["away_team"], dd["home_conf"], dd["away_conf"],
+                                             dd["neutral_venue"])
+    assert len(set(hc.tolist())) > 1
+    _venue_check(m, h, a, nv, (hc, ac), np.asarray(dd["home_goals"]), np.asarray(dd["away_goals"]))
+    # the plain and the venue entry points cannot be mixed on one context
+    from bpl._ffi import BPLHIP_ESTATE, BplHipError
+
+    with pytest.raises(BplHipError) as e:
+        m._device().predict_score_grid(h[:2], a[:2], 5)
+    assert e.value.code == BPLHIP_ESTATE
+    with pytest.raises(BplHipError):
+        m._device().predict_score_grid(h[:2], a[:2], 5, neutral=nv[:2])  # confederations missing

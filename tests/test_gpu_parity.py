@@ -1,14 +1,13 @@
 """GPU parity: the HIP path (through the C-ABI) vs the float64 oracle on the same seeded
 inputs.  Floating point path -> tolerances, stated here:
 
-  U     : |U_hip - U_oracle| <= 3e-7 * (|U| + 4N) / sqrt(P) + 1e-9,  P = unique pairs.
-          Per-fixture arithmetic is float32 with float64 accumulation; the rounding of the
-          per-team tables is corrected to first order, what remains is the rounding of
-          the rate product, identical for every fixture of a (home,away) pair, hence
-          ~6e-8 * sum(rates) / sqrt(P).  Points that force the rate clip at 15 (wild
-          parameter regions, k*log(rate) through v_log_f32) get 20x that.
-  gradU : max|dg| <= 3e-6 * max|g| + 1e-6   (float32 tables: ~2e-7 relative)
-Measured errors are far inside these (printed with -s).
+  U     : |U_hip - U_oracle| <= cases.u_tolerance(...): a bound built from the kernel's error sources
+          (the float32 rate product rounded once per pair, the float32 wave sums of a tile, v_log_f32
+          at the extended model's rate clip), with eps = 2^-24 and stated constants -- 7e-3 at
+          N = 1e6 (U = 3.6e6), against a measured 2e-3 .. 7e-3 there and SURVEY 8c's 5e-3.
+          Round 2's gate, 3e-7 (|U| + 4N) / sqrt(P) (x20 at the clip points), was 0.12.
+  gradU : max|dg| <= 5e-7 * max|g| + 1e-7   (float32 tables: measured <= 2.3e-7 relative; round 2: 3e-6)
+Measured errors are printed with -s; profiles/r03/parity_errors.txt holds a full run.
 """
 import numpy as np
 import pytest
@@ -43,16 +42,19 @@ def _run(ctx, model, fx, zs):
         (Uv.cpu().numpy(), gv.cpu().numpy(), auxv.cpu().numpy())
 
 
+def _tolU(model, fx, auxo, Uo):
+    return cases.u_tolerance(fx.home_idx, fx.away_idx, fx.home_goals, fx.away_goals, fx.weights,
+                             auxo["attack"], auxo["defence"], auxo["home_advantage"],
+                             model == O.MODEL_EXTENDED, Uo)
+
+
 def _check(model, fx, name, z, U, g, aux):
     Uo, go, auxo = O.potential_and_grad(model, fx, z)
-    P = len(set(zip(fx.home_idx.tolist(), fx.away_idx.tolist())))
-    tolU = 3e-7 * (abs(Uo) + 4.0 * fx.n) / np.sqrt(P) + 1e-9
-    if "/clip" in name:
-        tolU *= 20
+    tolU = _tolU(model, fx, auxo, Uo)
     gerr = np.abs(g - go).max()
-    gtol = 3e-6 * np.abs(go).max() + 1e-6
-    print(f"{name:28s} N={fx.n:8d} U={Uo:.6f} dU={U - Uo:+.3e} (tol {tolU:.1e}) "
-          f"dg={gerr:.3e} (tol {gtol:.1e}) rho={auxo['rho']:+.6f}")
+    gtol = 5e-7 * np.abs(go).max() + 1e-7
+    print(f"{name:28s} N={fx.n:8d} U={Uo:.6f} dU={U - Uo:+.3e} (tol {tolU:.1e}, {abs(U - Uo) / tolU:.2f}) "
+          f"dg={gerr:.3e} (tol {gtol:.1e}, {gerr / gtol:.2f}) rho={auxo['rho']:+.6f}")
     if not np.isfinite(Uo):
         assert not np.isfinite(U) or U > 1e300
         return
@@ -173,11 +175,11 @@ def test_chain_vectorised_matches_single(hip_ctx, name, model, chains):
     D = O.latent_dim(model, fx.n_teams, 0 if fx.covariates is None else fx.covariates.shape[1])
     zs = [np.random.RandomState(100 + i).uniform(-0.5, 0.5, D) for i in range(chains)]
     outs, _, (Uv, gv, auxv) = _run(hip_ctx, model, fx, zs)
-    P = len(set(zip(fx.home_idx.tolist(), fx.away_idx.tolist())))
     for i, (U, g, aux) in enumerate(outs):
         print(f"chain {i}: U={U:.6f} dU={Uv[i] - U:+.3e} dg={np.abs(gv[i] - g).max():.3e} "
               f"|g|={np.abs(g).max():.3e}")
-        assert abs(Uv[i] - U) <= 2 * (3e-7 * (abs(U) + 4.0 * fx.n) / np.sqrt(P) + 1e-9)
+        Uo, _, auxo = O.potential_and_grad(model, fx, zs[i])
+        assert abs(Uv[i] - U) <= _tolU(model, fx, auxo, Uo)
         assert np.abs(gv[i] - g).max() <= 1e-6 * np.abs(g).max()
         assert np.array_equal(auxv[i], aux)
     # deterministic

@@ -97,6 +97,18 @@ elif case == "predict":
         c.predict_score_grid(big[:, 0], big[:, 1], 15)
     meta.update(fixtures_per_launch=len(big), draws=S, posterior_bytes=S * (2 * T + 2) * 4,
                 output_bytes_per_launch=len(big) * 256 * 8)
+elif case == "predict_venue":   # the neutral-venue family's rate form, with confederations
+    S, C = 1000, 5
+    rs = np.random.RandomState(0)
+    tabs = [rs.normal(0, .2, (S, T)) for _ in range(6)]
+    c.predict_set_posterior_venue(*tabs, rs.uniform(-.1, .05, S), confederation_strength=rs.normal(0, .2, (S, C)))
+    pairs = np.array([(h, a) for h in range(T) for a in range(T) if h != a])
+    big = np.tile(pairs, (64, 1))
+    nv = (np.arange(len(big)) % 3 == 0).astype(np.uint8)
+    for _ in range(max(1, steps // 64)):
+        c.predict_score_grid(big[:, 0], big[:, 1], 15, neutral=nv, conf=(big[:, 0] % C, big[:, 1] % C))
+    meta.update(fixtures_per_launch=len(big), draws=S, posterior_bytes=S * (6 * T + C + 1) * 4,
+                output_bytes_per_launch=len(big) * 256 * 8)
 else:
     raise SystemExit(f"unknown case {case}")
 print(json.dumps(meta))
