@@ -141,6 +141,34 @@ def cpu_baseline(h, a, x, y, n_teams, zs, budget_s, with_torch=True):
     return out
 
 
+def init_collectives(world, rank, local, args):
+    """RCCL over xGMI for N > 1: the fixture broadcast + the timing barrier / max (no data-path
+    collective).  A rank whose RCCL init or probe fails exits non-zero: an N > 1 line is an RCCL
+    measurement or it is not printed (no silent fall-back to another backend).
+    Returns (label for config.collectives or None, device the control tensors live on)."""
+    import torch
+    import torch.distributed as dist
+
+    dev = torch.device("cuda", local)
+    if world == 1:
+        return None, dev
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    torch.cuda.set_device(local)
+    try:
+        dist.init_process_group("nccl", device_id=dev)
+        probe = torch.ones(1, device=dev)
+        dist.all_reduce(probe)
+        torch.cuda.synchronize()
+        if int(probe.item()) != world:
+            raise RuntimeError(f"all_reduce over RCCL saw {int(probe.item())} of {world} ranks")
+    except Exception as e:  # pylint: disable=broad-except
+        print(f"# rank {rank}: RCCL unavailable ({type(e).__name__}: {e}); --gpus {args.gpus} "
+              "needs RCCL, exiting non-zero", file=sys.stderr)
+        sys.stderr.flush()
+        os._exit(3)  # (the other ranks fail their collective and torchrun tears the job down)
+    return "nccl", dev
+
+
 def main():
     args = parse_args()
     # OpenMP placement of the CPU comparator (read when libgomp loads, so set before anything else)
@@ -154,34 +182,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if "BENCH_FORCE_DEVICE" in os.environ:  # test hook: several ranks on one GPU (1-GPU boxes)
-        local = int(os.environ["BENCH_FORCE_DEVICE"])
-    backend = None
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local)
-        if os.environ.get("BENCH_CONTROL_BACKEND") == "gloo":
-            # test hook (tests/test_gpu_bench.py): the multi-rank flow on a one-GPU box, where RCCL
-            # refuses two ranks on one device.  Recorded in config.collectives; the driver never sets it.
-            dist.init_process_group("gloo")
-            backend = "gloo (BENCH_CONTROL_BACKEND test hook)"
-        else:
-            # RCCL over xGMI: fixture broadcast + the timing barrier / max (no data-path collective).
-            # A rank whose RCCL init or probe fails exits non-zero: an N > 1 line is an RCCL
-            # measurement or it is not printed (no silent fall-back to another backend).
-            try:
-                dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-                probe = torch.ones(1, device=torch.device("cuda", local))
-                dist.all_reduce(probe)
-                torch.cuda.synchronize()
-                if int(probe.item()) != world:
-                    raise RuntimeError(f"all_reduce over RCCL saw {int(probe.item())} of {world} ranks")
-                backend = "nccl"
-            except Exception as e:  # pylint: disable=broad-except
-                print(f"# rank {rank}: RCCL unavailable ({type(e).__name__}: {e}); --gpus {args.gpus} "
-                      "needs RCCL, exiting non-zero", file=sys.stderr)
-                sys.stderr.flush()
-                os._exit(3)  # (the other ranks fail their collective and torchrun tears the job down)
+    backend, ctl_dev = init_collectives(world, rank, local, args)
     if world != args.gpus and rank == 0:
         print(f"# note: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
 
@@ -198,8 +199,7 @@ def main():
         x = y = np.zeros(0, np.uint8)
     # RCCL broadcast of the fixture SoA from rank 0 (the only data collective)
     bc = _dist.broadcast_fixtures({"home_idx": h, "away_idx": a, "home_goals": x,
-                                   "away_goals": y},
-                                  device=dev if backend in (None, "nccl") else torch.device("cpu"))
+                                   "away_goals": y}, device=ctl_dev)
     bc = {k: (v.to(dev) if v is not None else None) for k, v in bc.items()}
     ctx.set_fixtures(MODEL_BASIC, bc["home_idx"], bc["away_idx"], bc["home_goals"],
                      bc["away_goals"], T)
@@ -247,14 +247,18 @@ def main():
     ev0.record()
     run(args.steps)
     ev1.record()
+    # (the host spins on the end event instead of sleeping in the synchronize: a blocked thread's
+    # wake-up is 10-20 us, a tenth of the timed region at the driver's --steps 20; the synchronize
+    # that brackets the region then returns at once)
+    while not ev1.query():
+        pass
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
     ev_ms = ev0.elapsed_time(ev1)
-    tmax = torch.tensor([wall], dtype=torch.float64,
-                        device=dev if backend in (None, "nccl") else torch.device("cpu"))
+    tmax = torch.tensor([wall], dtype=torch.float64, device=ctl_dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     wall_max = float(tmax.item())

@@ -79,6 +79,7 @@ struct bplhip_ctx {
         int aw = dc::WAVES, tpw = 1, n_wg = 1, total_c = 0;
         bool staged = true;   // the tail stages the compact array in LDS
         DevBuf d_wg_off, d_wg_slots, d_col_off, d_wg_dst;
+        DevBuf d_ga_expect;   // contributions every accumulator row receives per evaluation (dc::ga_add)
     } parts[2];
     int n_parts = 1;
     EvalPart* ep = &parts[0];
@@ -89,6 +90,14 @@ struct bplhip_ctx {
     // device buffers (library owned)
     DevBuf d_h, d_a, d_x, d_y, d_w, d_pairs, d_xs, d_cA, d_cD, d_cH, d_tickets, d_debug, d_xsf, d_hbuf;
     DevBuf d_gacc;  // accumulator rows of dc_eval's hand-off (dc::GA_ROW)
+    // fault word: host memory mapped into the device.  A kernel whose bounded wait expires ORs its
+    // code in (dc::raise_fault); every entry point looks at it on the way in and on the way out
+    // (consume_fault), so a timed-out hand-off becomes BPLHIP_EHIP + a message instead of NaN outputs
+    // that a sampler would book as divergences.
+    unsigned int* h_fault = nullptr;
+    unsigned int* d_fault = nullptr;
+    bool dyn_fused_ok = true;   // cleared when the single-launch dynamic kernel timed out: four launches from then on
+    int dyn_fused_blocks_per_cu = -1;  // occupancy of dyn_fused (queried once)
     DevBuf d_zb;    // persistent evaluation kernel: the next position as tagged granules
     unsigned int loop_tag = 0;  // tags handed out so far (a launch of k steps takes k + 1 of them)
     int opt_persistent_kernel = 1;  // 1: a single chain's leapfrogs run inside one resident launch
@@ -124,7 +133,7 @@ struct bplhip_ctx {
     // (tables 0..7: attack, defence, home_advantage | home_attack, away_attack, home_defence,
     // away_defence, confederation_strength; float64 [S, cols] for the pointwise kernel and float32
     // team-major [cols, S] for the grid kernel)
-    DevBuf dp_tab[8], dp_tab32[8], dp_corr, dp_corr32, dp_q, dp_fact;
+    DevBuf dp_tab[8], dp_tab32[8], dp_corr, dp_corr32, dp_q;
     int pred_S = 0, pred_T = 0, pred_C = 0, pred_ha_stride = 0;
     bool pred_venue = false;
     double* h_pinned = nullptr;
@@ -188,7 +197,6 @@ int hb_stride_of(const bplhip_ctx* c) { return zo_stride_of(c->L); }
 size_t gacc_bytes_of(const bplhip_ctx* c, int chains) {
     return (size_t)chains * dc::ga_rows(c->L.T) * dc::GA_ROW * sizeof(long long);
 }
-
 // the partition a launch of `chains` chains uses: the short-stream one (part 0 of two) while its
 // workgroups still find a CU each
 void select_part(bplhip_ctx* c, int chains) {
@@ -301,11 +309,21 @@ int launch_eval_dynamic(bplhip_ctx* c, int chains, const double* z, double* pot,
         A.scratch_n = dcd::scratch_doubles(L.G, L.T, L.K);
         A.gw_off = c->dd_gwoff.as<const int>();
         A.tickets = c->dd_tick.as<unsigned int>();
+        A.fault = c->d_fault;
         const int team_blocks = (L.T + dcd::BACK_BLOCK / 64 - 1) / (dcd::BACK_BLOCK / 64);
         // one launch when every workgroup is resident and a wave spans all gameweeks
         // (and a workgroup's share of the fixtures is a few rounds of its threads)
-        if (c->opt_fused_small && L.G <= dcd::FUSED_DYN_MAX_G && L.T <= dcd::FUSED_DYN_MAX_T &&
-            c->n <= (long long)team_blocks * dcd::FUSED_DYN_BLOCK * 4) {
+        // ... and its workgroups wait for each other inside the launch (flagged cells, two grid barriers):
+        // every one of them must be resident at once, on THIS device in its current compute partition
+        if (c->dyn_fused_blocks_per_cu < 0) {
+            int per_cu = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dcd::dyn_fused, dcd::FUSED_DYN_BLOCK, 0) != hipSuccess)
+                per_cu = 0;
+            c->dyn_fused_blocks_per_cu = per_cu;
+        }
+        const bool co_resident = (long long)c->dyn_fused_blocks_per_cu * c->n_cu >= team_blocks;
+        if (c->opt_fused_small && c->dyn_fused_ok && co_resident && L.G <= dcd::FUSED_DYN_MAX_G &&
+            L.T <= dcd::FUSED_DYN_MAX_T && c->n <= (long long)team_blocks * dcd::FUSED_DYN_BLOCK * 4) {
             if (!c->dyn_scratch_clean) {  // (the four-launch path leaves its scratch and its cells as it ends)
                 HIP_TRY(c, hipMemsetAsync(A.acc, 0, A.scratch_n * 8, s));
                 HIP_TRY(c, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(A.cells), (int)dcd::CELL_EMPTY_WORD,
@@ -468,6 +486,7 @@ dc::EvalArgs eval_args(bplhip_ctx* c, int chains, const double* z, double* pot, 
     A.zo_stride = zo_stride_of(c->L);
     A.tickets = c->d_tickets.as<unsigned int>();
     A.gacc = c->d_gacc.as<long long>();
+    A.ga_expect = c->ep->d_ga_expect.as<const int>();
     A.chains = chains;
     A.z = z;
     A.potential = pot;
@@ -478,6 +497,7 @@ dc::EvalArgs eval_args(bplhip_ctx* c, int chains, const double* z, double* pot, 
     A.p_stride = 1;
     A.aux_stride = 4;
     A.debug = c->d_debug.as<unsigned long long>();
+    A.fault = c->d_fault;
     A.L = c->L;
     return A;
 }
@@ -667,10 +687,40 @@ void drop_graphs(bplhip_ctx* c) {  // (declared above ensure_slabs)
 
 // The C-ABI never lets a C++ exception escape (std::bad_alloc from a host buffer, std::system_error
 // from a host thread, ...): the entry points that allocate run inside this guard.
+
+// A raised fault word: name it, put the hand-off state back (counters, accumulator rows, the dynamic
+// model's scratch) and report.  The device is idle or running work that no longer matters when this
+// is called from an entry point; from inside a sampler it is called right after a stream sync.
+static int consume_fault(bplhip_ctx* c, const char* where) {
+    if (!c || !c->h_fault) return BPLHIP_OK;
+    const unsigned int f = __atomic_load_n(c->h_fault, __ATOMIC_RELAXED);
+    if (f == 0u) return BPLHIP_OK;
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    __atomic_store_n(c->h_fault, 0u, __ATOMIC_RELAXED);
+    (void)reset_handoff(c, nullptr, true);
+    if (f & dc::FAULT_DYN_BARRIER) {
+        c->dyn_fused_ok = false;
+        c->dyn_scratch_clean = false;
+        if (c->dd_tick.p) (void)hipMemset(c->dd_tick.p, 0, c->dd_tick.bytes);
+    }
+    return fail(c, BPLHIP_EHIP,
+                "%s: a device-side hand-off timed out (fault word 0x%x:%s%s%s%s); outputs of the affected evaluations are "
+                "NaN, the hand-off state has been reset%s",
+                where, f, (f & dc::FAULT_EVAL_ARRIVALS) ? " dc_eval arrivals" : "",
+                (f & dc::FAULT_LOOP_ARRIVALS) ? " dc_eval_loop arrivals" : "",
+                (f & dc::FAULT_LOOP_GRANULES) ? " dc_eval_loop granules" : "",
+                (f & dc::FAULT_DYN_BARRIER) ? " dyn_fused barrier" : "",
+                (f & dc::FAULT_DYN_BARRIER) ? ", the dynamic model uses its four-launch path from now on" : "");
+}
+
 template <class F>
 static int guarded(bplhip_ctx* c, const char* where, F&& body) {
     try {
-        return body();
+        int rc = consume_fault(c, where);   // raised by asynchronous work of an earlier call
+        if (rc != BPLHIP_OK) return rc;
+        rc = body();
+        return rc != BPLHIP_OK ? rc : consume_fault(c, where);
     } catch (const std::bad_alloc&) {
         return c ? fail(c, BPLHIP_ENOMEM, "%s: out of host memory", where) : BPLHIP_ENOMEM;
     } catch (const std::exception& e) {
@@ -705,6 +755,16 @@ static int bplhip_create_impl(bplhip_ctx** out, int device_id) {
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess && cus > 0)
         c->n_cu = cus;
+    void* hf = nullptr;
+    void* df = nullptr;
+    if (hipHostMalloc(&hf, 64, hipHostMallocMapped) != hipSuccess || hipHostGetDevicePointer(&df, hf, 0) != hipSuccess) {
+        if (hf) (void)hipHostFree(hf);
+        delete c;
+        return fail(nullptr, BPLHIP_EHIP, "bplhip_create: cannot map the fault word");
+    }
+    std::memset(hf, 0, 64);
+    c->h_fault = static_cast<unsigned int*>(hf);
+    c->d_fault = static_cast<unsigned int*>(df);
     *out = c;
     return BPLHIP_OK;
 }
@@ -712,6 +772,8 @@ static int bplhip_create_impl(bplhip_ctx** out, int device_id) {
 void bplhip_destroy(bplhip_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();  // (nothing may write the fault word after it is unmapped)
+    if (ctx->h_fault) (void)hipHostFree(ctx->h_fault);
     delete ctx;
 }
 
@@ -873,6 +935,17 @@ static int bplhip_set_fixtures_impl(bplhip_ctx* c, int model_kind, int64_t n, in
         HIP_TRY(c, hipMemcpy(ep.d_wg_slots.p, sp.wg_slots.data(), sp.wg_slots.size() * 4, hipMemcpyHostToDevice));
         HIP_TRY(c, hipMemcpy(ep.d_col_off.p, sp.col_off.data(), sp.col_off.size() * 4, hipMemcpyHostToDevice));
         HIP_TRY(c, hipMemcpy(ep.d_wg_dst.p, sp.wg_dst.data(), sp.wg_dst.size() * 4, hipMemcpyHostToDevice));
+        {   // how many workgroups add to each accumulator row per evaluation (the rows count their
+            // contributions: dc::ga_add): team row = the workgroups that touch the slot, scalar row
+            // (shard sh, scalar j) = the workgroups with index = sh (mod GA_SHARDS)
+            const int ncol = 3 * T;
+            std::vector<int> expect(dc::ga_rows(T), 0);
+            for (int cidx = 0; cidx < ncol; ++cidx) expect[cidx] = sp.col_off[cidx + 1] - sp.col_off[cidx];
+            for (int w = 0; w < ep.n_wg; ++w)
+                for (int j = 0; j < dc::N_SCAL; ++j) expect[ncol + (w % dc::GA_SHARDS) * dc::N_SCAL + j] += 1;
+            HIP_TRY(c, ep.d_ga_expect.ensure(expect.size() * 4));
+            HIP_TRY(c, hipMemcpy(ep.d_ga_expect.p, expect.data(), expect.size() * 4, hipMemcpyHostToDevice));
+        }
     }
     HIP_TRY(c, c->d_h.ensure(n_lanes * 4));
     HIP_TRY(c, c->d_a.ensure(n_lanes * 4));
@@ -981,6 +1054,10 @@ int bplhip_set_option(bplhip_ctx* c, const char* name, int value) {
         return BPLHIP_OK;
     }
 #endif
+    if (n == "debug_raise_fault") {  // test hook: raise the fault word as a timed-out kernel would
+        if (c->h_fault) __atomic_fetch_or(c->h_fault, (unsigned int)value, __ATOMIC_RELAXED);
+        return BPLHIP_OK;
+    }
     if (n == "dense_pairs") {  // 0: the rho bounds always walk the pair table
         c->opt_dense_pairs = value != 0;
         drop_graphs(c);
@@ -1891,6 +1968,10 @@ int run_chains_persistent(bplhip_ctx* c, hipStream_t s, const nuts::Config& nc, 
         HIP_TRY(c, hipMemcpy2DAsync(flags.data(), 8, ns + nsd + nd::P_ALLDONE, stride * 8, 8, C,
                                     hipMemcpyDeviceToHost, s));
         HIP_TRY(c, hipStreamSynchronize(s));
+        {   // a hand-off that timed out inside the chunk: stop here, not at the leapfrog bound
+            const int frc = consume_fault(c, "persistent nuts");
+            if (frc != BPLHIP_OK) return frc;
+        }
         all_done = true;
         for (int ch = 0; ch < C; ++ch) all_done = all_done && flags[ch] != 0.0;
     }
@@ -2399,20 +2480,8 @@ static int predict_score_grid_any(bplhip_ctx* c, const char* what, bool venue, i
             HIP_TRY(c, hipMemcpyAsync(q + 3 * m, away_conf, (size_t)m * 2, hipMemcpyHostToDevice, s));
         }
     }
-    if (!c->dp_fact.p) {  // c_k = rint(log2 k!) and 2^c_k / k! (dc_predict.hip.h), k = 0..63
-        struct { double scale[64]; float cexp[64]; } f;
-        for (int k = 0; k < 64; ++k) {
-            const double l2 = std::lgamma((double)k + 1.0) * 1.4426950408889634074;
-            const double ck = std::nearbyint(l2);
-            f.cexp[k] = (float)ck;
-            f.scale[k] = std::exp2(ck - l2);
-        }
-        HIP_TRY(c, c->dp_fact.ensure(sizeof f));
-        HIP_TRY(c, hipMemcpy(c->dp_fact.p, &f, sizeof f, hipMemcpyHostToDevice));
-    }
     dcp::GridArgs A{};
-    A.scale = c->dp_fact.as<const double>();
-    A.cexp = reinterpret_cast<const float*>(c->dp_fact.as<const double>() + 64);
+    for (int k = 0; k < 64; ++k) A.rk[k] = (float)(1.0 / ((double)k + 1.0));  // the constants of the pmf recurrence
     A.S = c->pred_S;
     A.T = c->pred_T;
     A.attack = c->dp_tab32[PT_ATT].as<const float>();

@@ -120,6 +120,7 @@ struct DynArgs {
     int random_walk;
     const int* gw_off;       // [G + 1] first fixture of each gameweek (fixtures are sorted by it)
     unsigned int* tickets;   // [2] arrival counters: dyn_front, dyn_back (zero between launches)
+    unsigned int* fault;     // the context's host-visible fault word (dc::raise_fault)
     DynLayout L;
 };
 
@@ -798,7 +799,7 @@ __device__ __forceinline__ void grid_arrive(unsigned int* ctr) {
 // counters in an unknown state: it sets TK_FAIL, and every later launch returns NaN until the
 // host re-zeroes the words (bplhip_set_fixtures_dynamic).
 __device__ __forceinline__ bool grid_wait(unsigned int* tickets, int which, unsigned int n, unsigned int failed,
-                                          int* s_ok) {
+                                          int* s_ok, unsigned int* fault) {
     if (threadIdx.x == 0) {
         unsigned int spins = 0;
         bool ok = failed == 0;
@@ -806,7 +807,10 @@ __device__ __forceinline__ bool grid_wait(unsigned int* tickets, int which, unsi
             if (++spins >= GRID_SPIN_LIMIT) ok = false;
             __builtin_amdgcn_s_sleep(1);
         }
-        if (!ok) __hip_atomic_store(tickets + TK_FAIL, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!ok) {
+            __hip_atomic_store(tickets + TK_FAIL, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            dc::raise_fault(fault, dc::FAULT_DYN_BARRIER);
+        }
         *s_ok = ok;
     }
     __syncthreads();
@@ -1055,7 +1059,10 @@ __global__ __launch_bounds__(FUSED_DYN_BLOCK) void dyn_fused(DynArgs A) {
         }
         __syncthreads();
         if (s_bad) {  // a cell never arrived: the launch gives up (sticky, like a barrier that times out)
-            if (tid == 0) __hip_atomic_store(A.tickets + TK_FAIL, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid == 0) {
+                __hip_atomic_store(A.tickets + TK_FAIL, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                dc::raise_fault(A.fault, dc::FAULT_DYN_BARRIER);
+            }
             give_up();
             return;
         }
@@ -1086,7 +1093,7 @@ __global__ __launch_bounds__(FUSED_DYN_BLOCK) void dyn_fused(DynArgs A) {
     const double rp = 2.0 * u - 1.0, vv = 1.0 - rp * rp, iv = dc::lean::rcp(vv), e = sd - rp * sa;
     const double dL_drp = e * sa * iv - rp * e * e * iv * iv + rp * iv;
     const double g_u = -((dc::lean::rcp(u) - 3.0 * dc::lean::rcp(1.0 - u)) * du + 2.0 * dL_drp * du + (1.0 - 2.0 * su));
-    if (!grid_wait(A.tickets, TK_B2, nb, failed, &s_ok)) { give_up(); return; }
+    if (!grid_wait(A.tickets, TK_B2, nb, failed, &s_ok, A.fault)) { give_up(); return; }
     DYN_STAMP(5);
 
     // ---- phase 3: value + adjoint
@@ -1166,7 +1173,7 @@ __global__ __launch_bounds__(FUSED_DYN_BLOCK) void dyn_fused(DynArgs A) {
         Lloc += -0.5 * sa * sa - HALF_LOG_2PI - 0.5 * e * e * iv - 0.5 * (2.0 * LN2 + log_u + log_1mu) - HALF_LOG_2PI;
         Lloc += -0.5 * (hat * hat + aat * aat + hdf * hdf + adf * adf) - 4.0 * HALF_LOG_2PI;
     }
-    if (!grid_wait(A.tickets, TK_B3, nb, failed, &s_ok)) { give_up(); return; }
+    if (!grid_wait(A.tickets, TK_B3, nb, failed, &s_ok, A.fault)) { give_up(); return; }
     DYN_STAMP(7);
 
     // ---- phase 4: this wave's team again

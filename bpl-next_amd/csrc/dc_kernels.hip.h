@@ -66,27 +66,41 @@ constexpr int TK_GROUPS = DC_TK_GROUPS;            // two-level arrival tickets:
 constexpr int TK_STRIDE = 32;            // ... one per 128-byte line
 constexpr int TK_WORDS = (1 + TK_GROUPS) * TK_STRIDE;  // u32 words per chain
 
-// ---- dc_eval's cross-workgroup hand-off: ACCUMULATOR ROWS in global memory.
+// ---- dc_eval's cross-workgroup hand-off: COUNTED ACCUMULATOR ROWS in global memory.
 // A streaming workgroup adds its per-team partial sums and its four scalars into one row per
-// value with agent-scope integer atomics; the memory system does the reduction, and the
-// last-arriving workgroup reads 3T + 4*GA_SHARDS values instead of staging and column-summing
-// one slab per workgroup (that staging + summing was 2.0 of the 8.4 us of an evaluation).
-// Integer adds commute, so the result is bitwise reproducible whatever the arrival order.
-// A double v is split as v = hi * 2^20 + lo * 2^-30 (|lo| <= 2^49 per contribution: thousands of
-// them fit an int64; hi is added only when non-zero, i.e. beyond 1e6): 9e-10 absolute resolution
-// -- the addends are float32-born run sums, 1e-4 absolute -- and 1.2e21 range (the
-// init_to_uniform(radius=2) region reaches potentials of 1e15).  Values outside it, infinities
-// and NaNs set a flag instead.  One 128-byte row per value: same-line atomics queue (~12 ns each).
+// value with agent-scope integer atomics; the memory system does the reduction, and the tail reads
+// 3T + 4*GA_SHARDS values instead of staging and column-summing one slab per workgroup (round 1:
+// 2.0 of the 8.4 us of an evaluation).  Integer adds commute, so the result is bitwise reproducible
+// whatever the arrival order.
+// A double v (in units of 2^-30) is split as v = hi * 2^47 + lo, |lo| <= 2^46; hi is added only when
+// non-zero, i.e. beyond 1.3e5.  Round 3: the row COUNTS ITS OWN CONTRIBUTIONS -- the lo word takes
+//     lo + 2^47 (a bias that keeps every addend positive) + 2^56 (one contribution)
+// in ONE atomic, so its top byte is the number of workgroups that have added (n_wg <= 255) and the
+// 56 bits below hold sum(lo) + count * 2^47.  A row's atomics hit one 128-byte line, i.e. one memory
+// channel, in issue order: a workgroup adds hi (and raises a flag bit for a non-finite value) BEFORE
+// the counted lo, so a row whose count is complete is complete.  That removes a whole stage from both
+// sides of the hand-off: the streaming workgroup no longer drains its atomics, barriers and bumps an
+// arrival counter (it is simply done), and the tail no longer polls counters and THEN loads the rows:
+// it polls the rows, the load that finds a row complete IS the data (the expected count of every row
+// is static, host-built).  Round 2's chain was three memory-side round trips between the last fixture
+// and the epilogue (2.3 us of a 7 us evaluation, profiles/r02/stamps_timeline.txt); this is one.
+// (Tried first this round and measured slower: a "tagged slab" of per-workgroup entries polled by
+// the tail -- 2400 uncached 16-byte loads from one CU take 2 us, profiles/r03/stamps_tagged_slab.txt.)
+// 9e-10 absolute resolution -- the addends are float32-born run sums, 1e-4 absolute -- and 1.5e20
+// range (the init_to_uniform(radius=2) region reaches potentials of 1e15).  Values outside it,
+// infinities and NaNs set a flag bit in the row's third word instead (and still count).
 #ifndef DC_GA_ROW
 #define DC_GA_ROW 16
 #endif
-constexpr int GA_ROW = DC_GA_ROW;        // int64 per row (one 128-byte line): [0] lo, [1] hi
+constexpr int GA_ROW = DC_GA_ROW;        // int64 per row (one 128-byte line): [0] lo + count, [1] hi, [2] flags
 constexpr int GA_SHARDS = 16;            // the four scalars are added by every workgroup: sharded
-constexpr double GA_HI_UNIT = 1048576.0;           // 2^20
+constexpr double GA_HI_UNIT = 131072.0;            // 2^17: the hi word's unit (real units)
 constexpr double GA_LO_SCALE = 1073741824.0;       // 2^30
-constexpr double GA_LIMIT = 1.1805916207174113e21; // 2^70
+constexpr double GA_LIMIT = 1.4757395258967641e20; // 2^67
+constexpr long long GA_BIAS = 1ll << 47;
+constexpr int GA_COUNT_SHIFT = 56;
 constexpr unsigned int GA_NEGINF = 1u, GA_BAD = 2u;
-__host__ __device__ inline int ga_rows(int T) { return 3 * T + N_SCAL * GA_SHARDS + 1; }
+__host__ __device__ inline int ga_rows(int T) { return 3 * T + N_SCAL * GA_SHARDS; }
 
 // z-only record written by the prior workgroup (doubles), per chain:
 //   [0..ZO_HDR)         scalars, see enum
@@ -164,8 +178,22 @@ struct EvalArgs {
     int persist_steps;
     unsigned int tag_base;
     unsigned long long* zg;  // [chains][D] granules
+    const int* ga_expect;    // [ga_rows(T)] contributions every accumulator row receives per evaluation (static)
+    // the context's fault word (host memory mapped into the device, bplhip.hip): a bounded wait that
+    // expires ORs its code in with a system-scope atomic -- nothing touches it otherwise -- and the
+    // host turns it into BPLHIP_EHIP at its next entry point or synchronisation
+    unsigned int* fault;
     Layout L;
 };
+enum : unsigned int {
+    FAULT_EVAL_ARRIVALS = 1u,   // dc_eval: the streaming workgroups never arrived
+    FAULT_LOOP_ARRIVALS = 2u,   // dc_eval_loop: the same inside the persistent kernel
+    FAULT_LOOP_GRANULES = 4u,   // dc_eval_loop: the next position never arrived
+    FAULT_DYN_BARRIER = 8u,     // dyn_fused: a grid barrier / a cell record timed out
+};
+__device__ __forceinline__ void raise_fault(unsigned int* fault, unsigned int code) {
+    if (fault) (void)__hip_atomic_fetch_or(fault, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 __device__ __forceinline__ const double* z_of(const EvalArgs& A, int c) { return A.z + (size_t)c * A.z_stride; }
 __device__ __forceinline__ double* grad_of(const EvalArgs& A, int c) { return A.grad + (size_t)c * A.g_stride; }
 __device__ __forceinline__ double* pot_of(const EvalArgs& A, int c) { return A.potential + (size_t)c * A.p_stride; }
@@ -523,39 +551,58 @@ __device__ __forceinline__ void st_sc1_x2(double* p, double a, double b) {
     asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 2" ::"v"(p), "v"(v) : "memory");
 }
 
-// ---- accumulator rows (see GA_ROW): add one double, take (read and re-arm) one row
+// ---- counted accumulator rows (see GA_ROW): add one double, read and re-arm one row
 // an integer-valued double |x| < 2^51 as int64: the low mantissa bits of x + 1.5 * 2^52
 __device__ __forceinline__ long long exact_i64(double x) {
     return __double_as_longlong(x + 6755399441055744.0) - 0x4338000000000000ll;
 }
-__device__ __forceinline__ void ga_add(long long* row, double v /* in units of 2^-30 */,
-                                       unsigned int* bad) {
+// one contribution of one workgroup to one row: flag / hi first, the COUNTED lo last (same line:
+// the memory channel performs them in this order)
+__device__ __forceinline__ void ga_add(long long* row, double v /* in units of 2^-30 */) {
+    double h = 0.0, r = 0.0;
     if (!(fabs(v) < GA_LIMIT * GA_LO_SCALE)) {  // inf, nan, or beyond the hi word's range
-        *bad |= (v == -__builtin_inf()) ? GA_NEGINF : GA_BAD;
-        return;
+        (void)__hip_atomic_fetch_or(reinterpret_cast<unsigned long long*>(row + 2),
+                                    (unsigned long long)((v == -__builtin_inf()) ? GA_NEGINF : GA_BAD),
+                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        h = rint(v * (1.0 / (GA_HI_UNIT * GA_LO_SCALE)));  // |h| < 2^50
+        r = fma(-h, GA_HI_UNIT * GA_LO_SCALE, v);          // exact, |r| <= 2^46
+        if (h != 0.0)
+            (void)__hip_atomic_fetch_add(row + 1, exact_i64(h), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    const double h = rint(v * (1.0 / (GA_HI_UNIT * GA_LO_SCALE)));  // |h| < 2^50
-    const double r = fma(-h, GA_HI_UNIT * GA_LO_SCALE, v);          // exact, |r| <= 2^49
-    (void)__hip_atomic_fetch_add(row, exact_i64(r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (h != 0.0)
-        (void)__hip_atomic_fetch_add(row + 1, exact_i64(h), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    (void)__hip_atomic_fetch_add(row, exact_i64(r) + GA_BIAS + (1ll << GA_COUNT_SHIFT), __ATOMIC_RELAXED,
+                                 __HIP_MEMORY_SCOPE_AGENT);
 }
 struct GaWords {
     long long lo, hi;
+    unsigned long long fl;
 };
-__device__ __forceinline__ GaWords ga_load(const long long* row) {  // L1-bypassing (sc1) loads
+// L1-bypassing (sc1) loads, lo FIRST: the channel serves a line's requests in order, so hi and the
+// flags are at least as recent as the count they are read behind
+__device__ __forceinline__ GaWords ga_load(const long long* row) {
     GaWords w;
     w.lo = __hip_atomic_load(row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     w.hi = __hip_atomic_load(row + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    w.fl = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(row + 2), __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
     return w;
 }
-__device__ __forceinline__ void ga_rearm(long long* row) {  // write-through zeros for the next launch
+__device__ __forceinline__ int ga_count(const GaWords& w) { return (int)((unsigned long long)w.lo >> GA_COUNT_SHIFT); }
+__device__ __forceinline__ void ga_rearm(long long* row, bool flags) {  // write-through zeros for the next evaluation
     __hip_atomic_store(row, 0ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(row + 1, 0ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (flags) __hip_atomic_store(row + 2, 0ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// the value of a complete row (real units); a raised flag replaces it: -inf (a clipped tau term:
+// log 0) or NaN (anything else)
 __device__ __forceinline__ double ga_value(const GaWords& w) {
-    return fma((double)w.hi, GA_HI_UNIT, (double)w.lo * (1.0 / GA_LO_SCALE));
+    const long long cnt = (long long)((unsigned long long)w.lo >> GA_COUNT_SHIFT);
+    const long long lo = (w.lo & ((1ll << GA_COUNT_SHIFT) - 1)) - cnt * GA_BIAS;
+    double v = fma((double)w.hi, GA_HI_UNIT, (double)lo * (1.0 / GA_LO_SCALE));
+    if (w.fl != 0ull) v = (w.fl & GA_BAD) ? __builtin_nan("") : -__builtin_inf();
+    return v;
 }
+constexpr int ARRIVE_SPIN_LIMIT = 1 << 18;   // bounded waits of the tail for the streaming workgroups (~0.1 s)
 
 // ---------------------------------------------------------------- LDS footprints
 
@@ -1819,7 +1866,14 @@ __host__ __device__ inline size_t acc_tail_lds_bytes(int T, int D, int K, int zo
 // the covariates, the NUTS leaf's state); after the wait only the accumulator rows are loaded.
 struct TailPre {
     double c0, z0, x0;
+    int expect;   // contributions this thread's (first) accumulator row receives per evaluation
 };
+// the (first) accumulator row a thread of the tail takes: waves 0..6 the team rows, wave 7 the scalar
+// rows, lane = 16*scalar + shard
+__device__ __forceinline__ int tail_row_of(int tid, int ncol) {
+    const int lane = tid & 63, wave = tid >> 6;
+    return wave < WAVES - 1 ? min(tid, ncol - 1) : ncol + (lane & 15) * N_SCAL + (lane >> 4);
+}
 template <bool SMALLT, bool NUTS>
 __device__ __forceinline__ void tail_preload(const EvalArgs& A, int chain, TailPre& P,
                                              nd::LeafState<1>& leaf1,
@@ -1833,6 +1887,7 @@ __device__ __forceinline__ void tail_preload(const EvalArgs& A, int chain, TailP
     P.c0 = i < ncol ? (i < T ? A.cA[i] : (i < 2 * T ? A.cD[i - T] : A.cH[i - 2 * T])) : 0.0;
     P.z0 = i < D ? z[i] : 0.0;
     P.x0 = (xs_staged && i < T * K) ? A.xs[i] : 0.0;
+    P.expect = A.ga_expect[tail_row_of(tid, ncol)];
     if (NUTS && SMALLT) {
         double* ns = nuts_of(A, chain);
         if (D <= 64) {
@@ -1850,10 +1905,12 @@ __device__ __forceinline__ void tail_preload(const EvalArgs& A, int chain, TailP
         }
     }
 }
+// (*okflag must hold 1 and a barrier must lie between that store and this call.)  false: the bounded
+// wait for the rows expired (the caller poisons the outputs).
 template <bool SMALLT, bool NUTS, bool EXT>
-__device__ __forceinline__ void tail_acc(const EvalArgs& A, int chain, char* smem, const TailPre& P,
+__device__ __forceinline__ bool tail_acc(const EvalArgs& A, int chain, char* smem, const TailPre& P,
                                          const nd::LeafState<1>& leaf1,
-                                         const double (&bigv)[nd::LEAF_STAGE_LOADS],
+                                         const double (&bigv)[nd::LEAF_STAGE_LOADS], int* okflag,
                                          unsigned int pub_tag = 0u) {
     const Layout& L = A.L;
     const int T = L.T, K = L.K, D = L.D;
@@ -1876,42 +1933,46 @@ __device__ __forceinline__ void tail_acc(const EvalArgs& A, int chain, char* sme
     const double* z = z_of(A, chain);
     long long* ga = A.gacc + (size_t)chain * ga_rows(T) * GA_ROW;
     const bool xs_staged = K > 0 && K <= 16;
+    // one row until its count is complete (wave-uniform exit; bounded like every wait in this file)
+    auto take_row = [&](const long long* row, int expect, GaWords* out) {
+        bool ok = false;
+        for (int spin = 0; spin < ARRIVE_SPIN_LIMIT; ++spin) {
+            *out = ga_load(row);
+            ok = __ballot(ga_count(*out) != expect) == 0ull;
+            if (ok) break;
+            __builtin_amdgcn_s_sleep(1);
+        }
+        return ok;
+    };
     {
-        // ---- 1. ONE round of loads: the rows (and the flag word)
+        // ---- 1. poll this thread's row until every workgroup that feeds it has added: the load that
+        // finds the count complete IS the hand-off (no arrival counter, no second round of loads)
         const int i = tid;
-        const int r0 = wave < WAVES - 1 ? min(i, ncol - 1) : ncol + (lane & 15) * N_SCAL + (lane >> 4);
-        const GaWords w0 = ga_load(ga + (size_t)r0 * GA_ROW);
-        const unsigned long long fl0 = __hip_atomic_load(
-            reinterpret_cast<const unsigned long long*>(ga + (size_t)(ncol + N_SCAL * GA_SHARDS) * GA_ROW),
-            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        GaWords w0;
+        bool ok = take_row(ga + (size_t)tail_row_of(tid, ncol) * GA_ROW, P.expect, &w0);
         if (i < ncol) cL[i] = P.c0;
         if (i < D) zL[i] = P.z0;
         if (xs_staged && i < T * K) xsL[i] = P.x0;
         if (wave < WAVES - 1) {
             if (i < ncol) col[i] = ga_value(w0);
-        } else {  // scalar rows: sum the shards (16-lane rows), apply the non-finite flags
+            // larger models: the remaining team rows, one round per pass
+            // (wave-uniform trip count: take_row ballots; lanes past the last row poll it again)
+            for (int b0 = (tid & ~63) + ROW_THREADS; b0 < ncol; b0 += ROW_THREADS) {
+                const int i2 = b0 + lane;
+                GaWords w;
+                const int r = min(i2, ncol - 1);
+                ok = take_row(ga + (size_t)r * GA_ROW, A.ga_expect[r], &w) && ok;
+                if (i2 < ncol) col[i2] = ga_value(w);
+            }
+        } else {  // scalar rows: sum the shards (16-lane rows; a flagged shard is -inf / NaN and stays so)
             double v = ga_value(w0);
             v += dpp_f64<0xB1>(0.0, v);   // quad_perm [1,0,3,2]
             v += dpp_f64<0x4E>(0.0, v);   // quad_perm [2,3,0,1]
             v += dpp_f64<0x124>(0.0, v);  // row_ror:4
             v += dpp_f64<0x128>(0.0, v);  // row_ror:8
-            const unsigned int fl = (unsigned int)fl0;
-            if (fl != 0u) {  // (uniform) a clipped tau term: log 0 = -inf; anything else: NaN
-                if (lane == 16 && (fl & GA_NEGINF)) v = -__builtin_inf();
-                if (lane == 0 && (fl & GA_BAD)) v = __builtin_nan("");
-                if (lane == 0)
-                    __hip_atomic_store(reinterpret_cast<unsigned long long*>(
-                                           ga + (size_t)(ncol + N_SCAL * GA_SHARDS) * GA_ROW),
-                                       0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
             if ((lane & 15) == 0) col[ncol + (lane >> 4)] = v;
         }
-    }
-    // larger models: the remaining team rows and static entries, one round per pass
-    for (int i = tid + ROW_THREADS; i < ncol; i += ROW_THREADS) {
-        if (wave == WAVES - 1) break;
-        const GaWords w = ga_load(ga + (size_t)i * GA_ROW);
-        col[i] = ga_value(w);
+        if (!ok && lane == 0) *okflag = 0;
     }
     for (int i = tid + BLOCK; i < ncol; i += BLOCK)
         cL[i] = i < T ? A.cA[i] : (i < 2 * T ? A.cD[i - T] : A.cH[i - 2 * T]);
@@ -1920,12 +1981,14 @@ __device__ __forceinline__ void tail_acc(const EvalArgs& A, int chain, char* sme
         for (int i = tid + BLOCK; i < T * K; i += BLOCK) xsL[i] = A.xs[i];
     __syncthreads();
     DC_STAMP(8);
+    if (*okflag == 0) return false;
     // re-arm the rows for this chain's next launch: write-through zeros, issued only now -- a
     // barrier waits for the wave's outstanding stores, and these take a memory round trip
+    // (the flag word only when a flag was seen: a row's flags are raised once in a blue moon)
     if (wave < WAVES - 1) {
-        for (int i = tid; i < ncol; i += ROW_THREADS) ga_rearm(ga + (size_t)i * GA_ROW);
+        for (int i = tid; i < ncol; i += ROW_THREADS) ga_rearm(ga + (size_t)i * GA_ROW, true);
     } else {
-        ga_rearm(ga + (size_t)(ncol + (lane & 15) * N_SCAL + (lane >> 4)) * GA_ROW);
+        ga_rearm(ga + (size_t)(ncol + (lane & 15) * N_SCAL + (lane >> 4)) * GA_ROW, true);
     }
     DC_STAMP(9);
     if (SMALLT) {  // lane = team: four waves, one output group each, no LDS traffic
@@ -1939,10 +2002,17 @@ __device__ __forceinline__ void tail_acc(const EvalArgs& A, int chain, char* sme
         }
         tail_waves<NUTS, EXT>(A, chain, zoL, cL, zL, col, xs_staged ? xsL : nullptr, gradL, leaf1, stg, pub_tag);
         DC_STAMP(10);
-        return;
+        return true;
     }
     tail_general<EXT>(A, chain, zoL, cL, zL, col, scratch);
     DC_STAMP(10);
+    return true;
+}
+// a flag word for the tail's wait, inside the tail's own arrays (its `scratch`, which nothing uses
+// before the epilogue): it can be set BEFORE the barrier that ends the prior part
+__device__ __forceinline__ int* acc_tail_flag(const EvalArgs& A, char* smem) {
+    const Layout& L = A.L;
+    return reinterpret_cast<int*>(reinterpret_cast<double*>(smem) + A.zo_stride + 3 * L.T + L.D + (3 * L.T + N_SCAL + 4));
 }
 // where tail_acc keeps its NUTS hand-over block gradL (grad | U | aux | sub_done | finished)
 __device__ __forceinline__ double* acc_tail_gradL(const EvalArgs& A, char* smem) {
@@ -2147,28 +2217,6 @@ __device__ __forceinline__ LaneOut lane_uniform(const LaneData& Ld, float rho,
 
 // ------------------------------------------------------------------------- dc_eval
 
-// The prior workgroup's wait for the `n_stream` streaming workgroups of its chain: lane g of one
-// wave polls group counter g (streaming workgroup w arrives at counter w % TK_GROUPS) with an
-// L1-bypassing load until every counter holds its member count, then re-arms them.  BOUNDED: the
-// streaming workgroups need nothing from this one, so they always finish; the limit (~0.1 s of
-// polling) only turns a fault elsewhere into NaN outputs instead of a hung kernel.
-constexpr int ARRIVE_SPIN_LIMIT = 1 << 18;
-__device__ __forceinline__ bool wait_arrivals(unsigned int* tk, int n_stream, int lane) {
-    const int g = lane < TK_GROUPS ? lane : TK_GROUPS - 1;
-    const unsigned int want = (unsigned int)((n_stream - g + TK_GROUPS - 1) / TK_GROUPS);
-    unsigned int* p = tk + (1 + g) * TK_STRIDE;
-    bool ok = false;
-    for (int spin = 0; spin < ARRIVE_SPIN_LIMIT; ++spin) {
-        const unsigned int v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        ok = __ballot(v != want) == 0ull;
-        if (ok) break;
-        __builtin_amdgcn_s_sleep(1);
-    }
-    if (lane < TK_GROUPS && want != 0u)
-        __hip_atomic_store(p, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return ok;
-}
-
 template <class T>
 __device__ __forceinline__ T* as_global(T* p) {
     return (T*)(__attribute__((address_space(1))) T*)p;
@@ -2236,7 +2284,6 @@ __global__ DC_LAUNCH_BOUNDS void dc_eval(EvalArgs A) {
         const size_t tail_bytes = (acc_tail_lds_bytes(T, L.D, L.K, A.zo_stride, STAGED && NUTS) + 15) & ~(size_t)15;
         prior_body<CLIP, true, !STAGED>(A, chain, smem + tail_bytes, reinterpret_cast<double*>(smem));
         DC_STAMP(4);
-        int* okflag = reinterpret_cast<int*>(smem + tail_bytes);  // (prior scratch: free after the barrier)
         // The tail reads its arguments from the kernarg segment again (scalar loads behind an
         // opaque pointer): kept live in SGPRs from the kernel entry they were spilled.
         // (Twice: once for the preload, once more after the wait -- the second copy comes from
@@ -2245,22 +2292,20 @@ __global__ DC_LAUNCH_BOUNDS void dc_eval(EvalArgs A) {
         nd::LeafState<1> leaf1{};            // D <= 64: the leaf's vectors in registers (waves 4, 5)
         double bigv[nd::LEAF_STAGE_LOADS];   // D > 64: waves 4..7 stage one 64-element slice each
         tail_preload<STAGED, NUTS>(reload_args(), chain, pre, leaf1, bigv);
+        if (tid == 0) *acc_tail_flag(A, smem) = 1;
         __syncthreads();
         DC_STAMP(5);
-        if (wave == 0) {
-            const bool ok = wait_arrivals(A.tickets + (size_t)chain * TK_WORDS, A.n_wg, lane);
-            if (lane == 0) *okflag = ok ? 1 : 0;
-        }
-        __syncthreads();
-        DC_STAMP(6);
-        if (*okflag == 0) {  // the streaming workgroups never arrived (bounded wait): poison the outputs
+        const EvalArgs B = reload_args();
+        // (tail_acc waits for the rows itself: every thread polls the row it will read)
+        if (!tail_acc<STAGED, NUTS, CLIP>(B, chain, smem, pre, leaf1, bigv, acc_tail_flag(B, smem))) {
+            // the streaming workgroups never arrived (bounded wait): poison the outputs
             double* grad = grad_of(A, chain);
             for (int i = tid; i < L.D; i += BLOCK) grad[i] = __builtin_nan("");
-            if (tid == 0) *pot_of(A, chain) = __builtin_nan("");
-            return;
+            if (tid == 0) {
+                *pot_of(A, chain) = __builtin_nan("");
+                raise_fault(A.fault, FAULT_EVAL_ARRIVALS);
+            }
         }
-        const EvalArgs B = reload_args();
-        tail_acc<STAGED, NUTS, CLIP>(B, chain, smem, pre, leaf1, bigv);
         return;
     }
     {
@@ -2402,45 +2447,27 @@ __global__ DC_LAUNCH_BOUNDS void dc_eval(EvalArgs A) {
         __syncthreads();
         DC_STAMP(11);
         {   // add the slots this workgroup's fixtures touch (static list) and its four scalars
-            // into the chain's accumulator rows (integer atomics at agent scope, no return)
+            // into the chain's counted accumulator rows (integer atomics at agent scope, no return):
+            // the count travels with the value, so nothing follows -- no drain, no barrier, no
+            // arrival counter; the workgroup is done
             long long* ga = A.gacc + (size_t)chain * ga_rows(T) * GA_ROW;
-            unsigned int bad = 0u;
             for (int k = o0 + tid; k < o1; k += BLOCK) {
                 const int slot = k == o0 + tid ? slot0 : A.wg_slots[k];
                 const int which = slot / T, t = slot - which * T;
-                ga_add(ga + (size_t)slot * GA_ROW, acc[which * T1 + t], &bad);
+                ga_add(ga + (size_t)slot * GA_ROW, acc[which * T1 + t]);
             }
             if (tid >= BLOCK - N_SCAL) {  // (the last wave: the slot lanes are the first ones)
                 const int k = tid - (BLOCK - N_SCAL);
                 double sv = 0.0;
 #pragma unroll
                 for (int wv = 0; wv < WAVES; ++wv) sv += red[wv * N_SCAL + k];
-                ga_add(ga + (size_t)(3 * T + (wgi % GA_SHARDS) * N_SCAL + k) * GA_ROW, sv, &bad);
+                ga_add(ga + (size_t)(3 * T + (wgi % GA_SHARDS) * N_SCAL + k) * GA_ROW, sv);
             }
-            if (bad != 0u)
-                (void)__hip_atomic_fetch_or(
-                    reinterpret_cast<unsigned int*>(ga + (size_t)(3 * T + N_SCAL * GA_SHARDS) * GA_ROW),
-                    bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         DC_STAMP(4);
+        DC_STAMP(5);
+        DC_STAMP(6);
     }
-
-    // ---- 5. arrive.  The sums were added with agent-scope atomics; every adding wave drains,
-    // the workgroup barriers, one lane adds to its group's arrival counter (no return value: the
-    // workgroup is done).  The prior workgroup polls the counters with L1-bypassing loads
-    // (MI355X_MICROARCH.md, hand-off table: "agent-scope atomic adds, one lane of each storing
-    // workgroup / a global_load sc1 poll of that counter / a workgroup barrier between that poll
-    // and every load of the bytes").  TK_GROUPS counters on separate lines: same-address
-    // atomics queue at ~12 ns each.
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    DC_STAMP(5);
-    if (tid == 0) {
-        unsigned int* tk = A.tickets + (size_t)chain * TK_WORDS;
-        (void)__hip_atomic_fetch_add(tk + (1 + (blockIdx.x - 1) % TK_GROUPS) * TK_STRIDE, 1u,
-                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    DC_STAMP(6);
 #ifdef DC_STAMPS  // shader clock of this workgroup's life: cycles (s_memtime) per 10 ns tick
     if (threadIdx.x == 0 && A.debug && blockIdx.y == 0)
         A.debug[(size_t)blockIdx.x * 16 + 9] = __builtin_amdgcn_s_memtime() - c_entry;
@@ -2541,7 +2568,6 @@ __global__ DC_LAUNCH_BOUNDS void dc_eval_loop(EvalArgs A) {
 
     if (blockIdx.x == 0) {
         const size_t tail_bytes = (acc_tail_lds_bytes(T, L.D, L.K, A.zo_stride, true) + 15) & ~(size_t)15;
-        int* okflag = reinterpret_cast<int*>(smem + tail_bytes);
         // step 0's position is where the previous launch (or the chain's start) left it
         if (wave == LEAF_WAVE) publish_z(zg, nd::vec(nuts_of(A, chain), L.D, nd::V_ZN), L.D, lane, A.tag_base + 1u);
         for (int s = 0; s < steps; ++s) {
@@ -2553,23 +2579,24 @@ __global__ DC_LAUNCH_BOUNDS void dc_eval_loop(EvalArgs A) {
             nd::LeafState<1> leaf1{};
             double bigv[nd::LEAF_STAGE_LOADS];
             tail_preload<STAGED, NUTS>(reload_args(), chain, pre, leaf1, bigv);
-            __syncthreads();
-            if (wave == 0) {
-                const bool ok = wait_arrivals(A.tickets + (size_t)chain * TK_WORDS, A.n_wg, lane);
-                if (lane == 0) *okflag = ok ? 1 : 0;
-            }
+            if (tid == 0) *acc_tail_flag(A, smem) = 1;
             __syncthreads();
             DC_STAMP(6);
-            if (*okflag == 0) {  // bounded wait expired: end the launch for everybody, poison the outputs
-                if (wave == LEAF_WAVE) publish_fin(zg, L.D, lane, fin_tag);
-                if (tid == 0) *pot_of(A, chain) = __builtin_nan("");
-                return;
-            }
             const bool last = s + 1 == steps;
+            bool done;
             {
                 const EvalArgs B = reload_args();
                 // (the last step of the launch publishes nothing: the next launch starts from V_ZN)
-                tail_acc<STAGED, NUTS, CLIP>(B, chain, smem, pre, leaf1, bigv, last ? 0u : A.tag_base + 2u + (unsigned int)s);
+                done = tail_acc<STAGED, NUTS, CLIP>(B, chain, smem, pre, leaf1, bigv, acc_tail_flag(B, smem),
+                                                    last ? 0u : A.tag_base + 2u + (unsigned int)s);
+            }
+            if (!done) {  // bounded wait expired: end the launch for everybody, poison the outputs
+                if (wave == LEAF_WAVE) publish_fin(zg, L.D, lane, fin_tag);
+                if (tid == 0) {
+                    *pot_of(A, chain) = __builtin_nan("");
+                    raise_fault(A.fault, FAULT_LOOP_ARRIVALS);
+                }
+                return;
             }
             __syncthreads();  // (also: this step's LDS is dead, the next prior may overwrite it)
             DC_STAMP(5);
@@ -2668,7 +2695,10 @@ __global__ DC_LAUNCH_BOUNDS void dc_eval_loop(EvalArgs A) {
         for (int i = tid; i < 3 * T1; i += BLOCK) acc[i] = 0.0;
         if (state != 1) *flag = state;  // (any thread: the chain finished, or a bounded wait expired)
         __syncthreads();
-        if (*flag != 1) return;
+        if (*flag != 1) {
+            if (*flag < 0 && tid == 0) raise_fault(A.fault, FAULT_LOOP_GRANULES);
+            return;
+        }
         DC_STAMP(1);
         float mP, mQ, mR;
         pair_maxima_f32<CLIP>(A, tabH, tabA, pr0, redm, tid, &mP, &mQ, &mR);
@@ -2723,32 +2753,24 @@ __global__ DC_LAUNCH_BOUNDS void dc_eval_loop(EvalArgs A) {
             red[wave * N_SCAL + 3] = dCLIP;
         }
         __syncthreads();
-        {
-            unsigned int bad = 0u;
+        {   // the counted rows: fire and forget, then straight on to the next position (which is
+            // published only after the tail has seen every row complete, i.e. after every thread
+            // here has read acc / red -- no barrier needed before the next step overwrites them)
             for (int k = o0 + tid; k < o1; k += BLOCK) {
                 const int slot = k == o0 + tid ? slot0 : A.wg_slots[k];
                 const int which = slot / T, t = slot - which * T;
-                ga_add(ga + (size_t)slot * GA_ROW, acc[which * T1 + t], &bad);
+                ga_add(ga + (size_t)slot * GA_ROW, acc[which * T1 + t]);
             }
             if (tid >= BLOCK - N_SCAL) {
                 const int k = tid - (BLOCK - N_SCAL);
                 double sv = 0.0;
 #pragma unroll
                 for (int wv = 0; wv < WAVES; ++wv) sv += red[wv * N_SCAL + k];
-                ga_add(ga + (size_t)(3 * T + (wgi % GA_SHARDS) * N_SCAL + k) * GA_ROW, sv, &bad);
+                ga_add(ga + (size_t)(3 * T + (wgi % GA_SHARDS) * N_SCAL + k) * GA_ROW, sv);
             }
-            if (bad != 0u)
-                (void)__hip_atomic_fetch_or(
-                    reinterpret_cast<unsigned int*>(ga + (size_t)(3 * T + N_SCAL * GA_SHARDS) * GA_ROW),
-                    bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         DC_STAMP(4);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
         DC_STAMP(5);
-        if (tid == 0)
-            (void)__hip_atomic_fetch_add(A.tickets + (size_t)chain * TK_WORDS + (1 + wgi % TK_GROUPS) * TK_STRIDE,
-                                         1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         DC_STAMP(6);
     }
 }

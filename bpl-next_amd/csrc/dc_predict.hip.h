@@ -91,30 +91,32 @@ __global__ __launch_bounds__(256) void predict_score_proba(PredictArgs A) {
     A.out[m] = acc / (double)A.S;
 }
 
-// ---- the grid kernel (round 3: no LDS traffic in the loop)
-// One WAVE per fixture, blocks of 64 posterior draws, two lane layouts:
+// ---- the grid kernel
+// One WAVE per fixture, blocks of 64 posterior draws, two lane layouts with a wave-private LDS strip
+// between them:
 //   lane = draw:  the posterior's float32 copies are TEAM-major ([T][S]: a team's draws are
 //     contiguous), so a block is one coalesced round of loads (the next block's are in flight while
-//     this one is worked on).  Each lane reduces its draw to FOUR numbers, in base-2 units:
-//     E_h = log2 lh, Q_h = -lh log2(e) (and the away pair) -- pmf(k; l) = 2^(k E + Q) / k!  -- and
-//     books the four tau corrections of the low scorelines as plain per-draw products.
+//     this one is worked on).  Each lane works out its draw's two Poisson pmf vectors for the tile's
+//     16 goal counts by the recurrence pmf(k + 1) = pmf(k) rate / (k + 1) -- both vectors at once, one
+//     v_pk_mul_f32 for the two factors and one for the two updates per goal count, two v_exp_f32 per
+//     draw in all -- and parks them in the strip, [goal][draw] (row stride 68 floats); the four tau
+//     corrections of the low scorelines are plain per-draw products here as well.
 //   lane = (goal count i = lane & 15, draw group k = lane >> 4):  v_mfma_f32_16x16x4_f32 takes
 //     A[i][k] and B[k][i] from lane 16 k + i.  The order of the draws inside the sum is free, so group
-//     k takes the 16 draws held by ITS OWN ROW of 16 lanes: for step g the operand of lane (i, k) is
-//     2^(i E + Q) of the draw on lane 16 k + g -- a DPP row broadcast (row_newbcast:g, folded into the
-//     VALU instruction that consumes it), one fma and one v_exp_f32 per operand.  No LDS round trip,
-//     no bank conflicts, no barrier: round 2's kernel wrote both pmf vectors of every draw to a
-//     wave-private LDS strip and read them back, 64 LDS operations per 16 MFMAs, and the LDS pipe
-//     (shared by the CU's four SIMDs) was as busy as the matrix pipe.
-//   The 1 / (x! y!) of the pmfs is applied ONCE, in float64, when the tile is written (with an
-//     exact power-of-two offset c_k = rint(log2 k!) inside the exponent so that 2^(k E + Q - c_k)
-//     stays in float32 range up to max_goals = 63): a float32 log2(k!) inside the exponent would be a
-//     rounding error common to all draws (1.3e-6 relative at k = 15).
-//   float32 MFMA accumulation over the 64 draws of a block, float64 across blocks.
+//     k takes draws 16 k .. 16 k + 15 of the block: lane (i, k) reads 16 CONSECUTIVE floats of row i
+//     of each strip -- four ds_read_b128 per operand per block (conflict free: the 16 lanes of a row
+//     group cover all banks) instead of one ds_read_b32 per MFMA -- and the 16 MFMAs of the block run
+//     from registers.
+// What bounds it (tools/micro/grid_pipes.hip, profiles/r03/grid_pipes.txt): on a SIMD the VALU and the
+// matrix pipe do NOT overlap -- a step costs MFMA (32 cycles for 16x16x4 f32) PLUS the VALU work
+// that makes its operands -- so the operands must be cheap in VALU instructions: the recurrence costs 2
+// packed multiplies per goal count for 64 draws, i.e. ~8 cycles per MFMA; an operand made in place by
+// a DPP row broadcast + fma + v_exp_f32 (no LDS at all, tried first this round) costs 20 per operand,
+// 72 per step: 317 us against round 2's 273.  The LDS pipe runs beside both.
 // History (24 320 fixtures x 1000 draws x 16 x 16): gathers attack[s, h] ... per group of four draws
 // inside the loop, pmf entries by one exp each, tau corrections in float64 on every step: 1010 us;
-// coalesced blocks + prefetch: 624 us; pmf by recurrence in the draw layout through an LDS strip:
-// 273 us (round 2); this kernel: see profiles/r03/kernels.md.
+// coalesced blocks + prefetch: 624 us; pmf by recurrence through an LDS strip, one ds_read_b32 per
+// operand per MFMA, recurrence constants from LDS: 273 us (round 2); this kernel: profiles/r03/kernels.md.
 struct GridArgs {
     int S, T;
     const float* attack;     // [T,S] float32, team-major
@@ -134,28 +136,18 @@ struct GridArgs {
     const uint16_t* hc;      // with confederations: [M] each
     const uint16_t* ac;
     double* out;             // [M, G+1, G+1]
-    const float* cexp;       // [64] c_k = rint(log2 k!)            (host-built once per context)
-    const double* scale;     // [64] 2^c_k / k!
+    float rk[64];            // 1 / (k + 1): by value, i.e. in the kernarg segment -- wave-uniform scalar loads
 };
 constexpr int GRID_MAX_GOALS = 63;
 constexpr int GRID_WAVES = 4;
+constexpr int GRID_ROW = 68;   // floats per goal count in a strip: 64 draws + 4 (16-byte aligned, rows 4 banks apart)
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-// t = Q[lane G of the caller's row of 16] - c + E[lane G of the row] * f: the base-2 exponent of one
-// pmf entry, two VALU instructions with the row broadcast folded in (the compiler's DPP combiner
-// folds it into the subtraction only and spends a v_mov_b32_dpp on the fma)
-template <int G> __device__ __forceinline__ float pmf_exponent(float E, float Q, float f, float c) {
-    float t;
-    asm("v_sub_f32_dpp %0, %1, %2 row_newbcast:%5 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %0, %3, %4 row_newbcast:%5 row_mask:0xf bank_mask:0xf"
-        : "=&v"(t) : "v"(Q), "v"(c), "v"(E), "v"(f), "n"(G));
-    return t;
-}
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 template <bool VENUE>
 __global__ __launch_bounds__(64 * GRID_WAVES) void predict_score_grid(GridArgs A) {
-    const float* __restrict__ cexp = A.cexp;
-    const double* __restrict__ scale = A.scale;
+    __shared__ __attribute__((aligned(16))) float strip[GRID_WAVES][2][16 * GRID_ROW];  // per wave: home, away [goal][draw]
+    const float* rk = A.rk;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, d = lane >> 4, i = lane & 15;
     const int f = blockIdx.x * GRID_WAVES + wave;
     if (f >= A.M) return;  // (wave uniform)
@@ -184,35 +176,49 @@ __global__ __launch_bounds__(64 * GRID_WAVES) void predict_score_grid(GridArgs A
     } else {
         ha_p = A.ha_stride ? A.home_adv + (size_t)h * S : A.home_adv;
     }
-    // a block's log-rates for this lane's draw (clamped index: the loads are unconditional)
-    struct Raw { float eh, ea, rho; };
+    // a block's raw values for this lane's draw (clamped index: the loads are unconditional).  Kept AS
+    // LOADED until the block is worked on: combining them here would make the wave wait for the
+    // loads it has just issued, i.e. no prefetch at all.
+    struct Raw { float ah, aa, dh, da, ha, rho, v0, v1, v2, v3, ch, ca; };
     auto load_raw = [&](int s0) {
         const int s = min(s0 + lane, S - 1);
-        Raw r;
+        Raw r{};
+        r.ah = att_h[s]; r.aa = att_a[s]; r.dh = def_h[s]; r.da = def_a[s];
         if constexpr (VENUE) {
-            // same association as the float64 restatement: ((att - def) + on hat) - on adf (+- dc)
-            const float ah = att_h[s], da = def_a[s], aa = att_a[s], dh = def_h[s];
-            const float v0 = hat_h[s], v1 = adf_a[s], v2 = aat_a[s], v3 = hdf_h[s];
-            r.eh = ah - da + on * v0 - on * v1;
-            r.ea = aa - dh + on * v2 - on * v3;
-            if (cf_h) {
-                const float dc = cf_h[s] - cf_a[s];
-                r.eh += dc;
-                r.ea -= dc;
-            }
+            r.v0 = hat_h[s]; r.v1 = adf_a[s]; r.v2 = aat_a[s]; r.v3 = hdf_h[s];
+            if (cf_h) { r.ch = cf_h[s]; r.ca = cf_a[s]; }
         } else {
-            r.eh = att_h[s] - def_a[s] + ha_p[s];
-            r.ea = att_a[s] - def_h[s];
+            r.ha = ha_p[s];
         }
         r.rho = A.corr[s];
         return r;
     };
+    // log-rates of a draw
+    auto log_rates = [&](const Raw& r, float* eh, float* ea) {
+        if constexpr (VENUE) {
+            // same association as the float64 restatement: ((att - def) + on hat) - on adf (+- dc)
+            *eh = r.ah - r.da + on * r.v0 - on * r.v1;
+            *ea = r.aa - r.dh + on * r.v2 - on * r.v3;
+            if (cf_h) {
+                const float dc = r.ch - r.ca;
+                *eh += dc;
+                *ea -= dc;
+            }
+        } else {
+            *eh = r.ah - r.da + r.ha;
+            *ea = r.aa - r.dh;
+        }
+    };
+    float* stH = strip[wave][0];
+    float* stA = strip[wave][1];
     for (int tx = 0; tx < nt; ++tx)
         for (int ty = 0; ty < nt; ++ty) {
             const int x0 = 16 * tx, y0 = 16 * ty;
             const bool low_tile = tx == 0 && ty == 0;
-            const float fx = (float)(x0 + i), fy = (float)(y0 + i);
-            const float cx = cexp[min(x0 + i, GRID_MAX_GOALS)], cy = cexp[min(y0 + i, GRID_MAX_GOALS)];
+            // (wave-uniform constants of the recurrence: scalar loads, hoisted out of the draw loop)
+            f32x2 inv[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) inv[k] = f32x2{rk[min(x0 + k, GRID_MAX_GOALS)], rk[min(y0 + k, GRID_MAX_GOALS)]};
             double accd[4] = {0.0, 0.0, 0.0, 0.0};
             // this lane's draws: tau corrections (float32 over the <= S / 64 blocks of a lane: each
             // term is at most a cell's own size, the rounding of the sum 1e-7 of it)
@@ -220,51 +226,65 @@ __global__ __launch_bounds__(64 * GRID_WAVES) void predict_score_grid(GridArgs A
             Raw nxt = load_raw(0);
             for (int s0 = 0; s0 < S; s0 += 64) {
                 const Raw cur = nxt;
-                if (s0 + 64 < S) nxt = load_raw(s0 + 64);     // in flight while this block is worked on
-                // lane = draw
-                const bool valid = s0 + lane < S;
-                float Eh = cur.eh * LOG2E, Ea = cur.ea * LOG2E;
-                const float lh = __builtin_amdgcn_exp2f(Eh), la = __builtin_amdgcn_exp2f(Ea);
-                float Qh = valid ? -lh * LOG2E : -__builtin_inff();   // 2^-inf = 0: a draw beyond S adds nothing
-                float Qa = -la * LOG2E;
-                if (low_tile) {
-                    // exp(log(clip(1 + rho c, 0))) - 1 for the four low scorelines (bpl/_util.py:58-91)
-                    const float ph = __builtin_amdgcn_exp2f(Qh), pa = __builtin_amdgcn_exp2f(Qa);
-                    const float rho = cur.rho, p1h = ph * lh, p1a = pa * la;
-                    c00 = fmaf(ph * pa, fmaxf(1.f - rho * lh * la, 0.f) - 1.f, c00);
-                    c01 = fmaf(ph * p1a, fmaxf(1.f + rho * lh, 0.f) - 1.f, c01);
-                    c10 = fmaf(p1h * pa, fmaxf(1.f + rho * la, 0.f) - 1.f, c10);
-                    c11 = fmaf(p1h * p1a, fmaxf(1.f - rho, 0.f) - 1.f, c11);
+                if (s0 + 64 < S) {
+                    nxt = load_raw(s0 + 64);     // in flight while this block is worked on
+                    // (opaque: or the compiler sinks the loads to their first use, the next iteration)
+                    asm volatile("" : "+v"(nxt.ah), "+v"(nxt.aa), "+v"(nxt.dh), "+v"(nxt.da), "+v"(nxt.rho));
                 }
-                // (the asm below reads these four through DPP: two wait states after the VALU that
-                // wrote them, which the compiler cannot see inside an asm block)
-                asm volatile("s_nop 1" : "+v"(Eh), "+v"(Qh), "+v"(Ea), "+v"(Qa));
-                // lane = (goal count, draw group): 16 rank-4 updates
+                {   // lane = draw: both pmf vectors of the tile into the strip
+                    const bool valid = s0 + lane < S;
+                    float eh, ea;
+                    log_rates(cur, &eh, &ea);
+                    const float lh = __builtin_amdgcn_exp2f(eh * LOG2E), la = __builtin_amdgcn_exp2f(ea * LOG2E);
+                    const f32x2 rate = {lh, la};
+                    // pmf(0) = exp(-rate); a draw beyond S adds nothing
+                    f32x2 p = {valid ? __builtin_amdgcn_exp2f(-lh * LOG2E) : 0.f, valid ? __builtin_amdgcn_exp2f(-la * LOG2E) : 0.f};
+                    if (low_tile) {
+                        // exp(log(clip(1 + rho c, 0))) - 1 for the four low scorelines (bpl/_util.py:58-91)
+                        const float ph = p.x, pa = p.y, rho = cur.rho, p1h = ph * lh, p1a = pa * la;
+                        c00 = fmaf(ph * pa, fmaxf(1.f - rho * lh * la, 0.f) - 1.f, c00);
+                        c01 = fmaf(ph * p1a, fmaxf(1.f + rho * lh, 0.f) - 1.f, c01);
+                        c10 = fmaf(p1h * pa, fmaxf(1.f + rho * la, 0.f) - 1.f, c10);
+                        c11 = fmaf(p1h * p1a, fmaxf(1.f - rho, 0.f) - 1.f, c11);
+                    } else {
+                        // a later tile starts at pmf(x0), pmf(y0): the same recurrence from 0
+                        for (int k = 0; k < max(x0, y0); ++k) {
+                            const f32x2 step = rate * f32x2{rk[k], rk[k]};
+                            if (k < x0) p.x *= step.x;
+                            if (k < y0) p.y *= step.y;
+                        }
+                    }
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) {
+                        stH[k * GRID_ROW + lane] = p.x;
+                        stA[k * GRID_ROW + lane] = p.y;
+                        p *= rate * inv[k];    // two v_pk_mul_f32 for both vectors
+                    }
+                }
+                // lane = (goal count, draw group): this lane's 16 draws of row i, then 16 rank-4 updates
+                // (the strip is wave-private and LDS operations of a wave complete in order: no barrier)
+                f32x4 ah[4], aa[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    ah[q] = *reinterpret_cast<const f32x4*>(stH + i * GRID_ROW + 16 * d + 4 * q);
+                    aa[q] = *reinterpret_cast<const f32x4*>(stA + i * GRID_ROW + 16 * d + 4 * q);
+                }
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#define DCP_STEP(g)                                                                              \
-    {                                                                                            \
-        const float ta = pmf_exponent<g>(Eh, Qh, fx, cx);                                        \
-        const float tb = pmf_exponent<g>(Ea, Qa, fy, cy);                                        \
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_amdgcn_exp2f(ta), __builtin_amdgcn_exp2f(tb), acc, 0, 0, 0); \
-    }
-                DCP_STEP(0) DCP_STEP(1) DCP_STEP(2) DCP_STEP(3) DCP_STEP(4) DCP_STEP(5) DCP_STEP(6) DCP_STEP(7)
-                DCP_STEP(8) DCP_STEP(9) DCP_STEP(10) DCP_STEP(11) DCP_STEP(12) DCP_STEP(13) DCP_STEP(14) DCP_STEP(15)
-#undef DCP_STEP
+#pragma unroll
+                for (int g = 0; g < 16; ++g)
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[g >> 2][g & 3], aa[g >> 2][g & 3], acc, 0, 0, 0);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) accd[j] += (double)acc[j];   // 64 draws per float32 accumulation
             }
-            // D[row = 4 (lane >> 4) + j][col = lane & 15], scaled by 2^(c_x + c_y) / (x! y!)
-            const double sy = scale[min(y0 + i, GRID_MAX_GOALS)];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) accd[j] *= scale[min(x0 + 4 * d + j, GRID_MAX_GOALS)] * sy;
             if (low_tile) {
                 double c4[4] = {(double)c00, (double)c01, (double)c10, (double)c11};
                 dc::wave_sum4_f64(c4);
                 // cell (x, y) lives on lane (d = x / 4, i = y), register j = x % 4: (0,0) and (1,0)
-                // on lane 0 (j = 0, 1), (0,1) and (1,1) on lane 1  (0! = 1! = 1: no scale)
+                // on lane 0 (j = 0, 1), (0,1) and (1,1) on lane 1
                 if (lane == 0) { accd[0] += c4[0]; accd[1] += c4[2]; }
                 if (lane == 1) { accd[0] += c4[1]; accd[1] += c4[3]; }
             }
+            // D[row = 4 (lane >> 4) + j][col = lane & 15]
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int xo = x0 + 4 * d + j, y = y0 + i;

@@ -46,7 +46,11 @@ enum {
     BPLHIP_OK = 0,
     BPLHIP_EINVAL = -1,   /* bad argument (null pointer, size, index out of range) */
     BPLHIP_ESTATE = -2,   /* call out of order (e.g. logp_grad before set_fixtures) */
-    BPLHIP_EHIP = -3,     /* a HIP runtime call failed; see bplhip_last_error       */
+    BPLHIP_EHIP = -3,     /* a HIP runtime call failed, or a device-side hand-off timed out
+                           * (the kernels' waits for each other are bounded; one that expires raises a
+                           * host-visible fault word which the NEXT entry point -- or the running
+                           * sampler at its next synchronisation -- reports and clears; the affected
+                           * evaluations' outputs are NaN); see bplhip_last_error  */
     BPLHIP_ENOMEM = -4,
     BPLHIP_EUNSUPPORTED = -5,
     BPLHIP_ENUMERIC = -6  /* NUTS could not find a finite initial point            */

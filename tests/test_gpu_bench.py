@@ -46,10 +46,10 @@ def test_bench_tiny_step_counts():
         assert out["steps"] == steps and out["value"] > 0
 
 
-def _two_ranks(port, **env_extra):
-    env = dict(os.environ, BENCH_FORCE_DEVICE="0", **env_extra)
+def _two_ranks(port, script="bench.py"):
+    env = dict(os.environ)
     return subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, script),
                            "--gpus", "2", "--steps", "128", "--warmup", "64", "--no-cpu-baseline", "--no-insitu"],
                           capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
 
@@ -57,8 +57,9 @@ def _two_ranks(port, **env_extra):
 def test_bench_two_ranks_flow():
     """The multi-rank flow of bench.py (fixture broadcast, barriers, max over ranks, rank 0 prints)
     with two ranks forced onto this box's single GPU.  RCCL refuses two ranks on one device, so the
-    control plane runs on gloo through the explicit test hook (recorded in the line)."""
-    p = _two_ranks(29517, BENCH_CONTROL_BACKEND="gloo")
+    harness tests/bench_two_ranks_gloo.py swaps bench.py's collectives for gloo (recorded in the line;
+    bench.py itself has no such switch)."""
+    p = _two_ranks(29517, os.path.join("tests", "bench_two_ranks_gloo.py"))
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, p.stdout
@@ -66,12 +67,12 @@ def test_bench_two_ranks_flow():
     assert out["n_gpus"] == 2 and out["steps"] == 128 and out["scaling"] == "weak"
     assert abs(out["value"] - 2 * 1e3 / out["ms_per_step"]) < 1e-6 * out["value"]
     assert "cpu_baseline" not in out  # rank 0 at N = 1 only
-    assert out["config"]["collectives"].startswith("gloo (BENCH_CONTROL_BACKEND")
+    assert out["config"]["collectives"].startswith("gloo (tests/bench_two_ranks_gloo.py")
 
 
 def test_bench_rccl_failure_is_fatal():
-    """Without the hook the same launch must NOT print a line: RCCL cannot serve two ranks on one
-    device, and an N > 1 value that is not an RCCL measurement is refused (non-zero exit)."""
+    """bench.py itself, two ranks, one GPU: no RCCL world can form (the second rank has no device),
+    and an N > 1 value that is not an RCCL measurement must NOT be printed (non-zero exit)."""
     p = _two_ranks(29519)
     assert p.returncode != 0
     assert not [ln for ln in p.stdout.splitlines() if ln.startswith("{")], p.stdout

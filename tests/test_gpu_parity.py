@@ -467,3 +467,35 @@ def test_launch_partitions_agree(hip_ctx):
     finally:
         hip_ctx.set_option("active_waves", 0)
         hip_ctx.set_option("vec_min_chains", 32)
+
+
+def test_hand_off_timeout_is_reported_not_silent(hip_ctx):
+    """A kernel whose bounded wait expires raises the context's fault word (host memory mapped into
+    the device, dc::raise_fault); the next entry point turns it into BPLHIP_EHIP with a message and
+    puts the hand-off state back, instead of NaN outputs that a sampler books as divergences.  The
+    wait itself cannot be made to expire on a healthy GPU, so the word is raised through the test hook
+    (option debug_raise_fault) exactly as the kernels raise it."""
+    import torch
+    from bpl._ffi import BPLHIP_EHIP, BplHipError, default_nuts_cfg
+
+    fx = cases.fixtures("league_1e5")
+    hip_ctx.set_fixtures(O.MODEL_BASIC, fx.home_idx.astype(np.uint16), fx.away_idx.astype(np.uint16),
+                         fx.home_goals.astype(np.uint8), fx.away_goals.astype(np.uint8), 20)
+    z = torch.tensor(np.random.RandomState(7).uniform(-0.5, 0.5, 45), dtype=torch.float64, device=hip_ctx.device)
+    U0, g0, _ = hip_ctx.logp_grad(z)
+    for code, word in ((1, "dc_eval arrivals"), (6, "dc_eval_loop")):
+        hip_ctx.set_option("debug_raise_fault", code)
+        with pytest.raises(BplHipError) as e:
+            hip_ctx.logp_grad(z)
+        assert e.value.code == BPLHIP_EHIP and "timed out" in str(e.value) and word in str(e.value)
+        U1, g1, _ = hip_ctx.logp_grad(z)  # sticky only until reported; the hand-off state was reset
+        assert torch.equal(U0, U1) and torch.equal(g0, g1)
+    # raised while a sampler runs: the run stops with the error instead of returning a posterior
+    cfg = default_nuts_cfg()
+    cfg.num_warmup, cfg.num_samples = 20, 20
+    hip_ctx.set_option("debug_raise_fault", 2)
+    with pytest.raises(BplHipError) as e:
+        hip_ctx.nuts_run(cfg, (0, 1))
+    assert e.value.code == BPLHIP_EHIP
+    d, st = hip_ctx.nuts_run(cfg, (0, 1))
+    assert np.isfinite(d).all()
