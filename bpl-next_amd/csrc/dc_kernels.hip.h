@@ -4,25 +4,32 @@
 // it is latency bound, so the design minimises the dependent chain of one launch:
 //
 //   dc_eval   ONE launch per evaluation, grid = (1 + n_wg) x chains, 512 threads.
-//     block 0  "prior" workgroup: everything that depends on z only, in float64 and in
+//     block 0  "prior" workgroup AND tail: everything that depends on z only, in float64 and in
 //              parallel with the streaming: priors + Jacobians and their gradient, the
 //              chain-rule scalars, the exact (float64) rates of every pair -> true rho,
 //              arg-extremal pairs for the adjoint of the rho bounds, and the rounding
-//              error of every float32 table entry (for a first-order correction of U).
+//              error of every float32 table entry (for a first-order correction of U).  Then it
+//              polls the counted accumulator rows (below) and runs the epilogue: adjoint of the
+//              bounds, first-order value corrections, chain rule -- adds and FMAs only -- and,
+//              in the NUTS-aware instantiation, the leapfrog's bookkeeping (nuts_dev.hip.h).
 //     blocks 1..n_wg  streaming workgroups:
 //       - fixture loads of the first tile are issued before anything else;
 //       - per-team tables {exp(att+ha), exp(-def)}, {exp(att), exp(-def)} rebuilt in LDS
 //         from z in float32 (v_exp_f32), rho from three DPP max reductions over the
 //         unique-pair table;
-//       - fixtures: 8 per lane from 16-B / 8-B vector loads (6 or 10 B per fixture);
+//       - fixtures: one lane = 32 consecutive fixtures of ONE (home, away) pair (runs are padded
+//         to the lane width), goals as packed bytes, indices once per lane (6 or 10 B per fixture
+//         in the caller's format, 2.25 / 6.25 B in the library's copy);
 //         per lane: 2 LDS gathers, 2 products, 4 tau terms (v_log_f32 + v_rcp_f32 each);
-//         per fixture: SWAR score-class test only (pair runs are lane aligned);
+//         per fixture: SWAR score-class test only;
 //         per-(home,away) run sums: in lane -> across the wave by DPP -> float64 LDS
-//         per-team accumulators; one slab of partial sums per workgroup, stored
-//         write-through (sc1).
-//     tail     the last-arriving workgroup (agent-scope ticket) reduces the slabs in a
-//              fixed order (deterministic), applies the adjoint of the bounds, the
-//              first-order value corrections and the chain rule -- adds and FMAs only.
+//         per-team accumulators (fixed point, units of 2^-30);
+//       - hand-off: every touched per-team sum and the four scalars are ADDED into the chain's
+//         COUNTED ACCUMULATOR ROWS (GA_ROW below: one integer atomic carries value and
+//         contribution count) -- and the workgroup is done.
+//   dc_eval_loop   the same roles inside ONE resident launch for up to 1024 leapfrogs of a
+//              device-resident chain (tiles in registers, the next position as data-tagged
+//              granules, the tail's copy of the position in LDS).
 //
 // Mathematics: SURVEY.md Appendix A (restating bpl/dixon_coles.py:39-84,
 // bpl/extended_dixon_coles.py:78-248, bpl/_util.py:17-93 under numpyro semantics).
@@ -947,12 +954,15 @@ __device__ __forceinline__ SigSite sig_site(double zc) {
 // the tail is a separate launch).
 // DENSE: the instantiation carries the separable bounds of complete pair tables (leagues of more
 // than 64 teams only: the small-league kernels keep their code size)
-template <bool CLIP, bool TO_LDS = false, bool DENSE = false>
-__device__ void prior_body(const EvalArgs& A, int chain, char* smem, double* zo_lds = nullptr) {
+// Z_LDS: the position is read from `z_lds` (the persistent kernel keeps it in LDS: the leaf wrote it
+// there a moment ago, and a load from memory would be a 0.6 us round trip at the head of the step)
+template <bool CLIP, bool TO_LDS = false, bool DENSE = false, bool Z_LDS = false>
+__device__ void prior_body(const EvalArgs& A, int chain, char* smem, double* zo_lds = nullptr,
+                           const double* z_lds = nullptr) {
     const Layout& L = A.L;
     const int T = L.T, K = L.K, D = L.D;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const double* z = z_of(A, chain);
+    const double* z = Z_LDS ? z_lds : z_of(A, chain);
     double* zo = TO_LDS ? zo_lds : A.hbuf + (size_t)chain * A.hb_stride;
     auto zput = [&](double* p, double v) {
         if (TO_LDS) *p = v;
@@ -1356,7 +1366,8 @@ template <bool NUTS, bool EXT>
 __device__ void tail_waves(const EvalArgs& A, int chain, const double* zoL, const double* cL,
                            const double* zL, const double* col, const double* xsL,
                            double* gradL, const nd::LeafState<1>& leaf1, double* stg,
-                           unsigned int pub_tag = 0u /* persistent kernel: tag of the NEXT step */) {
+                           unsigned int pub_tag = 0u /* persistent kernel: tag of the NEXT step */,
+                           double* zn_lds = nullptr /* persistent kernel: the LDS copy of the position */) {
     const Layout& L = A.L;
     const int T = L.T, K = L.K, D = L.D;
     const int t = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1509,9 +1520,11 @@ __device__ void tail_waves(const EvalArgs& A, int chain, const double* zoL, cons
         // the barriers (every wave reaches the end of this function: the persistent evaluation
         // kernel goes on to the next leapfrog from here)
         if (wave == LEAF_WAVE) {
+            // (zn_lds: the next position also goes to the tail's LDS copy -- every reader of this
+            // step's copy is behind the barrier above)
             const bool sub_done =
-                small ? nd::leaf_moves(ns, D, A.nuts_max_depth, t, gradL, lf1)
-                      : nd::leaf_moves_staged(ns, D, A.nuts_max_depth, t, gradL, stg, lf1.hv);
+                small ? nd::leaf_moves(ns, D, A.nuts_max_depth, t, gradL, lf1, zn_lds)
+                      : nd::leaf_moves_staged(ns, D, A.nuts_max_depth, t, gradL, stg, lf1.hv, zn_lds);
             DC_STAMP_LEAF(11);
             if (t == 0) {
                 gradL[D + 5] = sub_done ? 1.0 : 0.0;
@@ -1521,7 +1534,7 @@ __device__ void tail_waves(const EvalArgs& A, int chain, const double* zoL, cons
             // this wave stored it, so its own loads see it) -- the streaming workgroups start the
             // next leapfrog while the other half of the leaf is still being booked
             if (pub_tag != 0u && !sub_done)
-                publish_z(A.zg + (size_t)chain * D, nd::vec(ns, D, nd::V_ZN), D, t, pub_tag);
+                publish_z(A.zg + (size_t)chain * D, zn_lds ? zn_lds : nd::vec(ns, D, nd::V_ZN), D, t, pub_tag);
         } else if (wave == RNG_WAVE) {
             if (small) nd::leaf_weights(ns, D, t, gradL, lf1);
             else nd::leaf_weights_staged(ns, D, t, gradL, stg, lf1.hv, lf1.nhi, lf1.nlo, lf1.u_take);
@@ -1536,6 +1549,8 @@ __device__ void tail_waves(const EvalArgs& A, int chain, const double* zoL, cons
         __syncthreads();
         if (wave == LEAF_WAVE) {
             nd::persist_advance(ns, *A.persist, chain, t);
+            if (zn_lds)   // (rare: the new doubling / transition starts from a position only memory holds)
+                for (int i = t; i < D; i += 64) zn_lds[i] = nd::vec(ns, D, nd::V_ZN)[i];
             if (pub_tag != 0u) {  // a new doubling / transition starts somewhere else -- or nowhere
                 const bool fin = (ns + A.persist->pd_off)[nd::P_ALLDONE] != 0.0;
                 if (fin) {
@@ -1874,7 +1889,8 @@ __device__ __forceinline__ int tail_row_of(int tid, int ncol) {
     const int lane = tid & 63, wave = tid >> 6;
     return wave < WAVES - 1 ? min(tid, ncol - 1) : ncol + (lane & 15) * N_SCAL + (lane >> 4);
 }
-template <bool SMALLT, bool NUTS>
+// ZL: the position already sits in the tail's LDS copy zL (persistent kernel): not loaded, not staged
+template <bool SMALLT, bool NUTS, bool ZL = false>
 __device__ __forceinline__ void tail_preload(const EvalArgs& A, int chain, TailPre& P,
                                              nd::LeafState<1>& leaf1,
                                              double (&bigv)[nd::LEAF_STAGE_LOADS]) {
@@ -1885,7 +1901,7 @@ __device__ __forceinline__ void tail_preload(const EvalArgs& A, int chain, TailP
     const double* z = z_of(A, chain);
     const bool xs_staged = K > 0 && K <= 16;
     P.c0 = i < ncol ? (i < T ? A.cA[i] : (i < 2 * T ? A.cD[i - T] : A.cH[i - 2 * T])) : 0.0;
-    P.z0 = i < D ? z[i] : 0.0;
+    P.z0 = !ZL && i < D ? z[i] : 0.0;
     P.x0 = (xs_staged && i < T * K) ? A.xs[i] : 0.0;
     P.expect = A.ga_expect[tail_row_of(tid, ncol)];
     if (NUTS && SMALLT) {
@@ -1907,7 +1923,7 @@ __device__ __forceinline__ void tail_preload(const EvalArgs& A, int chain, TailP
 }
 // (*okflag must hold 1 and a barrier must lie between that store and this call.)  false: the bounded
 // wait for the rows expired (the caller poisons the outputs).
-template <bool SMALLT, bool NUTS, bool EXT>
+template <bool SMALLT, bool NUTS, bool EXT, bool ZL = false>
 __device__ __forceinline__ bool tail_acc(const EvalArgs& A, int chain, char* smem, const TailPre& P,
                                          const nd::LeafState<1>& leaf1,
                                          const double (&bigv)[nd::LEAF_STAGE_LOADS], int* okflag,
@@ -1951,7 +1967,7 @@ __device__ __forceinline__ bool tail_acc(const EvalArgs& A, int chain, char* sme
         GaWords w0;
         bool ok = take_row(ga + (size_t)tail_row_of(tid, ncol) * GA_ROW, P.expect, &w0);
         if (i < ncol) cL[i] = P.c0;
-        if (i < D) zL[i] = P.z0;
+        if (!ZL && i < D) zL[i] = P.z0;
         if (xs_staged && i < T * K) xsL[i] = P.x0;
         if (wave < WAVES - 1) {
             if (i < ncol) col[i] = ga_value(w0);
@@ -1976,7 +1992,8 @@ __device__ __forceinline__ bool tail_acc(const EvalArgs& A, int chain, char* sme
     }
     for (int i = tid + BLOCK; i < ncol; i += BLOCK)
         cL[i] = i < T ? A.cA[i] : (i < 2 * T ? A.cD[i - T] : A.cH[i - 2 * T]);
-    for (int i = tid + BLOCK; i < D; i += BLOCK) zL[i] = z[i];
+    if (!ZL)
+        for (int i = tid + BLOCK; i < D; i += BLOCK) zL[i] = z[i];
     if (xs_staged)
         for (int i = tid + BLOCK; i < T * K; i += BLOCK) xsL[i] = A.xs[i];
     __syncthreads();
@@ -2000,7 +2017,8 @@ __device__ __forceinline__ bool tail_acc(const EvalArgs& A, int chain, char* sme
                     if (i < D) stg[k * D + i] = bigv[k];
             }
         }
-        tail_waves<NUTS, EXT>(A, chain, zoL, cL, zL, col, xs_staged ? xsL : nullptr, gradL, leaf1, stg, pub_tag);
+        tail_waves<NUTS, EXT>(A, chain, zoL, cL, zL, col, xs_staged ? xsL : nullptr, gradL, leaf1, stg, pub_tag,
+                              ZL ? zL : nullptr);
         DC_STAMP(10);
         return true;
     }
@@ -2570,15 +2588,20 @@ __global__ DC_LAUNCH_BOUNDS void dc_eval_loop(EvalArgs A) {
         const size_t tail_bytes = (acc_tail_lds_bytes(T, L.D, L.K, A.zo_stride, true) + 15) & ~(size_t)15;
         // step 0's position is where the previous launch (or the chain's start) left it
         if (wave == LEAF_WAVE) publish_z(zg, nd::vec(nuts_of(A, chain), L.D, nd::V_ZN), L.D, lane, A.tag_base + 1u);
+        // ... and from here on the tail keeps the position in LDS (zL of tail_acc's layout): the leaf
+        // writes the next one there, the prior part and the epilogue read it from there
+        double* zL = reinterpret_cast<double*>(smem) + A.zo_stride + 3 * T;
+        for (int i = tid; i < L.D; i += BLOCK) zL[i] = nd::vec(nuts_of(A, chain), L.D, nd::V_ZN)[i];
+        __syncthreads();
         for (int s = 0; s < steps; ++s) {
             DC_STAMP(0);
             __builtin_amdgcn_s_dcache_inv();
-            prior_body<CLIP, true>(A, chain, smem + tail_bytes, reinterpret_cast<double*>(smem));
+            prior_body<CLIP, true, false, true>(A, chain, smem + tail_bytes, reinterpret_cast<double*>(smem), zL);
             DC_STAMP(4);
             TailPre pre;
             nd::LeafState<1> leaf1{};
             double bigv[nd::LEAF_STAGE_LOADS];
-            tail_preload<STAGED, NUTS>(reload_args(), chain, pre, leaf1, bigv);
+            tail_preload<STAGED, NUTS, true>(reload_args(), chain, pre, leaf1, bigv);
             if (tid == 0) *acc_tail_flag(A, smem) = 1;
             __syncthreads();
             DC_STAMP(6);
@@ -2587,8 +2610,8 @@ __global__ DC_LAUNCH_BOUNDS void dc_eval_loop(EvalArgs A) {
             {
                 const EvalArgs B = reload_args();
                 // (the last step of the launch publishes nothing: the next launch starts from V_ZN)
-                done = tail_acc<STAGED, NUTS, CLIP>(B, chain, smem, pre, leaf1, bigv, acc_tail_flag(B, smem),
-                                                    last ? 0u : A.tag_base + 2u + (unsigned int)s);
+                done = tail_acc<STAGED, NUTS, CLIP, true>(B, chain, smem, pre, leaf1, bigv, acc_tail_flag(B, smem),
+                                                          last ? 0u : A.tag_base + 2u + (unsigned int)s);
             }
             if (!done) {  // bounded wait expired: end the launch for everybody, poison the outputs
                 if (wave == LEAF_WAVE) publish_fin(zg, L.D, lane, fin_tag);

@@ -368,7 +368,7 @@ __device__ inline void leaf_weights(double* ns, int D, int lane, const double* g
 // S fully prefetched and prepared; returns (wave uniform) whether the subtree is complete
 template <int LEAF_NE>
 __device__ inline bool leaf_moves(double* ns, int D, int max_depth, int lane, const double* gL,
-                                  const LeafState<LEAF_NE>& S) {
+                                  const LeafState<LEAF_NE>& S, double* zn_lds = nullptr) {
     const double hv = S.hv;
     const double h_eps = hdr_word(hv, H_EPS), h_dir = hdr_word(hv, H_DIR);
     const double eps = h_eps * h_dir;
@@ -425,7 +425,9 @@ __device__ inline bool leaf_moves(double* ns, int D, int max_depth, int lane, co
             // next leapfrog starts from this leaf (the subtree grows in one direction)
             const double zn = S.zn[e];
             const double rn = r[e] - 0.5 * eps * g[e];
-            p_zn[i] = done ? zn : zn + eps * S.invM[e] * rn;
+            const double z_next = done ? zn : zn + eps * S.invM[e] * rn;
+            p_zn[i] = z_next;
+            if (zn_lds) zn_lds[i] = z_next;   // (the caller's LDS copy of the next position)
             p_rh[i] = done ? r[e] : rn;
             p_rsum[i] = rs[e];
             if (wl) { sl_z[i] = zn; sl_r[i] = r[e]; sl_g[i] = g[e]; }
@@ -490,7 +492,7 @@ __device__ inline void leaf_weights_staged(double* ns, int D, int lane, const do
     if (lane == 0) leaf_weights_header(ns, gL, D, W, E.e_new, nhi, nlo);
 }
 __device__ inline bool leaf_moves_staged(double* ns, int D, int max_depth, int lane, const double* gL,
-                                         double* stg, double hv) {
+                                         double* stg, double hv, double* zn_lds = nullptr) {
     const double* s_invM = stg;
     const double* s_zn = stg + D;
     double* s_rs = stg + 3 * D;   // running sum: before / after this leaf
@@ -558,7 +560,9 @@ __device__ inline bool leaf_moves_staged(double* ns, int D, int max_depth, int l
     for (int i = lane; i < D; i += 64) {
         const double r = s_r[i], g = gL[i], zn = s_zn[i], rs = s_rs[i];
         const double rn = r - 0.5 * eps * g;
-        p_zn[i] = done ? zn : zn + eps * s_invM[i] * rn;
+        const double z_next = done ? zn : zn + eps * s_invM[i] * rn;
+        p_zn[i] = z_next;
+        if (zn_lds) zn_lds[i] = z_next;   // (the caller's LDS copy of the next position)
         p_rh[i] = done ? r : rn;
         p_rsum[i] = rs;
         if (wl) { sl_z[i] = zn; sl_r[i] = r; sl_g[i] = g; }
