@@ -195,7 +195,7 @@ int zo_stride_of(const dc::Layout& L) { return (dc::ZO_HDR + L.D + 3 * L.T + 1) 
 // through the accumulator rows, d_gacc)
 int hb_stride_of(const bplhip_ctx* c) { return zo_stride_of(c->L); }
 size_t gacc_bytes_of(const bplhip_ctx* c, int chains) {
-    return (size_t)chains * dc::ga_rows(c->L.T) * dc::GA_ROW * sizeof(long long);
+    return (size_t)chains * 2 * dc::ga_set_words(c->L.T) * sizeof(long long);   // (two sets per chain)
 }
 // the partition a launch of `chains` chains uses: the short-stream one (part 0 of two) while its
 // workgroups still find a CU each

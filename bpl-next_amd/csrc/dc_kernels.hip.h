@@ -79,13 +79,17 @@ constexpr int TK_WORDS = (1 + TK_GROUPS) * TK_STRIDE;  // u32 words per chain
 // 3T + 4*GA_SHARDS values instead of staging and column-summing one slab per workgroup (round 1:
 // 2.0 of the 8.4 us of an evaluation).  Integer adds commute, so the result is bitwise reproducible
 // whatever the arrival order.
-// A double v (in units of 2^-30) is split as v = hi * 2^47 + lo, |lo| <= 2^46; hi is added only when
-// non-zero, i.e. beyond 1.3e5.  Round 3: the row COUNTS ITS OWN CONTRIBUTIONS -- the lo word takes
-//     lo + 2^47 (a bias that keeps every addend positive) + 2^56 (one contribution)
-// in ONE atomic, so its top byte is the number of workgroups that have added (n_wg <= 255) and the
-// 56 bits below hold sum(lo) + count * 2^47.  A row's atomics hit one 128-byte line, i.e. one memory
-// channel, in issue order: a workgroup adds hi (and raises a flag bit for a non-finite value) BEFORE
-// the counted lo, so a row whose count is complete is complete.  That removes a whole stage from both
+// A double v (in units of 2^-30) is split as v = hi * 2^44 + lo, |lo| <= 2^43; hi is added only when
+// non-zero, i.e. beyond 1.6e4.  Round 3: the row COUNTS ITS OWN CONTRIBUTIONS -- the lo word takes
+//     lo + 2^45 (a bias that keeps every addend positive) + 2^56 (one contribution)
+// in ONE atomic, so its top byte is the number of workgroups that have added (n_wg <= 255), the 54
+// bits below hold sum(lo) + count * 2^45 (< 2^54 for 255 contributions), and bits 54 / 55 are two
+// flag bits that no sum can reach.  A row's atomics hit one 128-byte line, i.e. one memory channel,
+// in issue order: a workgroup adds hi (or ORs a flag bit in for a non-finite value) BEFORE the
+// counted lo, so a row whose count is complete is complete -- and the tail reads {lo, hi} with ONE
+// 16-byte load per row (an L2-bypassing load is one request per lane to the memory side, and a CU
+// gets about one such request through per nanosecond: three 8-byte loads per row were 0.96 us of
+// poll, one 16-byte load is the round trip alone).  That removes a whole stage from both
 // sides of the hand-off: the streaming workgroup no longer drains its atomics, barriers and bumps an
 // arrival counter (it is simply done), and the tail no longer polls counters and THEN loads the rows:
 // it polls the rows, the load that finds a row complete IS the data (the expected count of every row
@@ -95,17 +99,17 @@ constexpr int TK_WORDS = (1 + TK_GROUPS) * TK_STRIDE;  // u32 words per chain
 // the tail -- 2400 uncached 16-byte loads from one CU take 2 us, profiles/r03/stamps_tagged_slab.txt.)
 // 9e-10 absolute resolution -- the addends are float32-born run sums, 1e-4 absolute -- and 1.5e20
 // range (the init_to_uniform(radius=2) region reaches potentials of 1e15).  Values outside it,
-// infinities and NaNs set a flag bit in the row's third word instead (and still count).
+// infinities and NaNs set a flag bit instead (and still count).
 #ifndef DC_GA_ROW
 #define DC_GA_ROW 16
 #endif
-constexpr int GA_ROW = DC_GA_ROW;        // int64 per row (one 128-byte line): [0] lo + count, [1] hi, [2] flags
+constexpr int GA_ROW = DC_GA_ROW;        // int64 per row (one 128-byte line): [0] lo + flags + count, [1] hi
 constexpr int GA_SHARDS = 16;            // the four scalars are added by every workgroup: sharded
-constexpr double GA_HI_UNIT = 131072.0;            // 2^17: the hi word's unit (real units)
+constexpr double GA_HI_UNIT = 16384.0;             // 2^14: the hi word's unit (real units)
 constexpr double GA_LO_SCALE = 1073741824.0;       // 2^30
-constexpr double GA_LIMIT = 1.4757395258967641e20; // 2^67
-constexpr long long GA_BIAS = 1ll << 47;
-constexpr int GA_COUNT_SHIFT = 56;
+constexpr double GA_LIMIT = 1.8446744073709552e19; // 2^64
+constexpr long long GA_BIAS = 1ll << 45;
+constexpr int GA_COUNT_SHIFT = 56, GA_FLAG_SHIFT = 54;
 constexpr unsigned int GA_NEGINF = 1u, GA_BAD = 2u;
 __host__ __device__ inline int ga_rows(int T) { return 3 * T + N_SCAL * GA_SHARDS; }
 
@@ -161,7 +165,7 @@ struct EvalArgs {
     int n_wg;               // streaming workgroups (grid.x = n_wg + 1)
     int zo_stride;
     unsigned int* tickets;  // [chains][TK_WORDS] arrival counters (top + TK_GROUPS groups)
-    long long* gacc;        // [chains][ga_rows(T)][GA_ROW] accumulator rows (dc_eval; dc_vec: unused)
+    long long* gacc;        // [chains][2][ga_rows(T)][GA_ROW] counted accumulator rows, two sets (dc_eval; dc_vec: unused)
     int chains;             // number of chains of this launch (dc_vec.hip.h)
     // in / out: chain c at z + c*z_stride, potential + c*p_stride, grad + c*g_stride,
     // aux + c*aux_stride (plain batches: D, 1, D, 4; device NUTS: all inside the state buffer)
@@ -568,12 +572,12 @@ __device__ __forceinline__ long long exact_i64(double x) {
 __device__ __forceinline__ void ga_add(long long* row, double v /* in units of 2^-30 */) {
     double h = 0.0, r = 0.0;
     if (!(fabs(v) < GA_LIMIT * GA_LO_SCALE)) {  // inf, nan, or beyond the hi word's range
-        (void)__hip_atomic_fetch_or(reinterpret_cast<unsigned long long*>(row + 2),
-                                    (unsigned long long)((v == -__builtin_inf()) ? GA_NEGINF : GA_BAD),
+        (void)__hip_atomic_fetch_or(reinterpret_cast<unsigned long long*>(row),
+                                    (unsigned long long)((v == -__builtin_inf()) ? GA_NEGINF : GA_BAD) << GA_FLAG_SHIFT,
                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
         h = rint(v * (1.0 / (GA_HI_UNIT * GA_LO_SCALE)));  // |h| < 2^50
-        r = fma(-h, GA_HI_UNIT * GA_LO_SCALE, v);          // exact, |r| <= 2^46
+        r = fma(-h, GA_HI_UNIT * GA_LO_SCALE, v);          // exact, |r| <= 2^43
         if (h != 0.0)
             (void)__hip_atomic_fetch_add(row + 1, exact_i64(h), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -582,31 +586,48 @@ __device__ __forceinline__ void ga_add(long long* row, double v /* in units of 2
 }
 struct GaWords {
     long long lo, hi;
-    unsigned long long fl;
 };
-// L1-bypassing (sc1) loads, lo FIRST: the channel serves a line's requests in order, so hi and the
-// flags are at least as recent as the count they are read behind
+// ONE L2-bypassing 16-byte load (the wait is part of it: the compiler does not count loads it
+// cannot see -- and vector loads return in order, so nothing younger is held up by waiting here)
 __device__ __forceinline__ GaWords ga_load(const long long* row) {
+    typedef long long i64x2 __attribute__((ext_vector_type(2)));
+    i64x2 v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(row) : "memory");
     GaWords w;
-    w.lo = __hip_atomic_load(row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    w.hi = __hip_atomic_load(row + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    w.fl = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(row + 2), __ATOMIC_RELAXED,
-                             __HIP_MEMORY_SCOPE_AGENT);
+    w.lo = v.x;
+    w.hi = v.y;
     return w;
 }
+// the accumulator rows of a chain: TWO sets.  Plain launches use set 0 (the kernel boundary orders
+// the tail's re-arm stores before the next launch's atomics); the persistent kernel alternates by
+// step parity, and the tail, while it waits for this step's set to fill, also waits until the OTHER
+// set -- the next step's, re-armed one step ago -- reads all zero, BEFORE it publishes the next
+// position: no store of a re-arm can land on a row that is being added to, and a row that looks
+// complete is never a stale one.
+__host__ __device__ inline size_t ga_set_words(int T) { return (size_t)ga_rows(T) * GA_ROW; }
+// two rows in ONE round trip (both loads issued, then one wait)
+__device__ __forceinline__ void ga_load2(const long long* row_a, const long long* row_b, GaWords* a, GaWords* b) {
+    typedef long long i64x2 __attribute__((ext_vector_type(2)));
+    i64x2 va, vb;
+    asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %3, off sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(va), "=&v"(vb) : "v"(row_a), "v"(row_b) : "memory");
+    a->lo = va.x; a->hi = va.y;
+    b->lo = vb.x; b->hi = vb.y;
+}
 __device__ __forceinline__ int ga_count(const GaWords& w) { return (int)((unsigned long long)w.lo >> GA_COUNT_SHIFT); }
-__device__ __forceinline__ void ga_rearm(long long* row, bool flags) {  // write-through zeros for the next evaluation
+__device__ __forceinline__ bool ga_is_zero(const GaWords& w) { return (w.lo | w.hi) == 0; }
+__device__ __forceinline__ void ga_rearm(long long* row) {  // write-through zeros for the next evaluation
     __hip_atomic_store(row, 0ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(row + 1, 0ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (flags) __hip_atomic_store(row + 2, 0ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // the value of a complete row (real units); a raised flag replaces it: -inf (a clipped tau term:
 // log 0) or NaN (anything else)
 __device__ __forceinline__ double ga_value(const GaWords& w) {
     const long long cnt = (long long)((unsigned long long)w.lo >> GA_COUNT_SHIFT);
-    const long long lo = (w.lo & ((1ll << GA_COUNT_SHIFT) - 1)) - cnt * GA_BIAS;
+    const unsigned int fl = (unsigned int)((unsigned long long)w.lo >> GA_FLAG_SHIFT) & 3u;
+    const long long lo = (w.lo & ((1ll << GA_FLAG_SHIFT) - 1)) - cnt * GA_BIAS;
     double v = fma((double)w.hi, GA_HI_UNIT, (double)lo * (1.0 / GA_LO_SCALE));
-    if (w.fl != 0ull) v = (w.fl & GA_BAD) ? __builtin_nan("") : -__builtin_inf();
+    if (fl != 0u) v = (fl & GA_BAD) ? __builtin_nan("") : -__builtin_inf();
     return v;
 }
 constexpr int ARRIVE_SPIN_LIMIT = 1 << 18;   // bounded waits of the tail for the streaming workgroups (~0.1 s)
@@ -1548,6 +1569,7 @@ __device__ void tail_waves(const EvalArgs& A, int chain, const double* zoL, cons
         if (wave == RNG_WAVE) nd::wave_mem_sync();
         __syncthreads();
         if (wave == LEAF_WAVE) {
+            __builtin_amdgcn_s_dcache_inv();   // (the advance reads chain state with uniform addresses)
             nd::persist_advance(ns, *A.persist, chain, t);
             if (zn_lds)   // (rare: the new doubling / transition starts from a position only memory holds)
                 for (int i = t; i < D; i += 64) zn_lds[i] = nd::vec(ns, D, nd::V_ZN)[i];
@@ -1923,11 +1945,40 @@ __device__ __forceinline__ void tail_preload(const EvalArgs& A, int chain, TailP
 }
 // (*okflag must hold 1 and a barrier must lie between that store and this call.)  false: the bounded
 // wait for the rows expired (the caller poisons the outputs).
+// one accumulator row until its count is complete (wave-uniform exit; bounded like every wait here)
+// `other` (persistent kernel): the same row of the chain's other set must read all zero as well (the
+// next step's rows, re-armed one step ago: see ga_set_words) -- requested in the SAME round of loads
+__device__ __forceinline__ bool ga_take_row(const long long* row, int expect, GaWords* out,
+                                            const long long* other = nullptr) {
+    bool ok = false;
+    for (int spin = 0; spin < ARRIVE_SPIN_LIMIT; ++spin) {
+        bool mine = true;
+        if (other != nullptr) {
+            GaWords o;
+            ga_load2(row, other, out, &o);
+            mine = ga_is_zero(o);
+        } else {
+            *out = ga_load(row);
+        }
+        mine = mine && ga_count(*out) == expect;
+        ok = __ballot(!mine) == 0ull;
+        if (ok) break;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    return ok;
+}
+// (Tried and measured slower, twice -- profiles/r03/stamps_early_poll.txt: polling the rows EARLY,
+// from waves that idle while one lane each of waves 0 and 1 finishes the prior record.  With one
+// dependent load per poll the first came back too early and the second too late (8.5 us per
+// leapfrog against 7.8); with four polls in flight the record's serial tail itself slowed down by
+// 1.2 us next to the polling waves (9.0).  The rows are polled when the prior part is done.)
+// `set`: which of the chain's two row sets this evaluation used; CHECK_OTHER (persistent kernel): the
+// wait also covers the other set reading all zero (see ga_set_words)
 template <bool SMALLT, bool NUTS, bool EXT, bool ZL = false>
 __device__ __forceinline__ bool tail_acc(const EvalArgs& A, int chain, char* smem, const TailPre& P,
                                          const nd::LeafState<1>& leaf1,
                                          const double (&bigv)[nd::LEAF_STAGE_LOADS], int* okflag,
-                                         unsigned int pub_tag = 0u) {
+                                         unsigned int pub_tag = 0u, int set = 0, bool check_other = false) {
     const Layout& L = A.L;
     const int T = L.T, K = L.K, D = L.D;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1947,37 +1998,29 @@ __device__ __forceinline__ bool tail_acc(const EvalArgs& A, int chain, char* sme
 
     const bool small = D <= 64;
     const double* z = z_of(A, chain);
-    long long* ga = A.gacc + (size_t)chain * ga_rows(T) * GA_ROW;
+    long long* ga = A.gacc + ((size_t)chain * 2 + set) * ga_set_words(T);
     const bool xs_staged = K > 0 && K <= 16;
-    // one row until its count is complete (wave-uniform exit; bounded like every wait in this file)
-    auto take_row = [&](const long long* row, int expect, GaWords* out) {
-        bool ok = false;
-        for (int spin = 0; spin < ARRIVE_SPIN_LIMIT; ++spin) {
-            *out = ga_load(row);
-            ok = __ballot(ga_count(*out) != expect) == 0ull;
-            if (ok) break;
-            __builtin_amdgcn_s_sleep(1);
-        }
-        return ok;
-    };
     {
         // ---- 1. poll this thread's row until every workgroup that feeds it has added: the load that
         // finds the count complete IS the hand-off (no arrival counter, no second round of loads)
         const int i = tid;
         GaWords w0;
-        bool ok = take_row(ga + (size_t)tail_row_of(tid, ncol) * GA_ROW, P.expect, &w0);
+        const size_t ro = (size_t)tail_row_of(tid, ncol) * GA_ROW;
+        // (persistent kernel: the next step's rows, re-armed one step ago, must read all zero too)
+        bool ok = ga_take_row(ga + ro, P.expect, &w0,
+                              check_other ? A.gacc + ((size_t)chain * 2 + (set ^ 1)) * ga_set_words(T) + ro : nullptr);
         if (i < ncol) cL[i] = P.c0;
         if (!ZL && i < D) zL[i] = P.z0;
         if (xs_staged && i < T * K) xsL[i] = P.x0;
         if (wave < WAVES - 1) {
             if (i < ncol) col[i] = ga_value(w0);
             // larger models: the remaining team rows, one round per pass
-            // (wave-uniform trip count: take_row ballots; lanes past the last row poll it again)
+            // (wave-uniform trip count: ga_take_row ballots; lanes past the last row poll it again)
             for (int b0 = (tid & ~63) + ROW_THREADS; b0 < ncol; b0 += ROW_THREADS) {
                 const int i2 = b0 + lane;
                 GaWords w;
                 const int r = min(i2, ncol - 1);
-                ok = take_row(ga + (size_t)r * GA_ROW, A.ga_expect[r], &w) && ok;
+                ok = ga_take_row(ga + (size_t)r * GA_ROW, A.ga_expect[r], &w) && ok;
                 if (i2 < ncol) col[i2] = ga_value(w);
             }
         } else {  // scalar rows: sum the shards (16-lane rows; a flagged shard is -inf / NaN and stays so)
@@ -2001,11 +2044,10 @@ __device__ __forceinline__ bool tail_acc(const EvalArgs& A, int chain, char* sme
     if (*okflag == 0) return false;
     // re-arm the rows for this chain's next launch: write-through zeros, issued only now -- a
     // barrier waits for the wave's outstanding stores, and these take a memory round trip
-    // (the flag word only when a flag was seen: a row's flags are raised once in a blue moon)
     if (wave < WAVES - 1) {
-        for (int i = tid; i < ncol; i += ROW_THREADS) ga_rearm(ga + (size_t)i * GA_ROW, true);
+        for (int i = tid; i < ncol; i += ROW_THREADS) ga_rearm(ga + (size_t)i * GA_ROW);
     } else {
-        ga_rearm(ga + (size_t)(ncol + (lane & 15) * N_SCAL + (lane >> 4)) * GA_ROW, true);
+        ga_rearm(ga + (size_t)(ncol + (lane & 15) * N_SCAL + (lane >> 4)) * GA_ROW);
     }
     DC_STAMP(9);
     if (SMALLT) {  // lane = team: four waves, one output group each, no LDS traffic
@@ -2468,7 +2510,7 @@ __global__ DC_LAUNCH_BOUNDS void dc_eval(EvalArgs A) {
             // into the chain's counted accumulator rows (integer atomics at agent scope, no return):
             // the count travels with the value, so nothing follows -- no drain, no barrier, no
             // arrival counter; the workgroup is done
-            long long* ga = A.gacc + (size_t)chain * ga_rows(T) * GA_ROW;
+            long long* ga = A.gacc + (size_t)chain * 2 * ga_set_words(T);
             for (int k = o0 + tid; k < o1; k += BLOCK) {
                 const int slot = k == o0 + tid ? slot0 : A.wg_slots[k];
                 const int which = slot / T, t = slot - which * T;
@@ -2595,14 +2637,17 @@ __global__ DC_LAUNCH_BOUNDS void dc_eval_loop(EvalArgs A) {
         __syncthreads();
         for (int s = 0; s < steps; ++s) {
             DC_STAMP(0);
-            __builtin_amdgcn_s_dcache_inv();
+            // (no scalar-cache invalidate here any more: what changes between steps is read through
+            // vector loads -- the position from LDS, the leaf's state lane-indexed, the rows with sc1 --
+            // and an invalidate made the kernel-argument reloads below miss, 0.3 us per step; the one
+            // path that reads state with uniform addresses, the chain advance, invalidates for itself)
+            if (tid == 0) *acc_tail_flag(A, smem) = 1;   // (in front of the prior part's first barrier)
             prior_body<CLIP, true, false, true>(A, chain, smem + tail_bytes, reinterpret_cast<double*>(smem), zL);
             DC_STAMP(4);
             TailPre pre;
             nd::LeafState<1> leaf1{};
             double bigv[nd::LEAF_STAGE_LOADS];
             tail_preload<STAGED, NUTS, true>(reload_args(), chain, pre, leaf1, bigv);
-            if (tid == 0) *acc_tail_flag(A, smem) = 1;
             __syncthreads();
             DC_STAMP(6);
             const bool last = s + 1 == steps;
@@ -2611,7 +2656,7 @@ __global__ DC_LAUNCH_BOUNDS void dc_eval_loop(EvalArgs A) {
                 const EvalArgs B = reload_args();
                 // (the last step of the launch publishes nothing: the next launch starts from V_ZN)
                 done = tail_acc<STAGED, NUTS, CLIP, true>(B, chain, smem, pre, leaf1, bigv, acc_tail_flag(B, smem),
-                                                          last ? 0u : A.tag_base + 2u + (unsigned int)s);
+                                                          last ? 0u : A.tag_base + 2u + (unsigned int)s, s & 1, true);
             }
             if (!done) {  // bounded wait expired: end the launch for everybody, poison the outputs
                 if (wave == LEAF_WAVE) publish_fin(zg, L.D, lane, fin_tag);
@@ -2647,7 +2692,7 @@ __global__ DC_LAUNCH_BOUNDS void dc_eval_loop(EvalArgs A) {
     const int o0 = A.wg_off[wgi], o1 = A.wg_off[wgi + 1];
     const int kq = min(o0 + tid, A.total_c - 1);
     const int slot0 = A.wg_slots[kq];
-    long long* ga = A.gacc + (size_t)chain * ga_rows(T) * GA_ROW;
+    long long* ga0 = A.gacc + (size_t)chain * 2 * ga_set_words(T);
     if (tid == 0) *flag = 1;
     // this thread's row of the standardised covariates: data, resident for the whole launch
     constexpr int KREG = 8;
@@ -2779,6 +2824,7 @@ __global__ DC_LAUNCH_BOUNDS void dc_eval_loop(EvalArgs A) {
         {   // the counted rows: fire and forget, then straight on to the next position (which is
             // published only after the tail has seen every row complete, i.e. after every thread
             // here has read acc / red -- no barrier needed before the next step overwrites them)
+            long long* ga = ga0 + (size_t)(s & 1) * ga_set_words(T);   // (the rows alternate by step parity)
             for (int k = o0 + tid; k < o1; k += BLOCK) {
                 const int slot = k == o0 + tid ? slot0 : A.wg_slots[k];
                 const int which = slot / T, t = slot - which * T;
