@@ -720,10 +720,22 @@ __device__ __forceinline__ TeamZ load_team_z(const Layout& L, const double* z, i
     v.h = EXT ? zld<SC1>(&z[L.o_hadec + t]) : 0.0;
     return v;
 }
-template <bool EXT, bool SC1 = false>
-__device__ __forceinline__ void f32_table_entry(const Layout& L, const F32Scalars& s,
-                                                const double* z, const float* xsf, int t,
-                                                const TeamZ& tz, float2* vh, float2* va) {
+// xs_at(t, k): the standardised covariate as float32 (a float copy in memory, or -- persistent
+// kernel, tail workgroup -- the LDS-resident float64 copy narrowed: the same value)
+struct XsFromF32 {
+    const float* p;
+    int K;
+    __device__ __forceinline__ float operator()(int t, int k) const { return p[(size_t)t * K + k]; }
+};
+struct XsFromF64 {
+    const double* p;
+    int K;
+    __device__ __forceinline__ float operator()(int t, int k) const { return (float)p[(size_t)t * K + k]; }
+};
+template <bool EXT, bool SC1 = false, class XS>
+__device__ __forceinline__ void f32_table_entry_x(const Layout& L, const F32Scalars& s,
+                                                  const double* z, XS xs_at, int t,
+                                                  const TeamZ& tz, float2* vh, float2* va) {
     float att, def, ha;
     if (!EXT) {
         att = s.s_a * (float)tz.a;
@@ -732,7 +744,7 @@ __device__ __forceinline__ void f32_table_entry(const Layout& L, const F32Scalar
     } else {
         float apm = 0.f, dpm = s.m;
         for (int k = 0; k < L.K; ++k) {
-            const float xv = xsf[(size_t)t * L.K + k];
+            const float xv = xs_at(t, k);
             apm += xv * (float)zld<SC1>(&z[L.o_bA + k]);
             dpm += xv * (float)zld<SC1>(&z[L.o_bD + k]);
         }
@@ -744,20 +756,26 @@ __device__ __forceinline__ void f32_table_entry(const Layout& L, const F32Scalar
     *vh = make_float2(exp_f32(att + ha), edn);
     *va = make_float2(exp_f32(att), edn);
 }
+template <bool EXT, bool SC1 = false>
+__device__ __forceinline__ void f32_table_entry(const Layout& L, const F32Scalars& s,
+                                                const double* z, const float* xsf, int t,
+                                                const TeamZ& tz, float2* vh, float2* va) {
+    f32_table_entry_x<EXT, SC1>(L, s, z, XsFromF32{xsf, L.K}, t, tz, vh, va);
+}
 // `first`: team `tid`'s entries of z, loaded by the caller BEFORE its bulk loads -- vector loads
 // return in order, and behind a tile's worth of fixture loads they would wait for HBM
 // SMALLT (at most 64 teams, fewer than threads): a thread builds at most ONE entry, from `first` --
 // no load inside the loop.  With the loop, the entry's z values are a phi of `first` and an in-loop
 // load, and the compiler waits for EVERY outstanding load (the first tile's among them) before it
 // uses them.
-template <bool EXT, bool SC1 = false, bool SMALLT = false>
-__device__ __forceinline__ void build_tables_f32(const Layout& L, const double* z,
-                                                 const float* xsf, float2* tabH, float2* tabA,
-                                                 int tid, const TeamZ& first, const F32Scalars& s) {
+template <bool EXT, bool SC1 = false, bool SMALLT = false, class XS>
+__device__ __forceinline__ void build_tables_f32_x(const Layout& L, const double* z,
+                                                   XS xs_at, float2* tabH, float2* tabA,
+                                                   int tid, const TeamZ& first, const F32Scalars& s) {
     if (SMALLT) {
         if (tid <= L.T) {
             float2 vh = make_float2(0.f, 0.f), va = vh;
-            if (tid < L.T) f32_table_entry<EXT, SC1>(L, s, z, xsf, tid, first, &vh, &va);
+            if (tid < L.T) f32_table_entry_x<EXT, SC1>(L, s, z, xs_at, tid, first, &vh, &va);
             tabH[tid] = vh;
             tabA[tid] = va;
         }
@@ -765,10 +783,16 @@ __device__ __forceinline__ void build_tables_f32(const Layout& L, const double* 
     }
     for (int t = tid; t <= L.T; t += BLOCK) {
         float2 vh = make_float2(0.f, 0.f), va = vh;
-        if (t < L.T) f32_table_entry<EXT, SC1>(L, s, z, xsf, t, t == tid ? first : load_team_z<EXT, SC1>(L, z, t), &vh, &va);
+        if (t < L.T) f32_table_entry_x<EXT, SC1>(L, s, z, xs_at, t, t == tid ? first : load_team_z<EXT, SC1>(L, z, t), &vh, &va);
         tabH[t] = vh;
         tabA[t] = va;
     }
+}
+template <bool EXT, bool SC1 = false, bool SMALLT = false>
+__device__ __forceinline__ void build_tables_f32(const Layout& L, const double* z,
+                                                 const float* xsf, float2* tabH, float2* tabA,
+                                                 int tid, const TeamZ& first, const F32Scalars& s) {
+    build_tables_f32_x<EXT, SC1, SMALLT>(L, z, XsFromF32{xsf, L.K}, tabH, tabA, tid, first, s);
 }
 // rho in float32 from the three float32 maxima (identical code in stream and prior)
 __device__ __forceinline__ float rho_f32(float mP, float mQ, float mR, float q) {
@@ -977,9 +1001,13 @@ __device__ __forceinline__ SigSite sig_site(double zc) {
 // than 64 teams only: the small-league kernels keep their code size)
 // Z_LDS: the position is read from `z_lds` (the persistent kernel keeps it in LDS: the leaf wrote it
 // there a moment ago, and a load from memory would be a 0.6 us round trip at the head of the step)
+// ... and, with it, the static per-team sums (c_lds = cA | cD | cH) and, when they fit, the
+// standardised covariates (xs_lds, null otherwise): the tail's LDS copies, filled once per launch --
+// per step they were a round of global loads at the head of the critical path
 template <bool CLIP, bool TO_LDS = false, bool DENSE = false, bool Z_LDS = false>
 __device__ void prior_body(const EvalArgs& A, int chain, char* smem, double* zo_lds = nullptr,
-                           const double* z_lds = nullptr) {
+                           const double* z_lds = nullptr, const double* c_lds = nullptr,
+                           const double* xs_lds = nullptr) {
     const Layout& L = A.L;
     const int T = L.T, K = L.K, D = L.D;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1007,13 +1035,17 @@ __device__ void prior_body(const EvalArgs& A, int chain, char* smem, double* zo_
     const bool sums_on_wave = T <= 64;
     double pre[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
     if (sums_on_wave && wave == WAVES - 1 && lane < T) {
-        pre[0] = A.cA[lane]; pre[1] = A.cD[lane]; pre[2] = A.cH[lane];
+        if (Z_LDS) { pre[0] = c_lds[lane]; pre[1] = c_lds[T + lane]; pre[2] = c_lds[2 * T + lane]; }
+        else { pre[0] = A.cA[lane]; pre[1] = A.cD[lane]; pre[2] = A.cH[lane]; }
         pre[3] = z[CLIP ? L.o_sat + lane : L.o_adec + lane];
         pre[4] = z[CLIP ? L.o_sdt + lane : L.o_ddec + lane];
         pre[5] = CLIP ? z[L.o_hadec + lane] : 0.0;
     }
     const F32Scalars fs = f32_scalars<CLIP>(L, z);
-    build_tables_f32<CLIP>(L, z, A.xsf, tabH, tabA, tid, load_team_z<CLIP>(L, z, min(tid, T - 1)), fs);
+    if (Z_LDS && xs_lds != nullptr)
+        build_tables_f32_x<CLIP>(L, z, XsFromF64{xs_lds, K}, tabH, tabA, tid, load_team_z<CLIP>(L, z, min(tid, T - 1)), fs);
+    else
+        build_tables_f32<CLIP>(L, z, A.xsf, tabH, tabA, tid, load_team_z<CLIP>(L, z, min(tid, T - 1)), fs);
 
     // ---- z-only scalars, one transcendental chain per wave, in parallel
     //   0 s_a  1 s_d  2 s_h  3..8 corr site  9..14 u site
@@ -1081,8 +1113,9 @@ __device__ void prior_body(const EvalArgs& A, int chain, char* smem, double* zo_
             ha = z[L.o_ha];
         } else {
             double apm = 0.0, dpm = m;
+            const double* xsp = Z_LDS && xs_lds != nullptr ? xs_lds : A.xs;
             for (int k = 0; k < K; ++k) {
-                const double xv = A.xs[(size_t)t * K + k];
+                const double xv = xsp[(size_t)t * K + k];
                 apm += xv * z[L.o_bA + k];
                 dpm += xv * z[L.o_bD + k];
             }
@@ -1922,9 +1955,10 @@ __device__ __forceinline__ void tail_preload(const EvalArgs& A, int chain, TailP
     const int ncol = 3 * T, i = tid;
     const double* z = z_of(A, chain);
     const bool xs_staged = K > 0 && K <= 16;
-    P.c0 = i < ncol ? (i < T ? A.cA[i] : (i < 2 * T ? A.cD[i - T] : A.cH[i - 2 * T])) : 0.0;
+    // (ZL: the persistent kernel filled cL / zL / xsL once; nothing to load per step)
+    P.c0 = !ZL && i < ncol ? (i < T ? A.cA[i] : (i < 2 * T ? A.cD[i - T] : A.cH[i - 2 * T])) : 0.0;
     P.z0 = !ZL && i < D ? z[i] : 0.0;
-    P.x0 = (xs_staged && i < T * K) ? A.xs[i] : 0.0;
+    P.x0 = (!ZL && xs_staged && i < T * K) ? A.xs[i] : 0.0;
     P.expect = A.ga_expect[tail_row_of(tid, ncol)];
     if (NUTS && SMALLT) {
         double* ns = nuts_of(A, chain);
@@ -2009,9 +2043,9 @@ __device__ __forceinline__ bool tail_acc(const EvalArgs& A, int chain, char* sme
         // (persistent kernel: the next step's rows, re-armed one step ago, must read all zero too)
         bool ok = ga_take_row(ga + ro, P.expect, &w0,
                               check_other ? A.gacc + ((size_t)chain * 2 + (set ^ 1)) * ga_set_words(T) + ro : nullptr);
-        if (i < ncol) cL[i] = P.c0;
+        if (!ZL && i < ncol) cL[i] = P.c0;
         if (!ZL && i < D) zL[i] = P.z0;
-        if (xs_staged && i < T * K) xsL[i] = P.x0;
+        if (!ZL && xs_staged && i < T * K) xsL[i] = P.x0;
         if (wave < WAVES - 1) {
             if (i < ncol) col[i] = ga_value(w0);
             // larger models: the remaining team rows, one round per pass
@@ -2033,12 +2067,13 @@ __device__ __forceinline__ bool tail_acc(const EvalArgs& A, int chain, char* sme
         }
         if (!ok && lane == 0) *okflag = 0;
     }
-    for (int i = tid + BLOCK; i < ncol; i += BLOCK)
-        cL[i] = i < T ? A.cA[i] : (i < 2 * T ? A.cD[i - T] : A.cH[i - 2 * T]);
-    if (!ZL)
+    if (!ZL) {
+        for (int i = tid + BLOCK; i < ncol; i += BLOCK)
+            cL[i] = i < T ? A.cA[i] : (i < 2 * T ? A.cD[i - T] : A.cH[i - 2 * T]);
         for (int i = tid + BLOCK; i < D; i += BLOCK) zL[i] = z[i];
-    if (xs_staged)
-        for (int i = tid + BLOCK; i < T * K; i += BLOCK) xsL[i] = A.xs[i];
+        if (xs_staged)
+            for (int i = tid + BLOCK; i < T * K; i += BLOCK) xsL[i] = A.xs[i];
+    }
     __syncthreads();
     DC_STAMP(8);
     if (*okflag == 0) return false;
@@ -2632,8 +2667,16 @@ __global__ DC_LAUNCH_BOUNDS void dc_eval_loop(EvalArgs A) {
         if (wave == LEAF_WAVE) publish_z(zg, nd::vec(nuts_of(A, chain), L.D, nd::V_ZN), L.D, lane, A.tag_base + 1u);
         // ... and from here on the tail keeps the position in LDS (zL of tail_acc's layout): the leaf
         // writes the next one there, the prior part and the epilogue read it from there
-        double* zL = reinterpret_cast<double*>(smem) + A.zo_stride + 3 * T;
+        // ... together with what never changes during the launch: the static per-team sums and (when
+        // they fit) the covariates
+        double* cL = reinterpret_cast<double*>(smem) + A.zo_stride;
+        double* zL = cL + 3 * T;
+        const bool xs_staged = L.K > 0 && L.K <= 16;
+        double* xsL = zL + L.D + (3 * T + N_SCAL + 4) + WAVES * 8;   // (tail_acc's layout)
         for (int i = tid; i < L.D; i += BLOCK) zL[i] = nd::vec(nuts_of(A, chain), L.D, nd::V_ZN)[i];
+        for (int i = tid; i < 3 * T; i += BLOCK) cL[i] = i < T ? A.cA[i] : (i < 2 * T ? A.cD[i - T] : A.cH[i - 2 * T]);
+        if (xs_staged)
+            for (int i = tid; i < T * L.K; i += BLOCK) xsL[i] = A.xs[i];
         __syncthreads();
         for (int s = 0; s < steps; ++s) {
             DC_STAMP(0);
@@ -2642,7 +2685,8 @@ __global__ DC_LAUNCH_BOUNDS void dc_eval_loop(EvalArgs A) {
             // and an invalidate made the kernel-argument reloads below miss, 0.3 us per step; the one
             // path that reads state with uniform addresses, the chain advance, invalidates for itself)
             if (tid == 0) *acc_tail_flag(A, smem) = 1;   // (in front of the prior part's first barrier)
-            prior_body<CLIP, true, false, true>(A, chain, smem + tail_bytes, reinterpret_cast<double*>(smem), zL);
+            prior_body<CLIP, true, false, true>(A, chain, smem + tail_bytes, reinterpret_cast<double*>(smem), zL, cL,
+                                                xs_staged ? xsL : nullptr);
             DC_STAMP(4);
             TailPre pre;
             nd::LeafState<1> leaf1{};

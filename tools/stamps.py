@@ -48,7 +48,12 @@ def run_nuts(n=1_000_000):
     from bpl._ffi import default_nuts_cfg, BplHipError
     os.environ["BPLHIP_DEBUG_MAX_STEPS"] = "3000"
     h, a, x, y = synthetic_league(n, 20)
-    c = HipContext(0); c.set_fixtures(MODEL_BASIC, h, a, x, y, 20)
+    k = int(os.environ.get("NUTS_K", "-1"))   # -1: basic model; >= 0: extended model with k covariates
+    cov = None
+    if k > 0:
+        cov = np.random.RandomState(0).normal(size=(20, k)); cov = (cov - cov.mean(0)) / cov.std(0)
+    w = np.exp(-np.linspace(5.0, 0.0, n)).astype(np.float32) if os.environ.get("NUTS_W") else None
+    c = HipContext(0); c.set_fixtures(MODEL_BASIC if k < 0 else MODEL_EXTENDED, h, a, x, y, 20, weights=w, covariates_std=cov)
     lib = c._lib
     lib.bplhip_debug_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int]; lib.bplhip_debug_stamps.restype = C.c_int
     nwg = lib.bplhip_debug_stamps(c._h, None, 0)
@@ -61,7 +66,7 @@ def run_nuts(n=1_000_000):
     lib.bplhip_debug_stamps(c._h, buf.ctypes.data_as(C.c_void_p), buf.size)
     st = buf[: nwg * 16].reshape(nwg, 16).astype(np.int64)
     rel = (st - st[:, 0].min()) * 0.01
-    print(f"--- NUTS-aware launch, N={n}, blocks={nwg}")
+    print(f"--- NUTS-aware launch, N={n}, blocks={nwg}, model={'basic' if k < 0 else f'extended K={k}'}{' weighted' if w is not None else ''}")
     print("  prior WG: entry=%.2f scalars=%.2f cells=%.2f bounds=%.2f done=%.2f ticket=%.2f" % (rel[0, 0], rel[0, 1], rel[0, 2], rel[0, 3], rel[0, 4], rel[0, 6]))
     for k, nm in [(0, "entry"), (1, "tables"), (2, "bounds"), (12, "loads-landed"), (3, "stream"), (4, "slab"), (6, "ticket")]:
         col = rel[1:, k]
