@@ -531,15 +531,22 @@ bool loop_ok(const bplhip_ctx* c) {
     const bplhip_ctx::EvalPart& ep = c->parts[0];
     return ep.staged && ep.n_wg + 1 <= c->n_cu && ctx_lds_bytes(c, true) <= 64 * 1024;
 }
-template <bool W, bool C>
-int launch_loop_t(bplhip_ctx* c, const dc::EvalArgs& A, hipStream_t s) {
+template <bool W, bool C, int LNE>
+int launch_loop_l(bplhip_ctx* c, const dc::EvalArgs& A, hipStream_t s) {
     const size_t lds = ctx_lds_bytes(c, true);
     if (lds > 48 * 1024)
-        HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(dc::dc_eval_loop<W, C>),
+        HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(dc::dc_eval_loop<W, C, LNE>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((dc::dc_eval_loop<W, C>), dim3(c->ep->n_wg + 1, 1), dim3(dc::BLOCK), lds, s, A);
+    hipLaunchKernelGGL((dc::dc_eval_loop<W, C, LNE>), dim3(c->ep->n_wg + 1, 1), dim3(dc::BLOCK), lds, s, A);
     HIP_TRY(c, hipGetLastError());
     return BPLHIP_OK;
+}
+template <bool W, bool C>
+int launch_loop_t(bplhip_ctx* c, const dc::EvalArgs& A, hipStream_t s) {
+    // the leaf's vectors in registers: one element per lane up to 64 latent entries, two up to 128
+    // (the extended model: 3T + 2K + 7); beyond, the LDS-staged leaf of the one-element kernel
+    if (C && c->L.D > 64 && c->L.D <= 128) return launch_loop_l<W, C, 2>(c, A, s);
+    return launch_loop_l<W, C, 1>(c, A, s);
 }
 int launch_eval_loop(bplhip_ctx* c, double* ns, int nuts_depth, const nd::Persist* persist, int steps,
                      hipStream_t s) {

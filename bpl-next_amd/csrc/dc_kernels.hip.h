@@ -1416,10 +1416,14 @@ __device__ __forceinline__ void publish_fin(unsigned long long* zg, int D, int l
 // Same arithmetic and the same summation order on every run (deterministic).  With NUTS the
 // workgroup then barriers and wave LEAF_WAVE (one of the four idle ones, so its header wait,
 // index arithmetic and threefry draws cost nothing) books the leaf.
-template <bool NUTS, bool EXT>
+// LNE: vector elements per lane the leaf keeps in REGISTERS (D <= 64 LNE; deduced from leaf1).  1
+// everywhere but in the persistent kernel, which takes 2 for 64 < D <= 128 (the extended model with
+// 20 teams: D = 67 .. 77) instead of staging the leaf's vectors in LDS -- a single resident chain
+// has the registers, and the staged leaf was 1.0 us slower per leapfrog.
+template <bool NUTS, bool EXT, int LNE>
 __device__ void tail_waves(const EvalArgs& A, int chain, const double* zoL, const double* cL,
                            const double* zL, const double* col, const double* xsL,
-                           double* gradL, const nd::LeafState<1>& leaf1, double* stg,
+                           double* gradL, const nd::LeafState<LNE>& leaf1, double* stg,
                            unsigned int pub_tag = 0u /* persistent kernel: tag of the NEXT step */,
                            double* zn_lds = nullptr /* persistent kernel: the LDS copy of the position */) {
     const Layout& L = A.L;
@@ -1561,8 +1565,8 @@ __device__ void tail_waves(const EvalArgs& A, int chain, const double* zoL, cons
     }
     DC_STAMP(14);
     if (nuts) {  // device-resident NUTS: the leaf wave finishes the leapfrog and books the leaf
-        const bool small = D <= 64;  // one vector element per lane: registers; else LDS (stg)
-        nd::LeafState<1> lf1 = leaf1;
+        const bool small = D <= 64 * LNE;  // LNE vector elements per lane: registers; else LDS (stg)
+        nd::LeafState<LNE> lf1 = leaf1;
         double* ns = nuts_of(A, chain);
         // preparation that needs the header only, while waves 0..3 write the outputs
         if (wave == LEAF_WAVE && small) nd::leaf_prepare<false>(lf1);
@@ -1945,9 +1949,9 @@ __device__ __forceinline__ int tail_row_of(int tid, int ncol) {
     return wave < WAVES - 1 ? min(tid, ncol - 1) : ncol + (lane & 15) * N_SCAL + (lane >> 4);
 }
 // ZL: the position already sits in the tail's LDS copy zL (persistent kernel): not loaded, not staged
-template <bool SMALLT, bool NUTS, bool ZL = false>
+template <bool SMALLT, bool NUTS, bool ZL = false, int LNE>
 __device__ __forceinline__ void tail_preload(const EvalArgs& A, int chain, TailPre& P,
-                                             nd::LeafState<1>& leaf1,
+                                             nd::LeafState<LNE>& leaf1,
                                              double (&bigv)[nd::LEAF_STAGE_LOADS]) {
     const Layout& L = A.L;
     const int T = L.T, K = L.K, D = L.D;
@@ -1962,9 +1966,9 @@ __device__ __forceinline__ void tail_preload(const EvalArgs& A, int chain, TailP
     P.expect = A.ga_expect[tail_row_of(tid, ncol)];
     if (NUTS && SMALLT) {
         double* ns = nuts_of(A, chain);
-        if (D <= 64) {
+        if (D <= 64 * LNE) {
             if (wave == LEAF_WAVE || wave == RNG_WAVE)
-                leaf1 = nd::leaf_prefetch<1>(ns, D, A.nuts_max_depth, lane);
+                leaf1 = nd::leaf_prefetch<LNE>(ns, D, A.nuts_max_depth, lane);
         } else if (wave >= 4) {
             static_assert(WAVES - 4 == nd::LEAF_NE_MAX, "one idle wave per 64-element slice");
             const int i4 = tid - 4 * 64;
@@ -2008,9 +2012,9 @@ __device__ __forceinline__ bool ga_take_row(const long long* row, int expect, Ga
 // 1.2 us next to the polling waves (9.0).  The rows are polled when the prior part is done.)
 // `set`: which of the chain's two row sets this evaluation used; CHECK_OTHER (persistent kernel): the
 // wait also covers the other set reading all zero (see ga_set_words)
-template <bool SMALLT, bool NUTS, bool EXT, bool ZL = false>
+template <bool SMALLT, bool NUTS, bool EXT, bool ZL = false, int LNE>
 __device__ __forceinline__ bool tail_acc(const EvalArgs& A, int chain, char* smem, const TailPre& P,
-                                         const nd::LeafState<1>& leaf1,
+                                         const nd::LeafState<LNE>& leaf1,
                                          const double (&bigv)[nd::LEAF_STAGE_LOADS], int* okflag,
                                          unsigned int pub_tag = 0u, int set = 0, bool check_other = false) {
     const Layout& L = A.L;
@@ -2030,7 +2034,7 @@ __device__ __forceinline__ bool tail_acc(const EvalArgs& A, int chain, char* sme
     double* stg = gradL + D + 8;                        // [7*D] NUTS leaf vectors when D > 64
     DC_STAMP(7);
 
-    const bool small = D <= 64;
+    const bool small = D <= 64 * LNE;
     const double* z = z_of(A, chain);
     long long* ga = A.gacc + ((size_t)chain * 2 + set) * ga_set_words(T);
     const bool xs_staged = K > 0 && K <= 16;
@@ -2648,7 +2652,8 @@ __device__ __forceinline__ float poll_one(const unsigned long long* g, unsigned 
     return __uint_as_float((unsigned int)v);
 }
 
-template <bool WEIGHTED, bool CLIP>
+// LNE: see tail_waves (the host takes 2 when 64 < D <= 128)
+template <bool WEIGHTED, bool CLIP, int LNE = 1>
 __global__ DC_LAUNCH_BOUNDS void dc_eval_loop(EvalArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr bool STAGED = true, NUTS = true;
@@ -2689,7 +2694,7 @@ __global__ DC_LAUNCH_BOUNDS void dc_eval_loop(EvalArgs A) {
                                                 xs_staged ? xsL : nullptr);
             DC_STAMP(4);
             TailPre pre;
-            nd::LeafState<1> leaf1{};
+            nd::LeafState<LNE> leaf1{};
             double bigv[nd::LEAF_STAGE_LOADS];
             tail_preload<STAGED, NUTS, true>(reload_args(), chain, pre, leaf1, bigv);
             __syncthreads();
