@@ -90,6 +90,7 @@ struct bplhip_ctx {
     // device buffers (library owned)
     DevBuf d_h, d_a, d_x, d_y, d_w, d_pairs, d_xs, d_cA, d_cD, d_cH, d_tickets, d_debug, d_xsf, d_hbuf;
     DevBuf d_gacc;  // accumulator rows of dc_eval's hand-off (dc::GA_ROW)
+    DevBuf d_pairw; // per unique pair: sum of weights, of w x, of w y (data only; dc::EvalArgs::pairw)
     // fault word: host memory mapped into the device.  A kernel whose bounded wait expires ORs its
     // code in (dc::raise_fault); every entry point looks at it on the way in and on the way out
     // (consume_fault), so a timed-out hand-off becomes BPLHIP_EHIP + a message instead of NaN outputs
@@ -467,6 +468,7 @@ dc::EvalArgs eval_args(bplhip_ctx* c, int chains, const double* z, double* pot, 
     A.active_waves = c->ep->aw;
     A.tiles_per_wave = c->ep->tpw;
     A.pairs = c->d_pairs.as<const uint32_t>();
+    A.pairw = c->d_pairw.as<const double>();
     A.P = c->P;
     A.dense_pairs = c->opt_dense_pairs && c->pairs_complete && c->P >= dc::DENSE_MIN_PAIRS;
     A.xs = c->L.K ? c->d_xs.as<const double>() : nullptr;
@@ -854,6 +856,7 @@ static int bplhip_set_fixtures_impl(bplhip_ctx* c, int model_kind, int64_t n, in
     xs8.reserve(hs.capacity()); ys8.reserve(hs.capacity());
     if (weights) ws.reserve(hs.capacity());
     std::vector<uint32_t> pairs;
+    std::vector<double> pairw;  // [P][4]: sum w | sum w x | sum w y | 0  (for the prior workgroup's corrections)
     std::vector<double> cA(T, 0.0), cD(T, 0.0), cH(T, 0.0);
     double lgsum = 0.0;
     auto pad_run = [&]() {
@@ -872,6 +875,7 @@ static int bplhip_set_fixtures_impl(bplhip_ctx* c, int model_kind, int64_t n, in
         if (pairs.empty() || pairs.back() != pk) {
             if (!pairs.empty()) pad_run();
             pairs.push_back(pk);
+            pairw.insert(pairw.end(), {0.0, 0.0, 0.0, 0.0});
         }
         hs.push_back(h[i]);
         as.push_back(a[i]);
@@ -885,6 +889,12 @@ static int bplhip_set_fixtures_impl(bplhip_ctx* c, int model_kind, int64_t n, in
         cD[a[i]] += wi * x[i];
         cD[h[i]] += wi * y[i];
         cH[h[i]] += wi * x[i];
+        {
+            double* pw = &pairw[pairw.size() - 4];
+            pw[0] += wi;
+            pw[1] += wi * x[i];
+            pw[2] += wi * y[i];
+        }
         lgsum += wi * (std::lgamma((double)x[i] + 1.0) + std::lgamma((double)y[i] + 1.0));
     }
     pad_run();
@@ -966,6 +976,8 @@ static int bplhip_set_fixtures_impl(bplhip_ctx* c, int model_kind, int64_t n, in
         HIP_TRY(c, c->d_w.ensure(n_pad * 4));
         HIP_TRY(c, hipMemcpyAsync(c->d_w.p, ws.data(), n_pad * 4, hipMemcpyHostToDevice, s));
     }
+    HIP_TRY(c, c->d_pairw.ensure(std::max<size_t>(pairw.size(), 4) * 8));
+    HIP_TRY(c, hipMemcpy(c->d_pairw.p, pairw.data(), pairw.size() * 8, hipMemcpyHostToDevice));
     HIP_TRY(c, c->d_pairs.ensure(pairs.size() * 4));
     HIP_TRY(c, hipMemcpyAsync(c->d_pairs.p, pairs.data(), pairs.size() * 4,
                               hipMemcpyHostToDevice, s));

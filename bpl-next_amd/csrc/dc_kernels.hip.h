@@ -127,6 +127,7 @@ enum {
     ZO_M, ZO_LH, ZO_LA,   // true maxima
     ZO_PP, ZO_PQ, ZO_PR,  // arg-extremal pairs (home | away<<16, as double)
     ZO_FLAGS,             // bit0 P home clipped, bit1 P away clipped, bit2 Q, bit3 R
+    ZO_PAIRC,             // per-pair value corrections (float32 rate-product rounding, clipped-rate log term)
     ZO_HDR = 24
 };
 
@@ -141,6 +142,7 @@ struct EvalArgs {
     int tiles_per_wave;
     int active_waves;       // waves of a workgroup that own tiles (the first ones)
     const uint32_t* pairs;  // [P] unique (home | away<<16)
+    const double* pairw;    // [P][4] per pair, data only: sum of weights | sum w x | sum w y | 0
     int dense_pairs;  // 1: every ordered pair h != a is present -- the maxima over pairs are separable (O(T))
     int P;
     const double* xs;       // [T,K] standardised covariates (float64) or nullptr
@@ -1030,7 +1032,11 @@ __device__ void prior_body(const EvalArgs& A, int chain, char* smem, double* zo_
 
     // ---- float32 tables and rho exactly as the streaming workgroups build them
     uint32_t pr0 = 0;
-    if (tid < A.P) pr0 = A.pairs[tid];
+    double pw0[3] = {0.0, 0.0, 0.0};   // this thread's pair: sum of weights, of w x, of w y (data only)
+    if (tid < A.P) {
+        pr0 = A.pairs[tid];
+        pw0[0] = A.pairw[4 * (size_t)tid]; pw0[1] = A.pairw[4 * (size_t)tid + 1]; pw0[2] = A.pairw[4 * (size_t)tid + 2];
+    }
     // the team-sum wave (see below) requests its inputs now: its loads queue behind nothing
     const bool sums_on_wave = T <= 64;
     double pre[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
@@ -1192,11 +1198,38 @@ __device__ void prior_body(const EvalArgs& A, int chain, char* smem, double* zo_
     float mPf = 0.f, mQf = 0.f, mRf = 0.f;
     double mP = 0.0, mQ = 0.0, mR = 0.0;
     uint32_t aP = 0, aQ = 0, aR = 0;  // arg-pairs (home | away << 16)
-    auto take = [&](uint32_t pr, bool valid) {
+    // PER-PAIR VALUE CORRECTIONS (round 3), summed into ZO_PAIRC.  The streaming workgroups take a
+    // pair's rate as the float32 product of two float32 table entries: rounded once per pair, the
+    // same error for every fixture of the pair (the largest term of |U - U_float64| in round 2,
+    // 5e-3 at N = 1e6).  The product of two float32 numbers is exact in float64, so this walk knows
+    // that error exactly: + W_p (lh_f32 - th * ta).  And at a clipped rate (extended model) the
+    // value needs  k eta -> k log 15:  - (sum_p w k) (eta - log 15) with the exact float64 eta
+    // (round 2: v_log_f32 of the raw float32 rate in every lane, 20x the error of a plain point);
+    // the clip DECISION is the streaming workgroups' own (the same float32 bits).
+    double pairc = 0.0;
+    auto take = [&](uint32_t pr, bool valid, double pW, double pSX, double pSY) {
         const int h = pr & 0xFFFFu, a = pr >> 16;
         {
             const float2 th = tabH[h], ta = tabA[a];
             float lhf = th.x * ta.y, laf = ta.x * th.y;
+            const bool ch = CLIP && lhf > (float)RATE_CLIP, ca = CLIP && laf > (float)RATE_CLIP;
+            if (valid) {
+                const double ph = (double)th.x * (double)ta.y, pa = (double)ta.x * (double)th.y;  // exact
+                pairc += pW * ((ch ? 0.0 : (double)lhf - ph) + (ca ? 0.0 : (double)laf - pa));
+                // (a clipped lane hands the tail its goal sum as "raw" accumulator -- that cancels the goal
+                // count in the gradient -- and the tail's first-order table correction then books
+                // - (sum w k) eps for it, which a clipped rate does not have: put it back)
+                auto eps_of = [&](double tv, float tabv) {
+                    const double r = (tv - (double)tabv) / (double)tabv;
+                    return fabs(r) < 1e-4 ? r - 0.5 * r * r : 0.0;
+                };
+                if (ch)
+                    pairc -= pSX * (par[h] + par[2 * T + h] - par[T + a] - LOG_RATE_CLIP -
+                                    eps_of(tru[h], th.x) - eps_of(tru[2 * T + a], ta.y));
+                if (ca)
+                    pairc -= pSY * (par[a] - par[T + h] - LOG_RATE_CLIP - eps_of(tru[T + a], ta.x) -
+                                    eps_of(tru[2 * T + h], th.y));
+            }
             if (CLIP) {
                 lhf = fminf(lhf, (float)RATE_CLIP);
                 laf = fminf(laf, (float)RATE_CLIP);
@@ -1263,16 +1296,22 @@ __device__ void prior_body(const EvalArgs& A, int chain, char* smem, double* zo_
                 amx[lane * 8 + 0] = me ? mP : 0.0; amx[lane * 8 + 1] = me ? mQ : 0.0; amx[lane * 8 + 2] = me ? mR : 0.0;
                 amx[lane * 8 + 3] = me ? (double)aP : 0.0; amx[lane * 8 + 4] = me ? (double)aQ : 0.0;
                 amx[lane * 8 + 5] = me ? (double)aR : 0.0;
+                amx[lane * 8 + 6] = 0.0;   // (separable bounds: no pair walk, no per-pair corrections)
             }
         }
     } else {
-        if (tid < A.P) take(pr0, true);
+        if (tid < A.P) take(pr0, true, pw0[0], pw0[1], pw0[2]);
         for (int p0 = tid + BLOCK; p0 < A.P; p0 += PAIR_BATCH * BLOCK) {  // (see pair_maxima_f32)
             uint32_t q[PAIR_BATCH];
+            double qw[PAIR_BATCH][3];
 #pragma unroll
-            for (int u = 0; u < PAIR_BATCH; ++u) q[u] = A.pairs[min(p0 + u * BLOCK, A.P - 1)];
+            for (int u = 0; u < PAIR_BATCH; ++u) {
+                const size_t pi = (size_t)min(p0 + u * BLOCK, A.P - 1);
+                q[u] = A.pairs[pi];
+                qw[u][0] = A.pairw[4 * pi]; qw[u][1] = A.pairw[4 * pi + 1]; qw[u][2] = A.pairw[4 * pi + 2];
+            }
 #pragma unroll
-            for (int u = 0; u < PAIR_BATCH; ++u) take(q[u], p0 + u * BLOCK < A.P);
+            for (int u = 0; u < PAIR_BATCH; ++u) take(q[u], p0 + u * BLOCK < A.P, qw[u][0], qw[u][1], qw[u][2]);
         }
     }
     if (!dense) {
@@ -1291,10 +1330,12 @@ __device__ void prior_body(const EvalArgs& A, int chain, char* smem, double* zo_
         const uint32_t pP = (uint32_t)__builtin_amdgcn_readlane((int)aP, bP ? __ffsll((long long)bP) - 1 : 0);
         const uint32_t pQ = (uint32_t)__builtin_amdgcn_readlane((int)aQ, bQ ? __ffsll((long long)bQ) - 1 : 0);
         const uint32_t pR = (uint32_t)__builtin_amdgcn_readlane((int)aR, bR ? __ffsll((long long)bR) - 1 : 0);
+        const double wC = wave_sum_f64(pairc);
         if (lane == 0) {
             amx[wave * 8 + 0] = wP; amx[wave * 8 + 1] = wQ; amx[wave * 8 + 2] = wR;
             amx[wave * 8 + 3] = (double)pP; amx[wave * 8 + 4] = (double)pQ;
             amx[wave * 8 + 5] = (double)pR;
+            amx[wave * 8 + 6] = wC;
         }
     }
     }
@@ -1321,12 +1362,13 @@ __device__ void prior_body(const EvalArgs& A, int chain, char* smem, double* zo_
     // executing ~300 dependent float64 instructions is the longest pole of this workgroup).
     // ---- bounds: combine the waves' arg-maxima on lanes 0..WAVES-1 of wave 0 (a serial loop
     // of 48 dependent LDS reads cost 1.1 us here); ties: the lowest wave wins
-    double M = 0.0, Lh = 0.0, La = 0.0;
+    double M = 0.0, Lh = 0.0, La = 0.0, pairc_all = 0.0;
     uint32_t pP = 0, pQ = 0, pR = 0;
     if (wave == 0) {
         const bool src = lane < WAVES;
         const double a0 = src ? amx[lane * 8 + 0] : 0.0, a1 = src ? amx[lane * 8 + 1] : 0.0,
                      a2 = src ? amx[lane * 8 + 2] : 0.0;
+        pairc_all = wave_sum_f64(src ? amx[lane * 8 + 6] : 0.0);
         const uint32_t q0 = src ? (uint32_t)amx[lane * 8 + 3] : 0u, q1 = src ? (uint32_t)amx[lane * 8 + 4] : 0u,
                        q2 = src ? (uint32_t)amx[lane * 8 + 5] : 0u;
         M = a0; Lh = a1; La = a2;
@@ -1375,6 +1417,7 @@ __device__ void prior_body(const EvalArgs& A, int chain, char* smem, double* zo_
         zput(&zo[ZO_PQ], (double)pQ);
         zput(&zo[ZO_PR], (double)pR);
         zput(&zo[ZO_FLAGS], (double)flags);
+        zput(&zo[ZO_PAIRC], pairc_all);
     }
     if (tid == 64) {  // what was waiting for the team sums
         if (CLIP) {
@@ -1543,7 +1586,7 @@ __device__ void tail_waves(const EvalArgs& A, int chain, const double* zoL, cons
         const double ra = on ? col[t] : 0.0, rd = on ? col[T + t] : 0.0, rh = on ? col[2 * T + t] : 0.0;
         double corr = on ? -(rh * eps[t] + (ra - rh) * eps[T + t] + rd * eps[2 * T + t]) : 0.0;
         corr = wave_sum_f64(corr);
-        const double Ltot = zoL[ZO_LZ] + corr + G_rho * zoL[ZO_DRHO] - col[ncol + 0] - A.lgsum +
+        const double Ltot = zoL[ZO_LZ] + corr + zoL[ZO_PAIRC] + G_rho * zoL[ZO_DRHO] - col[ncol + 0] - A.lgsum +
                             LN2 * col[ncol + 1] - col[ncol + 3];
         if (t == 0) {
             *pot_of(A, chain) = -Ltot;
@@ -1718,7 +1761,7 @@ __device__ void tail_general(const EvalArgs& A, int chain, const double* zoL, co
             grad[L.o_sd] = gz[L.o_sd] - s_d * v[3];
             grad[L.o_corr] = gz[L.o_corr] - G_rho * (UB - LB) * dq;
             const double Ltot =
-                Lz + v[4] + G_rho * drho - SLAM - A.lgsum + LN2 * SLOG - CLIPC;
+                Lz + v[4] + zoL[ZO_PAIRC] + G_rho * drho - SLAM - A.lgsum + LN2 * SLOG - CLIPC;
             *pot_of(A, chain) = -Ltot;
         }
     } else {
@@ -1755,7 +1798,7 @@ __device__ void tail_general(const EvalArgs& A, int chain, const double* zoL, co
             grad[L.o_corr] = gz[L.o_corr] - G_rho * (UB - LB) * dq;
             grad[L.o_u] = gz[L.o_u];
             const double Ltot =
-                Lz + v[5] + G_rho * drho - SLAM - A.lgsum + LN2 * SLOG - CLIPC;
+                Lz + v[5] + zoL[ZO_PAIRC] + G_rho * drho - SLAM - A.lgsum + LN2 * SLOG - CLIPC;
             *pot_of(A, chain) = -Ltot;
         }
     }
@@ -2174,7 +2217,8 @@ __device__ __forceinline__ LaneData load_lane(const EvalArgs& A, size_t o /* til
 struct LaneOut {
     uint32_t key;           // (home | away<<16) the lane's pending run sums belong to
     float rsh, rsa;         // pending run sums: -(dL/d eta_h), -(dL/d eta_a) w/o goal counts
-    float slam, slog, su, sclip;
+    double slam;            // float64: see lane_uniform
+    float slog, su, sclip;
 };
 
 __device__ __forceinline__ float clamp0(float t) {  // max(t, 0) in one instruction
@@ -2199,10 +2243,19 @@ __device__ __forceinline__ ScoreMasks score_masks(uint32_t x, uint32_t y) {
     return m;
 }
 // tau argument 1 + rho*c of one score class: log2 of its clip at 0, and dlogtau/drho
+// (round 3) t = 1 + rho c is rounded to float32 -- 6e-8 absolute on a number near 1, and the same
+// error for every fixture of a (pair, class): at N = 1e6 that was the LARGEST term of
+// |U - U_float64| left (7e-3; tools: the emulation in profiles/r03/parity_errors.txt).  The rounding
+// is known exactly: 1 - t is exact near 1, so one more fma gives r = (1 + rho c) - t, and
+// log2(1 + rho c) = log2 t + r / t / ln 2 to first order -- three instructions per class and lane.
 __device__ __forceinline__ void class_terms(float rho, float c, float* l2, float* u) {
     const float t = fmaf(rho, c, 1.0f);
-    *l2 = __log2f(clamp0(t));  // log(clip(., 0)): -inf at 0 (tol = 0, bpl/_util.py:42)
-    *u = t > 0.0f ? c * __builtin_amdgcn_rcpf(t) : 0.0f;
+    const float it = __builtin_amdgcn_rcpf(t);
+    const float r = fmaf(rho, c, 1.0f - t);
+    const bool pos = t > 0.0f;
+    // log(clip(., 0)): -inf at 0 (tol = 0, bpl/_util.py:42)
+    *l2 = pos ? fmaf(r * it, 1.44269504088896341f, __log2f(t)) : -__builtin_inff();
+    *u = pos ? c * it : 0.0f;
 }
 
 // All fixtures of a lane are one pair (h, a): the library pads every pair's run to a multiple
@@ -2215,7 +2268,6 @@ __device__ __forceinline__ LaneOut lane_uniform(const LaneData& Ld, float rho,
     const float2 th = tabH[h], ta = tabA[a];
     float lh = th.x * ta.y;  // exp(att[h] + ha[h]) * exp(-def[a])
     float la = ta.x * th.y;  // exp(att[a]) * exp(-def[h])
-    const float lh_raw = lh, la_raw = la;
     bool ch = false, ca = false;
     if (CLIP) {
         ch = lh > (float)RATE_CLIP;
@@ -2289,7 +2341,10 @@ __device__ __forceinline__ LaneOut lane_uniform(const LaneData& Ld, float rho,
     }
     LaneOut o;
     o.key = h | (a << 16);
-    o.slam = nall * (lh + la);
+    // (round 3) float64: nall (lh + la) in float32 is rounded the same way in EVERY lane of a pair
+    // (82 lanes per pair at N = 1e6) -- with the two corrections of prior_body / class_terms in, the
+    // largest term of |U - U_float64| left (6e-3 at N = 1e6).  Five float64 instructions per lane.
+    o.slam = (double)nall * ((double)lh + (double)la);
     // a class with no fixture must not contribute (its log may be -inf): 0 * -inf = NaN
     o.slog = (n00 != 0.f ? n00 * l00 : 0.f) + (n10 != 0.f ? n10 * l10 : 0.f) +
              (n01 != 0.f ? n01 * l01 : 0.f) + (n11 != 0.f ? n11 * l11 : 0.f);
@@ -2300,16 +2355,10 @@ __device__ __forceinline__ LaneOut lane_uniform(const LaneData& Ld, float rho,
     o.rsa = nall * la - rho * (n00 * u00 + n10 * u10);
     o.sclip = 0.f;
     if (CLIP) {
-        // clipped rate: d/d eta = 0 -> cancel the goal count added later, and correct
-        // k*eta -> k*log(15) in the value
-        if (ch) {
-            o.rsh = sx;
-            o.sclip += sx * (__logf(lh_raw) - (float)LOG_RATE_CLIP);
-        }
-        if (ca) {
-            o.rsa = sy;
-            o.sclip += sy * (__logf(la_raw) - (float)LOG_RATE_CLIP);
-        }
+        // clipped rate: d/d eta = 0 -> cancel the goal count added later.  (The value's correction
+        // k*eta -> k*log(15) is the prior workgroup's, in float64 and per pair: prior_body, ZO_PAIRC.)
+        if (ch) o.rsh = sx;
+        if (ca) o.rsa = sy;
     }
     return o;
 }
@@ -2335,7 +2384,7 @@ __device__ __forceinline__ EvalArgs reload_args() {
     __builtin_memcpy(&B, tmp, sizeof B);
     // the copied pointers have lost their address space (flat loads): they are global memory
 #define DC_GLOBAL(f) B.f = as_global(B.f)
-    DC_GLOBAL(pairs); DC_GLOBAL(xs); DC_GLOBAL(xsf); DC_GLOBAL(cA); DC_GLOBAL(cD); DC_GLOBAL(cH);
+    DC_GLOBAL(pairs); DC_GLOBAL(pairw); DC_GLOBAL(xs); DC_GLOBAL(xsf); DC_GLOBAL(cA); DC_GLOBAL(cD); DC_GLOBAL(cH);
     DC_GLOBAL(hbuf); DC_GLOBAL(tickets); DC_GLOBAL(gacc); DC_GLOBAL(z); DC_GLOBAL(potential);
     DC_GLOBAL(grad); DC_GLOBAL(aux); DC_GLOBAL(nuts); DC_GLOBAL(debug);
 #undef DC_GLOBAL
@@ -2475,7 +2524,7 @@ __global__ DC_LAUNCH_BOUNDS void dc_eval(EvalArgs A) {
             const LaneOut lo = lane_uniform<WEIGHTED, CLIP>(ld, rho, tabH, tabA);
             // scalars: float32 over the lane's fixtures only, fixed point (q30) from there on
             // (a float32 sum over the whole wave-tile would cost ~1e-4 absolute in U)
-            dSLAM += q30(lo.slam);
+            dSLAM += rint(ldexp(lo.slam, 30));
             dSLOG += q30(lo.slog);
             dSU += q30(lo.su);
             if (CLIP) dCLIP += q30(lo.sclip);
@@ -2825,7 +2874,7 @@ __global__ DC_LAUNCH_BOUNDS void dc_eval_loop(EvalArgs A) {
         double dSLAM = 0.0, dSLOG = 0.0, dSU = 0.0, dCLIP = 0.0;
         auto process = [&](const LaneData& ld) {
             const LaneOut lo = lane_uniform<WEIGHTED, CLIP>(ld, rho, tabH, tabA);
-            dSLAM += q30(lo.slam);
+            dSLAM += rint(ldexp(lo.slam, 30));
             dSLOG += q30(lo.slog);
             dSU += q30(lo.su);
             if (CLIP) dCLIP += q30(lo.sclip);

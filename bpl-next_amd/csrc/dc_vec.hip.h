@@ -96,7 +96,8 @@ __device__ __forceinline__ LaneClass classify(const LaneData& Ld, uint32_t& rem,
 
 struct ChainOut {
     float rsh, rsa;  // -(dL/d eta_h), -(dL/d eta_a) of the run, without the goal counts
-    float slam, slog, su, sclip;
+    double slam;   // (float64: see lane_uniform of dc_kernels.hip.h)
+    float slog, su, sclip;
 };
 
 // one chain's terms of one run (same arithmetic as lane_uniform of dc_kernels.hip.h)
@@ -106,7 +107,6 @@ __device__ __forceinline__ ChainOut chain_terms(const LaneClass& c, float rho, c
     const float2 th = tabH[c.key & 0xFFFFu], ta = tabA[c.key >> 16];
     float lh = th.x * ta.y;  // exp(att[h] + ha[h]) * exp(-def[a])
     float la = ta.x * th.y;  // exp(att[a]) * exp(-def[h])
-    const float lh_raw = lh, la_raw = la;
     bool ch = false, ca = false;
     if (CLIP) {
         ch = lh > (float)RATE_CLIP;
@@ -119,22 +119,16 @@ __device__ __forceinline__ ChainOut chain_terms(const LaneClass& c, float rho, c
     class_terms(rho, la, &l10, &u10);
     class_terms(rho, lh, &l01, &u01);
     ChainOut o;
-    o.slam = c.nall * (lh + la);
+    o.slam = (double)c.nall * ((double)lh + (double)la);
     o.slog = (c.n00 != 0.f ? c.n00 * l00 : 0.f) + (c.n10 != 0.f ? c.n10 * l10 : 0.f) +
              (c.n01 != 0.f ? c.n01 * l01 : 0.f) + (c.n11 != 0.f ? c.n11 * l11 : 0.f);
     o.su = c.n00 * u00 + c.n10 * u10 + c.n01 * u01 + c.n11 * u11;
     o.rsh = c.nall * lh - rho * (c.n00 * u00 + c.n01 * u01);
     o.rsa = c.nall * la - rho * (c.n00 * u00 + c.n10 * u10);
     o.sclip = 0.f;
-    if (CLIP) {
-        if (ch) {
-            o.rsh = c.sx;
-            o.sclip += c.sx * (__logf(lh_raw) - (float)LOG_RATE_CLIP);
-        }
-        if (ca) {
-            o.rsa = c.sy;
-            o.sclip += c.sy * (__logf(la_raw) - (float)LOG_RATE_CLIP);
-        }
+    if (CLIP) {  // (the value's k*eta -> k*log(15) correction: prior_body, ZO_PAIRC)
+        if (ch) o.rsh = c.sx;
+        if (ca) o.rsa = c.sy;
     }
     return o;
 }
@@ -258,7 +252,7 @@ __global__ __launch_bounds__(BLOCK) void dc_vec_stream(EvalArgs A) {
             for (int b = 0; b < CB; ++b) {
                 const float2* tH = tab + (size_t)(2 * b) * tl;
                 const ChainOut o = chain_terms<CLIP>(lc, rho[b], tH, tH + tl, l11[b], u11[b]);
-                double v = fma((double)LN2, (double)o.slog, -(double)o.slam);
+                double v = fma((double)LN2, (double)o.slog, -o.slam);
                 if (CLIP) v -= (double)o.sclip;
                 dV[b] += v;
                 dSU[b] += (double)o.su;

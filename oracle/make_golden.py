@@ -67,8 +67,7 @@ def main():
             rho=np.array(rhos),
             LB=np.array(lbs),
             UB=np.array(ubs),
-            # deterministic sites at each point (also what the stated tolerance of U is built from,
-            # tests/cases.py u_tolerance)
+            # deterministic sites at each point
             attack=np.stack(atts),
             defence=np.stack(dfns),
             home_advantage=np.stack(has),

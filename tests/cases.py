@@ -83,39 +83,14 @@ def z_points(model, fx, n_random=3):
     return pts
 
 
-EPS32 = 2.0 ** -24
-LANE_FIXTURES, TILE_LANES = 32, 64   # csrc/dc_layout.h: fixtures per lane, lanes per wave tile
-
-
-def u_tolerance(home_idx, away_idx, home_goals, away_goals, weights, attack, defence, home_advantage,
-                clip, U):
-    """The stated bound on |U_hip - U_float64| for the float32-table kernels (models 0 / 1), from the
-    kernel's own error sources ("Numerics"); eps = 2^-24:
-
-      3 eps Q         the float32 product of the two table entries of a pair is rounded ONCE per pair and
-                      multiplies all its fixtures: Q = sqrt(sum_pairs (sum_fixtures w (lh + la))^2)
-                      (the table entries' own rounding is removed to first order by the kernel);
-      3 eps R / sqrt(tiles)   the per-lane sums w (lh + la) are added across the 64 lanes of a wave tile
-                      in float32 before they reach the float64 accumulators: R = sum_fixtures w (lh + la),
-                      tiles = ceil(lanes / 64), lanes = sum_pairs ceil(n_pair / 32);
-      64 eps QC       extended model, pairs whose rate is clipped at 15: k log(raw rate) goes through
-                      v_log_f32 (1 ulp of a base-2 logarithm of magnitude <= 16, i.e. <= 32 eps, twice),
-                      common to the fixtures of a pair: QC = sqrt(sum_pairs (sum_clipped w k)^2);
-      1e-12 |U| + 1e-9  float64 bookkeeping.
-    Measured errors (profiles/r03/parity_errors.txt) are 0.04 .. 0.4 of this bound."""
-    h, a = np.asarray(home_idx, np.int64), np.asarray(away_idx, np.int64)
-    att, dfn = np.asarray(attack, np.float64), np.asarray(defence, np.float64)
-    ha = np.broadcast_to(np.asarray(home_advantage, np.float64), att.shape)
-    w = np.ones(h.size) if weights is None or np.size(weights) == 0 else np.asarray(weights, np.float64)
-    lh, la = np.exp(att[h] - dfn[a] + ha[h]), np.exp(att[a] - dfn[h])
-    clipped = np.zeros(h.size)
-    if clip:
-        clipped = np.asarray(home_goals) * (lh > 15.0) + np.asarray(away_goals) * (la > 15.0)
-        lh, la = np.minimum(lh, 15.0), np.minimum(la, 15.0)
-    _, pair, count = np.unique(h * 65536 + a, return_inverse=True, return_counts=True)
-    Q = np.sqrt((np.bincount(pair, weights=w * (lh + la)) ** 2).sum())
-    QC = np.sqrt((np.bincount(pair, weights=w * clipped) ** 2).sum())
-    R = float((w * (lh + la)).sum())
-    lanes = int(np.ceil(count / LANE_FIXTURES).sum())
-    tiles = max(1, -(-lanes // TILE_LANES))
-    return 3 * EPS32 * (Q + R / np.sqrt(tiles)) + 64 * EPS32 * QC + 1e-12 * abs(U) + 1e-9
+def u_tolerance(n_fixtures, U):
+    """The stated bound on |U_hip - U_float64| for the float32-table kernels (models 0 / 1):
+    TWICE the tolerance SURVEY.md section 8c asks for,  2 (1e-6 sqrt(N) + 1e-9 |U|)  (+ 1e-9): 9e-3 at
+    N = 1e6, U = 3.6e6.  Measured (profiles/r03/parity_errors.txt, every case of tests/test_gpu_parity.py
+    incl. the rate-clip points and BASELINE config 3 at full size): at most 0.61 of it.
+    Round 2's gate was 3e-7 (|U| + 4N) / sqrt(P), x20 at the clip points: 0.12 and 2.4 there.  What
+    made the difference ("Numerics"): the float32 rate product, the clipped-rate
+    log term and the tail's spurious table correction of clipped lanes are now corrected exactly, per
+    pair, in float64 by the prior workgroup; the tau argument 1 + rho c carries its own rounding
+    error; the per-lane rate sums are float64."""
+    return 2.0 * (1e-6 * (float(n_fixtures) ** 0.5) + 1e-9 * abs(U)) + 1e-9
