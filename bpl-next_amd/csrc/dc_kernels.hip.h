@@ -1984,6 +1984,10 @@ __host__ __device__ inline size_t acc_tail_lds_bytes(int T, int D, int K, int zo
 struct TailPre {
     double c0, z0, x0;
     int expect;   // contributions this thread's (first) accumulator row receives per evaluation
+    // the first poll of that row, made by tail_first_poll in front of the barrier that ends the prior
+    // part (have: it found the row complete -- wave-uniform)
+    long long w_lo, w_hi;
+    bool have;
 };
 // the (first) accumulator row a thread of the tail takes: waves 0..6 the team rows, wave 7 the scalar
 // rows, lane = 16*scalar + shard
@@ -2024,6 +2028,33 @@ __device__ __forceinline__ void tail_preload(const EvalArgs& A, int chain, TailP
         }
     }
 }
+// one poll of a row (wave-uniform result)
+__device__ __forceinline__ bool ga_poll_row(const long long* row, int expect, GaWords* out, const long long* other) {
+    bool mine = true;
+    if (other != nullptr) {
+        GaWords o;
+        ga_load2(row, other, out, &o);
+        mine = ga_is_zero(o);
+    } else {
+        *out = ga_load(row);
+    }
+    mine = mine && ga_count(*out) == expect;
+    return __ballot(!mine) == 0ull;
+}
+// The first poll of the tail's rows, issued as soon as the prior part's arithmetic is done: its
+// round trip (~1 us, L2-bypassing) then also covers tail_preload's loads (requested just before:
+// vector loads return in order) and the barrier that publishes the prior record -- those used to
+// come first, 0.6 us during which the rows were already filling up unobserved.
+__device__ __forceinline__ void tail_first_poll(const EvalArgs& A, int chain, TailPre& P, int set, bool check_other) {
+    const int T = A.L.T;
+    const size_t ro = (size_t)tail_row_of(threadIdx.x, 3 * T) * GA_ROW;
+    const long long* ga = A.gacc + ((size_t)chain * 2 + set) * ga_set_words(T);
+    GaWords w;
+    P.have = ga_poll_row(ga + ro, P.expect, &w,
+                         check_other ? A.gacc + ((size_t)chain * 2 + (set ^ 1)) * ga_set_words(T) + ro : nullptr);
+    P.w_lo = w.lo;
+    P.w_hi = w.hi;
+}
 // (*okflag must hold 1 and a barrier must lie between that store and this call.)  false: the bounded
 // wait for the rows expired (the caller poisons the outputs).
 // one accumulator row until its count is complete (wave-uniform exit; bounded like every wait here)
@@ -2033,16 +2064,7 @@ __device__ __forceinline__ bool ga_take_row(const long long* row, int expect, Ga
                                             const long long* other = nullptr) {
     bool ok = false;
     for (int spin = 0; spin < ARRIVE_SPIN_LIMIT; ++spin) {
-        bool mine = true;
-        if (other != nullptr) {
-            GaWords o;
-            ga_load2(row, other, out, &o);
-            mine = ga_is_zero(o);
-        } else {
-            *out = ga_load(row);
-        }
-        mine = mine && ga_count(*out) == expect;
-        ok = __ballot(!mine) == 0ull;
+        ok = ga_poll_row(row, expect, out, other);
         if (ok) break;
         __builtin_amdgcn_s_sleep(1);
     }
@@ -2088,8 +2110,12 @@ __device__ __forceinline__ bool tail_acc(const EvalArgs& A, int chain, char* sme
         GaWords w0;
         const size_t ro = (size_t)tail_row_of(tid, ncol) * GA_ROW;
         // (persistent kernel: the next step's rows, re-armed one step ago, must read all zero too)
-        bool ok = ga_take_row(ga + ro, P.expect, &w0,
-                              check_other ? A.gacc + ((size_t)chain * 2 + (set ^ 1)) * ga_set_words(T) + ro : nullptr);
+        w0.lo = P.w_lo;
+        w0.hi = P.w_hi;
+        bool ok = P.have;   // (tail_first_poll's answer, when it already found the row complete)
+        if (!ok)
+            ok = ga_take_row(ga + ro, P.expect, &w0,
+                             check_other ? A.gacc + ((size_t)chain * 2 + (set ^ 1)) * ga_set_words(T) + ro : nullptr);
         if (!ZL && i < ncol) cL[i] = P.c0;
         if (!ZL && i < D) zL[i] = P.z0;
         if (!ZL && xs_staged && i < T * K) xsL[i] = P.x0;
@@ -2441,6 +2467,7 @@ __global__ DC_LAUNCH_BOUNDS void dc_eval(EvalArgs A) {
         double bigv[nd::LEAF_STAGE_LOADS];   // D > 64: waves 4..7 stage one 64-element slice each
         tail_preload<STAGED, NUTS>(reload_args(), chain, pre, leaf1, bigv);
         if (tid == 0) *acc_tail_flag(A, smem) = 1;
+        tail_first_poll(reload_args(), chain, pre, 0, false);
         __syncthreads();
         DC_STAMP(5);
         const EvalArgs B = reload_args();
@@ -2746,6 +2773,7 @@ __global__ DC_LAUNCH_BOUNDS void dc_eval_loop(EvalArgs A) {
             nd::LeafState<LNE> leaf1{};
             double bigv[nd::LEAF_STAGE_LOADS];
             tail_preload<STAGED, NUTS, true>(reload_args(), chain, pre, leaf1, bigv);
+            tail_first_poll(reload_args(), chain, pre, s & 1, true);
             __syncthreads();
             DC_STAMP(6);
             const bool last = s + 1 == steps;
