@@ -1984,10 +1984,6 @@ __host__ __device__ inline size_t acc_tail_lds_bytes(int T, int D, int K, int zo
 struct TailPre {
     double c0, z0, x0;
     int expect;   // contributions this thread's (first) accumulator row receives per evaluation
-    // the first poll of that row, made by tail_first_poll in front of the barrier that ends the prior
-    // part (have: it found the row complete -- wave-uniform)
-    long long w_lo, w_hi;
-    bool have;
 };
 // the (first) accumulator row a thread of the tail takes: waves 0..6 the team rows, wave 7 the scalar
 // rows, lane = 16*scalar + shard
@@ -2041,20 +2037,6 @@ __device__ __forceinline__ bool ga_poll_row(const long long* row, int expect, Ga
     mine = mine && ga_count(*out) == expect;
     return __ballot(!mine) == 0ull;
 }
-// The first poll of the tail's rows, issued as soon as the prior part's arithmetic is done: its
-// round trip (~1 us, L2-bypassing) then also covers tail_preload's loads (requested just before:
-// vector loads return in order) and the barrier that publishes the prior record -- those used to
-// come first, 0.6 us during which the rows were already filling up unobserved.
-__device__ __forceinline__ void tail_first_poll(const EvalArgs& A, int chain, TailPre& P, int set, bool check_other) {
-    const int T = A.L.T;
-    const size_t ro = (size_t)tail_row_of(threadIdx.x, 3 * T) * GA_ROW;
-    const long long* ga = A.gacc + ((size_t)chain * 2 + set) * ga_set_words(T);
-    GaWords w;
-    P.have = ga_poll_row(ga + ro, P.expect, &w,
-                         check_other ? A.gacc + ((size_t)chain * 2 + (set ^ 1)) * ga_set_words(T) + ro : nullptr);
-    P.w_lo = w.lo;
-    P.w_hi = w.hi;
-}
 // (*okflag must hold 1 and a barrier must lie between that store and this call.)  false: the bounded
 // wait for the rows expired (the caller poisons the outputs).
 // one accumulator row until its count is complete (wave-uniform exit; bounded like every wait here)
@@ -2074,7 +2056,12 @@ __device__ __forceinline__ bool ga_take_row(const long long* row, int expect, Ga
 // from waves that idle while one lane each of waves 0 and 1 finishes the prior record.  With one
 // dependent load per poll the first came back too early and the second too late (8.5 us per
 // leapfrog against 7.8); with four polls in flight the record's serial tail itself slowed down by
-// 1.2 us next to the polling waves (9.0).  The rows are polled when the prior part is done.)
+// 1.2 us next to the polling waves (9.0).  The rows are polled when the prior part is done.
+// A third variant -- ONE poll issued in front of the barrier that ends the prior part, so that its
+// round trip covers tail_preload's loads and that barrier -- looked 0.6 us better in the stamped
+// build and is 7 % slower in the shipped one (profiles/r03/ab_first_poll.txt, same box: 119.7k against
+// 128-130k leapfrogs/s; the plain launch 7.05 against 6.77 us): there it comes back just before the
+// last rows are complete, and the poll that follows starts a full round trip later than it would have.)
 // `set`: which of the chain's two row sets this evaluation used; CHECK_OTHER (persistent kernel): the
 // wait also covers the other set reading all zero (see ga_set_words)
 template <bool SMALLT, bool NUTS, bool EXT, bool ZL = false, int LNE>
@@ -2110,12 +2097,8 @@ __device__ __forceinline__ bool tail_acc(const EvalArgs& A, int chain, char* sme
         GaWords w0;
         const size_t ro = (size_t)tail_row_of(tid, ncol) * GA_ROW;
         // (persistent kernel: the next step's rows, re-armed one step ago, must read all zero too)
-        w0.lo = P.w_lo;
-        w0.hi = P.w_hi;
-        bool ok = P.have;   // (tail_first_poll's answer, when it already found the row complete)
-        if (!ok)
-            ok = ga_take_row(ga + ro, P.expect, &w0,
-                             check_other ? A.gacc + ((size_t)chain * 2 + (set ^ 1)) * ga_set_words(T) + ro : nullptr);
+        bool ok = ga_take_row(ga + ro, P.expect, &w0,
+                              check_other ? A.gacc + ((size_t)chain * 2 + (set ^ 1)) * ga_set_words(T) + ro : nullptr);
         if (!ZL && i < ncol) cL[i] = P.c0;
         if (!ZL && i < D) zL[i] = P.z0;
         if (!ZL && xs_staged && i < T * K) xsL[i] = P.x0;
@@ -2467,7 +2450,6 @@ __global__ DC_LAUNCH_BOUNDS void dc_eval(EvalArgs A) {
         double bigv[nd::LEAF_STAGE_LOADS];   // D > 64: waves 4..7 stage one 64-element slice each
         tail_preload<STAGED, NUTS>(reload_args(), chain, pre, leaf1, bigv);
         if (tid == 0) *acc_tail_flag(A, smem) = 1;
-        tail_first_poll(reload_args(), chain, pre, 0, false);
         __syncthreads();
         DC_STAMP(5);
         const EvalArgs B = reload_args();
@@ -2773,7 +2755,6 @@ __global__ DC_LAUNCH_BOUNDS void dc_eval_loop(EvalArgs A) {
             nd::LeafState<LNE> leaf1{};
             double bigv[nd::LEAF_STAGE_LOADS];
             tail_preload<STAGED, NUTS, true>(reload_args(), chain, pre, leaf1, bigv);
-            tail_first_poll(reload_args(), chain, pre, s & 1, true);
             __syncthreads();
             DC_STAMP(6);
             const bool last = s + 1 == steps;
