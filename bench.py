@@ -217,13 +217,15 @@ def main():
     # gcd(K, W, graph_len) evaluations would be launch bound for odd counts)
     glen = min(args.graph_len, 64)
 
+    replayers = {}
+
     def run(k):
         if glen > 0:
             q, r = divmod(k, glen)
             if q:
-                ctx.logp_grad_graph(glen, z, U, g, replays=q)
+                replayers[glen](q)
             if r:
-                ctx.logp_grad_graph(r, z, U, g, replays=1)
+                replayers[r](1)
         else:
             for i in range(k):
                 j = i % 64
@@ -235,29 +237,40 @@ def main():
         for k in (args.warmup, args.steps):
             for n in ((glen,) if k >= glen else ()) + ((k % glen,) if k % glen else ()):
                 ctx.logp_grad_graph(n, z, U, g, replays=1)
+                replayers[n] = ctx.graph_replayer(n, z, U, g)   # (arguments marshalled once)
         torch.cuda.synchronize()
 
-    run(args.warmup)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()
-    run(args.steps)
-    ev1.record()
-    # (the host spins on the end event instead of sleeping in the synchronize: a blocked thread's
-    # wake-up is 10-20 us, a tenth of the timed region at the driver's --steps 20; the synchronize
-    # that brackets the region then returns at once)
-    while not ev1.query():
-        pass
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    wall = time.perf_counter() - t0
-    ev_ms = ev0.elapsed_time(ev1)
+    def bracket(k):
+        """k evaluations between barrier + synchronize on both sides: (wall seconds, HIP-event ms)."""
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()   # (torch creates the HIP event at its first record: not inside the region)
+        ev1.record()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ev0.record()
+        run(k)
+        ev1.record()
+        # (the host spins on the end event instead of sleeping in the synchronize: a blocked thread's
+        # wake-up is 10-20 us, a tenth of the timed region at the driver's --steps 20; the synchronize
+        # that brackets the region then returns at once)
+        while not ev1.query():
+            pass
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+        return time.perf_counter() - t0, ev0.elapsed_time(ev1)
+
+    # the warm-up goes through the SAME bracket as the timed steps (the first query, the first
+    # synchronize after a record: one-off host costs that are not the path's).  At --steps 20 the
+    # region was 178 us for 134 us of kernels; rehearsed 168, with the events created and the
+    # arguments marshalled outside it 162 (what is left is hipGraphLaunch reaching an idle GPU)
+    if args.warmup:
+        bracket(args.warmup)
+    wall, ev_ms = bracket(args.steps)
     tmax = torch.tensor([wall], dtype=torch.float64, device=ctl_dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -348,10 +361,10 @@ def main():
                 "frac_traffic": (traffic / per_eval_us / 1e3 / HBM_PEAK_GBS) if traffic else None,
                 "duration_note": "HIP events around the replayed graph divided by its evaluations: kernel "
                                  "duration plus the dependent-launch gap; rocprofv3's per-kernel average "
-                                 "(profiles/r02/kernels.md) is the duration alone",
+                                 "(profiles/r03/kernels.md) is the duration alone",
                 "regime": "latency bound at this size (an empty kernel in the same graph is 2.06 us of the "
-                          "~6.8 us launch); the same kernel reaches 79% of peak at N=1e7 and ~197% "
-                          "(algorithmic) at N=1e8: profiles/r02/n_sweep.txt",
+                          "~6.7 us launch); the same kernel reaches ~80% of peak at N=1e7 and ~197% "
+                          "(algorithmic) at N=1e8: profiles/r03/n_sweep.txt",
             },
         }
         out.update(extra)

@@ -416,6 +416,21 @@ class HipContext:
             )
         )
 
+    def graph_replayer(self, count: int, z, potential, grad):
+        """`logp_grad_graph` with its arguments marshalled once: returns `replay(replays=1)` for the
+        current stream (the per-call Python cost -- stream lookup, three data_ptr(), argument
+        conversion -- is ~5 us, which a caller replaying short graphs back to back can skip)."""
+        fn, check = self._lib.bplhip_logp_grad_graph, self._check
+        args = (self._h, C.c_int32(count), C.c_int32(z.shape[0]), C.c_void_p(z.data_ptr()),
+                C.c_void_p(potential.data_ptr()), C.c_void_p(grad.data_ptr()))
+        stream = self._stream()
+        keep = (z, potential, grad)
+
+        def replay(replays: int = 1, _keep=keep):
+            check(fn(*args, replays, stream))
+
+        return replay
+
     # -- predict path on the device
     def predict_set_posterior(self, attack, defence, home_advantage, corr_coef):
         att = np.ascontiguousarray(attack, dtype=np.float64)
