@@ -719,7 +719,7 @@ static int consume_fault(bplhip_ctx* c, const char* where) {
                 where, f, (f & dc::FAULT_EVAL_ARRIVALS) ? " dc_eval arrivals" : "",
                 (f & dc::FAULT_LOOP_ARRIVALS) ? " dc_eval_loop arrivals" : "",
                 (f & dc::FAULT_LOOP_GRANULES) ? " dc_eval_loop granules" : "",
-                (f & dc::FAULT_DYN_BARRIER) ? " dyn_fused barrier" : "",
+                (f & dc::FAULT_DYN_BARRIER) ? " dyn_fused barrier" : (f & nd::FAULT_LEAF_BARRIER) ? " wide leaf row barrier" : "",
                 (f & dc::FAULT_DYN_BARRIER) ? ", the dynamic model uses its four-launch path from now on" : "");
 }
 
@@ -1807,11 +1807,12 @@ int run_chains_persistent(bplhip_ctx* c, hipStream_t s, const nuts::Config& nc, 
     for (const auto& w : sched) win_end.push_back(w.end);
     if (win_end.empty()) win_end.push_back(-1);
 
-    DevBuf d_ns, d_norm, d_par, d_win, d_draws, d_stats, d_desc, d_part, d_tick;
+    DevBuf d_ns, d_norm, d_par, d_win, d_draws, d_stats, d_desc, d_part, d_tick, d_rowpart;
     if (wide) {
         HIP_TRY(c, d_part.ensure((size_t)C * GW * nd::KW_PW * 8));
-        HIP_TRY(c, d_tick.ensure((size_t)C * 4));
-        HIP_TRY(c, hipMemsetAsync(d_tick.p, 0, (size_t)C * 4, s));
+        HIP_TRY(c, d_tick.ensure((size_t)C * nd::RT_WORDS * 4));   // per chain: ticket, row barrier, exit counter
+        HIP_TRY(c, hipMemsetAsync(d_tick.p, 0, (size_t)C * nd::RT_WORDS * 4, s));
+        HIP_TRY(c, d_rowpart.ensure((size_t)C * nd::row_part_doubles() * 8));
     }
     HIP_TRY(c, d_ns.ensure((size_t)C * stride * 8));
     HIP_TRY(c, hipMemsetAsync(d_ns.p, 0, (size_t)C * stride * 8, s));
@@ -1927,7 +1928,8 @@ int run_chains_persistent(bplhip_ctx* c, hipStream_t s, const nuts::Config& nc, 
     HIP_TRY(c, hipMemcpy2D(evals0.data(), 8, ns + nd::H_EVALS, stride * 8, 8, C, hipMemcpyDeviceToHost));
 
     // ---- run: first transitions, then blind chunks of evaluations
-    if (wide) hipLaunchKernelGGL(nd::kw_start, dim3(C), dim3(nd::KW_NTB), 0, s, ns, stride, P);
+    if (wide) hipLaunchKernelGGL(nd::kw_start, dim3(GWB, C), dim3(nd::KW_NTB), 0, s, ns, stride, P,
+                                 d_tick.as<unsigned int>(), d_rowpart.as<double>(), c->d_fault);
     else hipLaunchKernelGGL(nd::kp_start, dim3(C), dim3(64), 0, s, ns, stride, P);
     const nd::Persist* dP = d_desc.as<const nd::Persist>();
     std::vector<double> flags(C);
@@ -1966,7 +1968,8 @@ int run_chains_persistent(bplhip_ctx* c, hipStream_t s, const nuts::Config& nc, 
                     hipLaunchKernelGGL(nd::kw_leaf_a, dim3(GW, C), dim3(nd::KW_NT), 0, s, ns, stride, D, md,
                                        d_part.as<double>());
                     hipLaunchKernelGGL(nd::kw_leaf_b, dim3(GWB, C), dim3(nd::KW_NTB), 0, s, ns, stride, D, md,
-                                       d_part.as<const double>(), GW, d_tick.as<unsigned int>(), P, 1);
+                                       d_part.as<const double>(), GW, d_tick.as<unsigned int>(), P, 1,
+                                       d_rowpart.as<double>(), c->d_fault);
                 } else {
                     hipLaunchKernelGGL(nd::kp_leaf, dim3(C), dim3(64), (size_t)(D + 8) * 8, s, ns, stride, D,
                                        md, P);

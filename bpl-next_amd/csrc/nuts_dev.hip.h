@@ -144,13 +144,49 @@ __device__ __forceinline__ double team_sum(double v, int tid, double* scr) {
     return s;
 }
 // stores of the team visible to its later loads (header words written by thread 0, vectors)
+// (A workgroup team -- NT > 64 -- lives on ONE CU: its waves share the vector L1, so workgroup scope
+// is all this needs.  Agent scope here was an L2 write-back of every dirty line of the chain's state
+// and an invalidate that sent the next pass over the vectors back to memory -- with the dynamic
+// model's 35 502-entry vectors ~200 us per chain advance, profiles/r03/dynamic_advance.txt.)
 template <int NT>
 __device__ __forceinline__ void team_sync() {
+    if (NT > 64) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        return;
+    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     __builtin_amdgcn_s_waitcnt(0);
-    if (NT > 64) __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 }
+// ---- teams.  The tree bookkeeping is written once, for a TEAM of threads that work on one chain's
+// state; a team says which elements a thread owns (first(), stride()), who writes header words
+// (leader()), how scalars of the state are read and written (ld / st), how it adds (sum, sum2) and
+// how it synchronises (sync; readers_done in front of a rewrite of scalars every thread has read).
+//   LocalTeam<64>   one wave (the leaf's wave inside dc_eval, the 64-thread launches): no barriers
+//   LocalTeam<NT>   one workgroup
+//   GridTeam        (below, with the wide leaf) every workgroup of a launch's grid row
+template <int NT>
+struct LocalTeam {
+    static constexpr int UNROLL = NT > 64 ? 4 : 1;
+    int tid;
+    double* scr;
+    __device__ __forceinline__ int first() const { return tid; }
+    __device__ __forceinline__ int stride() const { return NT; }
+    __device__ __forceinline__ bool leader() const { return tid == 0; }
+    __device__ __forceinline__ double ld(const double* p) const { return *p; }
+    __device__ __forceinline__ void st(double* p, double v) const { *p = v; }
+    __device__ __forceinline__ double sum(double v) { return team_sum<NT>(v, tid, scr); }
+    __device__ __forceinline__ void sum2(double& a, double& b) {
+        a = team_sum<NT>(a, tid, scr);
+        b = team_sum<NT>(b, tid, scr);
+    }
+    __device__ __forceinline__ void sync() { team_sync<NT>(); }
+    __device__ __forceinline__ void readers_done() {
+        if (NT > 64) __syncthreads();
+    }
+};
 // numpyro _is_turning with a diagonal inverse mass matrix
 template <int NT = 64>
 __device__ inline bool is_turning(const double* invM, const double* r_left, const double* r_right,
@@ -579,9 +615,8 @@ __device__ inline bool leaf_moves_staged(double* ns, int D, int max_depth, int l
 // ---------------------------------------------------------------- small kernels (1 wave)
 
 // start of a transition: tree = the current state with momentum r (uploaded to V_TL_R)
-template <int NT = 64>
-__device__ inline void init_body(double* ns, int D, double eps, double max_de, int lane,
-                                 double* scr = nullptr) {
+template <class Team>
+__device__ inline void init_body_t(double* ns, int D, double eps, double max_de, Team& tm) {
     // one pass: every element is loaded once (four loads in flight) and fanned out -- a chain of
     // copy loops was one dependent memory round trip each on the chain's serial path
     const double* __restrict__ invM = vec(ns, D, V_INVM);
@@ -593,8 +628,8 @@ __device__ inline void init_body(double* ns, int D, double eps, double max_de, i
     double* __restrict__ tr_g = vec(ns, D, V_TR_G); double* __restrict__ tp_z = vec(ns, D, V_TP_Z);
     double* __restrict__ tp_g = vec(ns, D, V_TP_G); double* __restrict__ t_rs = vec(ns, D, V_T_RSUM);
     double kin = 0.0;
-#pragma clang loop unroll_count(NT > 64 ? 4 : 1)
-    for (int i = lane; i < D; i += NT) {
+#pragma clang loop unroll_count(Team::UNROLL)
+    for (int i = tm.first(); i < D; i += tm.stride()) {
         const double ri = r[i], zi = zc[i], gi = gc[i];
         kin += invM[i] * ri * ri;
         tl_z[i] = zi; tl_g[i] = gi;
@@ -602,60 +637,72 @@ __device__ inline void init_body(double* ns, int D, double eps, double max_de, i
         tp_z[i] = zi; tp_g[i] = gi;
         t_rs[i] = ri;
     }
-    kin = 0.5 * team_sum<NT>(kin, lane, scr);
-    if (lane == 0) {
-        const double e0 = ns[H_CUR_PE] + kin;
-        ns[H_EPS] = eps;
-        ns[H_MAXDE] = max_de;
-        ns[H_E0] = e0;
-        ns[H_T_DEPTH] = 0.0; ns[H_T_WEIGHT] = 0.0; ns[H_T_TURN] = 0.0; ns[H_T_DIV] = 0.0;
-        ns[H_T_SUMACC] = 0.0; ns[H_T_NUM] = 0.0; ns[H_T_PE] = ns[H_CUR_PE]; ns[H_T_EPROP] = e0;
-        ns[H_STOP] = 0.0;
-        ns[H_S_DONE] = 1.0; ns[H_S_ACTIVE] = 0.0;
+    kin = 0.5 * tm.sum(kin);
+    if (tm.leader()) {
+        const double cur_pe = tm.ld(&ns[H_CUR_PE]);
+        const double e0 = cur_pe + kin;
+        tm.st(&ns[H_EPS], eps);
+        tm.st(&ns[H_MAXDE], max_de);
+        tm.st(&ns[H_E0], e0);
+        tm.st(&ns[H_T_DEPTH], 0.0); tm.st(&ns[H_T_WEIGHT], 0.0); tm.st(&ns[H_T_TURN], 0.0); tm.st(&ns[H_T_DIV], 0.0);
+        tm.st(&ns[H_T_SUMACC], 0.0); tm.st(&ns[H_T_NUM], 0.0); tm.st(&ns[H_T_PE], cur_pe); tm.st(&ns[H_T_EPROP], e0);
+        tm.st(&ns[H_STOP], 0.0);
+        tm.st(&ns[H_S_DONE], 1.0); tm.st(&ns[H_S_ACTIVE], 0.0);
     }
+}
+template <int NT = 64>
+__device__ inline void init_body(double* ns, int D, double eps, double max_de, int lane,
+                                 double* scr = nullptr) {
+    LocalTeam<NT> tm{lane, scr};
+    init_body_t(ns, D, eps, max_de, tm);
 }
 
 // start of doubling `j`: runs only if the tree is still at depth j and not finished
-template <int NT = 64>
-__device__ inline void begin_body(double* ns, int D, int j, int going_right, uint32_t khi,
-                                  uint32_t klo, int lane) {
-    const bool active = ns[H_STOP] == 0.0 && (int)ns[H_T_DEPTH] == j;
+template <class Team>
+__device__ inline void begin_body_t(double* ns, int D, int j, int going_right, uint32_t khi,
+                                    uint32_t klo, Team& tm) {
+    const bool active = tm.ld(&ns[H_STOP]) == 0.0 && (int)tm.ld(&ns[H_T_DEPTH]) == j;
     if (!active) {
-        if (lane == 0) { ns[H_S_ACTIVE] = 0.0; ns[H_S_DONE] = 1.0; }
+        if (tm.leader()) { tm.st(&ns[H_S_ACTIVE], 0.0); tm.st(&ns[H_S_DONE], 1.0); }
         return;
     }
     const double dir = going_right ? 1.0 : -1.0;
-    const double eps = ns[H_EPS] * dir;
+    const double eps = tm.ld(&ns[H_EPS]) * dir;
     const double* __restrict__ invM = vec(ns, D, V_INVM);
     const double* __restrict__ ez = vec(ns, D, going_right ? V_TR_Z : V_TL_Z);
     const double* __restrict__ er = vec(ns, D, going_right ? V_TR_R : V_TL_R);
     const double* __restrict__ eg = vec(ns, D, going_right ? V_TR_G : V_TL_G);
     double* __restrict__ zn = vec(ns, D, V_ZN);
     double* __restrict__ rh = vec(ns, D, V_RH);
-#pragma clang loop unroll_count(NT > 64 ? 4 : 1)
-    for (int i = lane; i < D; i += NT) {
+#pragma clang loop unroll_count(Team::UNROLL)
+    for (int i = tm.first(); i < D; i += tm.stride()) {
         const double r = er[i] - 0.5 * eps * eg[i];
         rh[i] = r;
         zn[i] = ez[i] + eps * invM[i] * r;
     }
-    if (lane == 0) {
-        ns[H_DIR] = dir;
-        ns[H_S_MAX] = (double)(1 << j);
-        ns[H_S_NUM] = 0.0; ns[H_S_WEIGHT] = 0.0; ns[H_S_TURN] = 0.0; ns[H_S_DIV] = 0.0;
-        ns[H_S_SUMACC] = 0.0;
-        ns[H_S_DONE] = 0.0; ns[H_S_ACTIVE] = 1.0;
-        ns[H_KEY_HI] = (double)khi; ns[H_KEY_LO] = (double)klo;
+    if (tm.leader()) {
+        tm.st(&ns[H_DIR], dir);
+        tm.st(&ns[H_S_MAX], (double)(1 << j));
+        tm.st(&ns[H_S_NUM], 0.0); tm.st(&ns[H_S_WEIGHT], 0.0); tm.st(&ns[H_S_TURN], 0.0); tm.st(&ns[H_S_DIV], 0.0);
+        tm.st(&ns[H_S_SUMACC], 0.0);
+        tm.st(&ns[H_S_DONE], 0.0); tm.st(&ns[H_S_ACTIVE], 1.0);
+        tm.st(&ns[H_KEY_HI], (double)khi); tm.st(&ns[H_KEY_LO], (double)klo);
     }
+}
+template <int NT = 64>
+__device__ inline void begin_body(double* ns, int D, int j, int going_right, uint32_t khi,
+                                  uint32_t klo, int lane) {
+    LocalTeam<NT> tm{lane, nullptr};
+    begin_body_t(ns, D, j, going_right, khi, klo, tm);
 }
 
 // end of a doubling: _combine_tree(tree, subtree, biased_transition=True)
-template <int NT = 64>
-__device__ inline void end_body(double* ns, int D, int max_depth, uint32_t thi, uint32_t tlo,
-                                int lane, double* scr = nullptr) {
-    if (ns[H_S_ACTIVE] == 0.0) return;
-    const bool going_right = ns[H_DIR] > 0.0;
-    const bool s_turn = ns[H_S_TURN] != 0.0, s_div = ns[H_S_DIV] != 0.0;
-    const double w_cur = ns[H_T_WEIGHT], w_new = ns[H_S_WEIGHT];
+template <class Team>
+__device__ inline void end_body_t(double* ns, int D, int max_depth, uint32_t thi, uint32_t tlo, Team& tm) {
+    if (tm.ld(&ns[H_S_ACTIVE]) == 0.0) return;
+    const bool going_right = tm.ld(&ns[H_DIR]) > 0.0;
+    const bool s_turn = tm.ld(&ns[H_S_TURN]) != 0.0, s_div = tm.ld(&ns[H_S_DIV]) != 0.0;
+    const double w_cur = tm.ld(&ns[H_T_WEIGHT]), w_new = tm.ld(&ns[H_S_WEIGHT]);
     double prob = exp(w_new - w_cur);
     if (s_turn || s_div) prob = 0.0;
     prob = fmin(prob, 1.0);
@@ -679,8 +726,8 @@ __device__ inline void end_body(double* ns, int D, int max_depth, uint32_t thi, 
     double* __restrict__ tp_z = vec(ns, D, V_TP_Z);
     double* __restrict__ tp_g = vec(ns, D, V_TP_G);
     double dl = 0.0, dr = 0.0;
-#pragma clang loop unroll_count(NT > 64 ? 4 : 1)
-    for (int i = lane; i < D; i += NT) {
+#pragma clang loop unroll_count(Team::UNROLL)
+    for (int i = tm.first(); i < D; i += tm.stride()) {
         const double ez = se_z[i], er = se_r[i], eg = se_g[i], orr = other_r[i];
         const double rsum = t_rsum[i] + s_rsum[i], im = invM[i];
         const double pz = sp_z[i], pg = sp_g[i];
@@ -692,43 +739,53 @@ __device__ inline void end_body(double* ns, int D, int max_depth, uint32_t thi, 
         dl += im * r_left * rs;
         dr += im * r_right * rs;
     }
-    dl = team_sum<NT>(dl, lane, scr);
-    dr = team_sum<NT>(dr, lane, scr);
+    tm.sum2(dl, dr);
     const bool turning = s_turn | ((dl <= 0.0) | (dr <= 0.0));
-    if (lane == 0) {
+    if (tm.leader()) {
         if (take) {
-            ns[H_T_PE] = ns[H_S_PE];
-            ns[H_T_EPROP] = ns[H_S_EPROP];
-            ns[H_T_AUX0] = ns[H_S_AUX0]; ns[H_T_AUX1] = ns[H_S_AUX1];
-            ns[H_T_AUX2] = ns[H_S_AUX2]; ns[H_T_AUX3] = ns[H_S_AUX3];
+            tm.st(&ns[H_T_PE], tm.ld(&ns[H_S_PE]));
+            tm.st(&ns[H_T_EPROP], tm.ld(&ns[H_S_EPROP]));
+            tm.st(&ns[H_T_AUX0], tm.ld(&ns[H_S_AUX0])); tm.st(&ns[H_T_AUX1], tm.ld(&ns[H_S_AUX1]));
+            tm.st(&ns[H_T_AUX2], tm.ld(&ns[H_S_AUX2])); tm.st(&ns[H_T_AUX3], tm.ld(&ns[H_S_AUX3]));
         }
-        const double depth = ns[H_T_DEPTH] + 1.0;
-        ns[H_T_DEPTH] = depth;
-        ns[H_T_WEIGHT] = logaddexp(w_cur, w_new);
-        ns[H_T_TURN] = turning ? 1.0 : 0.0;
-        ns[H_T_DIV] = s_div ? 1.0 : 0.0;
-        ns[H_T_SUMACC] += ns[H_S_SUMACC];
-        ns[H_T_NUM] += ns[H_S_NUM];
-        ns[H_STOP] = (turning || s_div || (int)depth >= max_depth) ? 1.0 : 0.0;
-        ns[H_S_ACTIVE] = 0.0;
-        ns[H_S_DONE] = 1.0;
+        const double depth = tm.ld(&ns[H_T_DEPTH]) + 1.0;
+        tm.st(&ns[H_T_DEPTH], depth);
+        tm.st(&ns[H_T_WEIGHT], logaddexp(w_cur, w_new));
+        tm.st(&ns[H_T_TURN], turning ? 1.0 : 0.0);
+        tm.st(&ns[H_T_DIV], s_div ? 1.0 : 0.0);
+        tm.st(&ns[H_T_SUMACC], tm.ld(&ns[H_T_SUMACC]) + tm.ld(&ns[H_S_SUMACC]));
+        tm.st(&ns[H_T_NUM], tm.ld(&ns[H_T_NUM]) + tm.ld(&ns[H_S_NUM]));
+        tm.st(&ns[H_STOP], (turning || s_div || (int)depth >= max_depth) ? 1.0 : 0.0);
+        tm.st(&ns[H_S_ACTIVE], 0.0);
+        tm.st(&ns[H_S_DONE], 1.0);
     }
+}
+template <int NT = 64>
+__device__ inline void end_body(double* ns, int D, int max_depth, uint32_t thi, uint32_t tlo,
+                                int lane, double* scr = nullptr) {
+    LocalTeam<NT> tm{lane, scr};
+    end_body_t(ns, D, max_depth, thi, tlo, tm);
 }
 
 // end of the transition: the proposal becomes the current state
-template <int NT = 64>
-__device__ inline void finish_body(double* ns, int D, int lane) {
+template <class Team>
+__device__ inline void finish_body_t(double* ns, int D, Team& tm) {
     const double* __restrict__ tp_z = vec(ns, D, V_TP_Z);
     const double* __restrict__ tp_g = vec(ns, D, V_TP_G);
     double* __restrict__ zc = vec(ns, D, V_Z);
     double* __restrict__ gc = vec(ns, D, V_G);
-#pragma clang loop unroll_count(NT > 64 ? 4 : 1)
-    for (int i = lane; i < D; i += NT) {
+#pragma clang loop unroll_count(Team::UNROLL)
+    for (int i = tm.first(); i < D; i += tm.stride()) {
         const double a = tp_z[i], b = tp_g[i];
         zc[i] = a;
         gc[i] = b;
     }
-    if (lane == 0) ns[H_CUR_PE] = ns[H_T_PE];
+    if (tm.leader()) tm.st(&ns[H_CUR_PE], tm.ld(&ns[H_T_PE]));
+}
+template <int NT = 64>
+__device__ inline void finish_body(double* ns, int D, int lane) {
+    LocalTeam<NT> tm{lane, nullptr};
+    finish_body_t(ns, D, tm);
 }
 
 // ---- one chain
@@ -804,78 +861,85 @@ __device__ __forceinline__ void wave_mem_sync() {  // stores of this wave visibl
 }
 
 // momentum of iteration `it` (r = mass_sqrt * unit normal), tree := current state, doubling 0
-template <int NT = 64>
-__device__ inline void persist_start_transition(double* ns, const Persist& P, int chain, int it,
-                                                int lane, double* scr = nullptr) {
+template <class Team>
+__device__ inline void persist_start_transition_t(double* ns, const Persist& P, int chain, int it, Team& tm) {
     const int D = P.D;
     double* pd = ns + P.pd_off;
     const double* msq = pd + P_N + 2 * (size_t)D;
     const double* nrm = P.normals + ((size_t)chain * P.n_iter + it) * D;
     double* __restrict__ r = vec(ns, D, V_TL_R);
-#pragma clang loop unroll_count(NT > 64 ? 4 : 1)
-    for (int i = lane; i < D; i += NT) r[i] = msq[i] * nrm[i];
-    team_sync<NT>();
-    init_body<NT>(ns, D, pd[P_STEP], pd[P_MAXDE], lane, scr);
-    team_sync<NT>();
+#pragma clang loop unroll_count(Team::UNROLL)
+    for (int i = tm.first(); i < D; i += tm.stride()) r[i] = msq[i] * nrm[i];
+    const double step = tm.ld(&pd[P_STEP]), max_de = tm.ld(&pd[P_MAXDE]);
+    tm.sync();
+    init_body_t(ns, D, step, max_de, tm);
+    tm.sync();
     const double* q = P.par + ((size_t)chain * P.n_iter + it) * P.max_depth * 5;
-    begin_body<NT>(ns, D, 0, q[0] != 0.0, (uint32_t)q[1], (uint32_t)q[2], lane);
+    begin_body_t(ns, D, 0, q[0] != 0.0, (uint32_t)q[1], (uint32_t)q[2], tm);
+}
+template <int NT = 64>
+__device__ inline void persist_start_transition(double* ns, const Persist& P, int chain, int it,
+                                                int lane, double* scr = nullptr) {
+    LocalTeam<NT> tm{lane, scr};
+    persist_start_transition_t(ns, P, chain, it, tm);
 }
 
-// called by the leaf's wave when the subtree of the current doubling is complete
-template <int NT = 64>
-__device__ inline void persist_advance(double* ns, const Persist& P, int chain, int lane,
-                                       double* scr = nullptr) {
+// called by the team that booked the last leaf when the subtree of the current doubling is complete
+template <class Team>
+__device__ inline void persist_advance_t(double* ns, const Persist& P, int chain, Team& tm) {
     const int D = P.D, md = P.max_depth;
     double* pd = ns + P.pd_off;
-    team_sync<NT>();
-    if (pd[P_ALLDONE] != 0.0) return;
-    const int it = (int)pd[P_ITER];
+    tm.sync();
+    if (tm.ld(&pd[P_ALLDONE]) != 0.0) return;
+    const int it = (int)tm.ld(&pd[P_ITER]);
     {   // end of the doubling: _combine_tree(tree, subtree, biased_transition=True)
-        const int j = (int)ns[H_T_DEPTH];
+        const int j = (int)tm.ld(&ns[H_T_DEPTH]);
         const double* q = P.par + (((size_t)chain * P.n_iter + it) * md + j) * 5;
-        end_body<NT>(ns, D, md, (uint32_t)q[3], (uint32_t)q[4], lane, scr);
-        team_sync<NT>();
+        end_body_t(ns, D, md, (uint32_t)q[3], (uint32_t)q[4], tm);
+        tm.sync();
     }
-    if (ns[H_STOP] == 0.0) {  // next doubling of the same transition
-        const int j = (int)ns[H_T_DEPTH];
+    if (tm.ld(&ns[H_STOP]) == 0.0) {  // next doubling of the same transition
+        const int j = (int)tm.ld(&ns[H_T_DEPTH]);
         const double* q = P.par + (((size_t)chain * P.n_iter + it) * md + j) * 5;
-        begin_body<NT>(ns, D, j, q[0] != 0.0, (uint32_t)q[1], (uint32_t)q[2], lane);
+        begin_body_t(ns, D, j, q[0] != 0.0, (uint32_t)q[1], (uint32_t)q[2], tm);
         return;
     }
     // ---- the transition is complete: proposal -> state, statistics, adaptation, next one
-    const double num = ns[H_T_NUM];
-    const double accept_prob = num > 0 ? ns[H_T_SUMACC] / num : 0.0;
-    const bool diverging = ns[H_T_DIV] != 0.0;
-    const double used_step = ns[H_EPS], t_pe = ns[H_T_PE], t_aux0 = ns[H_T_AUX0];
-    finish_body<NT>(ns, D, lane);
-    team_sync<NT>();
+    const double num = tm.ld(&ns[H_T_NUM]);
+    const double accept_prob = num > 0 ? tm.ld(&ns[H_T_SUMACC]) / num : 0.0;
+    const bool diverging = tm.ld(&ns[H_T_DIV]) != 0.0;
+    const double used_step = tm.ld(&ns[H_EPS]), t_pe = tm.ld(&ns[H_T_PE]), t_aux0 = tm.ld(&ns[H_T_AUX0]);
+    finish_body_t(ns, D, tm);
+    tm.sync();
     const double* zc = vec(ns, D, V_Z);
     double* w_mean = pd + P_N;
     double* w_m2 = w_mean + D;
     double* msq = w_m2 + D;
     double* invM = vec(ns, D, V_INVM);
-    const int warm = (int)pd[P_WARM], total = (int)pd[P_TOTAL];
-    double step = pd[P_STEP];
+    const int warm = (int)tm.ld(&pd[P_WARM]), total = (int)tm.ld(&pd[P_TOTAL]);
+    double step = tm.ld(&pd[P_STEP]);
     if (it < warm) {  // numpyro warmup_adapter.update_fn
-        const bool adapt_ss = pd[P_ADAPT_SS] != 0.0, adapt_mm = pd[P_ADAPT_MM] != 0.0;
-        double da_t = pd[P_DA_T], x_t = pd[P_DA_XT], x_avg = pd[P_DA_XAVG], g_avg = pd[P_DA_GAVG];
+        const bool adapt_ss = tm.ld(&pd[P_ADAPT_SS]) != 0.0, adapt_mm = tm.ld(&pd[P_ADAPT_MM]) != 0.0;
+        double da_t = tm.ld(&pd[P_DA_T]), x_t = tm.ld(&pd[P_DA_XT]), x_avg = tm.ld(&pd[P_DA_XAVG]),
+               g_avg = tm.ld(&pd[P_DA_GAVG]);
+        double prox = tm.ld(&pd[P_DA_PROX]);
         if (adapt_ss) {  // dual_averaging(t0 = 10, kappa = 0.75, gamma = 0.05)
-            const double g = pd[P_TARGET] - accept_prob;
+            const double g = tm.ld(&pd[P_TARGET]) - accept_prob;
             da_t += 1.0;
             g_avg = (1.0 - 1.0 / (da_t + 10.0)) * g_avg + g / (da_t + 10.0);
-            x_t = pd[P_DA_PROX] - sqrt(da_t) / 0.05 * g_avg;
+            x_t = prox - sqrt(da_t) / 0.05 * g_avg;
             const double weight_t = pow(da_t, -0.75);
             x_avg = (1.0 - weight_t) * x_avg + weight_t * x_t;
             const double sx = it == warm - 1 ? exp(x_avg) : exp(x_t);
             step = sx < 1.1754943508222875e-38 ? 1.1754943508222875e-38 : sx;
         }
-        int win = (int)pd[P_WIN];
-        const int nwin = (int)pd[P_NWIN];
+        int win = (int)tm.ld(&pd[P_WIN]);
+        const int nwin = (int)tm.ld(&pd[P_NWIN]);
         const bool is_middle = 0 < win && win < nwin - 1;
-        double w_n = pd[P_W_N];
+        double w_n = tm.ld(&pd[P_W_N]);
         if (adapt_mm && is_middle) {  // welford_covariance(diagonal=True)
             w_n += 1.0;
-            for (int i = lane; i < D; i += NT) {
+            for (int i = tm.first(); i < D; i += tm.stride()) {
                 const double d_pre = zc[i] - w_mean[i];
                 const double mnew = w_mean[i] + d_pre / w_n;
                 w_mean[i] = mnew;
@@ -884,10 +948,9 @@ __device__ inline void persist_advance(double* ns, const Persist& P, int chain, 
         }
         const bool at_end = it == P.win_end[win];
         if (at_end) win += 1;
-        double prox = pd[P_DA_PROX];
         if (at_end && is_middle) {
             if (adapt_mm) {
-                for (int i = lane; i < D; i += NT) {
+                for (int i = tm.first(); i < D; i += tm.stride()) {
                     double c = w_m2[i] / (w_n - 1.0);
                     c = (w_n / (w_n + 5.0)) * c + 1e-3 * (5.0 / (w_n + 5.0));
                     invM[i] = c;
@@ -902,41 +965,49 @@ __device__ inline void persist_advance(double* ns, const Persist& P, int chain, 
                 prox = log(10.0 * step);
             }
         }
-        if (NT > 64) __syncthreads();  // every thread has read the scalars rewritten below
-        if (lane == 0) {
-            pd[P_DA_T] = da_t; pd[P_DA_XT] = x_t; pd[P_DA_XAVG] = x_avg; pd[P_DA_GAVG] = g_avg;
-            pd[P_DA_PROX] = prox; pd[P_WIN] = (double)win; pd[P_W_N] = w_n; pd[P_STEP] = step;
+        tm.readers_done();  // every thread has read the scalars rewritten below
+        if (tm.leader()) {
+            tm.st(&pd[P_DA_T], da_t); tm.st(&pd[P_DA_XT], x_t); tm.st(&pd[P_DA_XAVG], x_avg); tm.st(&pd[P_DA_GAVG], g_avg);
+            tm.st(&pd[P_DA_PROX], prox); tm.st(&pd[P_WIN], (double)win); tm.st(&pd[P_W_N], w_n); tm.st(&pd[P_STEP], step);
         }
     } else {
         const int n = it - warm + 1;
-        const int thin = (int)pd[P_THIN], start_idx = (int)pd[P_START_IDX];
+        const int thin = (int)tm.ld(&pd[P_THIN]), start_idx = (int)tm.ld(&pd[P_START_IDX]);
         if (it >= start_idx && (it - start_idx) % thin == thin - 1) {
             const int idx = (it - start_idx) / thin;
-            double* dr = P.draws + ((size_t)chain * P.kept + idx) * D;
-            vcopy<NT>(dr, zc, D, lane);
-            if (lane == 0) {
+            double* __restrict__ dr = P.draws + ((size_t)chain * P.kept + idx) * D;
+#pragma clang loop unroll_count(Team::UNROLL)
+            for (int i = tm.first(); i < D; i += tm.stride()) dr[i] = zc[i];
+            if (tm.leader()) {
                 double* st = P.stats + ((size_t)chain * P.kept + idx) * 6;
                 st[0] = t_pe; st[1] = accept_prob; st[2] = used_step; st[3] = num;
                 st[4] = diverging ? 1.0 : 0.0; st[5] = t_aux0;
             }
         }
-        if (lane == 0) {
-            pd[P_MEAN_ACC] += (accept_prob - pd[P_MEAN_ACC]) / n;
-            if (diverging) pd[P_NDIV] += 1.0;
+        if (tm.leader()) {
+            const double ma = tm.ld(&pd[P_MEAN_ACC]);
+            tm.st(&pd[P_MEAN_ACC], ma + (accept_prob - ma) / n);
+            if (diverging) tm.st(&pd[P_NDIV], tm.ld(&pd[P_NDIV]) + 1.0);
         }
     }
     if (it + 1 >= total) {  // chain finished: every later launch is a no-op for it
-        if (lane == 0) {
-            pd[P_ITER] = (double)(it + 1);
-            pd[P_ALLDONE] = 1.0;
-            ns[H_S_DONE] = 1.0;
-            ns[H_S_ACTIVE] = 0.0;
+        if (tm.leader()) {
+            tm.st(&pd[P_ITER], (double)(it + 1));
+            tm.st(&pd[P_ALLDONE], 1.0);
+            tm.st(&ns[H_S_DONE], 1.0);
+            tm.st(&ns[H_S_ACTIVE], 0.0);
         }
         return;
     }
-    if (lane == 0) pd[P_ITER] = (double)(it + 1);
-    team_sync<NT>();
-    persist_start_transition<NT>(ns, P, chain, it + 1, lane, scr);
+    if (tm.leader()) tm.st(&pd[P_ITER], (double)(it + 1));
+    tm.sync();
+    persist_start_transition_t(ns, P, chain, it + 1, tm);
+}
+template <int NT = 64>
+__device__ inline void persist_advance(double* ns, const Persist& P, int chain, int lane,
+                                       double* scr = nullptr) {
+    LocalTeam<NT> tm{lane, scr};
+    persist_advance_t(ns, P, chain, tm);
 }
 
 // Leaf bookkeeping as its own launch, for models whose evaluation is not dc_eval (the float64
@@ -1006,6 +1077,112 @@ __device__ __forceinline__ WideLeaf wide_leaf(double hv) {
     W.n_lev = W.idx_max >= W.idx_min ? W.idx_max - W.idx_min + 1 : 0;
     return W;
 }
+// ---- the grid row of a wide launch as ONE team (see LocalTeam): the chain ADVANCE -- end of a
+// doubling, end of a transition, adaptation, the next transition's start -- is a handful of passes over
+// a dozen D-vectors, and on one workgroup that is one CU's load/store path: ~100 GB/s, 200 us per advance
+// with the dynamic model's 35 502 entries (profiles/r03/dynamic_advance.txt), five times the leapfrog it
+// follows.  Here every workgroup of kw_leaf_b's grid takes part:
+//   vectors   thread t of the row owns elements t, t + row size, ... in EVERY pass, the same split as the
+//             leaf's slice loop -- no element is ever read by a thread that did not write it, so the
+//             vectors need no cross-workgroup visibility at all inside the launch
+//   scalars   (header, adaptation block) are written by the row's leader with write-through stores and
+//             read by everybody with L2-bypassing loads, a row barrier in between
+//   sums      per-workgroup partials (write-through), a row barrier, then every wave adds the partials
+//             in the same fixed order: identical totals, identical decisions everywhere
+//   barrier   one agent-scope counter per chain, monotonic within the launch (barrier k is complete at
+//             k x workgroups), polled by one lane, bounded; the last workgroup to leave the launch
+//             (exit counter) zeroes both for the next one.
+// The number of barriers a launch takes depends on the chain's state only, which every workgroup reads
+// identically -- all workgroups walk the same sequence.
+constexpr unsigned int FAULT_LEAF_BARRIER = 16u;   // (dc::Fault's next bit: a row barrier of the wide leaf timed out)
+constexpr unsigned int ROW_SPIN_LIMIT = 1u << 22;
+enum { RT_TICKET = 0, RT_BAR, RT_EXIT, RT_WORDS = 4 };   // per chain: words of the wide leaf's counters
+__device__ __forceinline__ double nd_ld_sc1(const double* p) {
+    return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(p),
+                                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ void nd_st_sc1(double* p, double v) {
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+struct GridTeam {
+    static constexpr int NT = KW_NTB;
+    static constexpr int UNROLL = 2;
+    int tid, wg, nwg;
+    double* scr;            // LDS [2 * NT / 64]
+    int* s_ok;              // LDS
+    double* part;           // this chain's partials [2][KW_MAX_WG][2]
+    unsigned int* ctr;      // this chain's counters (RT_*)
+    unsigned int* fault;
+    unsigned int arrived;   // arrivals that completed the last barrier
+    int slot;
+    bool dead;              // a bounded wait expired (the launch runs to its end, the host is told)
+    __device__ __forceinline__ int first() const { return wg * NT + tid; }
+    __device__ __forceinline__ int stride() const { return nwg * NT; }
+    __device__ __forceinline__ bool leader() const { return wg == 0 && tid == 0; }
+    __device__ __forceinline__ double ld(const double* p) const { return nd_ld_sc1(p); }
+    __device__ __forceinline__ void st(double* p, double v) const { nd_st_sc1(p, v); }
+    __device__ __forceinline__ void barrier() {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this thread's write-through stores have landed
+        __syncthreads();
+        arrived += (unsigned int)nwg;
+        if (tid == 0) {
+            (void)__hip_atomic_fetch_add(ctr + RT_BAR, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            bool ok = !dead;
+            unsigned int spins = 0;
+            while (ok && __hip_atomic_load(ctr + RT_BAR, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < arrived) {
+                if (++spins >= ROW_SPIN_LIMIT) ok = false;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            *s_ok = ok;
+        }
+        __syncthreads();
+        if (*s_ok == 0) dead = true;
+    }
+    __device__ __forceinline__ void sync() { barrier(); }
+    __device__ __forceinline__ void readers_done() { barrier(); }
+    __device__ __forceinline__ void sum2(double& a, double& b) {
+        a = nd_wave_sum(a);
+        b = nd_wave_sum(b);
+        __syncthreads();   // (scr may still be read from the previous sum)
+        if ((tid & 63) == 0) { scr[2 * (tid >> 6)] = a; scr[2 * (tid >> 6) + 1] = b; }
+        __syncthreads();
+        double* mine = part + ((size_t)slot * KW_MAX_WG + wg) * 2;
+        if (tid == 0) {
+            double sa = 0.0, sb = 0.0;
+#pragma unroll
+            for (int w = 0; w < NT / 64; ++w) { sa += scr[2 * w]; sb += scr[2 * w + 1]; }
+            nd_st_sc1(mine, sa);
+            nd_st_sc1(mine + 1, sb);
+        }
+        barrier();
+        const int l = tid & 63;
+        const double* theirs = part + ((size_t)slot * KW_MAX_WG + (l < nwg ? l : 0)) * 2;
+        const double va = nd_ld_sc1(theirs), vb = nd_ld_sc1(theirs + 1);
+        a = nd_wave_sum(l < nwg ? va : 0.0);
+        b = nd_wave_sum(l < nwg ? vb : 0.0);
+        slot ^= 1;   // (the next sum's partials must not land on words a slow workgroup still reads)
+    }
+    __device__ __forceinline__ double sum(double v) {
+        double z = 0.0;
+        sum2(v, z);
+        return v;
+    }
+    // the launch is over for this workgroup: the last one to leave zeroes the counters
+    __device__ __forceinline__ void leave() {
+        __syncthreads();
+        if (tid == 0) {
+            if (dead && fault) (void)__hip_atomic_fetch_or(fault, FAULT_LEAF_BARRIER, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            const unsigned int k = __hip_atomic_fetch_add(ctr + RT_EXIT, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (k == (unsigned int)nwg - 1u) {
+                __hip_atomic_store(ctr + RT_BAR, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(ctr + RT_EXIT, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+};
+__host__ __device__ inline size_t row_part_doubles() { return 2 * (size_t)KW_MAX_WG * 2; }
+
 __global__ __launch_bounds__(KW_NT) void kw_leaf_a(double* ns_all, size_t stride, int D, int max_depth,
                                                    double* part) {
     __shared__ double scr[KW_NT / 64];
@@ -1052,8 +1229,9 @@ __global__ __launch_bounds__(KW_NT) void kw_leaf_a(double* ns_all, size_t stride
 }
 __global__ __launch_bounds__(KW_NTB) void kw_leaf_b(double* ns_all, size_t stride, int D, int max_depth,
                                                     const double* part, int gw_a,
-                                                    unsigned int* tickets, Persist P, int persist) {
-    __shared__ double scr[KW_NTB / 64];
+                                                    unsigned int* tickets, Persist P, int persist,
+                                                    double* row_part, unsigned int* fault) {
+    __shared__ double scr[2 * KW_NTB / 64];
     __shared__ double tot[KW_PW];
     __shared__ int s_last;
     const int chain = blockIdx.y;
@@ -1140,40 +1318,62 @@ __global__ __launch_bounds__(KW_NTB) void kw_leaf_b(double* ns_all, size_t strid
             ck_s[(size_t)W.idx_max * D + i] = rs;
         }
     }
-    // ---- the last workgroup of the chain writes the header (every other one has read it --
-    // the ticket alone orders that).  Only when the subtree is complete does it go on to read
-    // the other workgroups' slices: release them first (an agent-scope fence writes the L2
-    // back, ~10 us with these vectors: not on the common path).
+    // ---- the header: every workgroup has read it into registers by now, ONE rewrites it.
     const bool advance = persist && done;
-    if (advance) __threadfence();
-    __syncthreads();
-    if (tid == 0) s_last = atomicAdd(&tickets[chain], 1u) == (unsigned)(GW - 1);
-    __syncthreads();
-    if (!s_last) return;
-    if (advance) __threadfence();
-    if (tid == 0) {
-        tickets[chain] = 0u;
-        ns[H_S_NUM] = (double)new_num;
-        ns[H_S_DIV] = div_leaf ? 1.0 : 0.0;
-        ns[H_S_TURN] = turning ? 1.0 : 0.0;
-        ns[H_S_DONE] = done ? 1.0 : 0.0;
-        ns[H_EVALS] = evals + 1.0;
-        ns[H_S_WEIGHT] = LW.w_sub;
-        ns[H_S_SUMACC] = LW.sum_acc;
-        ns[H_KEY_HI] = (double)nhi;
-        ns[H_KEY_LO] = (double)nlo;
+    auto write_header = [&](auto put) {
+        put(&ns[H_S_NUM], (double)new_num);
+        put(&ns[H_S_DIV], div_leaf ? 1.0 : 0.0);
+        put(&ns[H_S_TURN], turning ? 1.0 : 0.0);
+        put(&ns[H_S_DONE], done ? 1.0 : 0.0);
+        put(&ns[H_EVALS], evals + 1.0);
+        put(&ns[H_S_WEIGHT], LW.w_sub);
+        put(&ns[H_S_SUMACC], LW.sum_acc);
+        put(&ns[H_KEY_HI], (double)nhi);
+        put(&ns[H_KEY_LO], (double)nlo);
         if (LW.take) {
-            ns[H_S_PE] = pe;
-            ns[H_S_EPROP] = e_new;
-            ns[H_S_AUX0] = aux0; ns[H_S_AUX1] = aux1; ns[H_S_AUX2] = aux2; ns[H_S_AUX3] = aux3;
+            put(&ns[H_S_PE], pe);
+            put(&ns[H_S_EPROP], e_new);
+            put(&ns[H_S_AUX0], aux0); put(&ns[H_S_AUX1], aux1); put(&ns[H_S_AUX2], aux2); put(&ns[H_S_AUX3], aux3);
         }
+    };
+    unsigned int* ctr = tickets + (size_t)chain * RT_WORDS;
+    if (!advance) {  // the common leaf: the last workgroup to finish writes it (the ticket alone orders that)
+        __syncthreads();
+        if (tid == 0) s_last = atomicAdd(ctr + RT_TICKET, 1u) == (unsigned)(GW - 1);
+        __syncthreads();
+        if (!s_last) return;
+        if (tid == 0) {
+            ctr[RT_TICKET] = 0u;
+            write_header([](double* p, double v) { *p = v; });
+        }
+        return;
     }
-    if (advance) persist_advance<KW_NTB>(ns, P, chain, tid, scr);
+    // ---- the subtree is complete: the whole row advances the chain (GridTeam)
+    GridTeam tm;
+    tm.tid = tid; tm.wg = blockIdx.x; tm.nwg = GW;
+    tm.scr = scr; tm.s_ok = &s_last;
+    tm.part = row_part + (size_t)chain * row_part_doubles();
+    tm.ctr = ctr; tm.fault = fault;
+    tm.arrived = 0u; tm.slot = 0; tm.dead = false;
+    tm.barrier();   // every workgroup has read the header (and written its slice)
+    if (tm.leader()) write_header([](double* p, double v) { nd_st_sc1(p, v); });
+    persist_advance_t(ns, P, chain, tm);   // (begins with a row barrier: the header is out)
+    tm.leave();
 }
-// first transition of every chain, one workgroup per chain
-__global__ __launch_bounds__(KW_NTB) void kw_start(double* ns, size_t stride, Persist P) {
-    __shared__ double scr[KW_NTB / 64];
-    persist_start_transition<KW_NTB>(ns + blockIdx.x * stride, P, blockIdx.x, 0, threadIdx.x, scr);
+// first transition of every chain: the same row as kw_leaf_b
+__global__ __launch_bounds__(KW_NTB) void kw_start(double* ns, size_t stride, Persist P, unsigned int* tickets,
+                                                   double* row_part, unsigned int* fault) {
+    __shared__ double scr[2 * KW_NTB / 64];
+    __shared__ int s_ok;
+    const int chain = blockIdx.y;
+    GridTeam tm;
+    tm.tid = threadIdx.x; tm.wg = blockIdx.x; tm.nwg = gridDim.x;
+    tm.scr = scr; tm.s_ok = &s_ok;
+    tm.part = row_part + (size_t)chain * row_part_doubles();
+    tm.ctr = tickets + (size_t)chain * RT_WORDS; tm.fault = fault;
+    tm.arrived = 0u; tm.slot = 0; tm.dead = false;
+    persist_start_transition_t(ns + chain * stride, P, chain, 0, tm);
+    tm.leave();
 }
 
 }  // namespace nd

@@ -76,6 +76,20 @@ elif case == "dyn_c4":
     for _ in range(steps):
         c.logp_grad(z)
     torch.cuda.synchronize()
+elif case == "dyn_nuts":   # config 4 in situ: evaluation + the wide leaf's launches per leapfrog
+    Tn, G = 100, 50
+    rs = np.random.RandomState(4)
+    h, a, gw = [], [], []
+    for g in range(G):
+        p = rs.permutation(Tn)
+        h += list(p[0::2]); a += list(p[1::2]); gw += [g] * (Tn // 2)
+    n = len(h)
+    c.set_fixtures_dynamic(np.array(h), np.array(a), rs.poisson(1.5, n), rs.poisson(1.2, n), np.array(gw),
+                           np.zeros(n, np.uint8), Tn, G)
+    cfg = default_nuts_cfg(); cfg.num_warmup, cfg.num_samples, cfg.max_tree_depth = 60, 20, 8
+    _, st = c.nuts_run(cfg, (0, 42))
+    meta.update(n=n, latent_dim=c.dim, launches=int(st["total_leapfrogs"]),
+                leapfrogs_per_s=st["total_leapfrogs"] / st["wall_seconds"])
 elif case == "neutral":
     N = 570
     rs = np.random.RandomState(11)
