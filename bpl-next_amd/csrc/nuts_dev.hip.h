@@ -730,14 +730,22 @@ __device__ inline void end_body_t(double* ns, int D, int max_depth, uint32_t thi
     for (int i = tm.first(); i < D; i += tm.stride()) {
         const double ez = se_z[i], er = se_r[i], eg = se_g[i], orr = other_r[i];
         const double rsum = t_rsum[i] + s_rsum[i], im = invM[i];
-        const double pz = sp_z[i], pg = sp_g[i];
         te_z[i] = ez; te_r[i] = er; te_g[i] = eg;
         t_rsum[i] = rsum;
-        if (take) { tp_z[i] = pz; tp_g[i] = pg; }
         const double r_left = going_right ? orr : er, r_right = going_right ? er : orr;
         const double rs = rsum - 0.5 * (r_left + r_right);
         dl += im * r_left * rs;
         dr += im * r_right * rs;
+    }
+    // (the proposal in a loop of its own: with its four pointers in the loop above, the one-wave
+    // instantiation -- a real call from dc_eval -- needed two registers more than dc_eval can give it)
+    if (take) {
+#pragma clang loop unroll_count(Team::UNROLL)
+        for (int i = tm.first(); i < D; i += tm.stride()) {
+            const double pz = sp_z[i], pg = sp_g[i];
+            tp_z[i] = pz;
+            tp_g[i] = pg;
+        }
     }
     tm.sum2(dl, dr);
     const bool turning = s_turn | ((dl <= 0.0) | (dr <= 0.0));
@@ -870,9 +878,8 @@ __device__ inline void persist_start_transition_t(double* ns, const Persist& P, 
     double* __restrict__ r = vec(ns, D, V_TL_R);
 #pragma clang loop unroll_count(Team::UNROLL)
     for (int i = tm.first(); i < D; i += tm.stride()) r[i] = msq[i] * nrm[i];
-    const double step = tm.ld(&pd[P_STEP]), max_de = tm.ld(&pd[P_MAXDE]);
     tm.sync();
-    init_body_t(ns, D, step, max_de, tm);
+    init_body_t(ns, D, tm.ld(&pd[P_STEP]), tm.ld(&pd[P_MAXDE]), tm);
     tm.sync();
     const double* q = P.par + ((size_t)chain * P.n_iter + it) * P.max_depth * 5;
     begin_body_t(ns, D, 0, q[0] != 0.0, (uint32_t)q[1], (uint32_t)q[2], tm);
@@ -908,7 +915,6 @@ __device__ inline void persist_advance_t(double* ns, const Persist& P, int chain
     const double num = tm.ld(&ns[H_T_NUM]);
     const double accept_prob = num > 0 ? tm.ld(&ns[H_T_SUMACC]) / num : 0.0;
     const bool diverging = tm.ld(&ns[H_T_DIV]) != 0.0;
-    const double used_step = tm.ld(&ns[H_EPS]), t_pe = tm.ld(&ns[H_T_PE]), t_aux0 = tm.ld(&ns[H_T_AUX0]);
     finish_body_t(ns, D, tm);
     tm.sync();
     const double* zc = vec(ns, D, V_Z);
@@ -922,12 +928,11 @@ __device__ inline void persist_advance_t(double* ns, const Persist& P, int chain
         const bool adapt_ss = tm.ld(&pd[P_ADAPT_SS]) != 0.0, adapt_mm = tm.ld(&pd[P_ADAPT_MM]) != 0.0;
         double da_t = tm.ld(&pd[P_DA_T]), x_t = tm.ld(&pd[P_DA_XT]), x_avg = tm.ld(&pd[P_DA_XAVG]),
                g_avg = tm.ld(&pd[P_DA_GAVG]);
-        double prox = tm.ld(&pd[P_DA_PROX]);
         if (adapt_ss) {  // dual_averaging(t0 = 10, kappa = 0.75, gamma = 0.05)
             const double g = tm.ld(&pd[P_TARGET]) - accept_prob;
             da_t += 1.0;
             g_avg = (1.0 - 1.0 / (da_t + 10.0)) * g_avg + g / (da_t + 10.0);
-            x_t = prox - sqrt(da_t) / 0.05 * g_avg;
+            x_t = tm.ld(&pd[P_DA_PROX]) - sqrt(da_t) / 0.05 * g_avg;
             const double weight_t = pow(da_t, -0.75);
             x_avg = (1.0 - weight_t) * x_avg + weight_t * x_t;
             const double sx = it == warm - 1 ? exp(x_avg) : exp(x_t);
@@ -948,6 +953,7 @@ __device__ inline void persist_advance_t(double* ns, const Persist& P, int chain
         }
         const bool at_end = it == P.win_end[win];
         if (at_end) win += 1;
+        double prox = tm.ld(&pd[P_DA_PROX]);
         if (at_end && is_middle) {
             if (adapt_mm) {
                 for (int i = tm.first(); i < D; i += tm.stride()) {
@@ -978,10 +984,10 @@ __device__ inline void persist_advance_t(double* ns, const Persist& P, int chain
             double* __restrict__ dr = P.draws + ((size_t)chain * P.kept + idx) * D;
 #pragma clang loop unroll_count(Team::UNROLL)
             for (int i = tm.first(); i < D; i += tm.stride()) dr[i] = zc[i];
-            if (tm.leader()) {
+            if (tm.leader()) {  // (the tree's header words stand until the next transition starts)
                 double* st = P.stats + ((size_t)chain * P.kept + idx) * 6;
-                st[0] = t_pe; st[1] = accept_prob; st[2] = used_step; st[3] = num;
-                st[4] = diverging ? 1.0 : 0.0; st[5] = t_aux0;
+                st[0] = tm.ld(&ns[H_T_PE]); st[1] = accept_prob; st[2] = tm.ld(&ns[H_EPS]); st[3] = num;
+                st[4] = diverging ? 1.0 : 0.0; st[5] = tm.ld(&ns[H_T_AUX0]);
             }
         }
         if (tm.leader()) {
@@ -1003,6 +1009,9 @@ __device__ inline void persist_advance_t(double* ns, const Persist& P, int chain
     tm.sync();
     persist_start_transition_t(ns, P, chain, it + 1, tm);
 }
+// (dc_eval CALLS the one-wave instantiation -- the compiler does not inline it -- and a kernel is
+// charged its callees' registers: this function's count decides whether the NUTS-aware dc_eval keeps
+// two workgroups per CU, tests/test_kernel_resources.py)
 template <int NT = 64>
 __device__ inline void persist_advance(double* ns, const Persist& P, int chain, int lane,
                                        double* scr = nullptr) {
