@@ -1794,10 +1794,10 @@ int run_chains_persistent(bplhip_ctx* c, hipStream_t s, const nuts::Config& nc, 
                           const tf::Key* keys, double* draws_out, std::vector<nuts::Result>* res) {
     const int D = bplhip_latent_dim(c), md = nc.max_tree_depth;
     // the leaf as its own launch(es) after a plain evaluation: one wave per chain (kp_leaf) up
-    // to 256 latent entries, GW workgroups per chain (kw_leaf_a/b) beyond
+    // to 256 latent entries, GW workgroups per chain (kw_leaf) beyond
     const bool generic = !leaf_in_tail(c);
     const bool wide = generic && D > 64 * nd::LEAF_NE_MAX;
-    const int GW = nd::kw_workgroups(D, nd::KW_NT), GWB = nd::kw_workgroups(D, nd::KW_NTB);
+    const int GWB = nd::kw_workgroups(D, nd::KW_NTB);
     const int n_iter = nc.num_warmup + nc.num_samples;
     const int kept = nc.num_samples / nc.thinning;
     const size_t nsd = (nd::ns_doubles(D, md) + 1) & ~(size_t)1;
@@ -1809,7 +1809,8 @@ int run_chains_persistent(bplhip_ctx* c, hipStream_t s, const nuts::Config& nc, 
 
     DevBuf d_ns, d_norm, d_par, d_win, d_draws, d_stats, d_desc, d_part, d_tick, d_rowpart;
     if (wide) {
-        HIP_TRY(c, d_part.ensure((size_t)C * GW * nd::KW_PW * 8));
+        HIP_TRY(c, d_part.ensure((size_t)C * GWB * nd::KW_PW * sizeof(nd::TaggedSum)));
+        HIP_TRY(c, hipMemsetAsync(d_part.p, 0, (size_t)C * GWB * nd::KW_PW * sizeof(nd::TaggedSum), s));   // (tag 0: nobody's)
         HIP_TRY(c, d_tick.ensure((size_t)C * nd::RT_WORDS * 4));   // per chain: ticket, row barrier, exit counter
         HIP_TRY(c, hipMemsetAsync(d_tick.p, 0, (size_t)C * nd::RT_WORDS * 4, s));
         HIP_TRY(c, d_rowpart.ensure((size_t)C * nd::row_part_doubles() * 8));
@@ -1965,11 +1966,9 @@ int run_chains_persistent(bplhip_ctx* c, hipStream_t s, const nuts::Config& nc, 
                 }
                 if (rc != BPLHIP_OK) return rc;
                 if (wide) {
-                    hipLaunchKernelGGL(nd::kw_leaf_a, dim3(GW, C), dim3(nd::KW_NT), 0, s, ns, stride, D, md,
-                                       d_part.as<double>());
-                    hipLaunchKernelGGL(nd::kw_leaf_b, dim3(GWB, C), dim3(nd::KW_NTB), 0, s, ns, stride, D, md,
-                                       d_part.as<const double>(), GW, d_tick.as<unsigned int>(), P, 1,
-                                       d_rowpart.as<double>(), c->d_fault);
+                    hipLaunchKernelGGL(nd::kw_leaf, dim3(GWB, C), dim3(nd::KW_NTB), 0, s, ns, stride, D, md,
+                                       d_part.as<nd::TaggedSum>(), d_tick.as<unsigned int>(), P, d_rowpart.as<double>(),
+                                       c->d_fault);
                 } else {
                     hipLaunchKernelGGL(nd::kp_leaf, dim3(C), dim3(64), (size_t)(D + 8) * 8, s, ns, stride, D,
                                        md, P);

@@ -127,7 +127,7 @@ __device__ __forceinline__ double nd_wave_sum(double v) {
 }
 // The tree bookkeeping below is written for a "team" of NT threads working on one chain's
 // state: one wave (NT = 64, no barriers: the leaf's wave inside dc_eval, or a 64-thread launch)
-// or a whole workgroup (NT > 64, for latent vectors of 10^4..10^5 entries: kw_leaf_b).  Thread
+// or a whole workgroup (NT > 64, for latent vectors of 10^4..10^5 entries: kw_leaf).  Thread
 // `tid` owns elements tid, tid + NT, ... in every loop, so element-wise read-after-write
 // between loops needs no synchronisation; header words are written by thread 0 only.
 // scr: LDS scratch of NT/64 doubles (unused for NT = 64).
@@ -1050,17 +1050,16 @@ __global__ __launch_bounds__(64) void kp_start(double* ns, size_t stride, Persis
 
 // ---------------------------------------------------------------- wide leaf (any D)
 // The leaf for latent vectors too long for one wave (dynamic model: D ~ 10^4..10^5, leagues of
-// more than 64 teams), as two launches of GW workgroups per chain after the evaluation:
-//   kw_leaf_a  partial sums of every reduction the leaf needs -- the kinetic energy and, for
-//              each checkpoint level this leaf closes, the two U-turn dot products -- into
-//              part[chain][workgroup][KW_PW]
-//   kw_leaf_b  every workgroup adds the partials in a fixed order (same totals everywhere,
-//              deterministic), takes the leaf's decisions and writes its slice of the vectors;
-//              the last workgroup to finish (ticket) writes the header and, when the subtree
-//              is complete, advances the chain with the whole workgroup as the team.
+// more than 64 teams), as ONE launch of GW workgroups per chain after the evaluation (kw_leaf):
+//   1  every workgroup adds its share of every reduction the leaf needs -- the kinetic energy and, for
+//      each checkpoint level this leaf closes, the two U-turn dot products -- and writes the partials
+//      (write-through) into part[chain][workgroup][KW_PW]
+//   2  it stores what does not depend on the decisions, then meets the others at a ROW BARRIER
+//   3  every workgroup adds the partials in a fixed order (same totals everywhere, deterministic),
+//      takes the leaf's decisions and writes the rest of its slice; the row's leader rewrites the header
+//   4  when the subtree is complete the whole row advances the chain (GridTeam below).
 // Same arithmetic per element as leaf_moves / leaf_weights; only the order of the sums differs.
-constexpr int KW_NT = 256;              // kw_leaf_a
-constexpr int KW_NTB = 1024;            // kw_leaf_b / kw_start: the team that also advances the chain
+constexpr int KW_NTB = 1024;            // kw_leaf / kw_start
 constexpr int KW_MAXL = 21;            // levels one leaf can close (max_tree_depth <= 20)
 constexpr int KW_PW = 1 + 2 * KW_MAXL; // kin | (dl, dr) per level
 constexpr int KW_MAX_WG = 64;
@@ -1090,7 +1089,7 @@ __device__ __forceinline__ WideLeaf wide_leaf(double hv) {
 // doubling, end of a transition, adaptation, the next transition's start -- is a handful of passes over
 // a dozen D-vectors, and on one workgroup that is one CU's load/store path: ~100 GB/s, 200 us per advance
 // with the dynamic model's 35 502 entries (profiles/r03/dynamic_advance.txt), five times the leapfrog it
-// follows.  Here every workgroup of kw_leaf_b's grid takes part:
+// follows.  Here every workgroup of kw_leaf's grid takes part:
 //   vectors   thread t of the row owns elements t, t + row size, ... in EVERY pass, the same split as the
 //             leaf's slice loop -- no element is ever read by a thread that did not write it, so the
 //             vectors need no cross-workgroup visibility at all inside the launch
@@ -1113,6 +1112,27 @@ __device__ __forceinline__ double nd_ld_sc1(const double* p) {
 __device__ __forceinline__ void nd_st_sc1(double* p, double v) {
     __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v),
                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// a partial sum and the tag of the leaf it belongs to, 16 bytes written by ONE write-through store and
+// read by ONE L2-bypassing load: the record is its own "ready" flag (no counter, no second round trip)
+struct TaggedSum {
+    double v;
+    unsigned long long tag;
+};
+__device__ __forceinline__ void st_tagged(TaggedSum* p, double v, unsigned long long tag) {
+    typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+    u64x2 w = {(unsigned long long)__double_as_longlong(v), tag};
+    // (the s_nop: a store of more than 64 bits reads its data registers a few cycles after issue)
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 2" ::"v"(p), "v"(w) : "memory");
+}
+__device__ __forceinline__ TaggedSum ld_tagged(const TaggedSum* p) {
+    typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+    u64x2 w;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(w) : "v"(p) : "memory");
+    TaggedSum r;
+    r.v = __longlong_as_double((long long)w.x);
+    r.tag = w.y;
+    return r;
 }
 struct GridTeam {
     static constexpr int NT = KW_NTB;
@@ -1192,63 +1212,20 @@ struct GridTeam {
 };
 __host__ __device__ inline size_t row_part_doubles() { return 2 * (size_t)KW_MAX_WG * 2; }
 
-__global__ __launch_bounds__(KW_NT) void kw_leaf_a(double* ns_all, size_t stride, int D, int max_depth,
-                                                   double* part) {
-    __shared__ double scr[KW_NT / 64];
-    double* ns = ns_all + blockIdx.y * stride;
-    const int tid = threadIdx.x, GW = gridDim.x;
-    const double hv = (tid & 63) < H_N ? ns[tid & 63] : 0.0;
-    if (hdr_word(hv, H_S_DONE) != 0.0) return;  // chain finished (uniform over the grid row)
-    const WideLeaf W = wide_leaf(hv);
-    const double* invM = vec(ns, D, V_INVM);
-    const double* rh = vec(ns, D, V_RH);
-    const double* g = vec(ns, D, V_GRAD);
-    const double* rsum = vec(ns, D, V_S_RSUM);
-    const double* c_r1 = vec(ns, D, W.going_right ? V_SR_R : V_SL_R);
-    const double* ck_r = vec(ns, D, V_CKPT);
-    const double* ck_s = ck_r + (size_t)max_depth * D;
-    double* out = part + ((size_t)blockIdx.y * GW + blockIdx.x) * KW_PW;
-    const int i0 = blockIdx.x * KW_NT + tid, step = GW * KW_NT;
-
-    double kin = 0.0;
-    for (int i = i0; i < D; i += step) {
-        const double r = rh[i] - 0.5 * W.eps * g[i];
-        kin += invM[i] * r * r;
-    }
-    kin = team_sum<KW_NT>(kin, tid, scr);
-    if (tid == 0) out[0] = kin;
-    for (int l = 0; l < W.n_lev; ++l) {  // (an odd leaf: num >= 1)
-        const int ci = W.idx_max - l;
-        double dl = 0.0, dr = 0.0;
-        for (int i = i0; i < D; i += step) {
-            const double r = rh[i] - 0.5 * W.eps * g[i];
-            const double rs_old = rsum[i], rs = rs_old + r;
-            // the first level is the previous leaf itself (see LeafState)
-            const double c_r = l == 0 ? c_r1[i] : ck_r[(size_t)ci * D + i];
-            const double c_s = l == 0 ? rs_old : ck_s[(size_t)ci * D + i];
-            const double sub = rs - c_s + c_r;
-            const double rsm = sub - 0.5 * (c_r + r);
-            dl += invM[i] * c_r * rsm;
-            dr += invM[i] * r * rsm;
-        }
-        dl = team_sum<KW_NT>(dl, tid, scr);
-        dr = team_sum<KW_NT>(dr, tid, scr);
-        if (tid == 0) { out[1 + 2 * l] = dl; out[2 + 2 * l] = dr; }
-    }
-}
-__global__ __launch_bounds__(KW_NTB) void kw_leaf_b(double* ns_all, size_t stride, int D, int max_depth,
-                                                    const double* part, int gw_a,
-                                                    unsigned int* tickets, Persist P, int persist,
-                                                    double* row_part, unsigned int* fault) {
+// ONE launch per leapfrog (round 3; round 2: kw_leaf_a + kw_leaf_b, 5.0 + 7.8 us and a launch gap at
+// D = 35 502).  Every thread keeps its (first two) elements in registers across the row barrier.
+__global__ __launch_bounds__(KW_NTB) void kw_leaf(double* ns_all, size_t stride, int D, int max_depth,
+                                                  TaggedSum* part, unsigned int* tickets, Persist P,
+                                                  double* row_part, unsigned int* fault) {
     __shared__ double scr[2 * KW_NTB / 64];
+    __shared__ double red[KW_NTB / 64][KW_PW];
     __shared__ double tot[KW_PW];
-    __shared__ int s_last;
+    __shared__ int s_ok;
     const int chain = blockIdx.y;
     double* ns = ns_all + chain * stride;
-    const int tid = threadIdx.x, GW = gridDim.x;
-    const double hv = (tid & 63) < H_N ? ns[tid & 63] : 0.0;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, GW = gridDim.x;
+    const double hv = lane < H_N ? ns[lane] : 0.0;
     // this thread's first two elements, requested before anything that waits for the header
-    // (one memory round trip less on the chain's serial path)
     const int el0 = blockIdx.x * KW_NTB + tid, estep = GW * KW_NTB;
     double pre[2][5];
 #pragma unroll
@@ -1263,14 +1240,97 @@ __global__ __launch_bounds__(KW_NTB) void kw_leaf_b(double* ns_all, size_t strid
     }
     if (hdr_word(hv, H_S_DONE) != 0.0) return;  // chain finished (uniform over the grid row)
     const WideLeaf W = wide_leaf(hv);
-    // totals: one wave per value, lane b reads workgroup b's partial (gw_a <= 64): one round of
-    // loads and a fixed-order wave sum (a serial loop is one memory round trip per workgroup)
-    static_assert(KW_MAX_WG <= 64, "one lane per partial");
-    for (int k = tid >> 6; k < 1 + 2 * W.n_lev; k += KW_NTB / 64) {
-        const int b = tid & 63;
-        const double v = b < gw_a ? part[((size_t)chain * gw_a + b) * KW_PW + k] : 0.0;
-        const double sum = nd_wave_sum(v);
-        if (b == 0) tot[k] = sum;
+    GridTeam tm;
+    tm.tid = tid; tm.wg = blockIdx.x; tm.nwg = GW;
+    tm.scr = scr; tm.s_ok = &s_ok;
+    tm.part = row_part + (size_t)chain * row_part_doubles();
+    tm.ctr = tickets + (size_t)chain * RT_WORDS; tm.fault = fault;
+    tm.arrived = 0u; tm.slot = 0; tm.dead = false;
+
+    const double* invM = vec(ns, D, V_INVM);
+    const double* g = vec(ns, D, V_GRAD);
+    double* p_zn = vec(ns, D, V_ZN); double* p_rh = vec(ns, D, V_RH); double* p_rsum = vec(ns, D, V_S_RSUM);
+    double* sl_z = vec(ns, D, V_SL_Z); double* sl_r = vec(ns, D, V_SL_R); double* sl_g = vec(ns, D, V_SL_G);
+    double* sr_z = vec(ns, D, V_SR_Z); double* sr_r = vec(ns, D, V_SR_R); double* sr_g = vec(ns, D, V_SR_G);
+    double* sp_z = vec(ns, D, V_SP_Z); double* sp_g = vec(ns, D, V_SP_G);
+    double* ck_r = vec(ns, D, V_CKPT);
+    double* ck_s = ck_r + (size_t)max_depth * D;
+    const double* c_r1 = W.going_right ? sr_r : sl_r;
+    struct Elem { double gi, zn, rh, rs_old, im; };
+    auto elem = [&](int it, int i) {
+        Elem e;
+        if (it < 2) {   // (selects, not an indexed register array)
+            const bool f = it == 0;
+            e.gi = f ? pre[0][0] : pre[1][0]; e.zn = f ? pre[0][1] : pre[1][1]; e.rh = f ? pre[0][2] : pre[1][2];
+            e.rs_old = f ? pre[0][3] : pre[1][3]; e.im = f ? pre[0][4] : pre[1][4];
+        } else {   // (longer vectors: from memory -- rs_old only before step 2 rewrites it)
+            e.gi = g[i]; e.zn = p_zn[i]; e.rh = p_rh[i]; e.rs_old = p_rsum[i]; e.im = invM[i];
+        }
+        return e;
+    };
+
+    // ---- 1. this workgroup's share of every sum the decisions need: the kinetic energy and, per
+    // checkpoint level this (odd) leaf closes, the two U-turn dot products
+    const int nv = 1 + 2 * W.n_lev;
+    {
+        double kin = 0.0;
+        int it = 0;
+        for (int i = el0; i < D; i += estep, ++it) {
+            const Elem e = elem(it, i);
+            const double r = e.rh - 0.5 * W.eps * e.gi;
+            kin += e.im * r * r;
+        }
+        kin = nd_wave_sum(kin);
+        if (lane == 0) red[wave][0] = kin;
+    }
+    for (int l = 0; l < W.n_lev; ++l) {
+        const int ci = W.idx_max - l;
+        double dl = 0.0, dr = 0.0;
+        int it = 0;
+        for (int i = el0; i < D; i += estep, ++it) {
+            const Elem e = elem(it, i);
+            const double r = e.rh - 0.5 * W.eps * e.gi;
+            const double rs = e.rs_old + r;
+            // the first level is the previous leaf itself (see LeafState)
+            const double c_r = l == 0 ? c_r1[i] : ck_r[(size_t)ci * D + i];
+            const double c_s = l == 0 ? e.rs_old : ck_s[(size_t)ci * D + i];
+            const double sub = rs - c_s + c_r;
+            const double rsm = sub - 0.5 * (c_r + r);
+            dl += e.im * c_r * rsm;
+            dr += e.im * r * rsm;
+        }
+        dl = nd_wave_sum(dl);
+        dr = nd_wave_sum(dr);
+        if (lane == 0) { red[wave][1 + 2 * l] = dl; red[wave][2 + 2 * l] = dr; }
+    }
+    __syncthreads();
+    // (tagged with this leaf's number: a record that carries it is this launch's -- the launches of a
+    // stream do not overlap, and the counter moves with every leaf)
+    const unsigned long long leaf_tag = (unsigned long long)hdr_word(hv, H_EVALS) + 1ull;
+    if (tid < nv) {
+        double sv = 0.0;
+#pragma unroll
+        for (int w = 0; w < KW_NTB / 64; ++w) sv += red[w][tid];
+        st_tagged(&part[((size_t)chain * GW + blockIdx.x) * KW_PW + tid], sv, leaf_tag);
+    }
+    // ---- 2. what does not depend on the decisions goes out while the partials travel: the running
+    // momentum sum, the subtree's edge on this side, the checkpoint of an even leaf
+    const bool wl = W.num == 0 || !W.going_right, wr = W.num == 0 || W.going_right;
+    const bool wck = (W.num & 1) == 0;
+    {
+        int it = 0;
+        for (int i = el0; i < D; i += estep, ++it) {
+            const Elem e = elem(it, i);
+            const double r = e.rh - 0.5 * W.eps * e.gi;
+            const double rs = W.num == 0 ? r : e.rs_old + r;
+            p_rsum[i] = rs;
+            if (wl) { sl_z[i] = e.zn; sl_r[i] = r; sl_g[i] = e.gi; }
+            if (wr) { sr_z[i] = e.zn; sr_r[i] = r; sr_g[i] = e.gi; }
+            if (wck) {
+                ck_r[(size_t)W.idx_max * D + i] = r;
+                ck_s[(size_t)W.idx_max * D + i] = rs;
+            }
+        }
     }
     // everything the decisions read from the header, before anyone rewrites it
     const double pe = hdr_word(hv, H_LEAF_PE), e0 = hdr_word(hv, H_E0), max_de = hdr_word(hv, H_MAXDE);
@@ -1282,7 +1342,33 @@ __global__ __launch_bounds__(KW_NTB) void kw_leaf_b(double* ns_all, size_t strid
     uint32_t nhi, nlo;
     float u_take;
     leaf_rng(hv, &nhi, &nlo, &u_take);
+    // ---- 3. the totals: one wave per value, lane b polls workgroup b's record until it carries this
+    // leaf's tag (bounded) -- the load that finds it IS the hand-off; then a wave sum in fixed order.
+    // A workgroup that has seen every record knows that every workgroup has read the header.
+    static_assert(KW_MAX_WG <= 64, "one lane per partial");
+    if (tid == 0) s_ok = 1;
     __syncthreads();
+    for (int k = wave; k < nv; k += KW_NTB / 64) {
+        const TaggedSum* rec = &part[((size_t)chain * GW + (lane < GW ? lane : 0)) * KW_PW + k];
+        TaggedSum t;
+        bool ok = false;
+        for (unsigned int spin = 0; spin < ROW_SPIN_LIMIT; ++spin) {
+            t = ld_tagged(rec);
+            ok = __ballot(t.tag != leaf_tag) == 0ull;
+            if (ok) break;
+            __builtin_amdgcn_s_sleep(1);
+        }
+        const double sum = nd_wave_sum(lane < GW ? t.v : 0.0);
+        if (lane == 0) {
+            tot[k] = sum;
+            if (!ok) s_ok = 0;
+        }
+    }
+    __syncthreads();
+    if (s_ok == 0) {   // a workgroup of the row never delivered: tell the host, leave the state alone
+        if (tid == 0 && fault) (void)__hip_atomic_fetch_or(fault, FAULT_LEAF_BARRIER, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        return;
+    }
 
     const double e_new = pe + 0.5 * tot[0];
     double delta = e_new - e0;
@@ -1296,39 +1382,19 @@ __global__ __launch_bounds__(KW_NTB) void kw_leaf_b(double* ns_all, size_t strid
     const int new_num = W.num + 1;
     const bool done = turning || div_leaf || new_num >= s_max;
 
-    // ---- this workgroup's slice of the vectors
-    const double* invM = vec(ns, D, V_INVM);
-    const double* g = vec(ns, D, V_GRAD);
-    double* p_zn = vec(ns, D, V_ZN); double* p_rh = vec(ns, D, V_RH); double* p_rsum = vec(ns, D, V_S_RSUM);
-    double* sl_z = vec(ns, D, V_SL_Z); double* sl_r = vec(ns, D, V_SL_R); double* sl_g = vec(ns, D, V_SL_G);
-    double* sr_z = vec(ns, D, V_SR_Z); double* sr_r = vec(ns, D, V_SR_R); double* sr_g = vec(ns, D, V_SR_G);
-    double* sp_z = vec(ns, D, V_SP_Z); double* sp_g = vec(ns, D, V_SP_G);
-    double* ck_r = vec(ns, D, V_CKPT);
-    double* ck_s = ck_r + (size_t)max_depth * D;
-    const bool wl = W.num == 0 || !W.going_right, wr = W.num == 0 || W.going_right;
-    const bool wck = (W.num & 1) == 0;
-    int it = 0;
-    for (int i = el0; i < D; i += estep, ++it) {
-        const bool fromreg = it < 2;
-        const double gi = fromreg ? pre[it & 1][0] : g[i], zn = fromreg ? pre[it & 1][1] : p_zn[i];
-        const double rh_i = fromreg ? pre[it & 1][2] : p_rh[i], rs_old = fromreg ? pre[it & 1][3] : p_rsum[i];
-        const double im = fromreg ? pre[it & 1][4] : invM[i];
-        const double r = rh_i - 0.5 * W.eps * gi;
-        const double rs = W.num == 0 ? r : rs_old + r;
-        const double rn = r - 0.5 * W.eps * gi;
-        p_zn[i] = done ? zn : zn + W.eps * im * rn;
-        p_rh[i] = done ? r : rn;
-        p_rsum[i] = rs;
-        if (wl) { sl_z[i] = zn; sl_r[i] = r; sl_g[i] = gi; }
-        if (wr) { sr_z[i] = zn; sr_r[i] = r; sr_g[i] = gi; }
-        if (LW.take) { sp_z[i] = zn; sp_g[i] = gi; }
-        if (wck) {
-            ck_r[(size_t)W.idx_max * D + i] = r;
-            ck_s[(size_t)W.idx_max * D + i] = rs;
+    // ---- 4. the rest of this workgroup's slice: the next position / half-stepped momentum, the proposal
+    {
+        int it = 0;
+        for (int i = el0; i < D; i += estep, ++it) {
+            const Elem e = elem(it, i);
+            const double r = e.rh - 0.5 * W.eps * e.gi;
+            const double rn = r - 0.5 * W.eps * e.gi;
+            p_zn[i] = done ? e.zn : e.zn + W.eps * e.im * rn;
+            p_rh[i] = done ? r : rn;
+            if (LW.take) { sp_z[i] = e.zn; sp_g[i] = e.gi; }
         }
     }
-    // ---- the header: every workgroup has read it into registers by now, ONE rewrites it.
-    const bool advance = persist && done;
+    // ---- 5. the header (every workgroup read it before the barrier): the row's leader rewrites it
     auto write_header = [&](auto put) {
         put(&ns[H_S_NUM], (double)new_num);
         put(&ns[H_S_DIV], div_leaf ? 1.0 : 0.0);
@@ -1345,31 +1411,15 @@ __global__ __launch_bounds__(KW_NTB) void kw_leaf_b(double* ns_all, size_t strid
             put(&ns[H_S_AUX0], aux0); put(&ns[H_S_AUX1], aux1); put(&ns[H_S_AUX2], aux2); put(&ns[H_S_AUX3], aux3);
         }
     };
-    unsigned int* ctr = tickets + (size_t)chain * RT_WORDS;
-    if (!advance) {  // the common leaf: the last workgroup to finish writes it (the ticket alone orders that)
-        __syncthreads();
-        if (tid == 0) s_last = atomicAdd(ctr + RT_TICKET, 1u) == (unsigned)(GW - 1);
-        __syncthreads();
-        if (!s_last) return;
-        if (tid == 0) {
-            ctr[RT_TICKET] = 0u;
-            write_header([](double* p, double v) { *p = v; });
-        }
-        return;
-    }
-    // ---- the subtree is complete: the whole row advances the chain (GridTeam)
-    GridTeam tm;
-    tm.tid = tid; tm.wg = blockIdx.x; tm.nwg = GW;
-    tm.scr = scr; tm.s_ok = &s_last;
-    tm.part = row_part + (size_t)chain * row_part_doubles();
-    tm.ctr = ctr; tm.fault = fault;
-    tm.arrived = 0u; tm.slot = 0; tm.dead = false;
-    tm.barrier();   // every workgroup has read the header (and written its slice)
     if (tm.leader()) write_header([](double* p, double v) { nd_st_sc1(p, v); });
-    persist_advance_t(ns, P, chain, tm);   // (begins with a row barrier: the header is out)
-    tm.leave();
+    // ---- 6. a complete subtree: the whole row advances the chain (the only launches that touch the
+    // row's counters)
+    if (done) {
+        persist_advance_t(ns, P, chain, tm);   // (begins with a row barrier: the header is out)
+        tm.leave();
+    }
 }
-// first transition of every chain: the same row as kw_leaf_b
+// first transition of every chain: the same row as kw_leaf
 __global__ __launch_bounds__(KW_NTB) void kw_start(double* ns, size_t stride, Persist P, unsigned int* tickets,
                                                    double* row_part, unsigned int* fault) {
     __shared__ double scr[2 * KW_NTB / 64];

@@ -14,9 +14,9 @@ for r in rows:
 for name, d in sorted(by.items()):
     d = np.array(d)
     print(f"{name:28s} n={d.size:5d}  median {np.median(d):7.1f}  mean {d.mean():7.1f}  p90 {np.percentile(d, 90):7.1f}  max {d.max():7.1f} us")
-b = np.array(by.get("nd::kw_leaf_b", [0.0]))
+b = np.array(by.get("nd::kw_leaf", [0.0]))
 slow = b[b > 3 * np.median(b)]
-print(f"kw_leaf_b launches that advance the chain (> 3 x median): {slow.size} of {b.size}, median {np.median(slow) if slow.size else 0:.1f} us, "
+print(f"kw_leaf launches that advance the chain (> 3 x median): {slow.size} of {b.size}, median {np.median(slow) if slow.size else 0:.1f} us, "
       f"{slow.sum() / max(b.sum(), 1e-9):.0%} of its total time")
 ts = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in rows)
 print(f"span {(ts[-1][1] - ts[0][0]) / 1e3:.0f} us, busy {sum(e - s for s, e in ts) / 1e3:.0f} us")
