@@ -227,7 +227,21 @@ __device__ __forceinline__ double* nuts_of(const EvalArgs& A, int c) { return A.
         if (threadIdx.x == (w) * 64 && A.debug && blockIdx.y == 0)                     \
             A.debug[(size_t)blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); \
     } while (0)
+// every wave of block 0, into the spare row behind the workgroups' records: which wave is the last
+// one at a barrier of the prior part (slot0 + wave)
+#define DC_STAMP_PW(slot0)                                                                                  \
+    do {                                                                                                    \
+        if ((threadIdx.x & 63) == 0 && blockIdx.x == 0 && A.debug && blockIdx.y == 0)                       \
+            A.debug[(size_t)gridDim.x * 16 + (slot0) + (threadIdx.x >> 6)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+#define DC_STAMP_SEQ(k)                                                                                     \
+    do {                                                                                                    \
+        if (threadIdx.x == 128 && blockIdx.x == 0 && A.debug && blockIdx.y == 0)                             \
+            A.debug[(size_t)gridDim.x * 16 + (k)] = __builtin_amdgcn_s_memrealtime();                        \
+    } while (0)
 #else
+#define DC_STAMP_SEQ(k) do { } while (0)
+#define DC_STAMP_PW(slot0) do { } while (0)
 #define DC_STAMP(k) do { } while (0)
 #define DC_STAMP_LEAF(k) do { } while (0)
 #define DC_STAMP_WAVE(w, k) do { } while (0)
@@ -417,6 +431,30 @@ __device__ __forceinline__ void wave_max3_f64(double& a, double& b, double& c) {
     a = readlane63_f64(a); b = readlane63_f64(b); c = readlane63_f64(c);
 }
 
+// the prior part's pair walk ends in three float32 maxima, three float64 maxima and one float64 sum:
+// seven chains of six dependent DPP steps -- issued one reduction after the other they were three
+// times six latencies, interleaved step by step they are six
+__device__ __forceinline__ void wave_bounds_reduce(float& a, float& b, float& c, double& p, double& q, double& r,
+                                                   double& sum) {
+#define DC_BR_STEP(...)                                                                                  \
+    a = fmaxf(a, dpp_f32<__VA_ARGS__>(0.f, a)); b = fmaxf(b, dpp_f32<__VA_ARGS__>(0.f, b));             \
+    c = fmaxf(c, dpp_f32<__VA_ARGS__>(0.f, c));                                                         \
+    p = fmax(p, dpp_f64<__VA_ARGS__>(0.0, p)); q = fmax(q, dpp_f64<__VA_ARGS__>(0.0, q));               \
+    r = fmax(r, dpp_f64<__VA_ARGS__>(0.0, r)); sum += dpp_f64<__VA_ARGS__>(0.0, sum);
+    DC_BR_STEP(0xB1)
+    DC_BR_STEP(0x4E)
+    DC_BR_STEP(0x124)
+    DC_BR_STEP(0x128)
+    DC_BR_STEP(0x142, 0xA)
+    DC_BR_STEP(0x143, 0xC)
+#undef DC_BR_STEP
+    a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a), 63));
+    b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b), 63));
+    c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c), 63));
+    p = readlane63_f64(p); q = readlane63_f64(q); r = readlane63_f64(r);
+    sum = readlane63_f64(sum);
+}
+
 // Inclusive scans over the 64 lanes without the LDS crossbar.  Prefix (lane 0 first): four
 // zero-filled row_shr steps give each 16-lane row its own prefix, row_bcast:15 / row_bcast:31 add
 // the totals of the rows below.  Suffix (lane 63 first): four row_shl steps, then the totals of
@@ -436,6 +474,26 @@ __device__ __forceinline__ double readlane_f64(double v, int l) {
     const int hi = __builtin_amdgcn_readlane((int)(x >> 32), l);
     return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
+// ... and the combine of the waves' records: eight values in lanes 0..7 (zeros elsewhere), three
+// maxima and a sum in THREE DPP steps (two quad_perms leave every lane with its quad's result;
+// row_ror:4 hands lane i the value of lane i - 4, so lanes 4..7 end with the result of all eight --
+// lanes 0..3 receive the zeros of lanes 12..15), interleaved; results from lane 4
+__device__ __forceinline__ void lanes8_max3_sum(double& p, double& q, double& r, double& sum, float& a, float& b,
+                                                float& c) {
+#define DC_L8_STEP(CTRL)                                                                                \
+    p = fmax(p, dpp_f64<CTRL>(0.0, p)); q = fmax(q, dpp_f64<CTRL>(0.0, q));                             \
+    r = fmax(r, dpp_f64<CTRL>(0.0, r)); sum += dpp_f64<CTRL>(0.0, sum);                                 \
+    a = fmaxf(a, dpp_f32<CTRL>(0.f, a)); b = fmaxf(b, dpp_f32<CTRL>(0.f, b)); c = fmaxf(c, dpp_f32<CTRL>(0.f, c));
+    DC_L8_STEP(0xB1)
+    DC_L8_STEP(0x4E)
+    DC_L8_STEP(0x124)
+#undef DC_L8_STEP
+    p = readlane_f64(p, 4); q = readlane_f64(q, 4); r = readlane_f64(r, 4); sum = readlane_f64(sum, 4);
+    a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a), 4));
+    b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b), 4));
+    c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c), 4));
+}
+
 __device__ __forceinline__ double wave_suffix_dpp_f64(double v, int lane) {
     v += dpp_f64<0x101>(0.0, v);       // row_shl:1
     v += dpp_f64<0x102>(0.0, v);       // row_shl:2
@@ -1315,30 +1373,31 @@ __device__ void prior_body(const EvalArgs& A, int chain, char* smem, double* zo_
         }
     }
     if (!dense) {
-    wave_max3_f32(mPf, mQf, mRf);
-    if (lane == 0) {
-        redm[wave * 4 + 0] = mPf;
-        redm[wave * 4 + 1] = mQf;
-        redm[wave * 4 + 2] = mRf;
-    }
-    {
-        double wP = mP, wQ = mQ, wR = mR;
-        wave_max3_f64(wP, wQ, wR);
-        // first lane holding the wave maximum (no cross-lane min-reduction, no reload)
-        const unsigned long long bP = __ballot(mP == wP), bQ = __ballot(mQ == wQ),
-                                 bR = __ballot(mR == wR);
-        const uint32_t pP = (uint32_t)__builtin_amdgcn_readlane((int)aP, bP ? __ffsll((long long)bP) - 1 : 0);
-        const uint32_t pQ = (uint32_t)__builtin_amdgcn_readlane((int)aQ, bQ ? __ffsll((long long)bQ) - 1 : 0);
-        const uint32_t pR = (uint32_t)__builtin_amdgcn_readlane((int)aR, bR ? __ffsll((long long)bR) - 1 : 0);
-        const double wC = wave_sum_f64(pairc);
+        // (a wave whose lanes hold no pair -- the team-sum wave among them -- files zeros: it was the
+        // last one at the barrier below, with seven reductions of nothing behind its own work)
+        const bool has_pairs = wave * 64 < A.P;
+        double wP = mP, wQ = mQ, wR = mR, wC = pairc;
+        uint32_t pP = 0, pQ = 0, pR = 0;
+        if (has_pairs) {
+            wave_bounds_reduce(mPf, mQf, mRf, wP, wQ, wR, wC);
+            // first lane holding the wave maximum (no cross-lane min-reduction, no reload)
+            const unsigned long long bP = __ballot(mP == wP), bQ = __ballot(mQ == wQ), bR = __ballot(mR == wR);
+            pP = (uint32_t)__builtin_amdgcn_readlane((int)aP, bP ? __ffsll((long long)bP) - 1 : 0);
+            pQ = (uint32_t)__builtin_amdgcn_readlane((int)aQ, bQ ? __ffsll((long long)bQ) - 1 : 0);
+            pR = (uint32_t)__builtin_amdgcn_readlane((int)aR, bR ? __ffsll((long long)bR) - 1 : 0);
+        }
         if (lane == 0) {
-            amx[wave * 8 + 0] = wP; amx[wave * 8 + 1] = wQ; amx[wave * 8 + 2] = wR;
+            redm[wave * 4 + 0] = has_pairs ? mPf : 0.f;
+            redm[wave * 4 + 1] = has_pairs ? mQf : 0.f;
+            redm[wave * 4 + 2] = has_pairs ? mRf : 0.f;
+            amx[wave * 8 + 0] = has_pairs ? wP : 0.0; amx[wave * 8 + 1] = has_pairs ? wQ : 0.0;
+            amx[wave * 8 + 2] = has_pairs ? wR : 0.0;
             amx[wave * 8 + 3] = (double)pP; amx[wave * 8 + 4] = (double)pQ;
             amx[wave * 8 + 5] = (double)pR;
-            amx[wave * 8 + 6] = wC;
+            amx[wave * 8 + 6] = has_pairs ? wC : 0.0;
         }
     }
-    }
+    DC_STAMP_PW(8);
     __syncthreads();
     DC_STAMP(3);
 
@@ -1363,16 +1422,19 @@ __device__ void prior_body(const EvalArgs& A, int chain, char* smem, double* zo_
     // ---- bounds: combine the waves' arg-maxima on lanes 0..WAVES-1 of wave 0 (a serial loop
     // of 48 dependent LDS reads cost 1.1 us here); ties: the lowest wave wins
     double M = 0.0, Lh = 0.0, La = 0.0, pairc_all = 0.0;
+    float cPf = 0.f, cQf = 0.f, cRf = 0.f;   // the workgroup's float32 maxima (walk: from the waves' records)
     uint32_t pP = 0, pQ = 0, pR = 0;
     if (wave == 0) {
         const bool src = lane < WAVES;
         const double a0 = src ? amx[lane * 8 + 0] : 0.0, a1 = src ? amx[lane * 8 + 1] : 0.0,
                      a2 = src ? amx[lane * 8 + 2] : 0.0;
-        pairc_all = wave_sum_f64(src ? amx[lane * 8 + 6] : 0.0);
+        pairc_all = src ? amx[lane * 8 + 6] : 0.0;
         const uint32_t q0 = src ? (uint32_t)amx[lane * 8 + 3] : 0u, q1 = src ? (uint32_t)amx[lane * 8 + 4] : 0u,
                        q2 = src ? (uint32_t)amx[lane * 8 + 5] : 0u;
         M = a0; Lh = a1; La = a2;
-        wave_max3_f64(M, Lh, La);
+        static_assert(WAVES == 8, "lanes8_max3_sum: one record per wave in lanes 0..7");
+        if (!dense && src) { cPf = redm[lane * 4 + 0]; cQf = redm[lane * 4 + 1]; cRf = redm[lane * 4 + 2]; }
+        lanes8_max3_sum(M, Lh, La, pairc_all, cPf, cQf, cRf);
         const unsigned long long bP = __ballot(src && a0 == M), bQ = __ballot(src && a1 == Lh),
                                  bR = __ballot(src && a2 == La);
         pP = (uint32_t)__builtin_amdgcn_readlane((int)q0, bP ? __ffsll((long long)bP) - 1 : 0);
@@ -1393,15 +1455,7 @@ __device__ void prior_body(const EvalArgs& A, int chain, char* smem, double* zo_
         const double rho = LB + q * (UB - LB);
         // the float32 rho every streaming workgroup computed (bit for bit)
         float fP = dPf, fQ = dQf, fR = dRf;   // (separable bounds: already the workgroup's maxima)
-        if (!dense) {
-            fP = fQ = fR = 0.f;
-#pragma unroll
-            for (int wv = 0; wv < WAVES; ++wv) {
-                fP = fmaxf(fP, redm[wv * 4 + 0]);
-                fQ = fmaxf(fQ, redm[wv * 4 + 1]);
-                fR = fmaxf(fR, redm[wv * 4 + 2]);
-            }
-        }
+        if (!dense) { fP = cPf; fQ = cQf; fR = cRf; }
         const float rho_f = rho_f32(fP, fQ, fR, fs.q);
         DC_STAMP(15);
         zput(&zo[ZO_Q], q);
