@@ -236,7 +236,7 @@ __device__ __forceinline__ double* nuts_of(const EvalArgs& A, int c) { return A.
     } while (0)
 #define DC_STAMP_SEQ(k)                                                                                     \
     do {                                                                                                    \
-        if (threadIdx.x == 128 && blockIdx.x == 0 && A.debug && blockIdx.y == 0)                             \
+        if (threadIdx.x == 256 && blockIdx.x == 0 && A.debug && blockIdx.y == 0)                             \
             A.debug[(size_t)gridDim.x * 16 + (k)] = __builtin_amdgcn_s_memrealtime();                        \
     } while (0)
 #else
@@ -1133,9 +1133,15 @@ __device__ void prior_body(const EvalArgs& A, int chain, char* smem, double* zo_
     const double m = z[L.o_md];
 
     // ---- scalar priors + Jacobians (L = log density) and their gradient: one lane of wave 1,
-    // while wave 0 builds the cells below (only the team sums v[] are still missing at the end)
+    // while wave 0 builds the cells below (only the team sums v[] are still missing at the end).
+    // DEFER (small leagues: up to 384 pairs, so wave 6 holds none and wave 7 is the team-sum wave): both
+    // this chain and the cells' rounding errors -- which nothing in here reads -- move behind the cells'
+    // barrier, onto those two waves, beside the pair walk: the barrier then waits for the cells' exp
+    // alone (it waited 0.56 us for either of the two, the other waves 0.4 us for them)
+    const bool defer = sums_on_wave && 6 * 64 >= A.P;
+    const int lz_tid = defer ? 6 * 64 : 64;
     double Lz = 0.0;
-    if (tid == 64) {
+    auto scalar_priors = [&]() {
         const double zsa = z[L.o_sa], zsd = z[L.o_sd];
         Lz = sc[5] + sc[6] + 1.791759469228055 /*log 6*/ + sc[7];  // Beta(2,2) + Jac
         Lz += -0.5 * s_a * s_a - HALF_LOG_2PI + LN2 + zsa;  // HalfNormal(1) + Exp Jacobian
@@ -1165,7 +1171,16 @@ __device__ void prior_body(const EvalArgs& A, int chain, char* smem, double* zo_
         zput(&zo[ZO_SA], s_a);
         zput(&zo[ZO_SD], s_d);
         zput(&zo[ZO_SH], s_h);
-    }
+    };
+    if (!defer && tid == 64) scalar_priors();
+    // eps = log(true/table) = log1p(r), r = (true - table)/table, |r| ~ 1e-7
+    auto put_eps = [&](int j, int t, double tv) {
+        const float tabv = j == 0 ? tabH[t].x : (j == 1 ? tabA[t].x : tabH[t].y);
+        const double r = (tv - (double)tabv) / (double)tabv;
+        double e = r - 0.5 * r * r;
+        e = fabs(r) < 1e-4 ? e : 0.0;  // under/overflowed entry: no meaningful correction
+        zput(&eps[j * T + t], e);
+    };
 
     // ---- per team: constrained sites, true (float64) tables, rounding errors eps
     for (int i = tid; i < 3 * T; i += BLOCK) {
@@ -1188,14 +1203,9 @@ __device__ void prior_body(const EvalArgs& A, int chain, char* smem, double* zo_
             ha = z[L.o_mha] + s_h * z[L.o_hadec + t];
         }
         const double arg = j == 0 ? att + ha : (j == 1 ? att : -def);
-        const float tabv = j == 0 ? tabH[t].x : (j == 1 ? tabA[t].x : tabH[t].y);
         const double tv = lean::exp(arg);
         tru[j * T + t] = tv;
-        // eps = log(true/table) = log1p(r), r = (true - table)/table, |r| ~ 1e-7
-        const double r = (tv - (double)tabv) / (double)tabv;
-        double e = r - 0.5 * r * r;
-        e = fabs(r) < 1e-4 ? e : 0.0;  // under/overflowed entry: no meaningful correction
-        zput(&eps[j * T + t], e);
+        if (!defer || CLIP) put_eps(j, t, tv);   // (extended model: the team-sum wave is the longer pole already)
         if (j == 0) {
             par[t] = att;
             par[T + t] = def;
@@ -1204,6 +1214,14 @@ __device__ void prior_body(const EvalArgs& A, int chain, char* smem, double* zo_
     }
     __syncthreads();
     DC_STAMP(2);
+    if (defer) {
+        if (tid == lz_tid) scalar_priors();
+        if (!CLIP && wave == WAVES - 1)
+            for (int i = lane; i < 3 * T; i += 64) {
+                const int j = i / T, t = i - j * T;
+                put_eps(j, t, tru[i]);
+            }
+    }
 
     // ---- bounds: float32 maxima (-> rho_f32 of the streaming workgroups, same expressions as
     // pair_maxima_f32) and the true float64 maxima with their arg-pairs, in ONE pass over the
@@ -1473,7 +1491,7 @@ __device__ void prior_body(const EvalArgs& A, int chain, char* smem, double* zo_
         zput(&zo[ZO_FLAGS], (double)flags);
         zput(&zo[ZO_PAIRC], pairc_all);
     }
-    if (tid == 64) {  // what was waiting for the team sums
+    if (tid == lz_tid) {  // what was waiting for the team sums
         if (CLIP) {
             const double u = sc[9], du = sc[10];
             zput(&gz[L.o_u], -(2.0 * v[1] * du + (1.0 / u - 3.0 / (1.0 - u)) * du +
@@ -2046,13 +2064,14 @@ __device__ __forceinline__ int tail_row_of(int tid, int ncol) {
     return wave < WAVES - 1 ? min(tid, ncol - 1) : ncol + (lane & 15) * N_SCAL + (lane >> 4);
 }
 // ZL: the position already sits in the tail's LDS copy zL (persistent kernel): not loaded, not staged
-template <bool SMALLT, bool NUTS, bool ZL = false, int LNE>
-__device__ __forceinline__ void tail_preload(const EvalArgs& A, int chain, TailPre& P,
-                                             nd::LeafState<LNE>& leaf1,
-                                             double (&bigv)[nd::LEAF_STAGE_LOADS]) {
+// the data-only part (z, static sums, covariates, expected counts): a plain launch requests it at
+// kernel entry, IN FRONT of the prior part -- requested behind it, the barrier that follows waited a
+// memory round trip (0.4 us) for it with the prior record already done
+template <bool ZL = false>
+__device__ __forceinline__ void tail_preload_static(const EvalArgs& A, int chain, TailPre& P) {
     const Layout& L = A.L;
     const int T = L.T, K = L.K, D = L.D;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x;
     const int ncol = 3 * T, i = tid;
     const double* z = z_of(A, chain);
     const bool xs_staged = K > 0 && K <= 16;
@@ -2061,6 +2080,15 @@ __device__ __forceinline__ void tail_preload(const EvalArgs& A, int chain, TailP
     P.z0 = !ZL && i < D ? z[i] : 0.0;
     P.x0 = (!ZL && xs_staged && i < T * K) ? A.xs[i] : 0.0;
     P.expect = A.ga_expect[tail_row_of(tid, ncol)];
+}
+template <bool SMALLT, bool NUTS, bool ZL = false, int LNE>
+__device__ __forceinline__ void tail_preload(const EvalArgs& A, int chain, TailPre& P,
+                                             nd::LeafState<LNE>& leaf1,
+                                             double (&bigv)[nd::LEAF_STAGE_LOADS], bool static_done = false) {
+    const Layout& L = A.L;
+    const int D = L.D;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (!static_done) tail_preload_static<ZL>(A, chain, P);
     if (NUTS && SMALLT) {
         double* ns = nuts_of(A, chain);
         if (D <= 64 * LNE) {
@@ -2493,16 +2521,17 @@ __global__ DC_LAUNCH_BOUNDS void dc_eval(EvalArgs A) {
         // workgroup's own drain + ticket, 1.1 us, made it the last arriver.)
         if (NUTS && nuts_done != 0.0) return;
         const size_t tail_bytes = (acc_tail_lds_bytes(T, L.D, L.K, A.zo_stride, STAGED && NUTS) + 15) & ~(size_t)15;
+        TailPre pre;
+        tail_preload_static(A, chain, pre);
         prior_body<CLIP, true, !STAGED>(A, chain, smem + tail_bytes, reinterpret_cast<double*>(smem));
         DC_STAMP(4);
         // The tail reads its arguments from the kernarg segment again (scalar loads behind an
         // opaque pointer): kept live in SGPRs from the kernel entry they were spilled.
         // (Twice: once for the preload, once more after the wait -- the second copy comes from
         // the scalar cache, and nothing is held in SGPRs across the polling loop.)
-        TailPre pre;
         nd::LeafState<1> leaf1{};            // D <= 64: the leaf's vectors in registers (waves 4, 5)
         double bigv[nd::LEAF_STAGE_LOADS];   // D > 64: waves 4..7 stage one 64-element slice each
-        tail_preload<STAGED, NUTS>(reload_args(), chain, pre, leaf1, bigv);
+        tail_preload<STAGED, NUTS>(reload_args(), chain, pre, leaf1, bigv, true);
         if (tid == 0) *acc_tail_flag(A, smem) = 1;
         __syncthreads();
         DC_STAMP(5);
