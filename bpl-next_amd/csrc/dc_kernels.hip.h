@@ -1089,11 +1089,23 @@ __device__ void prior_body(const EvalArgs& A, int chain, char* smem, double* zo_
     double* amx = scratch + WAVES * 8;                            // [WAVES*8] argmax
 
     // ---- float32 tables and rho exactly as the streaming workgroups build them
-    uint32_t pr0 = 0;
-    double pw0[3] = {0.0, 0.0, 0.0};   // this thread's pair: sum of weights, of w x, of w y (data only)
-    if (tid < A.P) {
-        pr0 = A.pairs[tid];
-        pw0[0] = A.pairw[4 * (size_t)tid]; pw0[1] = A.pairw[4 * (size_t)tid + 1]; pw0[2] = A.pairw[4 * (size_t)tid + 2];
+    // This thread's pair(s) and their data-only sums (weights, w x, w y).  Up to BLOCK pairs sit TWO per
+    // thread on the first four waves -- consecutive pairs, so lanes and waves stay in ascending pair
+    // order (the tie rule below) -- one wave per SIMD: the walk ends in seven wave reductions, VALU
+    // bound, and with a pair per thread on eight waves two of them shared every SIMD.
+    // (Not the extended model: its walk is the heavier part -- clip branches, the clipped lanes'
+    // corrections -- and two of those per lane cost more than the shared SIMDs: 9.0 against 8.8 us.)
+    const bool two_each = !CLIP && A.P <= BLOCK;
+    const int pfirst = two_each ? 2 * tid : tid;
+    uint32_t pr0 = 0, pr1 = 0;
+    double pw0[3] = {0.0, 0.0, 0.0}, pw1[3] = {0.0, 0.0, 0.0};
+    if (pfirst < A.P) {
+        pr0 = A.pairs[pfirst];
+        pw0[0] = A.pairw[4 * (size_t)pfirst]; pw0[1] = A.pairw[4 * (size_t)pfirst + 1]; pw0[2] = A.pairw[4 * (size_t)pfirst + 2];
+    }
+    if (two_each && pfirst + 1 < A.P) {
+        pr1 = A.pairs[pfirst + 1];
+        pw1[0] = A.pairw[4 * (size_t)pfirst + 4]; pw1[1] = A.pairw[4 * (size_t)pfirst + 5]; pw1[2] = A.pairw[4 * (size_t)pfirst + 6];
     }
     // the team-sum wave (see below) requests its inputs now: its loads queue behind nothing
     const bool sums_on_wave = T <= 64;
@@ -1134,11 +1146,11 @@ __device__ void prior_body(const EvalArgs& A, int chain, char* smem, double* zo_
 
     // ---- scalar priors + Jacobians (L = log density) and their gradient: one lane of wave 1,
     // while wave 0 builds the cells below (only the team sums v[] are still missing at the end).
-    // DEFER (small leagues: up to 384 pairs, so wave 6 holds none and wave 7 is the team-sum wave): both
+    // DEFER (small leagues: wave 6 holds no pair and wave 7 is the team-sum wave): both
     // this chain and the cells' rounding errors -- which nothing in here reads -- move behind the cells'
     // barrier, onto those two waves, beside the pair walk: the barrier then waits for the cells' exp
     // alone (it waited 0.56 us for either of the two, the other waves 0.4 us for them)
-    const bool defer = sums_on_wave && 6 * 64 >= A.P;
+    const bool defer = sums_on_wave && (two_each || 6 * 64 >= A.P);
     const int lz_tid = defer ? 6 * 64 : 64;
     double Lz = 0.0;
     auto scalar_priors = [&]() {
@@ -1376,8 +1388,9 @@ __device__ void prior_body(const EvalArgs& A, int chain, char* smem, double* zo_
             }
         }
     } else {
-        if (tid < A.P) take(pr0, true, pw0[0], pw0[1], pw0[2]);
-        for (int p0 = tid + BLOCK; p0 < A.P; p0 += PAIR_BATCH * BLOCK) {  // (see pair_maxima_f32)
+        if (pfirst < A.P) take(pr0, true, pw0[0], pw0[1], pw0[2]);
+        if (two_each && pfirst + 1 < A.P) take(pr1, true, pw1[0], pw1[1], pw1[2]);
+        for (int p0 = tid + BLOCK; !two_each && p0 < A.P; p0 += PAIR_BATCH * BLOCK) {  // (see pair_maxima_f32)
             uint32_t q[PAIR_BATCH];
             double qw[PAIR_BATCH][3];
 #pragma unroll
@@ -1393,7 +1406,7 @@ __device__ void prior_body(const EvalArgs& A, int chain, char* smem, double* zo_
     if (!dense) {
         // (a wave whose lanes hold no pair -- the team-sum wave among them -- files zeros: it was the
         // last one at the barrier below, with seven reductions of nothing behind its own work)
-        const bool has_pairs = wave * 64 < A.P;
+        const bool has_pairs = wave * (two_each ? 128 : 64) < A.P;
         double wP = mP, wQ = mQ, wR = mR, wC = pairc;
         uint32_t pP = 0, pQ = 0, pR = 0;
         if (has_pairs) {
