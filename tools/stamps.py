@@ -75,7 +75,7 @@ def run_nuts(n=1_000_000):
     print("  tail WG", last, " ".join(f"{nm}={rel[last, k]:.2f}" for k, nm in [(6, "ticket"), (7, "tail:start"), (8, "tail:loads"), (9, "tail:colsums"), (14, "outputs"), (13, "leaf:prepared"), (12, "leaf:start"), (11, "moves:end"), (15, "weights:end"), (5, "published (persistent kernel)")]))
     print("  (persistent kernel: a step's record; entry = the step's start in that workgroup; tail WG entry=%.2f)" % rel[0, 0])
     pw = (buf[nwg * 16: (nwg + 1) * 16].astype(np.int64) - st[:, 0].min()) * 0.01
-    print("  prior part, wave 4 through the bounds phase (after the cells barrier | before its pair | after | before the reductions | after | records filed): " + " ".join(f"{v:.2f}" for v in pw[:6]))
+    print("  prior part, thread 0 after the bounds barrier (team sums read | records read | combined | arg-pairs | record written): " + " ".join(f"{v:.2f}" for v in pw[:5]))
     print("  prior part, per wave, arrival at the barrier that ends the bounds: " + " ".join(f"{v:.2f}" for v in pw[8:]))
     c.close()
 
