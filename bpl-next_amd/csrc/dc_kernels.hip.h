@@ -377,13 +377,9 @@ __device__ __forceinline__ float wave_max_f32(float v) {  // v >= 0
 }
 // three maxima at once, interleaved step by step (a single wave issues a dependent DPP + max only
 // every ~20 cycles)
+// (written out, fused v_max_f32_dpp: dc_wave_reduce.hip.h)
 __device__ __forceinline__ void wave_max3_f32(float& a, float& b, float& c) {  // all >= 0
-    a = fmaxf(a, dpp_f32<0xB1>(0.f, a)); b = fmaxf(b, dpp_f32<0xB1>(0.f, b)); c = fmaxf(c, dpp_f32<0xB1>(0.f, c));
-    a = fmaxf(a, dpp_f32<0x4E>(0.f, a)); b = fmaxf(b, dpp_f32<0x4E>(0.f, b)); c = fmaxf(c, dpp_f32<0x4E>(0.f, c));
-    a = fmaxf(a, dpp_f32<0x124>(0.f, a)); b = fmaxf(b, dpp_f32<0x124>(0.f, b)); c = fmaxf(c, dpp_f32<0x124>(0.f, c));
-    a = fmaxf(a, dpp_f32<0x128>(0.f, a)); b = fmaxf(b, dpp_f32<0x128>(0.f, b)); c = fmaxf(c, dpp_f32<0x128>(0.f, c));
-    a = fmaxf(a, dpp_f32<0x142, 0xA>(0.f, a)); b = fmaxf(b, dpp_f32<0x142, 0xA>(0.f, b)); c = fmaxf(c, dpp_f32<0x142, 0xA>(0.f, c));
-    a = fmaxf(a, dpp_f32<0x143, 0xC>(0.f, a)); b = fmaxf(b, dpp_f32<0x143, 0xC>(0.f, b)); c = fmaxf(c, dpp_f32<0x143, 0xC>(0.f, c));
+    wave_reduce_max3_f32_raw(a, b, c);
     a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a), 63));
     b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b), 63));
     c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c), 63));
