@@ -39,7 +39,7 @@
 
 #include "dc_layout.h"
 #include "nuts_dev.hip.h"
-#include "dc_wave_reduce.hip.h"
+#include "wave_reduce.hip.h"
 
 namespace dc {
 
@@ -377,9 +377,9 @@ __device__ __forceinline__ float wave_max_f32(float v) {  // v >= 0
 }
 // three maxima at once, interleaved step by step (a single wave issues a dependent DPP + max only
 // every ~20 cycles)
-// (written out, fused v_max_f32_dpp: dc_wave_reduce.hip.h)
+// (written out, fused v_max_f32_dpp: wave_reduce.hip.h)
 __device__ __forceinline__ void wave_max3_f32(float& a, float& b, float& c) {  // all >= 0
-    wave_reduce_max3_f32_raw(a, b, c);
+    wr::wave_reduce_max3_f32_raw(a, b, c);
     a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a), 63));
     b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b), 63));
     c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c), 63));
@@ -390,21 +390,21 @@ __device__ __forceinline__ double readlane63_f64(double v) {
     const int hi = __builtin_amdgcn_readlane((int)(x >> 32), 63);
     return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
-__device__ __forceinline__ double wave_sum_f64(double v) {
-    v += dpp_f64<0xB1>(0.0, v);
-    v += dpp_f64<0x4E>(0.0, v);
-    v += dpp_f64<0x124>(0.0, v);
-    v += dpp_f64<0x128>(0.0, v);
-    v += dpp_f64<0x142, 0xA>(0.0, v);
-    v += dpp_f64<0x143, 0xC>(0.0, v);
+__device__ __forceinline__ double wave_sum_f64(double v) {   // (written out: wave_reduce.hip.h)
+    wr::wave_reduce_sum1_f64_raw(v);
     return readlane63_f64(v);
+}
+__device__ __forceinline__ void wave_sum2_f64(double& a, double& b) {
+    wr::wave_reduce_sum2_f64_raw(a, b);
+    a = readlane63_f64(a);
+    b = readlane63_f64(b);
 }
 // four independent sums, interleaved step by step: a single wave issues a dependent DPP + add
 // only every ~20 cycles, so one sum after another leaves the pipeline three quarters empty
-// (round 3: written out in dc_wave_reduce.hip.h -- the compiler's schedule of the interleaved C++
+// (round 3: written out in wave_reduce.hip.h -- the compiler's schedule of the interleaved C++
 // serialised the four chains on one pair of temporaries)
 __device__ __forceinline__ void wave_sum4_f64(double (&v)[4]) {
-    wave_reduce_sum4_f64_raw(v[0], v[1], v[2], v[3]);
+    wr::wave_reduce_sum4_f64_raw(v[0], v[1], v[2], v[3]);
 #pragma unroll
     for (int j = 0; j < 4; ++j) v[j] = readlane63_f64(v[j]);
 }
@@ -424,7 +424,7 @@ __device__ __forceinline__ void wave_max3_f64(double& a, double& b, double& c) {
 // times six latencies, interleaved step by step they are six
 __device__ __forceinline__ void wave_bounds_reduce(float& a, float& b, float& c, double& p, double& q, double& r,
                                                    double& sum) {
-    wave_reduce_bounds_raw(a, b, c, p, q, r, sum);
+    wr::wave_reduce_bounds_raw(a, b, c, p, q, r, sum);
     a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a), 63));
     b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b), 63));
     c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c), 63));
@@ -457,7 +457,7 @@ __device__ __forceinline__ double readlane_f64(double v, int l) {
 // lanes 0..3 receive the zeros of lanes 12..15), interleaved; results from lane 4
 __device__ __forceinline__ void lanes8_max3_sum(double& p, double& q, double& r, double& sum, float& a, float& b,
                                                 float& c) {
-    lanes8_reduce_bounds_raw(a, b, c, p, q, r, sum);
+    wr::lanes8_reduce_bounds_raw(a, b, c, p, q, r, sum);
     p = readlane_f64(p, 4); q = readlane_f64(q, 4); r = readlane_f64(r, 4); sum = readlane_f64(sum, 4);
     a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a), 4));
     b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b), 4));
@@ -1246,7 +1246,8 @@ __device__ void prior_body(const EvalArgs& A, int chain, char* smem, double* zo_
     };
     if (sums_on_wave && wave == WAVES - 1) {
         if (lane < T) team_term(lane, pre[0], pre[1], pre[2], pre[3], pre[4], pre[5]);
-        const double s0 = wave_sum_f64(v[0]), s1 = wave_sum_f64(v[1]);
+        double s0 = v[0], s1 = v[1];
+        wave_sum2_f64(s0, s1);
         if (lane == 0) {
             sc[32] = s0;
             sc[33] = s1;
@@ -1613,8 +1614,7 @@ __device__ void tail_waves(const EvalArgs& A, int chain, const double* zoL, cons
         const double dec = on ? zL[o + t] : 0.0;
         if (on) put(o + t, gz[o + t] - s_d * gd);
         double sum_gd = gd, dot_d = dec * gd;
-        sum_gd = wave_sum_f64(sum_gd);
-        dot_d = wave_sum_f64(dot_d);
+        wave_sum2_f64(sum_gd, dot_d);
         if (t == 0) {
             put(L.o_md, gz[L.o_md] - sum_gd);
             put(L.o_sd, gz[L.o_sd] - s_d * dot_d);

@@ -14,6 +14,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "wave_reduce.hip.h"
+
 namespace nd {
 
 // The integrator arithmetic below must round exactly like the host driver's (nuts.hpp,
@@ -113,17 +115,21 @@ __device__ __forceinline__ double nd_dpp_add(double v) {
     const int hi = __builtin_amdgcn_update_dpp(0, (int)(x >> 32), CTRL, ROW_MASK, 0xF, false);
     return v + __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
-__device__ __forceinline__ double nd_wave_sum(double v) {
-    v = nd_dpp_add<0xB1, 0xF>(v);   // quad_perm [1,0,3,2]
-    v = nd_dpp_add<0x4E, 0xF>(v);   // quad_perm [2,3,0,1]
-    v = nd_dpp_add<0x124, 0xF>(v);  // row_ror:4
-    v = nd_dpp_add<0x128, 0xF>(v);  // row_ror:8
-    v = nd_dpp_add<0x142, 0xA>(v);  // row_bcast:15 into rows 1,3
-    v = nd_dpp_add<0x143, 0xC>(v);  // row_bcast:31 into rows 2,3
+__device__ __forceinline__ double nd_readlane63(double v) {
     const long long x = __double_as_longlong(v);
     const int lo = __builtin_amdgcn_readlane((int)x, 63);
     const int hi = __builtin_amdgcn_readlane((int)(x >> 32), 63);
     return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+// (the DPP steps written out -- wave_reduce.hip.h: no zeroed temporaries, two chains interleaved)
+__device__ __forceinline__ double nd_wave_sum(double v) {
+    wr::wave_reduce_sum1_f64_raw(v);
+    return nd_readlane63(v);
+}
+__device__ __forceinline__ void nd_wave_sum2(double& a, double& b) {
+    wr::wave_reduce_sum2_f64_raw(a, b);
+    a = nd_readlane63(a);
+    b = nd_readlane63(b);
 }
 // The tree bookkeeping below is written for a "team" of NT threads working on one chain's
 // state: one wave (NT = 64, no barriers: the leaf's wave inside dc_eval, or a 64-thread launch)
@@ -441,8 +447,7 @@ __device__ inline bool leaf_moves(double* ns, int D, int max_depth, int lane, co
             dl += S.invM[e] * c_r[e] * rsm;
             dr += S.invM[e] * r[e] * rsm;
         }
-        dl = nd_wave_sum(dl);
-        dr = nd_wave_sum(dr);
+        nd_wave_sum2(dl, dr);
         turning = (dl <= 0.0) | (dr <= 0.0);
     }
     const int new_num = num + 1;
@@ -566,8 +571,7 @@ __device__ inline bool leaf_moves_staged(double* ns, int D, int max_depth, int l
     }
     bool turning = false;
     if (cmp) {
-        dl = nd_wave_sum(dl);
-        dr = nd_wave_sum(dr);
+        nd_wave_sum2(dl, dr);
         turning = (dl <= 0.0) | (dr <= 0.0);
     }
     for (int ci = idx_max - 1; ci >= idx_min && !turning; --ci) {  // deeper levels: from memory
@@ -580,8 +584,7 @@ __device__ inline bool leaf_moves_staged(double* ns, int D, int max_depth, int l
             dl += s_invM[i] * c_r * rsm;
             dr += s_invM[i] * r * rsm;
         }
-        dl = nd_wave_sum(dl);
-        dr = nd_wave_sum(dr);
+        nd_wave_sum2(dl, dr);
         turning = (dl <= 0.0) | (dr <= 0.0);
     }
     const int new_num = num + 1;
@@ -1171,8 +1174,7 @@ struct GridTeam {
     __device__ __forceinline__ void sync() { barrier(); }
     __device__ __forceinline__ void readers_done() { barrier(); }
     __device__ __forceinline__ void sum2(double& a, double& b) {
-        a = nd_wave_sum(a);
-        b = nd_wave_sum(b);
+        nd_wave_sum2(a, b);
         __syncthreads();   // (scr may still be read from the previous sum)
         if ((tid & 63) == 0) { scr[2 * (tid >> 6)] = a; scr[2 * (tid >> 6) + 1] = b; }
         __syncthreads();
@@ -1299,8 +1301,7 @@ __global__ __launch_bounds__(KW_NTB) void kw_leaf(double* ns_all, size_t stride,
             dl += e.im * c_r * rsm;
             dr += e.im * r * rsm;
         }
-        dl = nd_wave_sum(dl);
-        dr = nd_wave_sum(dr);
+        nd_wave_sum2(dl, dr);
         if (lane == 0) { red[wave][1 + 2 * l] = dl; red[wave][2 + 2 * l] = dr; }
     }
     __syncthreads();
