@@ -2676,8 +2676,8 @@ __global__ DC_LAUNCH_BOUNDS void dc_eval(EvalArgs A) {
             long long* ga = A.gacc + (size_t)chain * 2 * ga_set_words(T);
             for (int k = o0 + tid; k < o1; k += BLOCK) {
                 const int slot = k == o0 + tid ? slot0 : A.wg_slots[k];
-                const int which = slot / T, t = slot - which * T;
-                ga_add(ga + (size_t)slot * GA_ROW, acc[which * T1 + t]);
+                const int which = (slot >= T) + (slot >= 2 * T);   // (0 <= slot < 3T; acc is [3][T + 1]: no division)
+                ga_add(ga + (size_t)slot * GA_ROW, acc[slot + which]);
             }
             if (tid >= BLOCK - N_SCAL) {  // (the last wave: the slot lanes are the first ones)
                 const int k = tid - (BLOCK - N_SCAL);
@@ -3001,8 +3001,8 @@ __global__ DC_LAUNCH_BOUNDS void dc_eval_loop(EvalArgs A) {
             long long* ga = ga0 + (size_t)(s & 1) * ga_set_words(T);   // (the rows alternate by step parity)
             for (int k = o0 + tid; k < o1; k += BLOCK) {
                 const int slot = k == o0 + tid ? slot0 : A.wg_slots[k];
-                const int which = slot / T, t = slot - which * T;
-                ga_add(ga + (size_t)slot * GA_ROW, acc[which * T1 + t]);
+                const int which = (slot >= T) + (slot >= 2 * T);   // (0 <= slot < 3T; acc is [3][T + 1]: no division)
+                ga_add(ga + (size_t)slot * GA_ROW, acc[slot + which]);
             }
             if (tid >= BLOCK - N_SCAL) {
                 const int k = tid - (BLOCK - N_SCAL);
