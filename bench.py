@@ -267,7 +267,8 @@ def main():
     # the warm-up goes through the SAME bracket as the timed steps (the first query, the first
     # synchronize after a record: one-off host costs that are not the path's).  At --steps 20 the
     # region was 178 us for 134 us of kernels; rehearsed 168, with the events created and the
-    # arguments marshalled outside it 162 (what is left is hipGraphLaunch reaching an idle GPU)
+    # arguments marshalled outside it 162 (what is left -- ~25 us -- is hipGraphLaunch reaching an
+    # idle GPU and the host seeing the end event)
     if args.warmup:
         bracket(args.warmup)
     wall, ev_ms = bracket(args.steps)
@@ -363,7 +364,7 @@ def main():
                                  "duration plus the dependent-launch gap; rocprofv3's per-kernel average "
                                  "(profiles/r03/kernels.md) is the duration alone",
                 "regime": "latency bound at this size (an empty kernel in the same graph is 2.06 us of the "
-                          "~6.7 us launch); the same kernel reaches ~80% of peak at N=1e7 and ~197% "
+                          "~5.9 us launch); the same kernel reaches ~83% of peak at N=1e7 and ~205% "
                           "(algorithmic) at N=1e8: profiles/r03/n_sweep.txt",
             },
         }
