@@ -2814,17 +2814,15 @@ __global__ DC_LAUNCH_BOUNDS void dc_eval_loop(EvalArgs A) {
             // and an invalidate made the kernel-argument reloads below miss, 0.3 us per step; the one
             // path that reads state with uniform addresses, the chain advance, invalidates for itself)
             if (tid == 0) *acc_tail_flag(A, smem) = 1;   // (in front of the prior part's first barrier)
-            TailPre pre;
-            nd::LeafState<LNE> leaf1{};
-            double bigv[nd::LEAF_STAGE_LOADS];
-            // LNE == 1: the leaf's state (written by the previous step's leaf, a barrier ago) is requested
-            // NOW and rides through the prior part in registers -- requested behind it, the barrier below
-            // waited 0.3 us for it with the rows filling up unobserved.  (LNE == 2 has no registers to spare.)
-            if (LNE == 1) tail_preload<STAGED, NUTS, true>(reload_args(), chain, pre, leaf1, bigv);
             prior_body<CLIP, true, false, true>(A, chain, smem + tail_bytes, reinterpret_cast<double*>(smem), zL, cL,
                                                 xs_staged ? xsL : nullptr);
             DC_STAMP(4);
-            if (LNE != 1) tail_preload<STAGED, NUTS, true>(reload_args(), chain, pre, leaf1, bigv);
+            TailPre pre;
+            nd::LeafState<LNE> leaf1{};
+            double bigv[nd::LEAF_STAGE_LOADS];
+            // (requesting the leaf's state in FRONT of the prior part, so that the barrier below has nothing to
+            // wait for, was measured neutral -- +1 % at N = 1e6, -1.5 % at 1e5 -- for 20 more registers)
+            tail_preload<STAGED, NUTS, true>(reload_args(), chain, pre, leaf1, bigv);
             __syncthreads();
             DC_STAMP(6);
             const bool last = s + 1 == steps;
