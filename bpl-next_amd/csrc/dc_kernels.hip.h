@@ -366,13 +366,8 @@ __device__ __forceinline__ void wave_sum2_f32(float& a, float& b) {
 __device__ __forceinline__ uint32_t prev_lane_u32(uint32_t v, uint32_t fill) {
     return (uint32_t)dpp_i32<0x138>((int)fill, (int)v);
 }
-__device__ __forceinline__ float wave_max_f32(float v) {  // v >= 0
-    v = fmaxf(v, dpp_f32<0xB1>(0.f, v));
-    v = fmaxf(v, dpp_f32<0x4E>(0.f, v));
-    v = fmaxf(v, dpp_f32<0x124>(0.f, v));
-    v = fmaxf(v, dpp_f32<0x128>(0.f, v));
-    v = fmaxf(v, dpp_f32<0x142, 0xA>(0.f, v));
-    v = fmaxf(v, dpp_f32<0x143, 0xC>(0.f, v));
+__device__ __forceinline__ float wave_max_f32(float v) {  // v >= 0  (written out: wave_reduce.hip.h)
+    wr::wave_reduce_max1_f32_raw(v);
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 // three maxima at once, interleaved step by step (a single wave issues a dependent DPP + max only
@@ -503,13 +498,8 @@ __device__ __forceinline__ void row_sum_f64(double (&v)[NV]) {
 #pragma unroll
     for (int j = 0; j < NV; ++j) v[j] += dpp_f64<0x128>(0.0, v[j]);
 }
-__device__ __forceinline__ double wave_max_f64(double v) {  // v >= 0
-    v = fmax(v, dpp_f64<0xB1>(0.0, v));
-    v = fmax(v, dpp_f64<0x4E>(0.0, v));
-    v = fmax(v, dpp_f64<0x124>(0.0, v));
-    v = fmax(v, dpp_f64<0x128>(0.0, v));
-    v = fmax(v, dpp_f64<0x142, 0xA>(0.0, v));
-    v = fmax(v, dpp_f64<0x143, 0xC>(0.0, v));
+__device__ __forceinline__ double wave_max_f64(double v) {  // v >= 0  (written out: wave_reduce.hip.h)
+    wr::wave_reduce_max1_f64_raw(v);
     return readlane63_f64(v);
 }
 
@@ -642,6 +632,18 @@ __device__ __forceinline__ void ga_load2(const long long* row_a, const long long
                  : "=&v"(va), "=&v"(vb) : "v"(row_a), "v"(row_b) : "memory");
     a->lo = va.x; a->hi = va.y;
     b->lo = vb.x; b->hi = vb.y;
+}
+// four rows in ONE round trip (larger leagues: a thread of the tail takes several rows; one after the
+// other they were a memory round trip each)
+__device__ __forceinline__ void ga_load4(const long long* r0, const long long* r1, const long long* r2,
+                                         const long long* r3, GaWords (&w)[4]) {
+    typedef long long i64x2 __attribute__((ext_vector_type(2)));
+    i64x2 v0, v1, v2, v3;
+    asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %5, off sc1\n\t"
+                 "global_load_dwordx4 %2, %6, off sc1\n\tglobal_load_dwordx4 %3, %7, off sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3) : "v"(r0), "v"(r1), "v"(r2), "v"(r3) : "memory");
+    w[0].lo = v0.x; w[0].hi = v0.y; w[1].lo = v1.x; w[1].hi = v1.y;
+    w[2].lo = v2.x; w[2].hi = v2.y; w[3].lo = v3.x; w[3].hi = v3.y;
 }
 __device__ __forceinline__ int ga_count(const GaWords& w) { return (int)((unsigned long long)w.lo >> GA_COUNT_SHIFT); }
 __device__ __forceinline__ bool ga_is_zero(const GaWords& w) { return (w.lo | w.hi) == 0; }
@@ -2161,21 +2163,42 @@ __device__ __forceinline__ bool tail_acc(const EvalArgs& A, int chain, char* sme
         GaWords w0;
         const size_t ro = (size_t)tail_row_of(tid, ncol) * GA_ROW;
         // (persistent kernel: the next step's rows, re-armed one step ago, must read all zero too)
-        bool ok = ga_take_row(ga + ro, P.expect, &w0,
+        // (larger leagues: a team-row thread takes its first row with the others, in one round trip)
+        const bool batched = !SMALLT && !check_other && wave < WAVES - 1 && ncol > ROW_THREADS;
+        bool ok = batched ||
+                  ga_take_row(ga + ro, P.expect, &w0,
                               check_other ? A.gacc + ((size_t)chain * 2 + (set ^ 1)) * ga_set_words(T) + ro : nullptr);
         if (!ZL && i < ncol) cL[i] = P.c0;
         if (!ZL && i < D) zL[i] = P.z0;
         if (!ZL && xs_staged && i < T * K) xsL[i] = P.x0;
         if (wave < WAVES - 1) {
-            if (i < ncol) col[i] = ga_value(w0);
-            // larger models: the remaining team rows, one round per pass
-            // (wave-uniform trip count: ga_take_row ballots; lanes past the last row poll it again)
-            for (int b0 = (tid & ~63) + ROW_THREADS; b0 < ncol; b0 += ROW_THREADS) {
-                const int i2 = b0 + lane;
-                GaWords w;
-                const int r = min(i2, ncol - 1);
-                ok = ga_take_row(ga + (size_t)r * GA_ROW, A.ga_expect[r], &w) && ok;
-                if (i2 < ncol) col[i2] = ga_value(w);
+            if (!batched && i < ncol) col[i] = ga_value(w0);
+            // larger models: the remaining team rows, FOUR per thread and poll in flight together
+            // (wave-uniform trip count: the polls ballot; lanes past the last row poll it again)
+            for (int b0 = (tid & ~63) + (batched ? 0 : ROW_THREADS); b0 < ncol; b0 += 4 * ROW_THREADS) {
+                int r[4], ex[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    r[k] = min(b0 + k * ROW_THREADS + lane, ncol - 1);
+                    ex[k] = A.ga_expect[r[k]];
+                }
+                GaWords w[4];
+                bool got = false;
+                for (int spin = 0; spin < ARRIVE_SPIN_LIMIT; ++spin) {
+                    ga_load4(ga + (size_t)r[0] * GA_ROW, ga + (size_t)r[1] * GA_ROW, ga + (size_t)r[2] * GA_ROW,
+                             ga + (size_t)r[3] * GA_ROW, w);
+                    const bool mine = ga_count(w[0]) == ex[0] && ga_count(w[1]) == ex[1] && ga_count(w[2]) == ex[2] &&
+                                      ga_count(w[3]) == ex[3];
+                    got = __ballot(!mine) == 0ull;
+                    if (got) break;
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                ok = got && ok;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int i2 = b0 + k * ROW_THREADS + lane;
+                    if (i2 < ncol) col[i2] = ga_value(w[k]);
+                }
             }
         } else {  // scalar rows: sum the shards (16-lane rows; a flagged shard is -inf / NaN and stays so)
             double v = ga_value(w0);

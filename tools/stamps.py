@@ -40,6 +40,9 @@ def run(n, model=MODEL_BASIC, max_wg=255, k=0, weighted=False):
     last = int(np.argmax(st[:, 10]))
     print("  tail WG", last, " ".join(f"{names[k]}={rel[last, k]:.2f}" for k in range(11)),
           f"epi:sums={rel[last, 11]:.2f} epi:puts={rel[last, 14]:.2f}")
+    pw = (buf[nwg * 16: (nwg + 1) * 16].astype(np.int64) - t0) * 0.01
+    print("  prior part, per wave, arrival at the barrier that ends the bounds: " + " ".join(f"{v:.2f}" for v in pw[8:]))
+    print("  seq (thread 0): " + " ".join(f"{v:.2f}" for v in pw[:4]))
     c.close()
 
 def run_nuts(n=1_000_000):
@@ -77,6 +80,7 @@ def run_nuts(n=1_000_000):
     pw = (buf[nwg * 16: (nwg + 1) * 16].astype(np.int64) - st[:, 0].min()) * 0.01
     print("  prior part, thread 0 after the bounds barrier (team sums read | records read | combined | arg-pairs | record written): " + " ".join(f"{v:.2f}" for v in pw[:5]))
     print("  prior part, per wave, arrival at the barrier that ends the bounds: " + " ".join(f"{v:.2f}" for v in pw[8:]))
+    print("  seq (thread 0): " + " ".join(f"{v:.2f}" for v in pw[:4]))
     c.close()
 
 if len(sys.argv) > 1 and sys.argv[1] == "nuts":
