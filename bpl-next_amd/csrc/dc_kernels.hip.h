@@ -404,13 +404,8 @@ __device__ __forceinline__ void wave_sum4_f64(double (&v)[4]) {
     for (int j = 0; j < 4; ++j) v[j] = readlane63_f64(v[j]);
 }
 // three maxima at once, interleaved step by step
-__device__ __forceinline__ void wave_max3_f64(double& a, double& b, double& c) {  // all >= 0
-    a = fmax(a, dpp_f64<0xB1>(0.0, a)); b = fmax(b, dpp_f64<0xB1>(0.0, b)); c = fmax(c, dpp_f64<0xB1>(0.0, c));
-    a = fmax(a, dpp_f64<0x4E>(0.0, a)); b = fmax(b, dpp_f64<0x4E>(0.0, b)); c = fmax(c, dpp_f64<0x4E>(0.0, c));
-    a = fmax(a, dpp_f64<0x124>(0.0, a)); b = fmax(b, dpp_f64<0x124>(0.0, b)); c = fmax(c, dpp_f64<0x124>(0.0, c));
-    a = fmax(a, dpp_f64<0x128>(0.0, a)); b = fmax(b, dpp_f64<0x128>(0.0, b)); c = fmax(c, dpp_f64<0x128>(0.0, c));
-    a = fmax(a, dpp_f64<0x142, 0xA>(0.0, a)); b = fmax(b, dpp_f64<0x142, 0xA>(0.0, b)); c = fmax(c, dpp_f64<0x142, 0xA>(0.0, c));
-    a = fmax(a, dpp_f64<0x143, 0xC>(0.0, a)); b = fmax(b, dpp_f64<0x143, 0xC>(0.0, b)); c = fmax(c, dpp_f64<0x143, 0xC>(0.0, c));
+__device__ __forceinline__ void wave_max3_f64(double& a, double& b, double& c) {  // all >= 0  (wave_reduce.hip.h)
+    wr::wave_reduce_max3_f64_raw(a, b, c);
     a = readlane63_f64(a); b = readlane63_f64(b); c = readlane63_f64(c);
 }
 
@@ -470,6 +465,12 @@ __device__ __forceinline__ double wave_suffix_dpp_f64(double v, int lane) {
 // NV independent sums, interleaved step by step like wave_sum4_f64
 template <int NV>
 __device__ __forceinline__ void wave_sumN_f64(double (&v)[NV]) {
+    if constexpr (NV == 2) {   // (written out: wave_reduce.hip.h)
+        wr::wave_reduce_sum2_f64_raw(v[0], v[1]);
+        v[0] = readlane63_f64(v[0]);
+        v[1] = readlane63_f64(v[1]);
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < NV; ++j) v[j] += dpp_f64<0xB1>(0.0, v[j]);
 #pragma unroll
@@ -489,6 +490,10 @@ __device__ __forceinline__ void wave_sumN_f64(double (&v)[NV]) {
 // quad_perm, quad_perm, row_ror:4, row_ror:8 -- four steps, no cross-row traffic
 template <int NV>
 __device__ __forceinline__ void row_sum_f64(double (&v)[NV]) {
+    if constexpr (NV == 6) {   // (written out: wave_reduce.hip.h)
+        wr::row_reduce_sum6_f64_raw(v[0], v[1], v[2], v[3], v[4], v[5]);
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < NV; ++j) v[j] += dpp_f64<0xB1>(0.0, v[j]);
 #pragma unroll
