@@ -1785,8 +1785,12 @@ static bool leaf_in_tail(const bplhip_ctx* c) {
     return !c->neutral && !c->dynamic && c->L.T <= 64 && staged && c->L.D <= 64 * nd::LEAF_NE_MAX;
 }
 // persistent chains keep all momentum draws of a run on the device: [C][n_iter][D] doubles
+// ... and the wide leaf's grid row (kw_leaf: its workgroups poll each other's records and, when a
+// subtree is complete, meet at row barriers) must fit the device at once.  Workgroups are dispatched in
+// order, so a row never waits for a later one -- but a row that does not fit would wait for itself.
 static bool persistent_fits(const bplhip_ctx* c, const bplhip_nuts_cfg* cfg, int C) {
     const double bytes = (double)C * (cfg->num_warmup + cfg->num_samples) * bplhip_latent_dim(c) * 8.0;
+    if (nd::kw_workgroups(bplhip_latent_dim(c), nd::KW_NTB) > c->n_cu) return false;
     return bytes <= 16.0 * 1024 * 1024 * 1024;
 }
 
