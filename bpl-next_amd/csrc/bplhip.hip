@@ -2507,6 +2507,13 @@ static int predict_score_grid_any(bplhip_ctx* c, const char* what, bool venue, i
     }
     dcp::GridArgs A{};
     for (int k = 0; k < 64; ++k) A.rk[k] = (float)(1.0 / ((double)k + 1.0));  // the constants of the pmf recurrence
+    {
+        double fct = 1.0;
+        for (int k = 0; k < 16; ++k) {
+            A.rfact[k] = 1.0 / fct;
+            fct *= (double)(k + 1);
+        }
+    }
     A.S = c->pred_S;
     A.T = c->pred_T;
     A.attack = c->dp_tab32[PT_ATT].as<const float>();

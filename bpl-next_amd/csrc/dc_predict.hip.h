@@ -137,6 +137,7 @@ struct GridArgs {
     const uint16_t* ac;
     double* out;             // [M, G+1, G+1]
     float rk[64];            // 1 / (k + 1): by value, i.e. in the kernarg segment -- wave-uniform scalar loads
+    double rfact[16];        // 1 / k!, k < 16 (the first tile's cells are scaled at the end)
 };
 constexpr int GRID_MAX_GOALS = 63;
 constexpr int GRID_WAVES = 4;
@@ -180,17 +181,22 @@ __global__ __launch_bounds__(64 * GRID_WAVES) void predict_score_grid(GridArgs A
     // LOADED until the block is worked on: combining them here would make the wave wait for the
     // loads it has just issued, i.e. no prefetch at all.
     struct Raw { float ah, aa, dh, da, ha, rho, v0, v1, v2, v3, ch, ca; };
+    // (uniform base + ONE 32-bit byte offset per lane: the loads take the scalar-base form and share
+    // their address register -- six 64-bit address computations per block otherwise)
+    auto at = [](const float* base, unsigned int boff) {
+        return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + boff);
+    };
     auto load_raw = [&](int s0) {
-        const int s = min(s0 + lane, S - 1);
+        const unsigned int b = (unsigned int)min(s0 + lane, S - 1) * 4u;
         Raw r{};
-        r.ah = att_h[s]; r.aa = att_a[s]; r.dh = def_h[s]; r.da = def_a[s];
+        r.ah = at(att_h, b); r.aa = at(att_a, b); r.dh = at(def_h, b); r.da = at(def_a, b);
         if constexpr (VENUE) {
-            r.v0 = hat_h[s]; r.v1 = adf_a[s]; r.v2 = aat_a[s]; r.v3 = hdf_h[s];
-            if (cf_h) { r.ch = cf_h[s]; r.ca = cf_a[s]; }
+            r.v0 = at(hat_h, b); r.v1 = at(adf_a, b); r.v2 = at(aat_a, b); r.v3 = at(hdf_h, b);
+            if (cf_h) { r.ch = at(cf_h, b); r.ca = at(cf_a, b); }
         } else {
-            r.ha = ha_p[s];
+            r.ha = at(ha_p, b);
         }
-        r.rho = A.corr[s];
+        r.rho = at(A.corr, b);
         return r;
     };
     // log-rates of a draw
@@ -220,6 +226,9 @@ __global__ __launch_bounds__(64 * GRID_WAVES) void predict_score_grid(GridArgs A
 #pragma unroll
             for (int k = 0; k < 16; ++k) inv[k] = f32x2{rk[min(x0 + k, GRID_MAX_GOALS)], rk[min(y0 + k, GRID_MAX_GOALS)]};
             double accd[4] = {0.0, 0.0, 0.0, 0.0};
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};   // float32 over FOLD blocks of 64 draws, then folded into accd
+            constexpr int FOLD = 4;
+            int in_acc = 0;
             // this lane's draws: tau corrections (float32 over the <= S / 64 blocks of a lane: each
             // term is at most a cell's own size, the rounding of the sum 1e-7 of it)
             float c00 = 0.f, c01 = 0.f, c10 = 0.f, c11 = 0.f;
@@ -254,11 +263,23 @@ __global__ __launch_bounds__(64 * GRID_WAVES) void predict_score_grid(GridArgs A
                             if (k < y0) p.y *= step.y;
                         }
                     }
+                    if (low_tile) {
+                        // the first tile carries e^-rate rate^k WITHOUT the 1 / k! (one v_pk_mul_f32 per goal
+                        // count for both vectors instead of two); 1 / (x! y!) multiplies the finished cell.
+                        // e^-r r^k <= 1.3e11 for k <= 15 and any r: no overflow, products included.
 #pragma unroll
-                    for (int k = 0; k < 16; ++k) {
-                        stH[k * GRID_ROW + lane] = p.x;
-                        stA[k * GRID_ROW + lane] = p.y;
-                        p *= rate * inv[k];    // two v_pk_mul_f32 for both vectors
+                        for (int k = 0; k < 16; ++k) {
+                            stH[k * GRID_ROW + lane] = p.x;
+                            stA[k * GRID_ROW + lane] = p.y;
+                            p *= rate;
+                        }
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 16; ++k) {
+                            stH[k * GRID_ROW + lane] = p.x;
+                            stA[k * GRID_ROW + lane] = p.y;
+                            p *= rate * inv[k];    // two v_pk_mul_f32 for both vectors
+                        }
                     }
                 }
                 // lane = (goal count, draw group): this lane's 16 draws of row i, then 16 rank-4 updates
@@ -269,12 +290,19 @@ __global__ __launch_bounds__(64 * GRID_WAVES) void predict_score_grid(GridArgs A
                     ah[q] = *reinterpret_cast<const f32x4*>(stH + i * GRID_ROW + 16 * d + 4 * q);
                     aa[q] = *reinterpret_cast<const f32x4*>(stA + i * GRID_ROW + 16 * d + 4 * q);
                 }
-                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int g = 0; g < 16; ++g)
                     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[g >> 2][g & 3], aa[g >> 2][g & 3], acc, 0, 0, 0);
+                if (++in_acc == FOLD || s0 + 64 >= S) {   // (reading the accumulator waits for the matrix pipe)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) accd[j] += (double)acc[j];   // 64 draws per float32 accumulation
+                    for (int j = 0; j < 4; ++j) accd[j] += (double)acc[j];
+                    acc = f32x4{0.f, 0.f, 0.f, 0.f};
+                    in_acc = 0;
+                }
+            }
+            if (low_tile) {   // the factorials the first tile left out: cell (x, y) = (4 d + j, i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) accd[j] *= A.rfact[4 * d + j] * A.rfact[i];
             }
             if (low_tile) {
                 double c4[4] = {(double)c00, (double)c01, (double)c10, (double)c11};
