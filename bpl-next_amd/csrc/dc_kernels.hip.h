@@ -1433,15 +1433,21 @@ __device__ void prior_body(const EvalArgs& A, int chain, char* smem, double* zo_
     float cPf = 0.f, cQf = 0.f, cRf = 0.f;   // the workgroup's float32 maxima (walk: from the waves' records)
     uint32_t pP = 0, pQ = 0, pR = 0;
     if (wave == 0) {
+        // (unconditional reads of a clamped record, then selects: behind `src ? ... : 0` every read sat in
+        // its own exec-masked block with its own wait)
         const bool src = lane < WAVES;
-        const double a0 = src ? amx[lane * 8 + 0] : 0.0, a1 = src ? amx[lane * 8 + 1] : 0.0,
-                     a2 = src ? amx[lane * 8 + 2] : 0.0;
-        pairc_all = src ? amx[lane * 8 + 6] : 0.0;
-        const uint32_t q0 = src ? (uint32_t)amx[lane * 8 + 3] : 0u, q1 = src ? (uint32_t)amx[lane * 8 + 4] : 0u,
-                       q2 = src ? (uint32_t)amx[lane * 8 + 5] : 0u;
+        const double* rec = amx + (src ? lane : 0) * 8;
+        const double r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3], r4 = rec[4], r5 = rec[5], r6 = rec[6];
+        const double a0 = src ? r0 : 0.0, a1 = src ? r1 : 0.0, a2 = src ? r2 : 0.0;
+        pairc_all = src ? r6 : 0.0;
+        const uint32_t q0 = src ? (uint32_t)r3 : 0u, q1 = src ? (uint32_t)r4 : 0u, q2 = src ? (uint32_t)r5 : 0u;
         M = a0; Lh = a1; La = a2;
         static_assert(WAVES == 8, "lanes8_max3_sum: one record per wave in lanes 0..7");
-        if (!dense && src) { cPf = redm[lane * 4 + 0]; cQf = redm[lane * 4 + 1]; cRf = redm[lane * 4 + 2]; }
+        if (!dense) {
+            const float* rf = redm + (src ? lane : 0) * 4;
+            const float f0 = rf[0], f1 = rf[1], f2 = rf[2];
+            cPf = src ? f0 : 0.f; cQf = src ? f1 : 0.f; cRf = src ? f2 : 0.f;
+        }
         lanes8_max3_sum(M, Lh, La, pairc_all, cPf, cQf, cRf);
         const unsigned long long bP = __ballot(src && a0 == M), bQ = __ballot(src && a1 == Lh),
                                  bR = __ballot(src && a2 == La);
@@ -1458,8 +1464,11 @@ __device__ void prior_body(const EvalArgs& A, int chain, char* smem, double* zo_
             if (tru[T + (pR >> 16)] * tru[2 * T + (pR & 0xFFFFu)] > RATE_CLIP) flags |= 8u;
         }
         DC_STAMP(13);
-        const double UB = M > 1.0 ? 1.0 / M : 1.0;
-        const double LB = -1.0 / fmax(Lh, La);
+        // (lean::rcp: estimate + two Newton steps, a third of a float64 division's dependent chain; the
+        // division itself where the operand is not an ordinary number)
+        auto inv = [](double x) { return x > 1e-300 && x < 1e300 ? lean::rcp(x) : 1.0 / x; };
+        const double UB = M > 1.0 ? inv(M) : 1.0;
+        const double LB = -inv(fmax(Lh, La));
         const double rho = LB + q * (UB - LB);
         // the float32 rho every streaming workgroup computed (bit for bit)
         float fP = dPf, fQ = dQf, fR = dRf;   // (separable bounds: already the workgroup's maxima)
@@ -1552,36 +1561,31 @@ __device__ void tail_waves(const EvalArgs& A, int chain, const double* zoL, cons
     // (waves COV_WAVE_A / COV_WAVE_D, otherwise idle, take the covariate coefficients: they
     // rebuild the attack / defence adjoint themselves and run beside waves 0..3)
     const bool cov_a = K > 0 && wave == COV_WAVE_A, cov_d = K > 0 && wave == COV_WAVE_D;
-    if (A.P > 0 && (wave < 3 || cov_a || cov_d)) {
+    {   // (every record word read up front, then selects: with the reads inside the branches each one was
+        // waited for on its own -- 0.5 us at the head of every epilogue wave)
         const double M = zoL[ZO_M], Lh = zoL[ZO_LH], La = zoL[ZO_LA];
-        const uint32_t pP = (uint32_t)zoL[ZO_PP], pQ = (uint32_t)zoL[ZO_PQ],
-                       pR = (uint32_t)zoL[ZO_PR];
-        const unsigned int flags = (unsigned int)zoL[ZO_FLAGS];
-        if (M > 1.0) {
-            const double v = G_rho * q * (-UB);
+        const double fP = zoL[ZO_PP], fQ = zoL[ZO_PQ], fR = zoL[ZO_PR], fF = zoL[ZO_FLAGS];
+        const bool use = A.P > 0 && (wave < 3 || cov_a || cov_d);
+        const uint32_t pP = (uint32_t)fP, pQ = (uint32_t)fQ, pR = (uint32_t)fR;
+        const unsigned int flags = (unsigned int)fF;
+        {
+            const double v = use && M > 1.0 ? G_rho * q * (-UB) : 0.0;
             const int h = pP & 0xFFFFu, a = pP >> 16;
-            if (!(flags & 1u)) {
-                if (t == h) { ja += v; jh += v; }
-                if (t == a) jd -= v;
-            }
-            if (!(flags & 2u)) {
-                if (t == a) ja += v;
-                if (t == h) jd -= v;
-            }
+            const double v1 = (flags & 1u) ? 0.0 : v, v2 = (flags & 2u) ? 0.0 : v;
+            ja += (t == h ? v1 : 0.0) + (t == a ? v2 : 0.0);
+            jh += t == h ? v1 : 0.0;
+            jd -= (t == a ? v1 : 0.0) + (t == h ? v2 : 0.0);
         }
-        const double v = G_rho * (1.0 - q) * (-LB);
-        if (Lh >= La) {
-            const int h = pQ & 0xFFFFu, a = pQ >> 16;
-            if (!(flags & 4u)) {
-                if (t == h) { ja += v; jh += v; }
-                if (t == a) jd -= v;
-            }
-        } else {
-            const int h = pR & 0xFFFFu, a = pR >> 16;
-            if (!(flags & 8u)) {
-                if (t == a) ja += v;
-                if (t == h) jd -= v;
-            }
+        {
+            const double v = use ? G_rho * (1.0 - q) * (-LB) : 0.0;
+            const bool lb_home = Lh >= La;
+            const uint32_t pL = lb_home ? pQ : pR;
+            const int h = pL & 0xFFFFu, a = pL >> 16;
+            const double vv = (flags & (lb_home ? 4u : 8u)) ? 0.0 : v;
+            // home rate: attack + home advantage of h, defence of a; away rate: attack of a, defence of h
+            ja += lb_home ? (t == h ? vv : 0.0) : (t == a ? vv : 0.0);
+            jh += lb_home && t == h ? vv : 0.0;
+            jd -= lb_home ? (t == a ? vv : 0.0) : (t == h ? vv : 0.0);
         }
     }
     const bool basic = !EXT;
