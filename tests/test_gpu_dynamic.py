@@ -140,6 +140,42 @@ def test_dynamic_chain_on_device_matches_host_tree(hip_ctx):
     assert np.isfinite(d).all() and st["total_divergences"] <= 2 and 0.5 < st["mean_accept_prob"] <= 1.0
 
 
+def test_dynamic_wide_leaf_row_of_workgroups(hip_ctx):
+    """A latent vector long enough for SEVERAL workgroups per chain in the wide leaf (kw_leaf: tagged
+    partial records polled across the grid row; the whole row advances the chain behind row barriers):
+    same trees and draws as the host tree engine, two chains side by side, adaptation included."""
+    from bpl._ffi import default_nuts_cfg
+
+    T, G, n = 40, 16, 1500
+    rs = np.random.RandomState(13)
+    h = rs.randint(0, T, n)
+    a = (h + 1 + rs.randint(0, T - 1, n)) % T
+    fx = DO.DynFixtures(h, a, rs.poisson(1.5, n), rs.poisson(1.2, n), np.sort(rs.randint(0, G, n)),
+                        (rs.rand(n) < 0.1).astype(int), T, G)
+    hip_ctx.set_fixtures_dynamic(fx.home_idx, fx.away_idx, fx.home_goals, fx.away_goals, fx.gameweek,
+                                 fx.neutral, T, G)
+    assert hip_ctx.dim > 2 * 2048   # (at least three workgroups of 1024 threads, two elements each)
+    cfg = default_nuts_cfg()
+    cfg.num_warmup, cfg.num_samples, cfg.step_size, cfg.max_tree_depth = 0, 5, 0.01, 5
+    z0 = np.random.RandomState(5).uniform(-0.05, 0.05, hip_ctx.dim)
+    hip_ctx.set_option("device_nuts", 0)
+    try:
+        d0, s0 = hip_ctx.nuts_run(cfg, (0, 11), z0)
+    finally:
+        hip_ctx.set_option("device_nuts", 1)
+    d1, s1 = hip_ctx.nuts_run(cfg, (0, 11), z0)
+    assert s0["total_leapfrogs"] > 30
+    assert s1["num_steps"].tolist() == s0["num_steps"].tolist()
+    assert np.abs(d1[:2] - d0[:2]).max() < 1e-9 and np.abs(d1 - d0).max() < 1e-4
+    # two chains side by side (one grid row each), still without adaptation: each is the chain it is alone
+    res = hip_ctx.nuts_run_chains(cfg, [(0, 11), (0, 12)], z0=np.stack([z0, z0]))
+    assert np.abs(res[0][0] - d1).max() < 1e-6 and res[0][1]["num_steps"].tolist() == s1["num_steps"].tolist()
+    # adaptation (dual averaging, Welford mass matrix, window ends) through the grid-row team
+    cfg.num_warmup, cfg.num_samples, cfg.step_size, cfg.max_tree_depth = 80, 10, 1.0, 6
+    d, st = hip_ctx.nuts_run(cfg, (0, 31))
+    assert np.isfinite(d).all() and st["total_divergences"] <= 2 and 0.5 < st["mean_accept_prob"] <= 1.0
+
+
 def test_dynamic_chains_together_equal_chains_alone(hip_ctx):
     """Several dynamic-model chains share the wide leaf launches (grid.y = chain); each must be
     the chain it would be alone: same seed -> the same draws, also with thinning and a depth cap
