@@ -302,12 +302,16 @@ __global__ __launch_bounds__(BLOCK) void dc_vec_stream(EvalArgs A) {
     }
 
     // ---- 3. workgroup reduction of the scalars, then the slabs of all chains
+    static_assert(CB % 2 == 0, "two chains' sums per written-out reduction");
 #pragma unroll
-    for (int b = 0; b < CB; ++b) {
-        const double v = wave_sum_f64(dV[b]), u = wave_sum_f64(dSU[b]);
+    for (int b = 0; b < CB; b += 2) {   // (four chains of DPP steps at a time: one after the other they were 1.6 us)
+        double q[4] = {dV[b], dSU[b], dV[b + 1], dSU[b + 1]};
+        wave_sum4_f64(q);
         if (lane == 0) {
-            red[(wave * CB + b) * 2 + 0] = v;
-            red[(wave * CB + b) * 2 + 1] = u;
+            red[(wave * CB + b) * 2 + 0] = q[0];
+            red[(wave * CB + b) * 2 + 1] = q[1];
+            red[(wave * CB + b + 1) * 2 + 0] = q[2];
+            red[(wave * CB + b + 1) * 2 + 1] = q[3];
         }
     }
     __syncthreads();
