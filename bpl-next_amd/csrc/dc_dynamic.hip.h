@@ -868,14 +868,16 @@ __device__ __forceinline__ void final_fused(const DynArgs& A, const Bounds& b, d
         grad[o] = -(dc::ld_sc1(&A.cov[k]) - z[o]);
         Lg += -0.5 * z[o] * z[o] - HALF_LOG_2PI;
     }
-    // everything this launch accumulated is read: back to zero for the next evaluation
+    // everything this launch accumulated is read: back to zero for the next evaluation.  (Plain stores:
+    // the words are next touched by the NEXT launch's atomics, and the kernel boundary writes them back
+    // first; write-through stores here were waited for by the kernel's completion.)
     if (on) {
 #pragma unroll
-        for (int j = 0; j < 10; ++j) dc::st_sc1(&A.gsum[j * G + g], 0.0);
+        for (int j = 0; j < 10; ++j) A.gsum[j * G + g] = 0.0;
     }
-    if (lane < SC_N) dc::st_sc1(&A.sc[lane], 0.0);
-    if (lane < R_N) dc::st_sc1(&A.red[lane], 0.0);
-    for (int k = lane; k < 2 * K; k += 64) dc::st_sc1(&A.cov[k], 0.0);
+    if (lane < SC_N) A.sc[lane] = 0.0;
+    if (lane < R_N) A.red[lane] = 0.0;
+    for (int k = lane; k < 2 * K; k += 64) A.cov[k] = 0.0;
     Lg = dc::wave_sum_f64(Lg);
     if (lane == 0) {
         grad[L.o_md] = -(r_md - m);

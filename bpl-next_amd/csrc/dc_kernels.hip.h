@@ -31,6 +31,11 @@
 //              device-resident chain (tiles in registers, the next position as data-tagged
 //              granules, the tail's copy of the position in LDS).
 //
+//   Wave reductions of several values at once (the ends of the pair walk, of a tile, of the epilogue's
+//   waves) are written out in wave_reduce.hip.h (generated: tools/gen/wave_reduce_asm.py): at this time
+//   scale the compiler's schedule of interleaved DPP chains -- one pair of temporaries for all chains,
+//   canonicalising maxima -- was 0.3-0.6 us per reduction.
+//
 // Mathematics: SURVEY.md Appendix A (restating bpl/dixon_coles.py:39-84,
 // bpl/extended_dixon_coles.py:78-248, bpl/_util.py:17-93 under numpyro semantics).
 #pragma once
