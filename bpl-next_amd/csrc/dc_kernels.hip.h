@@ -922,10 +922,15 @@ __device__ __forceinline__ bool dense_maxima_f32(int T, const float2* tabH, cons
         }
     }
     __syncthreads();
-    auto m1 = [&](int k) { return rec[k * 4]; };
-    auto m2 = [&](int k) { return rec[k * 4 + 1]; };
-    auto i1 = [&](int k) { return __float_as_int(rec[k * 4 + 2]); };
-    auto i2 = [&](int k) { return __float_as_int(rec[k * 4 + 3]); };
+    // (all twenty record words in ONE round of LDS reads: read where they are used -- inside the
+    // branches of dense_pair_max -- each one was waited for on its own)
+    float rv[DENSE_ARRAYS * 4];
+#pragma unroll
+    for (int k = 0; k < DENSE_ARRAYS * 4; ++k) rv[k] = rec[k];
+    auto m1 = [&](int k) { return rv[k * 4]; };
+    auto m2 = [&](int k) { return rv[k * 4 + 1]; };
+    auto i1 = [&](int k) { return __float_as_int(rv[k * 4 + 2]); };
+    auto i2 = [&](int k) { return __float_as_int(rv[k * 4 + 3]); };
     int h, a;
     const float mQ = dense_pair_max<float>(m1(0), i1(0), m2(0), i2(0), m1(2), i1(2), m2(2), i2(2), &h, &a);
     // la(h,a) = AA_a * BD_h: x runs over the away side
@@ -1342,10 +1347,13 @@ __device__ void prior_body(const EvalArgs& A, int chain, char* smem, double* zo_
         // (the values are wave-uniform already: no reductions, nothing written over the records; wave 0
         // files the float64 maxima and their arg-pairs for the combine below, zeros for the other waves)
         if (wave == 0) {
-            auto m1 = [&](int k) { return rec64[k * 4]; };
-            auto m2 = [&](int k) { return rec64[k * 4 + 1]; };
-            auto i1 = [&](int k) { return (int)rec64[k * 4 + 2]; };
-            auto i2 = [&](int k) { return (int)rec64[k * 4 + 3]; };
+            double rv[DENSE_ARRAYS * 4];   // (one round of LDS reads, see dense_maxima_f32)
+#pragma unroll
+            for (int k = 0; k < DENSE_ARRAYS * 4; ++k) rv[k] = rec64[k];
+            auto m1 = [&](int k) { return rv[k * 4]; };
+            auto m2 = [&](int k) { return rv[k * 4 + 1]; };
+            auto i1 = [&](int k) { return (int)rv[k * 4 + 2]; };
+            auto i2 = [&](int k) { return (int)rv[k * 4 + 3]; };
             int h, a;
             mQ = dense_pair_max<double>(m1(0), i1(0), m2(0), i2(0), m1(2), i1(2), m2(2), i2(2), &h, &a);
             aQ = (uint32_t)h | ((uint32_t)a << 16);
