@@ -1137,7 +1137,9 @@ __device__ void prior_body(const EvalArgs& A, int chain, char* smem, double* zo_
     // barrier, onto those two waves, beside the pair walk: the barrier then waits for the cells' exp
     // alone (it waited 0.56 us for either of the two, the other waves 0.4 us for them)
     const bool defer = sums_on_wave && (two_each || 6 * 64 >= A.P);
-    const int lz_tid = defer ? 6 * 64 : 64;
+    // (not deferred: the chain sits on a wave that builds no cells -- wave 6 up to 128 teams, wave 7 up to
+    // 149; on wave 1 it ran in FRONT of that wave's cells, 0.5 us of the phase at 100 teams)
+    const int lz_tid = defer || 3 * T <= 6 * 64 ? 6 * 64 : (3 * T <= 7 * 64 ? 7 * 64 : 64);
     double Lz = 0.0;
     auto scalar_priors = [&]() {
         const double zsa = z[L.o_sa], zsd = z[L.o_sd];
@@ -1170,7 +1172,7 @@ __device__ void prior_body(const EvalArgs& A, int chain, char* smem, double* zo_
         zput(&zo[ZO_SD], s_d);
         zput(&zo[ZO_SH], s_h);
     };
-    if (!defer && tid == 64) scalar_priors();
+    if (!defer && tid == lz_tid) scalar_priors();
     // eps = log(true/table) = log1p(r), r = (true - table)/table, |r| ~ 1e-7
     auto put_eps = [&](int j, int t, double tv) {
         const float tabv = j == 0 ? tabH[t].x : (j == 1 ? tabA[t].x : tabH[t].y);
