@@ -519,8 +519,22 @@ __device__ __forceinline__ double wave_max_f64(double v) {  // v >= 0  (written 
 template <int NV>
 __device__ __forceinline__ void block_sum(double (&v)[NV], double* scratch, int tid) {
     const int lane = tid & 63, wave = tid >> 6;
+    if constexpr (NV >= 4) {   // (four chains of DPP steps at a time: wave_reduce.hip.h)
+        double q4[4] = {v[0], v[1], v[2], v[3]};
+        wave_sum4_f64(q4);
+        v[0] = q4[0]; v[1] = q4[1]; v[2] = q4[2]; v[3] = q4[3];
+        if constexpr (NV == 6) {
+            wave_sum2_f64(v[4], v[5]);
+        } else {
 #pragma unroll
-    for (int i = 0; i < NV; ++i) v[i] = wave_sum_f64(v[i]);
+            for (int i = 4; i < NV; ++i) v[i] = wave_sum_f64(v[i]);
+        }
+    } else if constexpr (NV == 2) {
+        wave_sum2_f64(v[0], v[1]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) v[i] = wave_sum_f64(v[i]);
+    }
     __syncthreads();
     if (lane == 0) {
 #pragma unroll
