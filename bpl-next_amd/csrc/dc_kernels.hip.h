@@ -2875,8 +2875,8 @@ __global__ DC_LAUNCH_BOUNDS void dc_eval_loop(EvalArgs A) {
             // and an invalidate made the kernel-argument reloads below miss, 0.3 us per step; the one
             // path that reads state with uniform addresses, the chain advance, invalidates for itself)
             if (tid == 0) *acc_tail_flag(A, smem) = 1;   // (in front of the prior part's first barrier)
-            prior_body<CLIP, true, false, true>(A, chain, smem + tail_bytes, reinterpret_cast<double*>(smem), zL, cL,
-                                                xs_staged ? xsL : nullptr);
+            prior_body<CLIP, true, false, true>(reload_args(), chain, smem + tail_bytes, reinterpret_cast<double*>(smem),
+                                                zL, cL, xs_staged ? xsL : nullptr);
             DC_STAMP(4);
             TailPre pre;
             nd::LeafState<LNE> leaf1{};
