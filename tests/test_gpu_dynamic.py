@@ -108,7 +108,7 @@ def test_dynamic_fit_smoke(hip_ctx):
 
 def test_dynamic_chain_on_device_matches_host_tree(hip_ctx):
     """The dynamic model's latent vector (here D = 700+) is booked by the wide leaf launches
-    (nuts_dev.hip.h kw_leaf_a/b) with the whole chain on the device; with a fixed step size it
+    (nuts_dev.hip.h kw_leaf) with the whole chain on the device; with a fixed step size it
     builds the same trees as the host tree engine on the same threefry streams."""
     from bpl._ffi import default_nuts_cfg
 
