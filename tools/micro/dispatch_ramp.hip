@@ -39,5 +39,32 @@ int main() {
                 printf("lds %6d block %4d grid %4d: last-first %.2f us (median of 9; min %.2f), half of the blocks by %.2f us\n",
                        lds, b, g, med[4], med[0], (s[g / 2] - s[0]) * 0.01);
             }
+    // start time by blockIdx % 8 (= XCD, round robin): is the ramp a skew between XCDs?
+    for (int g : {125, 249}) {
+        double acc[8] = {0}, cnt[8] = {0};
+        for (int rep = 0; rep < 50; ++rep) {
+            hipLaunchKernelGGL(k, dim3(g), dim3(512), 4096, 0, d, 40);
+            hipDeviceSynchronize();
+            hipMemcpy(h.data(), d, g * 8, hipMemcpyDeviceToHost);
+            unsigned long long lo = ~0ull;
+            for (int i = 0; i < g; ++i) lo = std::min(lo, h[i]);
+            for (int i = 0; i < g; ++i) { acc[i % 8] += (h[i] - lo) * 0.01; cnt[i % 8] += 1; }
+        }
+        printf("grid %d, mean start by blockIdx %% 8:", g);
+        for (int x = 0; x < 8; ++x) printf(" %.2f", acc[x] / cnt[x]);
+        printf(" us\n");
+        double byq[4] = {0}, cq[4] = {0};
+        for (int rep = 0; rep < 50; ++rep) {
+            hipLaunchKernelGGL(k, dim3(g), dim3(512), 4096, 0, d, 40);
+            hipDeviceSynchronize();
+            hipMemcpy(h.data(), d, g * 8, hipMemcpyDeviceToHost);
+            unsigned long long lo = ~0ull;
+            for (int i = 0; i < g; ++i) lo = std::min(lo, h[i]);
+            for (int i = 0; i < g; ++i) { byq[i * 4 / g] += (h[i] - lo) * 0.01; cq[i * 4 / g] += 1; }
+        }
+        printf("grid %d, mean start by quarter of the block index:", g);
+        for (int x = 0; x < 4; ++x) printf(" %.2f", byq[x] / cq[x]);
+        printf(" us\n");
+    }
     return 0;
 }
