@@ -21,7 +21,11 @@ def run(n, model=MODEL_BASIC, max_wg=255, k=0, weighted=False):
     lib.bplhip_debug_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int]; lib.bplhip_debug_stamps.restype = C.c_int
     nwg = lib.bplhip_debug_stamps(c._h, None, 0)
     z = torch.tensor(np.random.RandomState(7).uniform(-.5, .5, c.dim), dtype=torch.float64, device=c.device)
-    for _ in range(5): c.logp_grad(z)
+    if os.environ.get("STAMPS_GRAPH"):   # the last launch of a replayed graph (dependent launches, as bench.py times them)
+        zz = z.repeat(8, 1).contiguous(); UU = torch.zeros(8, dtype=torch.float64, device=c.device); gg = torch.zeros_like(zz)
+        c.logp_grad_graph(8, zz, UU, gg, replays=3)
+    else:
+        for _ in range(5): c.logp_grad(z)
     torch.cuda.synchronize()
     buf = np.zeros((nwg + 1) * 16, dtype=np.uint64)
     lib.bplhip_debug_stamps(c._h, buf.ctypes.data_as(C.c_void_p), buf.size)
