@@ -97,6 +97,7 @@ struct bplhip_ctx {
     // that a sampler would book as divergences.
     unsigned int* h_fault = nullptr;
     unsigned int* d_fault = nullptr;
+    int opt_chunk_graph = 1;
     bool dyn_fused_ok = true;   // cleared when the single-launch dynamic kernel timed out: four launches from then on
     int dyn_fused_blocks_per_cu = -1;  // occupancy of dyn_fused (queried once)
     DevBuf d_zb;    // persistent evaluation kernel: the next position as tagged granules
@@ -1102,6 +1103,10 @@ int bplhip_set_option(bplhip_ctx* c, const char* name, int value) {
         c->opt_vec_tpw = value;
         return BPLHIP_OK;
     }
+    if (n == "chunk_graph") {  // persistent chains: a chunk of leapfrogs as one replayed hipGraph (1) or launch by launch (0)
+        c->opt_chunk_graph = value != 0;
+        return BPLHIP_OK;
+    }
     if (n == "max_wg") {  // takes effect at the next bplhip_set_fixtures
         if (value < 1 || value > 1024) return fail(c, BPLHIP_EINVAL, "max_wg out of range [1,1024]");
         c->opt_max_wg = value;
@@ -1944,6 +1949,69 @@ int run_chains_persistent(bplhip_ctx* c, hipStream_t s, const nuts::Config& nc, 
     // every launch advances every unfinished chain by one leapfrog: an upper bound exists
     const double max_steps = (double)n_iter * (double)((1u << md) - 1) + 2.0 * chunk;
     double steps_done = 0.0;
+    // one leapfrog of every unfinished chain: the launches a chunk repeats `chunk` times (same arguments
+    // every time: everything lives in the chains' state buffers)
+    auto enqueue_leapfrogs = [&](hipStream_t st, int count) -> int {
+        int erc = BPLHIP_OK;
+        for (int k = 0; k < count; ++k) {
+            if (generic && neutral_leaf_fusable(c)) {  // evaluation + leaf of every chain in ONE launch
+                erc = launch_eval_neutral(c, C, nullptr, nullptr, nullptr, nullptr, st, ns, stride, md, &P);
+                if (erc != BPLHIP_OK) return erc;
+                continue;
+            }
+            if (generic) {
+                for (int ch = 0; ch < C && erc == BPLHIP_OK; ++ch) {
+                    double* nsc = ns + (size_t)ch * stride;
+                    erc = launch_eval(c, 1, nd::vec(nsc, D, nd::V_ZN), nsc + nd::H_LEAF_PE,
+                                      nd::vec(nsc, D, nd::V_GRAD), nsc + nd::H_LEAF_AUX0, st);
+                }
+                if (erc != BPLHIP_OK) return erc;
+                if (wide) {
+                    hipLaunchKernelGGL(nd::kw_leaf, dim3(GWB, C), dim3(nd::KW_NTB), 0, st, ns, stride, D, md,
+                                       d_part.as<nd::TaggedSum>(), d_tick.as<unsigned int>(), P, d_rowpart.as<double>(),
+                                       c->d_fault);
+                } else {
+                    hipLaunchKernelGGL(nd::kp_leaf, dim3(C), dim3(64), (size_t)(D + 8) * 8, st, ns, stride, D,
+                                       md, P);
+                }
+                continue;
+            }
+            // up to `gridy_max_chains` chains run as grid.y copies of the single-chain launch
+            // (62 workgroups each at N = 1e6; measured faster than sharing up to ~32 chains);
+            // more chains share the chain-vectorised kernel
+            erc = C <= c->opt_gridy_max_chains
+                      ? launch_eval(c, C, nd::vec(ns, D, nd::V_ZN), ns + nd::H_LEAF_PE, nd::vec(ns, D, nd::V_GRAD),
+                                    ns + nd::H_LEAF_AUX0, st, ns, md, dP, C > 1 ? (int)stride : 0)
+                      : launch_eval_vec(c, C, nd::vec(ns, D, nd::V_ZN), ns + nd::H_LEAF_PE,
+                                        nd::vec(ns, D, nd::V_GRAD), ns + nd::H_LEAF_AUX0, st, ns, (int)stride,
+                                        md, dP);
+            if (erc != BPLHIP_OK) return erc;
+        }
+        return BPLHIP_OK;
+    };
+    // The chunk as ONE hipGraph, captured once per run and replayed (option chunk_graph, default on): the
+    // launches of a chunk are identical, and enqueued one by one each of them paid the host's launch
+    // path and the XCDs' staggered start of a stand-alone launch (profiles/r03/dispatch_ramp.txt) --
+    // dependent launches of a graph pay neither.
+    struct ExecGuard {
+        hipGraphExec_t e = nullptr;
+        ~ExecGuard() { if (e) (void)hipGraphExecDestroy(e); }
+    } chunk_graph;
+    if (!looped && c->opt_chunk_graph) {
+        if (!c->cap_stream) HIP_TRY(c, hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking));
+        HIP_TRY(c, hipStreamBeginCapture(c->cap_stream, hipStreamCaptureModeThreadLocal));
+        const int crc = enqueue_leapfrogs(c->cap_stream, chunk);
+        hipGraph_t g = nullptr;
+        const hipError_t e = hipStreamEndCapture(c->cap_stream, &g);
+        if (crc != BPLHIP_OK) {
+            if (g) (void)hipGraphDestroy(g);
+            return crc;
+        }
+        HIP_TRY(c, e);
+        const hipError_t e2 = hipGraphInstantiate(&chunk_graph.e, g, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(g);
+        HIP_TRY(c, e2);
+    }
     while (!all_done) {
         if (steps_done > max_steps)
             return fail(c, BPLHIP_EHIP, "persistent nuts: chains did not finish within the leapfrog bound");
@@ -1955,39 +2023,10 @@ int run_chains_persistent(bplhip_ctx* c, hipStream_t s, const nuts::Config& nc, 
         if (looped) {  // the whole chunk inside one resident launch
             rc = launch_eval_loop(c, ns, md, dP, chunk, s);
             if (rc != BPLHIP_OK) return rc;
-        } else
-        for (int k = 0; k < chunk; ++k) {
-            if (generic && neutral_leaf_fusable(c)) {  // evaluation + leaf of every chain in ONE launch
-                rc = launch_eval_neutral(c, C, nullptr, nullptr, nullptr, nullptr, s, ns, stride, md, &P);
-                if (rc != BPLHIP_OK) return rc;
-                continue;
-            }
-            if (generic) {
-                for (int ch = 0; ch < C && rc == BPLHIP_OK; ++ch) {
-                    double* nsc = ns + (size_t)ch * stride;
-                    rc = launch_eval(c, 1, nd::vec(nsc, D, nd::V_ZN), nsc + nd::H_LEAF_PE,
-                                     nd::vec(nsc, D, nd::V_GRAD), nsc + nd::H_LEAF_AUX0, s);
-                }
-                if (rc != BPLHIP_OK) return rc;
-                if (wide) {
-                    hipLaunchKernelGGL(nd::kw_leaf, dim3(GWB, C), dim3(nd::KW_NTB), 0, s, ns, stride, D, md,
-                                       d_part.as<nd::TaggedSum>(), d_tick.as<unsigned int>(), P, d_rowpart.as<double>(),
-                                       c->d_fault);
-                } else {
-                    hipLaunchKernelGGL(nd::kp_leaf, dim3(C), dim3(64), (size_t)(D + 8) * 8, s, ns, stride, D,
-                                       md, P);
-                }
-                continue;
-            }
-            // up to `gridy_max_chains` chains run as grid.y copies of the single-chain launch
-            // (62 workgroups each at N = 1e6; measured faster than sharing up to ~32 chains);
-            // more chains share the chain-vectorised kernel
-            rc = C <= c->opt_gridy_max_chains
-                     ? launch_eval(c, C, nd::vec(ns, D, nd::V_ZN), ns + nd::H_LEAF_PE, nd::vec(ns, D, nd::V_GRAD),
-                                   ns + nd::H_LEAF_AUX0, s, ns, md, dP, C > 1 ? (int)stride : 0)
-                        : launch_eval_vec(c, C, nd::vec(ns, D, nd::V_ZN), ns + nd::H_LEAF_PE,
-                                          nd::vec(ns, D, nd::V_GRAD), ns + nd::H_LEAF_AUX0, s, ns, (int)stride,
-                                          md, dP);
+        } else if (chunk_graph.e) {
+            HIP_TRY(c, hipGraphLaunch(chunk_graph.e, s));
+        } else {
+            rc = enqueue_leapfrogs(s, chunk);
             if (rc != BPLHIP_OK) return rc;
         }
         HIP_TRY(c, hipMemcpy2DAsync(flags.data(), 8, ns + nsd + nd::P_ALLDONE, stride * 8, 8, C,
