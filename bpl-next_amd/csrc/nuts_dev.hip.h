@@ -1067,7 +1067,7 @@ constexpr int KW_MAXL = 21;            // levels one leaf can close (max_tree_de
 constexpr int KW_PW = 1 + 2 * KW_MAXL; // kin | (dl, dr) per level
 constexpr int KW_MAX_WG = 64;
 __host__ __device__ inline int kw_workgroups(int D, int nt) {
-    const int g = (D + 2 * nt - 1) / (2 * nt);
+    const int g = (D + nt - 1) / nt;   // (one element per thread up to 64 workgroups)
     return g < 1 ? 1 : (g > KW_MAX_WG ? KW_MAX_WG : g);
 }
 struct WideLeaf {  // what both launches derive from the header (identical in every thread)
