@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "lean_math.hip.h"
 #include "wave_reduce.hip.h"
 
 namespace nd {
@@ -348,17 +349,19 @@ struct LeafWeights {
 // (w_cur, s_sumacc: the subtree's weight and accept sum so far; only read when num != 0)
 template <class F>
 __device__ __forceinline__ LeafWeights leaf_weigh_f(int num, double delta, float u_take, F hdr) {
+    // (the short exp / log1p / reciprocal of lean_math.hip.h, 1-2 ulp: this chain sits on the leaf's serial
+    // path, and the device library's versions are 100-250 dependent instructions each)
     const double w_leaf = -delta;
-    const double acc_leaf = fmin(1.0, exp(-delta));
+    const double acc_leaf = fmin(1.0, dc::lean::exp(-delta));
     LeafWeights W{true, w_leaf, acc_leaf};
     if (num != 0) {
         const double w_cur = hdr(H_S_WEIGHT);
         // expit(d) for the uniform transition and logaddexp(w_cur, w_leaf) share one exp
         const double d = w_leaf - w_cur;
-        const double ex = exp(-fabs(d));
-        const double prob = (d >= 0.0 ? 1.0 : ex) / (1.0 + ex);
+        const double ex = dc::lean::exp(-fabs(d));
+        const double prob = (d >= 0.0 ? 1.0 : ex) * dc::lean::rcp(1.0 + ex);
         W.take = (double)u_take < prob;
-        W.w_sub = w_cur == w_leaf ? w_cur + 0.6931471805599453 : fmax(w_cur, w_leaf) + log1p(ex);
+        W.w_sub = w_cur == w_leaf ? w_cur + 0.6931471805599453 : fmax(w_cur, w_leaf) + dc::lean::log1p_pos(ex);
         W.sum_acc = hdr(H_S_SUMACC) + acc_leaf;
     }
     return W;
