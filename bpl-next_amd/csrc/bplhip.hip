@@ -100,6 +100,11 @@ struct bplhip_ctx {
     int opt_chunk_graph = 1;
     bool dyn_fused_ok = true;   // cleared when the single-launch dynamic kernel timed out: four launches from then on
     int dyn_fused_blocks_per_cu = -1;  // occupancy of dyn_fused (queried once)
+    long long dyn_max_gw = 0;          // fixtures of the largest gameweek (dyn_fused<true> sizes its LDS by it)
+    int opt_dyn_big_wgs = 0;           // dyn_fused<true>: workgroups aimed for (0: one per CU)
+    size_t dyn_big_lds = 0;            // ... the LDS size its cached occupancy belongs to
+    int dyn_big_blocks_per_cu = 0;
+    bool dyn_big_attr_set = false, neu_big_attr_set = false;
     DevBuf d_zb;    // persistent evaluation kernel: the next position as tagged granules
     unsigned int loop_tag = 0;  // tags handed out so far (a launch of k steps takes k + 1 of them)
     int opt_persistent_kernel = 1;  // 1: a single chain's leapfrogs run inside one resident launch
@@ -157,6 +162,7 @@ struct bplhip_ctx {
     int neu_slots = 0;
     int opt_debug_stop = 0;         // diagnostic build only
     DevBuf dd_gwoff, dd_tick;  // dynamic model: first fixture of each gameweek; arrival counters
+    DevBuf dd_fx8;             // dynamic model: one packed word per fixture (dcd::pack_fixture), dyn_fused<true>
     bool dyn_attr_set = false;
     std::map<GraphKey, hipGraphExec_t> graphs;
     hipStream_t cap_stream = nullptr;
@@ -319,22 +325,70 @@ int launch_eval_dynamic(bplhip_ctx* c, int chains, const double* z, double* pot,
         // every one of them must be resident at once, on THIS device in its current compute partition
         if (c->dyn_fused_blocks_per_cu < 0) {
             int per_cu = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dcd::dyn_fused, dcd::FUSED_DYN_BLOCK, 0) != hipSuccess)
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dcd::dyn_fused<false>, dcd::FUSED_DYN_BLOCK, 0) != hipSuccess)
                 per_cu = 0;
             c->dyn_fused_blocks_per_cu = per_cu;
         }
         const bool co_resident = (long long)c->dyn_fused_blocks_per_cu * c->n_cu >= team_blocks;
-        if (c->opt_fused_small && c->dyn_fused_ok && co_resident && L.G <= dcd::FUSED_DYN_MAX_G &&
-            L.T <= dcd::FUSED_DYN_MAX_T && c->n <= (long long)team_blocks * dcd::FUSED_DYN_BLOCK * 4) {
+        const bool fused_shape = c->opt_fused_small && c->dyn_fused_ok && L.G <= dcd::FUSED_DYN_MAX_G &&
+                                 L.T <= dcd::FUSED_DYN_MAX_T;
+        auto arm_scratch = [&]() -> int {
             if (!c->dyn_scratch_clean) {  // (the four-launch path leaves its scratch and its cells as it ends)
                 HIP_TRY(c, hipMemsetAsync(A.acc, 0, A.scratch_n * 8, s));
                 HIP_TRY(c, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(A.cells), (int)dcd::CELL_EMPTY_WORD,
                                              GT * dcd::P_N * 2, s));
                 c->dyn_scratch_clean = true;
             }
-            hipLaunchKernelGGL(dcd::dyn_fused, dim3(team_blocks), dim3(dcd::FUSED_DYN_BLOCK), 0, s, A);
+            return BPLHIP_OK;
+        };
+        if (fused_shape && co_resident && c->opt_dyn_big_wgs <= 0 &&
+            c->n <= (long long)team_blocks * dcd::FUSED_DYN_BLOCK * 4) {
+            if (int rc = arm_scratch()) return rc;
+            hipLaunchKernelGGL(dcd::dyn_fused<false>, dim3(team_blocks), dim3(dcd::FUSED_DYN_BLOCK), 0, s, A);
             HIP_TRY(c, hipGetLastError());
             continue;
+        }
+        if (fused_shape) {
+            // more fixtures: the same single launch with `wpg` workgroups per gameweek, a gameweek's slice
+            // of the fixtures each (its cell records, accumulators and rates in LDS) -- when the slices fit
+            // and every workgroup is resident
+            constexpr size_t STATIC_LDS = 24 * 1024;   // dyn_fused's own arrays (20.7 KB), rounded up
+            const int want = c->opt_dyn_big_wgs > 0 ? c->opt_dyn_big_wgs : c->n_cu;
+            bool launched = false;
+            for (int mult = 1; mult <= 4 && !launched; ++mult) {
+                const int wpg = std::max(1, want * mult / L.G);
+                const int nbig = std::max(team_blocks, wpg * L.G);
+                const long long cap = (c->dyn_max_gw + wpg - 1) / wpg;
+                if (cap > (1 << 24)) continue;
+                // (the slice's fixture words in LDS too when they fit beside its rates)
+                const bool stage = dcd::fused_big_lds_bytes(L.T, (int)cap, true) + STATIC_LDS <= LDS_LIMIT;
+                const size_t lds = dcd::fused_big_lds_bytes(L.T, (int)cap, stage);
+                if (lds + STATIC_LDS > LDS_LIMIT) continue;
+                if (!c->dyn_big_attr_set) {
+                    HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(dcd::dyn_fused<true>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                   (int)(LDS_LIMIT - STATIC_LDS)));
+                    c->dyn_big_attr_set = true;
+                }
+                if (c->dyn_big_lds != lds) {
+                    int per_cu = 0;
+                    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dcd::dyn_fused<true>,
+                                                                     dcd::FUSED_DYN_BLOCK, lds) != hipSuccess)
+                        per_cu = 0;
+                    c->dyn_big_lds = lds;
+                    c->dyn_big_blocks_per_cu = per_cu;
+                }
+                if ((long long)c->dyn_big_blocks_per_cu * c->n_cu < nbig) continue;
+                if (int rc = arm_scratch()) return rc;
+                A.wpg = wpg;
+                A.rate_cap = (int)cap;
+                A.fx8 = c->dd_fx8.as<const unsigned long long>();
+                A.stage_fx = stage ? 1 : 0;
+                hipLaunchKernelGGL(dcd::dyn_fused<true>, dim3(nbig), dim3(dcd::FUSED_DYN_BLOCK), lds, s, A);
+                HIP_TRY(c, hipGetLastError());
+                launched = true;
+            }
+            if (launched) continue;
         }
         if (!c->dyn_attr_set) {
             HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(dcd::dyn_pass2),
@@ -434,12 +488,50 @@ int launch_eval_neutral(bplhip_ctx* c, int chains, const double* z, double* pot,
         F.L.K = L.K;
         F.L.o_corr = L.o_corr;
         A.L = L;
+        F.scratch_n = (size_t)L.T * dcd::A_N + dcd::SC_N + L.C;
+        F.tickets = c->dd_tick.as<unsigned int>();
+        F.fault = c->d_fault;
+        if (c->opt_fused_small && c->dyn_fused_ok && F.tickets) {
+            // one launch (dcn::neu_big): a slice of the fixtures per workgroup, one workgroup per CU, when the
+            // slice's rates fit the LDS and every workgroup is resident
+            constexpr size_t STATIC_LDS = 2 * 1024;
+            const int want = c->opt_dyn_big_wgs > 0 ? c->opt_dyn_big_wgs : c->n_cu;
+            const int nbig = (int)std::max<long long>(1, std::min<long long>(want, (c->n + dcn::NEU_BIG_BLOCK - 1) / dcn::NEU_BIG_BLOCK));
+            const long long cap = (c->n + nbig - 1) / nbig;
+            const size_t lds = dcn::big_lds_bytes(L, cap);
+            if (lds + STATIC_LDS <= LDS_LIMIT) {
+                if (!c->neu_big_attr_set) {
+                    HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(dcn::neu_big),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                   (int)(LDS_LIMIT - STATIC_LDS)));
+                    c->neu_big_attr_set = true;
+                }
+                if (c->dyn_big_lds != lds) {
+                    int per_cu = 0;
+                    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dcn::neu_big, dcn::NEU_BIG_BLOCK, lds) != hipSuccess)
+                        per_cu = 0;
+                    c->dyn_big_lds = lds;
+                    c->dyn_big_blocks_per_cu = per_cu;
+                }
+                if ((long long)c->dyn_big_blocks_per_cu * c->n_cu >= nbig) {
+                    if (!c->dyn_scratch_clean) {  // (the multi-launch path leaves its scratch as it ends)
+                        HIP_TRY(c, hipMemsetAsync(F.acc, 0, F.scratch_n * 8, s));
+                        c->dyn_scratch_clean = true;
+                    }
+                    F.rate_cap = (int)cap;
+                    A.fxp = c->dd_fpack.as<const dcn::FusedFixture>();
+                    hipLaunchKernelGGL(dcn::neu_big, dim3(nbig), dim3(dcn::NEU_BIG_BLOCK), lds, s, A);
+                    HIP_TRY(c, hipGetLastError());
+                    continue;
+                }
+            }
+        }
+        c->dyn_scratch_clean = false;
         const int fb = c->n >= (1 << 18) ? dcd::FIX_BLOCK : 256;  // threads per workgroup
         const long long nb_all = (c->n + fb - 1) / fb;
         const int nb = (int)std::min<long long>(nb_all, 1024);
         F.chunk = ((c->n + nb - 1) / nb + fb - 1) / fb * fb;
         const int nb2 = (int)((c->n + F.chunk - 1) / F.chunk);
-        F.scratch_n = (size_t)L.T * dcd::A_N + dcd::SC_N + L.C;
         hipLaunchKernelGGL(dcn::neu_cells, dim3((L.T + 255) / 256), dim3(256), 0, s, A);
         if (!c->lds_attr_set) {
             HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(dcd::dyn_pass2),
@@ -1059,6 +1151,14 @@ int bplhip_set_option(bplhip_ctx* c, const char* name, int value) {
         c->opt_device_nuts = value != 0;
         return BPLHIP_OK;
     }
+    if (n == "dyn_big_wgs") {  // dynamic model, single launch: > 0 takes the sliced form (dyn_fused<true>) whatever
+                               // N is, aiming for that many workgroups; 0: sliced form past 1024 fixtures per
+                               // team workgroup, one workgroup per CU
+        if (value < 0 || value > 65535) return fail(c, BPLHIP_EINVAL, "set_option: dyn_big_wgs out of range");
+        c->opt_dyn_big_wgs = value;
+        drop_graphs(c);
+        return BPLHIP_OK;
+    }
     if (n == "persistent_nuts") {
         c->opt_persistent_nuts = value != 0;
         return BPLHIP_OK;
@@ -1271,8 +1371,27 @@ static int bplhip_set_fixtures_neutral_impl(bplhip_ctx* c, int64_t n, int32_t n_
             HIP_TRY(c, hipMemcpy(c->dd_slot_off.p, slot_off.data(), slot_off.size() * 4, hipMemcpyHostToDevice));
         }
     }
+    if (!c->neu_fusable) {  // dcn::neu_big streams the same 16-byte records
+        std::vector<dcn::FusedFixture> pack(n);
+        for (int64_t i = 0; i < n; ++i) {
+            dcn::FusedFixture f{};
+            f.h = h[i]; f.a = a[i]; f.x = x[i]; f.y = y[i]; f.nv = nv[i];
+            f.hc = n_conf ? hcv[i] : 0;
+            f.ac = n_conf ? acv[i] : 0;
+            f.w = weights ? w[i] : 1.0f;
+            pack[i] = f;
+        }
+        HIP_TRY(c, c->dd_fpack.ensure(pack.size() * sizeof(dcn::FusedFixture)));
+        HIP_TRY(c, hipMemcpy(c->dd_fpack.p, pack.data(), pack.size() * sizeof(dcn::FusedFixture), hipMemcpyHostToDevice));
+    }
     HIP_TRY(c, c->dd_cells.ensure((size_t)n_teams * dcd::P_N * 8));
     HIP_TRY(c, c->dd_acc.ensure(((size_t)n_teams * dcd::A_N + dcd::SC_N + n_conf) * 8));
+    // the single-launch kernel for large N (dcn::neu_big) finds its scratch and its counters zeroed, and leaves them so
+    HIP_TRY(c, hipMemset(c->dd_acc.p, 0, ((size_t)n_teams * dcd::A_N + dcd::SC_N + n_conf) * 8));
+    HIP_TRY(c, c->dd_tick.ensure(dcd::TICKET_BYTES));
+    HIP_TRY(c, hipMemset(c->dd_tick.p, 0, dcd::TICKET_BYTES));
+    c->dyn_scratch_clean = true;
+    c->dyn_big_lds = 0;   // (the cached occupancy belongs to one kernel and one LDS size)
     c->h_xs.clear();
     if (k > 0) {
         c->h_xs.assign(covariates, covariates + (size_t)n_teams * k);
@@ -1353,6 +1472,10 @@ static int bplhip_set_fixtures_dynamic_impl(bplhip_ctx* c, int64_t n, int32_t n_
     HIP_TRY(c, hipMemcpyAsync(c->d_y.p, y.data(), n, hipMemcpyHostToDevice, s));
     HIP_TRY(c, hipMemcpyAsync(c->dd_gw.p, g.data(), n * 2, hipMemcpyHostToDevice, s));
     HIP_TRY(c, hipMemcpyAsync(c->dd_nv.p, nv.data(), n, hipMemcpyHostToDevice, s));
+    std::vector<unsigned long long> fx8(n);   // (kept alive until the stream is synchronised below)
+    for (int64_t i = 0; i < n; ++i) fx8[i] = dcd::pack_fixture(h[i], a[i], x[i], y[i], nv[i]);
+    HIP_TRY(c, c->dd_fx8.ensure(n * 8));
+    HIP_TRY(c, hipMemcpyAsync(c->dd_fx8.p, fx8.data(), n * 8, hipMemcpyHostToDevice, s));
     HIP_TRY(c, c->dd_cells.ensure(GT * dcd::P_N * 8));
     HIP_TRY(c, c->dd_acc.ensure(dcd::scratch_doubles(n_gameweeks, n_teams, k) * 8));
     // the single-launch kernel finds its scratch zeroed and its cell records armed (and leaves them so):
@@ -1361,15 +1484,18 @@ static int bplhip_set_fixtures_dynamic_impl(bplhip_ctx* c, int64_t n, int32_t n_
     HIP_TRY(c, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(c->dd_cells.p), (int)dcd::CELL_EMPTY_WORD,
                                  GT * dcd::P_N * 2, s));
     c->dyn_scratch_clean = true;
+    c->dyn_big_lds = 0;   // (the cached occupancy belongs to one kernel and one LDS size)
     HIP_TRY(c, c->dd_hyp.ensure((size_t)6 * n_gameweeks * 8));
     {   // first fixture of every gameweek (sorted), and the two arrival counters
         std::vector<int> gw_off(n_gameweeks + 1, 0);
         for (int64_t i = 0; i < n; ++i) gw_off[g[i] + 1] += 1;
+        c->dyn_max_gw = 0;
+        for (int j = 0; j < n_gameweeks; ++j) c->dyn_max_gw = std::max<long long>(c->dyn_max_gw, gw_off[j + 1]);
         for (int j = 0; j < n_gameweeks; ++j) gw_off[j + 1] += gw_off[j];
         HIP_TRY(c, c->dd_gwoff.ensure(gw_off.size() * 4));
         HIP_TRY(c, hipMemcpy(c->dd_gwoff.p, gw_off.data(), gw_off.size() * 4, hipMemcpyHostToDevice));
-        HIP_TRY(c, c->dd_tick.ensure(64));
-        HIP_TRY(c, hipMemset(c->dd_tick.p, 0, 64));
+        HIP_TRY(c, c->dd_tick.ensure(dcd::TICKET_BYTES));
+        HIP_TRY(c, hipMemset(c->dd_tick.p, 0, dcd::TICKET_BYTES));
         HIP_TRY(c, hipMemset(c->dd_acc.p, 0, dcd::scratch_doubles(n_gameweeks, n_teams, k) * 8));
     }
     c->h_xs.clear();

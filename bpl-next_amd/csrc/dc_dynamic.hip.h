@@ -121,6 +121,10 @@ struct DynArgs {
     const int* gw_off;       // [G + 1] first fixture of each gameweek (fixtures are sorted by it)
     unsigned int* tickets;   // [2] arrival counters: dyn_front, dyn_back (zero between launches)
     unsigned int* fault;     // the context's host-visible fault word (dc::raise_fault)
+    int wpg;                 // dyn_fused<true>: workgroups per gameweek (each takes a contiguous slice of it)
+    int rate_cap;            // dyn_fused<true>: fixtures whose rates a workgroup's LDS holds (>= its slice)
+    const unsigned long long* fx8;   // dyn_fused<true>: one word per fixture {h:16, a:16, x:8, y:8, venue:8} (pack_fixture)
+    int stage_fx;            // dyn_fused<true>: 1 = the slice's words are copied into LDS in front of phase 2
     DynLayout L;
 };
 
@@ -467,17 +471,19 @@ __device__ inline SigSite sig_site(double zr) {
     }
     return r;
 }
+// (SC1: the scratch words were written by other workgroups of THIS launch -- L1-bypassing loads)
+template <bool SC1 = false>
 __device__ inline Bounds bounds_from(const DynArgs& A, double q, double dq, double sq) {
     Bounds b;
-    const unsigned long long* scu = reinterpret_cast<const unsigned long long*>(A.sc);
-    b.M = __longlong_as_double((long long)scu[SC_MAXP]);
-    b.Lh = __longlong_as_double((long long)scu[SC_MAXH]);
-    b.La = __longlong_as_double((long long)scu[SC_MAXA]);
+    auto ld = [&](int k) { return SC1 ? dc::ld_sc1(&A.sc[k]) : A.sc[k]; };
+    b.M = ld(SC_MAXP);      // (positive doubles stored as their bit patterns)
+    b.Lh = ld(SC_MAXH);
+    b.La = ld(SC_MAXA);
     b.q = q; b.dq = dq; b.sq = sq;
     b.UB = b.M > 1.0 ? 1.0 / b.M : 1.0;
     b.LB = -1.0 / fmax(b.Lh, b.La);
     b.rho = b.LB + b.q * (b.UB - b.LB);
-    b.G_rho = A.sc[SC_GRHO];
+    b.G_rho = ld(SC_GRHO);
     return b;
 }
 __device__ inline Bounds load_bounds(const DynArgs& A) {
@@ -500,12 +506,18 @@ __device__ inline Bounds load_bounds(const DynArgs& A) {
 struct CouplingFix {
     int g, h, a, nv, hc, ac, have;
 };
+// (`pre`: the three index words SC_IDXP, SC_IDXQ, SC_IDXR when the caller has loaded them already)
+template <bool SC1 = false>
 __device__ inline void build_coupling(const DynArgs& A, const Bounds& b, Coupling* C, CouplingFix* F,
-                                      int tid) {
+                                      int tid, const unsigned long long* pre = nullptr) {
     const unsigned long long* scu = reinterpret_cast<const unsigned long long*>(A.sc);
     const bool lb_home = b.Lh >= b.La;
     if (tid < 2) {
-        const unsigned long long w = tid == 0 ? scu[SC_IDXP] : (lb_home ? scu[SC_IDXQ] : scu[SC_IDXR]);
+        static_assert(SC_IDXQ == SC_IDXP + 1 && SC_IDXR == SC_IDXP + 2, "index words in a row");
+        const int which = tid == 0 ? 0 : (lb_home ? 1 : 2);
+        const unsigned long long* wp = &scu[SC_IDXP + which];
+        const unsigned long long w = pre ? pre[which]
+                                   : SC1 ? __hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *wp;
         CouplingFix f{};
         f.have = w != 0 && (tid == 1 || b.M > 1.0);
         // all six fields in one round of loads: index clamped instead of a branch, absent arrays
@@ -817,6 +829,65 @@ __device__ __forceinline__ bool grid_wait(unsigned int* tickets, int which, unsi
     return *s_ok != 0;
 }
 
+// Hundreds of workgroups on ONE counter: agent-scope atomics (and polls) of one address are served one
+// after another at the memory side, ~35 ns each -- 9 us per barrier with 250 workgroups (stamped:
+// profiles/r03/dynamic_big_stamps.txt).  The sliced forms (dyn_fused<true>, dcn::neu_big) arrive through a
+// two-level tree of counters, each on a cache line of its own (<= 16 arrivals per address), and poll one of
+// 16 release flags the last arrival sets.  Words: tickets[TREE_BASE + barrier * TREE_WORDS + line * 16],
+// lines 0..15 group counters, 16 the top counter, 17..32 the flags; put back to zero by the launch's last
+// workgroup (tree_reset).
+constexpr int TREE_FAN = 16, TREE_LINES = 2 * TREE_FAN + 1, TREE_WORDS = TREE_LINES * 16, TREE_BASE = 64;
+enum { TB_1 = 0, TB_2, TB_3, TB_FINAL, TB_N };
+constexpr size_t TICKET_BYTES = (size_t)(TREE_BASE + TB_N * TREE_WORDS) * 4;
+__device__ __forceinline__ unsigned int* tree_word(unsigned int* tickets, int b, int line) {
+    return tickets + TREE_BASE + b * TREE_WORDS + line * 16;
+}
+// One thread.  Arrival `idx` of `n`; true for the arrival that completes the barrier.
+__device__ __forceinline__ bool tree_arrive_one(unsigned int* tickets, int b, unsigned int idx, unsigned int n,
+                                                bool set_flags) {
+    const unsigned int gs = (n + TREE_FAN - 1) / TREE_FAN;   // arrivals per group
+    const unsigned int grp = idx / gs, ngrp = (n + gs - 1) / gs;
+    const unsigned int mine = n - grp * gs < gs ? n - grp * gs : gs;
+    if (__hip_atomic_fetch_add(tree_word(tickets, b, (int)grp), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != mine - 1)
+        return false;
+    if (__hip_atomic_fetch_add(tree_word(tickets, b, TREE_FAN), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != ngrp - 1)
+        return false;
+    if (set_flags)
+        for (int f = 0; f < TREE_FAN; ++f)
+            __hip_atomic_store(tree_word(tickets, b, TREE_FAN + 1 + f), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return true;
+}
+__device__ __forceinline__ void tree_arrive(unsigned int* tickets, int b, unsigned int idx, unsigned int n) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's stores and atomics are in L2
+    __syncthreads();
+    if (threadIdx.x == 0) (void)tree_arrive_one(tickets, b, idx, n, true);
+}
+// false: the barrier did not complete within the spin limit, or an earlier launch gave up (as grid_wait)
+__device__ __forceinline__ bool tree_wait(unsigned int* tickets, int b, unsigned int failed, int* s_ok,
+                                          unsigned int* fault) {
+    if (threadIdx.x == 0) {
+        unsigned int spins = 0;
+        bool ok = failed == 0;
+        const unsigned int* flag = tree_word(tickets, b, TREE_FAN + 1 + (int)(blockIdx.x % TREE_FAN));
+        while (ok && __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+            if (++spins >= GRID_SPIN_LIMIT) ok = false;
+            __builtin_amdgcn_s_sleep(1);
+        }
+        if (!ok) {
+            __hip_atomic_store(tickets + TK_FAIL, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            dc::raise_fault(fault, dc::FAULT_DYN_BARRIER);
+        }
+        *s_ok = ok;
+    }
+    __syncthreads();
+    return *s_ok != 0;
+}
+// the launch's last workgroup (every other one is past every barrier): all tree words back to zero
+__device__ __forceinline__ void tree_reset(unsigned int* tickets) {
+    for (int k = threadIdx.x; k < TB_N * TREE_LINES; k += blockDim.x)
+        __hip_atomic_store(tickets + TREE_BASE + k * 16, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 struct DynFx {
     int g, h, a, x, y, nv;
 };
@@ -901,7 +972,7 @@ __device__ __forceinline__ void final_fused(const DynArgs& A, const Bounds& b, d
 #define DYN_STAMP(k) stamp_[k] = __builtin_amdgcn_s_memrealtime()
 #define DYN_STAMP_FLUSH                                                                          \
     do {                                                                                         \
-        if (tid == 0)                                                                            \
+        if (tid == 0 && t < T)                                                                   \
             for (int k_ = 0; k_ < 10 && k_ < G; ++k_) grad[L.o_u + k_ * T + t] = (double)stamp_[k_]; \
     } while (0)
 #else
@@ -909,8 +980,43 @@ __device__ __forceinline__ void final_fused(const DynArgs& A, const Bounds& b, d
 #define DYN_STAMP(k) do { } while (0)
 #define DYN_STAMP_FLUSH do { } while (0)
 #endif
+// BIG (any number of fixtures whose gameweek slices fit the LDS; BASELINE config 4's throughput
+// variant, N = 1e6): the grid is `wpg` workgroups per gameweek (>= the team workgroups; the ones
+// past the last team only stream fixtures), each with ONE gameweek's slice of the fixtures.  It
+// copies that gameweek's cell records into LDS as they arrive (the same flagged records), gathers
+// from there, keeps its fixtures' rates in LDS between the two fixture phases (phase 3 has no exp),
+// accumulates the six per-cell adjoints with LDS float64 atomics and flushes T x 6 words with global
+// atomics: 8 memory-side atomics per fixture, as the small form issues, would be 0.5 GB per
+// evaluation at N = 1e6.
+constexpr int FUSED_BIG_UNROLL = 4;   // fixtures of a thread in flight per round
+// per-team accumulators of the sliced form, by ROLE: {home side, away side} x {own venue, neutral venue} x
+// {d/d eta_home, d/d eta_away} -- four LDS atomics per fixture instead of the eight of the six per-cell
+// adjoints, which are sums of these (big_adjoint)
+constexpr int R_N8 = 8;
+__host__ __device__ inline size_t fused_big_lds_bytes(int T, int rate_cap, bool stage_fx) {
+    return ((size_t)T * (P_N + R_N8) + (stage_fx ? 3 : 2) * (size_t)rate_cap) * 8;
+}
+__host__ __device__ inline unsigned long long pack_fixture(unsigned int h, unsigned int a, unsigned int x, unsigned int y,
+                                                           unsigned int nv) {
+    return (unsigned long long)h | ((unsigned long long)a << 16) | ((unsigned long long)x << 32) |
+           ((unsigned long long)y << 40) | ((unsigned long long)(nv != 0) << 48);
+}
+// adjoint j (A_*) of a team from its eight role sums r = {Hh, Ha, Hh_n, Ha_n, Ah, Aa, Ah_n, Aa_n}
+// (H/A: the team was home / away; h/a: d/d eta_home / eta_away; _n: at a neutral venue)
+__device__ __forceinline__ double big_adjoint(const double* r, int j) {
+    switch (j) {
+        case A_ATT:  return (r[0] + r[2]) + (r[5] + r[7]);
+        case A_DEF:  return -((r[1] + r[3]) + (r[4] + r[6]));
+        case A_HATT: return r[0];
+        case A_ADEF: return -r[4];
+        case A_AATT: return r[5];
+        default:     return -r[1];   // A_HDEF
+    }
+}
+template <bool BIG>
 __global__ __launch_bounds__(FUSED_DYN_BLOCK) void dyn_fused(DynArgs A) {
     constexpr int WAVES = FUSED_DYN_BLOCK / 64;
+    extern __shared__ double big_lds[];   // BIG: cells [T][P_N] | accumulators [T][A_N] | rates [cap][2]
     __shared__ double lsum[WAVES][10][64];
     __shared__ unsigned long long shm[3 * WAVES];
     __shared__ double shr[2 * WAVES];
@@ -934,15 +1040,34 @@ __global__ __launch_bounds__(FUSED_DYN_BLOCK) void dyn_fused(DynArgs A) {
     };
 
     // ---- phase 1: every load first, unconditional with clamped indices
-    const long long share = (A.n + nb - 1) / nb;                     // fixtures per workgroup
-    const long long i_lo = (long long)blockIdx.x * share, i_hi = i_lo + share < A.n ? i_lo + share : A.n;
+    long long share = (A.n + nb - 1) / nb;                           // fixtures per workgroup
+    long long i_lo = (long long)blockIdx.x * share, i_hi = i_lo + share < A.n ? i_lo + share : A.n;
+    int gi = 0;                                                      // BIG: this workgroup's gameweek
+    if (BIG) {
+        gi = (int)blockIdx.x / A.wpg;
+        const int part = (int)blockIdx.x - gi * A.wpg;
+        if (gi < G) {
+            const long long o0 = A.gw_off[gi], o1 = A.gw_off[gi + 1];
+            share = (o1 - o0 + A.wpg - 1) / A.wpg;
+            i_lo = o0 + part * share < o1 ? o0 + part * share : o1;
+            i_hi = i_lo + share < o1 ? i_lo + share : o1;
+        } else {
+            gi = 0;
+            i_lo = i_hi = 0;
+        }
+    }
+    double* const lcell = big_lds;
+    double* const lacc = lcell + (size_t)T * P_N;                    // [T][R_N8]
+    double* const lrate = lacc + (size_t)T * R_N8;                   // [cap][2]
+    unsigned long long* const lfx = reinterpret_cast<unsigned long long*>(lrate + 2 * (size_t)A.rate_cap);   // [cap]
     auto load_fx = [&](long long i) {
         DynFx f;
         f.g = A.gw[i]; f.h = A.h[i]; f.a = A.a[i]; f.x = A.x[i]; f.y = A.y[i]; f.nv = A.nv[i];
         return f;
     };
     const long long i_first = i_lo + tid;
-    const DynFx first = load_fx(i_first < A.n ? i_first : A.n - 1);
+    DynFx first{};
+    if (!BIG) first = load_fx(i_first < A.n ? i_first : A.n - 1);
     const int o_std[6] = {L.o_s_att, L.o_s_def, L.o_s_ha, L.o_s_aa, L.o_s_hd, L.o_s_ad};
     double zstd[6];
 #pragma unroll
@@ -990,6 +1115,8 @@ __global__ __launch_bounds__(FUSED_DYN_BLOCK) void dyn_fused(DynArgs A) {
             dc::st_sc1_x2(&P[P_ATT], canon(a_), canon(d_));
         }
     }
+    if (BIG && blockIdx.x * WAVES < (unsigned int)T)   // (a workgroup with teams)
+        tree_arrive(A.tickets, TB_1, blockIdx.x, (unsigned int)((T + WAVES - 1) / WAVES));
     DYN_STAMP(1);
     // corr_coef_raw's sigmoid (phase 3 needs it) -- while the other workgroups' cells travel.  The
     // rest of what does not depend on the fixtures runs in the barriers' shadows (a grid barrier is
@@ -1040,18 +1167,95 @@ __global__ __launch_bounds__(FUSED_DYN_BLOCK) void dyn_fused(DynArgs A) {
         *eh = __longlong_as_double((long long)u0) - __longlong_as_double((long long)u1);
         *ea = __longlong_as_double((long long)u2) - __longlong_as_double((long long)u3);
     };
+    double Ui_big = 0.0;  // BIG: the Poisson part of the value is summed in phase 2 (it does not depend on rho)
     {
         double mP = 0.0, mH = 0.0, mA = 0.0;
-        for (long long i = i_first; i < i_hi; i += FUSED_DYN_BLOCK) {
-            DynFx f = first;
-            if (i != i_first) f = load_fx(i);
-            double eh, ea;
-            etas_wait(f, &eh, &ea);
-            const double lh = dc::lean::exp(eh), la = dc::lean::exp(ea);
-            if (i == i_first) { eh0 = eh; ea0 = ea; lh0 = lh; la0 = la; }
-            mP = fmax(mP, lh * la);
-            mH = fmax(mH, lh);
-            mA = fmax(mA, la);
+        if (BIG) {
+            // (in the shadow of the cells' hand-off: this workgroup's fixture words into LDS -- 8 B per fixture
+            // in one coalesced stream; read straight from memory, each round of phases 2 and 3 waited a
+            // memory latency with four waves per CU)
+            const int n_mine = (int)(i_hi - i_lo);
+            if (A.stage_fx) {
+                for (int k0 = 0; k0 < n_mine; k0 += FUSED_DYN_BLOCK * 8) {
+                    unsigned long long w[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int k = k0 + j * FUSED_DYN_BLOCK + tid;
+                        w[j] = A.fx8[i_lo + (k < n_mine ? k : n_mine - 1)];
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int k = k0 + j * FUSED_DYN_BLOCK + tid;
+                        if (k < n_mine) lfx[k] = w[j];
+                    }
+                }
+            }
+            const unsigned long long* const fxs = A.stage_fx ? lfx : A.fx8 + i_lo;
+            // this gameweek's cell records into LDS once every team workgroup has stored its own (a counted
+            // hand-off: with ~256 workgroups re-reading 6T words each until none is armed -- the small form's
+            // flagged records -- the polls themselves load the memory side); the accumulators to zero
+            if (!tree_wait(A.tickets, TB_1, failed, &s_ok, A.fault)) {
+                give_up();
+                return;
+            }
+            if (n_mine > 0) {
+                const double* src = A.cells + (size_t)gi * T * P_N;
+                const int nw = T * P_N;
+                for (int k0 = 0; k0 < nw; k0 += FUSED_DYN_BLOCK * 4) {
+                    double u[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {   // (all four requested before the first is used)
+                        const int kk = k0 + j * FUSED_DYN_BLOCK + tid;
+                        u[j] = dc::ld_sc1(src + (kk < nw ? kk : nw - 1));
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int kk = k0 + j * FUSED_DYN_BLOCK + tid;
+                        if (kk < nw) lcell[kk] = u[j];
+                    }
+                }
+                for (int k = tid; k < T * R_N8; k += FUSED_DYN_BLOCK) lacc[k] = 0.0;
+            }
+            __syncthreads();
+            for (int base = 0; base < n_mine; base += FUSED_DYN_BLOCK * FUSED_BIG_UNROLL) {
+                unsigned long long w[FUSED_BIG_UNROLL];
+#pragma unroll
+                for (int j = 0; j < FUSED_BIG_UNROLL; ++j) {   // (index clamped: every read of the round in flight at once)
+                    const int k = base + j * FUSED_DYN_BLOCK + tid;
+                    w[j] = fxs[k < n_mine ? k : n_mine - 1];
+                }
+#pragma unroll
+                for (int j = 0; j < FUSED_BIG_UNROLL; ++j) {
+                    const int k = base + j * FUSED_DYN_BLOCK + tid;
+                    if (k >= n_mine) continue;
+                    const int fh = (int)(w[j] & 0xFFFF), fa = (int)(w[j] >> 16) & 0xFFFF;
+                    const int fx = (int)(w[j] >> 32) & 0xFF, fy = (int)(w[j] >> 40) & 0xFF;
+                    const bool nvf = (w[j] >> 48) & 1;
+                    const double* Ph = lcell + fh * P_N;
+                    const double* Pa = lcell + fa * P_N;
+                    const double eh = Ph[nvf ? P_ATT : P_AH] - Pa[nvf ? P_DEF : P_BA];
+                    const double ea = Pa[nvf ? P_ATT : P_AA] - Ph[nvf ? P_DEF : P_BH];
+                    const double lh = dc::lean::exp(eh), la = dc::lean::exp(ea);
+                    lrate[2 * k] = lh;
+                    lrate[2 * k + 1] = la;
+                    Ui_big += fx * eh - lh + fy * ea - la;
+                    mP = fmax(mP, lh * la);
+                    mH = fmax(mH, lh);
+                    mA = fmax(mA, la);
+                }
+            }
+        } else {
+            for (long long i = i_first; i < i_hi; i += FUSED_DYN_BLOCK) {
+                DynFx f = first;
+                if (i != i_first) f = load_fx(i);
+                double eh, ea;
+                etas_wait(f, &eh, &ea);
+                const double lh = dc::lean::exp(eh), la = dc::lean::exp(ea);
+                if (i == i_first) { eh0 = eh; ea0 = ea; lh0 = lh; la0 = la; }
+                mP = fmax(mP, lh * la);
+                mH = fmax(mH, lh);
+                mA = fmax(mA, la);
+            }
         }
         dc::wave_max3_f64(mP, mH, mA);
         if (lane == 0) {  // (positive doubles order like their bit patterns)
@@ -1075,7 +1279,8 @@ __global__ __launch_bounds__(FUSED_DYN_BLOCK) void dyn_fused(DynArgs A) {
         }
     }
     DYN_STAMP(4);
-    grid_arrive(A.tickets + TK_B2);
+    if (BIG) tree_arrive(A.tickets, TB_2, blockIdx.x, nb);
+    else grid_arrive(A.tickets + TK_B2);
     // (second shadow: the u site.  u = sigmoid(zu) ~ Beta(2,4): one exp + one log1p serve the
     // value, its derivative, log u = -sp(-zu), log(1-u) = -sp(zu) and the Jacobian; then its part
     // of the gradient)
@@ -1095,7 +1300,8 @@ __global__ __launch_bounds__(FUSED_DYN_BLOCK) void dyn_fused(DynArgs A) {
     const double rp = 2.0 * u - 1.0, vv = 1.0 - rp * rp, iv = dc::lean::rcp(vv), e = sd - rp * sa;
     const double dL_drp = e * sa * iv - rp * e * e * iv * iv + rp * iv;
     const double g_u = -((dc::lean::rcp(u) - 3.0 * dc::lean::rcp(1.0 - u)) * du + 2.0 * dL_drp * du + (1.0 - 2.0 * su));
-    if (!grid_wait(A.tickets, TK_B2, nb, failed, &s_ok, A.fault)) { give_up(); return; }
+    if (!(BIG ? tree_wait(A.tickets, TB_2, failed, &s_ok, A.fault)
+              : grid_wait(A.tickets, TK_B2, nb, failed, &s_ok, A.fault))) { give_up(); return; }
     DYN_STAMP(5);
 
     // ---- phase 3: value + adjoint
@@ -1106,8 +1312,67 @@ __global__ __launch_bounds__(FUSED_DYN_BLOCK) void dyn_fused(DynArgs A) {
     b.LB = -1.0 / fmax(b.Lh, b.La);
     b.rho = b.LB + b.q * (b.UB - b.LB);
     {
-        double Ui = 0.0, ui = 0.0;
-        for (long long i = i_first; i < i_hi; i += FUSED_DYN_BLOCK) {
+        double Ui = Ui_big, ui = 0.0;
+        if (BIG) {
+            const int n_mine = (int)(i_hi - i_lo);
+            const unsigned long long* const fxs = A.stage_fx ? lfx : A.fx8 + i_lo;
+            for (int base = 0; base < n_mine; base += FUSED_DYN_BLOCK * FUSED_BIG_UNROLL) {
+                unsigned long long w[FUSED_BIG_UNROLL];
+                double rl[FUSED_BIG_UNROLL][2];
+#pragma unroll
+                for (int j = 0; j < FUSED_BIG_UNROLL; ++j) {
+                    const int k = base + j * FUSED_DYN_BLOCK + tid;
+                    const int kc = k < n_mine ? k : n_mine - 1;
+                    w[j] = fxs[kc];
+                    rl[j][0] = lrate[2 * kc];
+                    rl[j][1] = lrate[2 * kc + 1];
+                }
+#pragma unroll
+                for (int j = 0; j < FUSED_BIG_UNROLL; ++j) {
+                    const int k = base + j * FUSED_DYN_BLOCK + tid;
+                    if (k >= n_mine) continue;
+                    const int fh = (int)(w[j] & 0xFFFF), fa = (int)(w[j] >> 16) & 0xFFFF;
+                    const int x = (int)(w[j] >> 32) & 0xFF, y = (int)(w[j] >> 40) & 0xFF;
+                    const int nvi = (int)(w[j] >> 48) & 1;
+                    const double lh = rl[j][0], la = rl[j][1];
+                    double gh = x - lh, ga = y - la;
+                    if (x <= 1 && y <= 1) {
+                        const double cc = x == 0 ? (y == 0 ? -lh * la : lh) : (y == 0 ? la : -1.0);
+                        const double arg = 1.0 + b.rho * cc;
+                        if (arg > 0.0) {
+                            Ui += dc::lean::log(arg);
+                            const double uu = cc / arg;
+                            ui += uu;
+                            if (x == 0) gh += b.rho * uu;
+                            if (y == 0) ga += b.rho * uu;
+                        } else {
+                            Ui += log(0.0);  // -inf (tol = 0, bpl/_util.py:42)
+                        }
+                    }
+                    const long long i = i_lo + k;
+                    const unsigned long long key =
+                        ((unsigned long long)(0x1FFFFFFF - i) << 35) | ((unsigned long long)gi << 25) |
+                        ((unsigned long long)fh << 13) | ((unsigned long long)fa << 1) | (unsigned long long)nvi;
+                    if (lh * la == b.M) atomicMax(&scu[SC_IDXP], key);
+                    if (lh == b.Lh) atomicMax(&scu[SC_IDXQ], key);
+                    if (la == b.La) atomicMax(&scu[SC_IDXR], key);
+                    double* Rh = lacc + fh * R_N8 + 2 * nvi;        // home side: {Hh, Ha} or {Hh_n, Ha_n}
+                    double* Ra = lacc + fa * R_N8 + 4 + 2 * nvi;    // away side: {Ah, Aa} or {Ah_n, Aa_n}
+                    atomicAdd(&Rh[0], gh);
+                    atomicAdd(&Rh[1], ga);
+                    atomicAdd(&Ra[0], gh);
+                    atomicAdd(&Ra[1], ga);
+                }
+            }
+            __syncthreads();
+            if (n_mine > 0)
+                for (int k = tid; k < T * A_N; k += FUSED_DYN_BLOCK) {
+                    const int tt = k / A_N, j = k - tt * A_N;
+                    const double v = big_adjoint(lacc + tt * R_N8, j);
+                    if (v != 0.0) atomicAdd(&A.acc[(size_t)gi * T * A_N + k], v);
+                }
+        }
+        for (long long i = i_first; !BIG && i < i_hi; i += FUSED_DYN_BLOCK) {
             DynFx f = first;
             double eh = eh0, ea = ea0, lh = lh0, la = la0;
             if (i != i_first) {
@@ -1166,7 +1431,8 @@ __global__ __launch_bounds__(FUSED_DYN_BLOCK) void dyn_fused(DynArgs A) {
         }
     }
     DYN_STAMP(6);
-    grid_arrive(A.tickets + TK_B3);
+    if (BIG) tree_arrive(A.tickets, TB_3, blockIdx.x, nb);
+    else grid_arrive(A.tickets + TK_B3);
     // (third shadow: log-density of this wave's cell sites -- log(1 - rho'^2) = log(4 u (1-u)) --
     // the Jacobian of corr_coef_raw's sigmoid came with the first shadow)
     double Lloc = 0.0;
@@ -1175,7 +1441,8 @@ __global__ __launch_bounds__(FUSED_DYN_BLOCK) void dyn_fused(DynArgs A) {
         Lloc += -0.5 * sa * sa - HALF_LOG_2PI - 0.5 * e * e * iv - 0.5 * (2.0 * LN2 + log_u + log_1mu) - HALF_LOG_2PI;
         Lloc += -0.5 * (hat * hat + aat * aat + hdf * hdf + adf * adf) - 4.0 * HALF_LOG_2PI;
     }
-    if (!grid_wait(A.tickets, TK_B3, nb, failed, &s_ok, A.fault)) { give_up(); return; }
+    if (!(BIG ? tree_wait(A.tickets, TB_3, failed, &s_ok, A.fault)
+              : grid_wait(A.tickets, TK_B3, nb, failed, &s_ok, A.fault))) { give_up(); return; }
     DYN_STAMP(7);
 
     // ---- phase 4: this wave's team again
@@ -1266,13 +1533,17 @@ __global__ __launch_bounds__(FUSED_DYN_BLOCK) void dyn_fused(DynArgs A) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
-        const unsigned int k = __hip_atomic_fetch_add(A.tickets + TK_FINAL, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = k == nb - 1;
-        if (s_last) {  // everyone is past every barrier: the counters go back to zero for the next launch
-            __hip_atomic_store(A.tickets + TK_FINAL, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(A.tickets + TK_B1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(A.tickets + TK_B2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(A.tickets + TK_B3, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (BIG) {
+            s_last = tree_arrive_one(A.tickets, TB_FINAL, blockIdx.x, nb, false);
+        } else {
+            const unsigned int k = __hip_atomic_fetch_add(A.tickets + TK_FINAL, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = k == nb - 1;
+            if (s_last) {  // everyone is past every barrier: the counters go back to zero for the next launch
+                __hip_atomic_store(A.tickets + TK_FINAL, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(A.tickets + TK_B1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(A.tickets + TK_B2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(A.tickets + TK_B3, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
     }
     // this wave's gradient entries, and its accumulators back to zero for the next evaluation
@@ -1303,6 +1574,7 @@ __global__ __launch_bounds__(FUSED_DYN_BLOCK) void dyn_fused(DynArgs A) {
         DYN_STAMP_FLUSH;
         return;
     }
+    if (BIG) tree_reset(A.tickets);   // (everyone is past every barrier)
     if (wave == 0) final_fused(A, b, jac_corr, lane);
     DYN_STAMP(9);
     DYN_STAMP_FLUSH;

@@ -62,9 +62,17 @@ inline NeuLayout make_neu_layout(int T, int K, int C = 0) {
     return L;
 }
 
+struct alignas(16) FusedFixture {  // one 16-byte load per fixture
+    uint16_t h, a;
+    uint8_t x, y, nv, hc, ac, pad[3];
+    float w;
+};
+static_assert(sizeof(FusedFixture) == 16, "FusedFixture is one dwordx4");
+
 struct NeuArgs {
     dcd::DynArgs F;   // fixtures, cells, scratch (acc | sc), z / potential / grad / aux
     NeuLayout L;
+    const FusedFixture* fxp;   // neu_big: the fixtures again, one 16-byte record each (weight 1 when unweighted)
 };
 
 // ---- per team: constrained sites -> cell record (dcd::P_*)
@@ -102,8 +110,33 @@ constexpr int NEU_EPI = 256;
 // (hat, aat, hdf, adf) | 8..11 sum dec_x G_x | 12 log-density of the team sites | 13.. cov
 constexpr int NEU_SUMS = 13;
 
-__global__ __launch_bounds__(NEU_EPI) void neu_epilogue(NeuArgs A) {
-    extern __shared__ double sums[];  // [NEU_SUMS + 2K]
+// dcd::sig_site through the short float64 routines (lean_math.hip.h: <= 2 ulp; a libm call is ~1 us of
+// dependent instructions on the one lane that runs it)
+__device__ inline dcd::SigSite sig_site_lean(double zr) {
+    const double az = fabs(zr), ez = dc::lean::exp(-az), l1 = dc::lean::log1p_pos(ez);
+    const double sp_pos = az + l1;                 // softplus(|z|)
+    const double s_abs = dc::lean::rcp(1.0 + ez);
+    dcd::SigSite r;
+    r.sig = zr >= 0 ? s_abs : 1.0 - s_abs;
+    r.sp_sum = sp_pos + l1;
+    r.v = r.sig;
+    r.dv = r.sig * (1.0 - r.sig);
+    r.log_v = zr >= 0 ? -l1 : -sp_pos;             // log sigmoid(z)   = -softplus(-z)
+    r.log_1mv = zr >= 0 ? -sp_pos : -l1;           // log(1-sigmoid(z)) = -softplus(z)
+    if (r.sig < dc::SIG_LO || r.sig > dc::SIG_HI) {
+        r.v = r.sig < dc::SIG_LO ? dc::SIG_LO : dc::SIG_HI;
+        r.dv = 0.0;
+        r.log_v = log(r.v);
+        r.log_1mv = log1p(-r.v);
+    }
+    return r;
+}
+
+// BLOCK threads of ONE workgroup; SC1: the accumulators and scratch words were produced by other
+// workgroups of THIS launch (neu_big's last-arriving workgroup): L1-bypassing loads
+template <int BLOCK, bool SC1>
+__device__ __forceinline__ void epilogue_body(const NeuArgs& A, double* sums) {
+    constexpr int NEU_EPI = BLOCK;
     const NeuLayout& L = A.L;
     const int T = L.T, K = L.K;
     const int tid = threadIdx.x;
@@ -116,9 +149,22 @@ __global__ __launch_bounds__(NEU_EPI) void neu_epilogue(NeuArgs A) {
         const int t0 = tid < T ? tid : 0;
         const double* Ac = A.F.acc + (size_t)t0 * dcd::A_N;
 #pragma unroll
-        for (int j = 0; j < dcd::A_N; ++j) pG[j] = Ac[j];
+        for (int j = 0; j < dcd::A_N; ++j) pG[j] = SC1 ? dc::ld_sc1(&Ac[j]) : Ac[j];
         pz[0] = z[L.o_sat + t0]; pz[1] = z[L.o_sdt + t0]; pz[2] = z[L.o_hat + t0];
         pz[3] = z[L.o_aat + t0]; pz[4] = z[L.o_hdf + t0]; pz[5] = z[L.o_adf + t0];
+    }
+    // (SC1: the maxima, dL/d rho and the arg-extremal fixtures' indices in the same round of loads)
+    double pre_sc[4] = {0.0, 0.0, 0.0, 0.0};
+    unsigned long long pre_idx[3] = {0ull, 0ull, 0ull};
+    if (SC1) {
+        const unsigned long long* scu = reinterpret_cast<const unsigned long long*>(A.F.sc);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            pre_sc[j] = dc::ld_sc1(&A.F.sc[dcd::SC_MAXP + j]);
+            pre_idx[j] = __hip_atomic_load(&scu[dcd::SC_IDXP + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        static_assert(dcd::SC_MAXH == dcd::SC_MAXP + 1 && dcd::SC_MAXA == dcd::SC_MAXP + 2, "maxima in a row");
+        pre_sc[3] = dc::ld_sc1(&A.F.sc[dcd::SC_GRHO]);
     }
     for (int i = tid; i < NEU_SUMS + 2 * K; i += NEU_EPI) sums[i] = 0.0;
     // scalar sites first, in parallel lanes of one wave (a float64 libm call costs ~1 us of
@@ -128,20 +174,30 @@ __global__ __launch_bounds__(NEU_EPI) void neu_epilogue(NeuArgs A) {
     if (tid < 6) {
         const int o = tid == 0 ? L.o_s_att : tid == 1 ? L.o_s_def : tid == 2 ? L.o_s_ha
                     : tid == 3 ? L.o_s_aa : tid == 4 ? L.o_s_hd : L.o_s_ad;
-        scal[tid] = exp(z[o]);
+        scal[tid] = dc::lean::exp(z[o]);
     } else if (tid < 8) {
-        const dcd::SigSite ss = dcd::sig_site(z[tid == 6 ? L.o_u : L.o_corr]);
+        const dcd::SigSite ss = sig_site_lean(z[tid == 6 ? L.o_u : L.o_corr]);
         double* q = scal + 6 + (tid - 6) * 6;
         q[0] = ss.v; q[1] = ss.dv; q[2] = ss.log_v; q[3] = ss.log_1mv; q[4] = ss.sig; q[5] = ss.sp_sum;
     }
     __syncthreads();
     const double* su_ = scal + 6;       // u site
     const double* sc_ = scal + 12;      // corr_coef_raw site
-    const dcd::Bounds b = dcd::bounds_from(A.F, sc_[0], sc_[1], sc_[4]);
+    dcd::Bounds b;
+    if (SC1) {
+        b.M = pre_sc[0]; b.Lh = pre_sc[1]; b.La = pre_sc[2];
+        b.q = sc_[0]; b.dq = sc_[1]; b.sq = sc_[4];
+        b.UB = b.M > 1.0 ? 1.0 / b.M : 1.0;
+        b.LB = -1.0 / fmax(b.Lh, b.La);
+        b.rho = b.LB + b.q * (b.UB - b.LB);
+        b.G_rho = pre_sc[3];
+    } else {
+        b = dcd::bounds_from(A.F, sc_[0], sc_[1], sc_[4]);
+    }
     // adjoint of the bounds: one table per workgroup in LDS
     __shared__ dcd::Coupling C;
     __shared__ dcd::CouplingFix CF[2];
-    dcd::build_coupling(A.F, b, &C, CF, tid);
+    dcd::build_coupling<SC1>(A.F, b, &C, CF, tid, SC1 ? pre_idx : nullptr);
     const int cn = C.n;
     auto coupled = [&](int cell, int which, double base) {
         double v = base;
@@ -152,7 +208,7 @@ __global__ __launch_bounds__(NEU_EPI) void neu_epilogue(NeuArgs A) {
     const double s_att = scal[0], s_def = scal[1], s_ha = scal[2], s_aa = scal[3], s_hd = scal[4],
                  s_ad = scal[5];
     const double u = su_[0], du = su_[1], su = su_[4];
-    const double rp = 2.0 * u - 1.0, vv = 1.0 - rp * rp, log_vv = log(vv);
+    const double rp = 2.0 * u - 1.0, vv = 1.0 - rp * rp, log_vv = dc::lean::log(vv);
 
     double loc[NEU_SUMS];
 #pragma unroll
@@ -161,7 +217,7 @@ __global__ __launch_bounds__(NEU_EPI) void neu_epilogue(NeuArgs A) {
         const double* Ac = A.F.acc + (size_t)t * dcd::A_N;
         double G6[dcd::A_N];
 #pragma unroll
-        for (int j = 0; j < dcd::A_N; ++j) G6[j] = t == tid ? pG[j] : Ac[j];
+        for (int j = 0; j < dcd::A_N; ++j) G6[j] = t == tid ? pG[j] : SC1 ? dc::ld_sc1(&Ac[j]) : Ac[j];
         bool hit = false;  // (at most three fixtures' teams carry a bounds adjoint)
         for (int e = 0; e < cn; ++e) hit = hit || (C.cell[e] == t && C.which[e] < dcd::A_N);
         if (hit) {
@@ -211,7 +267,7 @@ __global__ __launch_bounds__(NEU_EPI) void neu_epilogue(NeuArgs A) {
         grad[o] = -(sums[NEU_SUMS + k] - z[o]);
     }
     for (int cf = tid; cf < L.C; cf += NEU_EPI) {  // confederation strengths ~ N(0,1) (loc 0, scale 1)
-        const double G = coupled(cf, dcd::A_N, A.F.cacc[cf]);
+        const double G = coupled(cf, dcd::A_N, SC1 ? dc::ld_sc1(&A.F.cacc[cf]) : A.F.cacc[cf]);
         grad[L.o_conf + cf] = -(G - z[L.o_conf + cf]);
     }
     // scalar sites, one per lane of wave 0: 0..5 HalfNormal stds | 6..9 Normal means | 10 u | 11 corr
@@ -256,7 +312,7 @@ __global__ __launch_bounds__(NEU_EPI) void neu_epilogue(NeuArgs A) {
         }
         Lp = dcd::wave_sum(Lp);
         if (tid == 0) {
-            const double Ltot = sums[12] + A.F.sc[dcd::SC_U] - A.F.lgsum + Lp;
+            const double Ltot = sums[12] + (SC1 ? dc::ld_sc1(&A.F.sc[dcd::SC_U]) : A.F.sc[dcd::SC_U]) - A.F.lgsum + Lp;
             A.F.potential[0] = -Ltot;
             if (A.F.aux) {
                 A.F.aux[0] = b.rho;
@@ -268,6 +324,266 @@ __global__ __launch_bounds__(NEU_EPI) void neu_epilogue(NeuArgs A) {
     }
 }
 
+
+__global__ __launch_bounds__(NEU_EPI) void neu_epilogue(NeuArgs A) {
+    extern __shared__ double sums[];  // [NEU_SUMS + 2K]
+    epilogue_body<NEU_EPI, false>(A, sums);
+}
+
+// ---- the whole evaluation in ONE launch for any number of fixtures (the multi-launch path above is
+// four launches: 58 us at N = 1e6, 16 of them the one-workgroup epilogue and its launch boundary).
+// Every workgroup (one per CU, all resident) works the T cell records out for itself in LDS -- the
+// z side is O(T): no hand-off -- and takes one contiguous slice of the fixtures:
+//   2  rates (kept in LDS for phase 3), the weighted Poisson part of the value, maxima
+//   -- grid barrier (dcd::tree_arrive / tree_wait on the context's counters)
+//   3  tau terms and the adjoints into LDS-private accumulators (a wave that sits on one
+//      (venue, home, away) run -- the fixtures are sorted by it -- adds its sums once), flushed with
+//      6T + C global float64 atomics per workgroup
+//   -- arrival ticket: the last workgroup runs the epilogue (epilogue_body, L1-bypassing loads) and puts
+//      the scratch and the counters back to zero for the next launch
+constexpr int NEU_BIG_BLOCK = 1024;
+__host__ __device__ inline size_t big_lds_bytes(const NeuLayout& L, long long rate_cap) {
+    return ((size_t)L.T * (dcd::P_N + dcd::A_N) + (size_t)L.C + 4 * (size_t)rate_cap + NEU_SUMS + 2 * (size_t)L.K + 2) * 8;
+}
+__global__ __launch_bounds__(NEU_BIG_BLOCK) void neu_big(NeuArgs A) {
+    constexpr int WAVES = NEU_BIG_BLOCK / 64;
+    extern __shared__ __attribute__((aligned(16))) double big_lds[];   // fixtures [cap] (16 B) | rates [cap][2] | cells [T][P_N] | accumulators [T][A_N] + [C] | epilogue sums
+    __shared__ unsigned long long shm[3 * WAVES];
+    __shared__ double shr[2 * WAVES];
+    __shared__ int s_ok, s_last;
+    const NeuLayout& L = A.L;
+    const dcd::DynArgs& F = A.F;
+    const int T = L.T, K = L.K, C = L.C;
+    const double* z = F.z;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned int nb = gridDim.x;
+    FusedFixture* const lfx = reinterpret_cast<FusedFixture*>(big_lds);   // (16-byte aligned: first)
+    double* const lrate = big_lds + 2 * (size_t)F.rate_cap;
+    double* const lcell = lrate + 2 * (size_t)F.rate_cap;
+    double* const lacc = lcell + (size_t)T * dcd::P_N;   // [T][A_N] then [C]
+    double* const lconf = lacc + (size_t)T * dcd::A_N;
+    double* const sums = lconf + C;
+    unsigned long long* scu = reinterpret_cast<unsigned long long*>(F.sc);
+    const unsigned int failed = __hip_atomic_load(F.tickets + dcd::TK_FAIL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const long long share = (F.n + nb - 1) / nb;
+    const long long i_lo = (long long)blockIdx.x * share < F.n ? (long long)blockIdx.x * share : F.n;
+    const long long i_hi = i_lo + share < F.n ? i_lo + share : F.n;
+
+    // ---- this workgroup's fixtures into LDS (one 16-byte record each, every load in flight before the first
+    // store: read from memory round by round, each round of phases 2 and 3 waited a memory latency)
+    const int n_mine = (int)(i_hi - i_lo);
+    {
+        static_assert(sizeof(FusedFixture) == sizeof(uint4), "one dwordx4");
+        const uint4* src = reinterpret_cast<const uint4*>(A.fxp + i_lo);
+        uint4* dst = reinterpret_cast<uint4*>(lfx);
+        for (int k0 = 0; k0 < n_mine; k0 += NEU_BIG_BLOCK * 4) {
+            uint4 w[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = k0 + j * NEU_BIG_BLOCK + tid;
+                w[j] = src[k < n_mine ? k : n_mine - 1];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = k0 + j * NEU_BIG_BLOCK + tid;
+                if (k < n_mine) dst[k] = w[j];
+            }
+        }
+    }
+    // ---- cells of every team, accumulators to zero
+    {
+        const double e_att = dc::lean::exp(z[L.o_s_att]), e_def = dc::lean::exp(z[L.o_s_def]),
+                     e_ha = dc::lean::exp(z[L.o_s_ha]), e_aa = dc::lean::exp(z[L.o_s_aa]),
+                     e_hd = dc::lean::exp(z[L.o_s_hd]), e_ad = dc::lean::exp(z[L.o_s_ad]);
+        const double m_def = z[L.o_md], m_ha = z[L.o_mha], m_aa = z[L.o_maa], m_hd = z[L.o_mhd], m_ad = z[L.o_mad];
+        for (int t = tid; t < T; t += NEU_BIG_BLOCK) {
+            double att = 0.0, def = m_def;
+            for (int k = 0; k < K; ++k) {
+                const double xv = F.xs[(size_t)t * K + k];
+                att += xv * z[L.o_bA + k];
+                def += xv * z[L.o_bD + k];
+            }
+            att += z[L.o_sat + t] * e_att;
+            def += z[L.o_sdt + t] * e_def;
+            const double hat = m_ha + e_ha * z[L.o_hat + t];
+            const double aat = m_aa + e_aa * z[L.o_aat + t];
+            const double hdf = m_hd + e_hd * z[L.o_hdf + t];
+            const double adf = m_ad + e_ad * z[L.o_adf + t];
+            double* P = lcell + (size_t)t * dcd::P_N;
+            P[dcd::P_AH] = att + hat;
+            P[dcd::P_AA] = att + aat;
+            P[dcd::P_BH] = def + hdf;
+            P[dcd::P_BA] = def + adf;
+            P[dcd::P_ATT] = att;
+            P[dcd::P_DEF] = def;
+        }
+        for (int k = tid; k < T * dcd::A_N + C; k += NEU_BIG_BLOCK) lacc[k] = 0.0;
+    }
+    __syncthreads();
+
+    // ---- phase 2: rates, Poisson part of the value, maxima
+    double Ui = 0.0;
+    {
+        double mP = 0.0, mH = 0.0, mA = 0.0;
+        for (int k = tid; k < n_mine; k += NEU_BIG_BLOCK) {
+            const FusedFixture f = lfx[k];
+            const int h = f.h, a = f.a, x = f.x, y = f.y;
+            const bool nvf = f.nv != 0;
+            const double wi = (double)f.w;
+            const double* Ph = lcell + h * dcd::P_N;
+            const double* Pa = lcell + a * dcd::P_N;
+            double eh = Ph[nvf ? dcd::P_ATT : dcd::P_AH] - Pa[nvf ? dcd::P_DEF : dcd::P_BA];
+            double ea = Pa[nvf ? dcd::P_ATT : dcd::P_AA] - Ph[nvf ? dcd::P_DEF : dcd::P_BH];
+            if (C) {  // bpl/neutral_dixon_coles_WC.py:188-203
+                const double d = F.cs[f.hc] - F.cs[f.ac];
+                eh += d;
+                ea -= d;
+            }
+            const double lh = dc::lean::exp(eh), la = dc::lean::exp(ea);
+            lrate[2 * k] = lh;
+            lrate[2 * k + 1] = la;
+            Ui += wi * (x * eh - lh + y * ea - la);
+            mP = fmax(mP, lh * la);
+            mH = fmax(mH, lh);
+            mA = fmax(mA, la);
+        }
+        dc::wave_max3_f64(mP, mH, mA);
+        if (lane == 0) {  // (positive doubles order like their bit patterns)
+            shm[wave * 3 + 0] = (unsigned long long)__double_as_longlong(mP);
+            shm[wave * 3 + 1] = (unsigned long long)__double_as_longlong(mH);
+            shm[wave * 3 + 2] = (unsigned long long)__double_as_longlong(mA);
+        }
+        __syncthreads();
+        if (tid < 3) {
+            unsigned long long m = 0;
+            for (int w = 0; w < WAVES; ++w) m = shm[w * 3 + tid] > m ? shm[w * 3 + tid] : m;
+            if (m) atomicMax(&scu[dcd::SC_MAXP + tid], m);
+        }
+    }
+    dcd::tree_arrive(F.tickets, dcd::TB_2, blockIdx.x, nb);
+    // (in the barrier's shadow: corr_coef_raw's sigmoid)
+    double q, dq, sq;
+    {
+        const double z_corr = z[L.o_corr];
+        const double ezc = dc::lean::exp(-fabs(z_corr));
+        const double sc_abs = dc::lean::rcp(1.0 + ezc);
+        sq = z_corr >= 0 ? sc_abs : 1.0 - sc_abs;
+        q = sq < dc::SIG_LO ? dc::SIG_LO : sq > dc::SIG_HI ? dc::SIG_HI : sq;
+        dq = (sq < dc::SIG_LO || sq > dc::SIG_HI) ? 0.0 : sq * (1.0 - sq);
+    }
+    auto give_up = [&]() {
+        if (blockIdx.x == 0 && tid == 0) F.potential[0] = __builtin_nan("");
+    };
+    if (!dcd::tree_wait(F.tickets, dcd::TB_2, failed, &s_ok, F.fault)) { give_up(); return; }
+
+    // ---- phase 3: tau terms, adjoints
+    {
+        const double M = dc::ld_sc1(&F.sc[dcd::SC_MAXP]), Lh = dc::ld_sc1(&F.sc[dcd::SC_MAXH]),
+                     La = dc::ld_sc1(&F.sc[dcd::SC_MAXA]);
+        const double UB = M > 1.0 ? 1.0 / M : 1.0;
+        const double LB = -1.0 / fmax(Lh, La);
+        const double rho = LB + q * (UB - LB);
+        (void)dq;
+        double ui = 0.0;
+        for (int base = 0; base < n_mine; base += NEU_BIG_BLOCK) {  // (wave-uniform trip count)
+            const int k = base + tid;
+            const long long i = i_lo + k;
+            const bool active = k < n_mine;
+            int h = 0, a = 0, nv = 0, hcv = 0, acv = 0;
+            double gh = 0.0, ga = 0.0;
+            if (active) {
+                const FusedFixture f = lfx[k];
+                h = f.h; a = f.a; nv = f.nv; hcv = f.hc; acv = f.ac;
+                const int x = f.x, y = f.y;
+                const double wi = (double)f.w;
+                const double lh = lrate[2 * k], la = lrate[2 * k + 1];
+                gh = x - lh;
+                ga = y - la;
+                if (x <= 1 && y <= 1) {
+                    const double cc = x == 0 ? (y == 0 ? -lh * la : lh) : (y == 0 ? la : -1.0);
+                    const double arg = 1.0 + rho * cc;
+                    if (arg > 0.0) {
+                        Ui += wi * dc::lean::log(arg);
+                        const double uu = cc / arg;
+                        ui += wi * uu;
+                        if (x == 0) gh += rho * uu;
+                        if (y == 0) ga += rho * uu;
+                    } else {
+                        Ui += wi * log(0.0);  // -inf (tol = 0, bpl/_util.py:42)
+                    }
+                }
+                gh *= wi;
+                ga *= wi;
+                // arg-extremal fixtures: smallest index among those attaining the maximum
+                // (stored as ~0 - i under atomicMax, so the zeroed word means "none")
+                if (lh * la == M) atomicMax(&scu[dcd::SC_IDXP], ~0ull - (unsigned long long)i);
+                if (lh == Lh) atomicMax(&scu[dcd::SC_IDXQ], ~0ull - (unsigned long long)i);
+                if (la == La) atomicMax(&scu[dcd::SC_IDXR], ~0ull - (unsigned long long)i);
+            }
+            const unsigned long long am = __ballot(active);
+            if (am == 0ull) continue;
+            const int first = __ffsll((long long)am) - 1;
+            const int k_h = __shfl(h, first, 64), k_a = __shfl(a, first, 64), k_nv = __shfl(nv, first, 64),
+                      k_hc = __shfl(hcv, first, 64), k_ac = __shfl(acv, first, 64);
+            const bool same = !active || (h == k_h && a == k_a && nv == k_nv && hcv == k_hc && acv == k_ac);
+            const bool uniform = __all(same);
+            if (uniform) {
+                dc::wave_sum2_f64(gh, ga);
+                h = k_h; a = k_a; nv = k_nv; hcv = k_hc; acv = k_ac;
+            }
+            if (uniform ? lane == first : active) {
+                double* Ah = lacc + h * dcd::A_N;
+                double* Aa = lacc + a * dcd::A_N;
+                atomicAdd(&Ah[dcd::A_ATT], gh);
+                atomicAdd(&Aa[dcd::A_DEF], -gh);
+                atomicAdd(&Aa[dcd::A_ATT], ga);
+                atomicAdd(&Ah[dcd::A_DEF], -ga);
+                if (!nv) {
+                    atomicAdd(&Ah[dcd::A_HATT], gh);
+                    atomicAdd(&Aa[dcd::A_ADEF], -gh);
+                    atomicAdd(&Aa[dcd::A_AATT], ga);
+                    atomicAdd(&Ah[dcd::A_HDEF], -ga);
+                }
+                if (C) {
+                    atomicAdd(&lconf[hcv], gh - ga);
+                    atomicAdd(&lconf[acv], ga - gh);
+                }
+            }
+        }
+        double both[2] = {Ui, ui};
+        dc::wave_sumN_f64(both);
+        if (lane == 0) {
+            shr[wave * 2] = both[0];
+            shr[wave * 2 + 1] = both[1];
+        }
+        __syncthreads();
+        if (tid < 2) {
+            double v = 0.0;
+            for (int w = 0; w < WAVES; ++w) v += shr[w * 2 + tid];
+            if (v != 0.0) atomicAdd(&F.sc[tid == 0 ? dcd::SC_U : dcd::SC_GRHO], v);
+        }
+        for (int k = tid; k < T * dcd::A_N; k += NEU_BIG_BLOCK) {
+            const double v = lacc[k];
+            if (v != 0.0) atomicAdd(&F.acc[k], v);
+        }
+        for (int k = tid; k < C; k += NEU_BIG_BLOCK) {
+            const double v = lconf[k];
+            if (v != 0.0) atomicAdd(&F.cacc[k], v);
+        }
+    }
+    // ---- arrive (atomics drained); the last workgroup runs the epilogue
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) s_last = dcd::tree_arrive_one(F.tickets, dcd::TB_FINAL, blockIdx.x, nb, false);
+    __syncthreads();
+    if (!s_last) return;
+    dcd::tree_reset(F.tickets);   // everyone is past the barrier: the counters go back to zero for the next launch
+    epilogue_body<NEU_BIG_BLOCK, true>(A, sums);
+    // everything this launch accumulated is read: back to zero for the next one (plain stores: the words are
+    // next touched by the NEXT launch's atomics, and the kernel boundary writes them back first)
+    __syncthreads();
+    for (size_t k = tid; k < F.scratch_n; k += NEU_BIG_BLOCK) F.acc[k] = 0.0;
+}
 
 // ---- the whole evaluation in ONE workgroup (one workgroup per chain), everything in LDS.
 // The four-launch path above is bound by its three kernel boundaries and by global round trips
@@ -317,12 +633,6 @@ enum {
     FX_N = FX_SUMS
 };
 
-struct alignas(16) FusedFixture {  // one 16-byte load per fixture
-    uint16_t h, a;
-    uint8_t x, y, nv, hc, ac, pad[3];
-    float w;
-};
-static_assert(sizeof(FusedFixture) == 16, "FusedFixture is one dwordx4");
 // incidence entry of a team: fixture index << 2 | venue neutral << 1 | team is the away side
 constexpr uint32_t INC_NONE = 0xFFFFFFFFu;
 

@@ -10,10 +10,11 @@ import dc_dynamic_oracle as DO
 pytestmark = pytest.mark.gpu
 
 
-def _eval(ctx, fx, z, random_walk=True, fused=1):
+def _eval(ctx, fx, z, random_walk=True, fused=1, big_wgs=0):
     import torch
 
     ctx.set_option("fused_small", fused)  # 1: one launch with grid barriers (small leagues); 0: four launches
+    ctx.set_option("dyn_big_wgs", big_wgs)  # > 0: the single launch in its sliced form (dyn_fused<true>)
     cov = None if fx.covariates is None else DO.standardise_covariates(fx.covariates)
     ctx.set_fixtures_dynamic(fx.home_idx, fx.away_idx, fx.home_goals, fx.away_goals, fx.gameweek,
                              fx.neutral, fx.n_teams, fx.n_gameweeks, covariates_std=cov,
@@ -24,6 +25,7 @@ def _eval(ctx, fx, z, random_walk=True, fused=1):
     U2, g2, _ = ctx.logp_grad(zt)
     assert abs(float(U2[0]) - float(U[0])) <= 1e-12 * abs(float(U[0]))
     ctx.set_option("fused_small", 1)
+    ctx.set_option("dyn_big_wgs", 0)
     return float(U.cpu()[0]), g.cpu().numpy(), aux.cpu().numpy()[0]
 
 
@@ -46,6 +48,35 @@ def test_dynamic_logp_grad_matches_oracle(hip_ctx, case, random_walk, fused):
         assert abs(U - Uo) <= 1e-9 * abs(Uo)
         assert np.abs(g - go).max() <= 1e-9 * np.abs(go).max()
         assert abs(aux[0] - auxo["rho"]) <= 1e-12
+
+
+@pytest.mark.parametrize("big_wgs", [1, 37, 300])
+@pytest.mark.parametrize("case", ["small_cov", "config4", "ragged"])
+def test_dynamic_sliced_single_launch_matches_oracle(hip_ctx, case, big_wgs):
+    """dyn_fused<true> (a gameweek's slice of the fixtures per workgroup, cells / accumulators / rates in
+    LDS; taken by default past 1024 fixtures per team workgroup) forced on small leagues: fewer
+    workgroups than team workgroups, workgroups without fixtures, workgroups without teams; `ragged`:
+    empty gameweeks, neutral venues, one gameweek with most of the fixtures."""
+    if case == "ragged":
+        rs = np.random.RandomState(12)
+        T, G, n = 23, 9, 5000
+        h = rs.randint(0, T, n)
+        a = (h + 1 + rs.randint(0, T - 1, n)) % T
+        gw = np.where(rs.rand(n) < 0.6, 4, rs.choice([0, 1, 3, 4, 6, 8], n))   # gameweeks 2, 5, 7 are empty
+        fx = DO.DynFixtures(h, a, rs.poisson(1.5, n), rs.poisson(1.2, n), gw, (rs.rand(n) < 0.3).astype(int), T, G)
+    else:
+        fx = {"small_cov": lambda: DO.small_recipe(k=3), "config4": DO.config4_recipe}[case]()
+    D = DO.latent_dim(fx.n_gameweeks, fx.n_teams, fx.k)
+    for random_walk in (True, False):
+        z = np.random.RandomState(7).uniform(-0.3, 0.3, D)
+        Uo, go, auxo = DO.potential_and_grad(fx, z, random_walk)
+        U, g, aux = _eval(hip_ctx, fx, z, random_walk, 1, big_wgs)
+        assert abs(U - Uo) <= 1e-9 * abs(Uo)
+        assert np.abs(g - go).max() <= 1e-9 * np.abs(go).max()
+        assert abs(aux[0] - auxo["rho"]) <= 1e-12
+        # and the four-launch path right after it on the same context (scratch handed over clean)
+        U4, g4, _ = _eval(hip_ctx, fx, z, random_walk, 0)
+        assert abs(U4 - Uo) <= 1e-9 * abs(Uo) and np.abs(g4 - go).max() <= 1e-9 * np.abs(go).max()
 
 
 def test_dynamic_throughput_variant_1e6(hip_ctx):

@@ -44,8 +44,10 @@ def test_logp_grad_matches_oracle(hip_ctx, name, fx):
     fx.weights = fx.weights.astype(np.float32).astype(np.float64)  # what the device holds
     _bind(hip_ctx, fx)
     D = hip_ctx.dim
-    # both evaluation paths: the single-launch kernel (small leagues) and the four-launch one
-    for fused in (1, 0):
+    # both evaluation paths: a single launch (neu_fused: one workgroup, small leagues; neu_big: a slice of
+    # the fixtures per workgroup, any N) and the four-launch one -- and the single launch again after it
+    # (it must find the scratch the four launches left behind cleared)
+    for fused in (1, 0, 1):
         hip_ctx.set_option("fused_small", fused)
         for seed, scale in ((1, 0.2), (2, 0.5), (3, 1.0)):
             z = np.random.RandomState(seed).uniform(-scale, scale, D)

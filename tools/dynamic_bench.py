@@ -16,7 +16,12 @@ def big(N=1_000_000, T=100, G=50, seed=5):
     return h, a, rs.poisson(1.5, N), rs.poisson(1.2, N), np.sort(rs.randint(0, G, N)), np.zeros(N, int)
 
 c = HipContext(0)
-for name, (h, a, x, y, g, nv) in (("config4 N=2500", config4()), ("N=1e6", big())):
+CASES = [("config4 N=2500", config4(), 0, 1), ("N=1e6", big(), 0, 1)]
+if os.environ.get('SWEEP', '0') == '1':   # the sliced single launch at other grid sizes, and the four-launch path
+    CASES += [(f"N=1e6 wgs={w}", big(), w, 1) for w in (128, 384, 512, 768)] + [("N=1e6 four launches", big(), 0, 0)]
+    CASES += [("N=2e5", big(200_000), 0, 1), ("N=4e6", big(4_000_000), 0, 1)]
+for name, (h, a, x, y, g, nv), wgs, fused in CASES:
+    c.set_option('dyn_big_wgs', wgs); c.set_option('fused_small', fused)
     c.set_fixtures_dynamic(h, a, x, y, g, nv, 100, 50)
     D = c.dim
     z = torch.tensor(np.random.RandomState(7).uniform(-.3, .3, (8, D)), dtype=torch.float64, device=c.device)

@@ -5,6 +5,7 @@ os.environ["BPLHIP_LIB"] = os.environ.get("STAMPS_LIB", "libbplhip_stamps.so")
 import numpy as np, torch
 from bpl._ffi import HipContext
 c = HipContext(0)
+if os.environ.get('WGS'): c.set_option('dyn_big_wgs', int(os.environ['WGS']))   # the sliced form at another grid size
 Tn, G = 100, 50
 rs = np.random.RandomState(4)
 h, a, gw = [], [], []
@@ -12,6 +13,10 @@ for g in range(G):
     p = rs.permutation(Tn)
     h += list(p[0::2]); a += list(p[1::2]); gw += [g] * (Tn // 2)
 n = len(h)
+if os.environ.get('BIGN'):   # the sliced form (dyn_fused<true>) on N random fixtures: stamps of the 25 workgroups with teams
+    n = int(float(os.environ['BIGN'])); rs = np.random.RandomState(5)
+    h = rs.randint(0, Tn, n); a = (h + 1 + rs.randint(0, Tn - 1, n)) % Tn; gw = np.sort(rs.randint(0, G, n))
+    print(f"N = {n}")
 c.set_fixtures_dynamic(np.array(h), np.array(a), rs.poisson(1.5, n), rs.poisson(1.2, n), np.array(gw),
                        np.zeros(n, np.uint8), Tn, G)
 D = c.dim

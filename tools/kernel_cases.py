@@ -101,6 +101,28 @@ elif case == "neutral":
     for _ in range(steps):
         c.logp_grad(z)
     torch.cuda.synchronize()
+elif case == "dyn_1e6":   # BASELINE config 4's throughput variant: N = 1e6 over the same 100 teams x 50 gameweeks
+    Tn, G, N = 100, 50, 1_000_000
+    rs = np.random.RandomState(5)
+    h = rs.randint(0, Tn, N); a = (h + 1 + rs.randint(0, Tn - 1, N)) % Tn
+    x, y, gw = rs.poisson(1.5, N), rs.poisson(1.2, N), np.sort(rs.randint(0, G, N))
+    c.set_fixtures_dynamic(h, a, x, y, gw, np.zeros(N, np.uint8), Tn, G)
+    meta.update(n=N, algorithmic_bytes_per_launch=N * 8, latent_dim=c.dim)
+    z = torch.tensor(np.random.RandomState(7).uniform(-.3, .3, c.dim), dtype=torch.float64, device=c.device)
+    for _ in range(steps):
+        c.logp_grad(z)
+    torch.cuda.synchronize()
+elif case == "neutral_1e6":
+    N = 1_000_000
+    rs = np.random.RandomState(11)
+    h = rs.randint(0, T, N); a = (h + 1 + rs.randint(0, T - 1, N)) % T
+    c.set_fixtures_neutral(h, a, rs.poisson(1.4, N), rs.poisson(1.1, N), rs.randint(0, 2, N), T,
+                           weights=rs.uniform(0.2, 3.0, N).astype(np.float32))
+    meta.update(n=N, algorithmic_bytes_per_launch=N * 11, latent_dim=c.dim)
+    z = torch.tensor(np.random.RandomState(7).uniform(-.3, .3, c.dim), dtype=torch.float64, device=c.device)
+    for _ in range(steps):
+        c.logp_grad(z)
+    torch.cuda.synchronize()
 elif case == "predict":
     S = 1000
     rs = np.random.RandomState(0)
