@@ -299,6 +299,7 @@ int launch_eval_dynamic(bplhip_ctx* c, int chains, const double* z, double* pot,
         A.gsum = A.sc + dcd::SC_N;
         A.red = A.gsum + 10 * (size_t)L.G;
         A.cov = A.red + dcd::R_N;
+        A.grp = A.cov + 2 * (size_t)L.K;
         A.hyp = c->dd_hyp.as<double>();
         A.z = z + (size_t)ch * L.D;
         A.potential = pot + ch;
@@ -515,7 +516,7 @@ int launch_eval_neutral(bplhip_ctx* c, int chains, const double* z, double* pot,
                 }
                 if ((long long)c->dyn_big_blocks_per_cu * c->n_cu >= nbig) {
                     if (!c->dyn_scratch_clean) {  // (the multi-launch path leaves its scratch as it ends)
-                        HIP_TRY(c, hipMemsetAsync(F.acc, 0, F.scratch_n * 8, s));
+                        HIP_TRY(c, hipMemsetAsync(F.acc, 0, F.scratch_n * 8 * dcn::NEU_BIG_GROUPS, s));
                         c->dyn_scratch_clean = true;
                     }
                     F.rate_cap = (int)cap;
@@ -1272,8 +1273,12 @@ static int bplhip_set_fixtures_neutral_impl(bplhip_ctx* c, int64_t n, int32_t n_
     {
         for (int64_t i = 0; i < n; ++i) order[i] = (uint32_t)i;
         std::stable_sort(order.begin(), order.end(), [&](uint32_t p, uint32_t q) {
-            const uint64_t kp = ((uint64_t)nv[p] << 32) | ((uint64_t)h[p] << 16) | a[p];
-            const uint64_t kq = ((uint64_t)nv[q] << 32) | ((uint64_t)h[q] << 16) | a[q];
+            // (last key: the fixtures with a tau term -- both sides <= 1 goal -- first within a run, so that a
+            // wave's 64 consecutive fixtures mostly agree on having one: dcn::neu_big)
+            const uint64_t kp = ((uint64_t)nv[p] << 33) | ((uint64_t)h[p] << 17) | ((uint64_t)a[p] << 1) |
+                                (uint64_t)!(x[p] <= 1 && y[p] <= 1);
+            const uint64_t kq = ((uint64_t)nv[q] << 33) | ((uint64_t)h[q] << 17) | ((uint64_t)a[q] << 1) |
+                                (uint64_t)!(x[q] <= 1 && y[q] <= 1);
             return kp < kq;
         });
         auto permute = [&](auto& v) {
@@ -1385,9 +1390,11 @@ static int bplhip_set_fixtures_neutral_impl(bplhip_ctx* c, int64_t n, int32_t n_
         HIP_TRY(c, hipMemcpy(c->dd_fpack.p, pack.data(), pack.size() * sizeof(dcn::FusedFixture), hipMemcpyHostToDevice));
     }
     HIP_TRY(c, c->dd_cells.ensure((size_t)n_teams * dcd::P_N * 8));
-    HIP_TRY(c, c->dd_acc.ensure(((size_t)n_teams * dcd::A_N + dcd::SC_N + n_conf) * 8));
+    // (dcn::neu_big adds into NEU_BIG_GROUPS copies of the scratch; the multi-launch path uses the first)
+    const size_t neu_scratch_bytes = ((size_t)n_teams * dcd::A_N + dcd::SC_N + n_conf) * 8 * dcn::NEU_BIG_GROUPS;
+    HIP_TRY(c, c->dd_acc.ensure(neu_scratch_bytes));
     // the single-launch kernel for large N (dcn::neu_big) finds its scratch and its counters zeroed, and leaves them so
-    HIP_TRY(c, hipMemset(c->dd_acc.p, 0, ((size_t)n_teams * dcd::A_N + dcd::SC_N + n_conf) * 8));
+    HIP_TRY(c, hipMemset(c->dd_acc.p, 0, neu_scratch_bytes));
     HIP_TRY(c, c->dd_tick.ensure(dcd::TICKET_BYTES));
     HIP_TRY(c, hipMemset(c->dd_tick.p, 0, dcd::TICKET_BYTES));
     c->dyn_scratch_clean = true;
@@ -1457,6 +1464,16 @@ static int bplhip_set_fixtures_dynamic_impl(bplhip_ctx* c, int64_t n, int32_t n_
             for (int64_t i = 0; i < n; ++i) w[i] = v[order[i]];
             v.swap(w);
         };
+        // ... and inside a gameweek, in blocks of 1024, the fixtures with a tau term (both sides <= 1 goal)
+        // first: a wave's 64 consecutive fixtures then mostly agree on whether they have one, and the sliced
+        // single launch (dyn_fused<true>) runs its log / reciprocal for a third of the waves, not for all
+        for (int64_t b0 = 0; b0 < n;) {
+            int64_t b1 = b0;
+            while (b1 < n && b1 - b0 < 1024 && g[order[b1]] == g[order[b0]]) ++b1;
+            std::stable_partition(order.begin() + b0, order.begin() + b1,
+                                  [&](uint32_t p) { return x[p] <= 1 && y[p] <= 1; });
+            b0 = b1;
+        }
         permute(h); permute(a); permute(x); permute(y); permute(nv); permute(g);
     }
     const size_t GT = (size_t)n_teams * n_gameweeks;

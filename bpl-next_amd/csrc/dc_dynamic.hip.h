@@ -83,8 +83,11 @@ enum { A_ATT = 0, A_DEF, A_HATT, A_ADEF, A_AATT, A_HDEF, A_N = 6 };
 // red: 0 d/d mean_defence, 1 log-density of the cell sites
 enum { R_MD = 0, R_L = 1, R_N = 4 };
 
+// ... | grp [SC_GROUPS][SC_N]: copies of `sc` for the sliced single launch (dyn_fused<true>), whose hundreds of
+// workgroups would otherwise all add to / take the maximum of the same few words (see tree_arrive)
+constexpr int SC_GROUPS = 16;
 inline size_t scratch_doubles(int G, int T, int K) {
-    return (size_t)G * T * A_N + SC_N + 10 * (size_t)G + R_N + 2 * (size_t)K;
+    return (size_t)G * T * A_N + SC_N + 10 * (size_t)G + R_N + 2 * (size_t)K + (size_t)SC_GROUPS * SC_N;
 }
 
 struct DynArgs {
@@ -112,6 +115,7 @@ struct DynArgs {
     double* gsum;
     double* red;
     double* cov;
+    double* grp;         // [SC_GROUPS][SC_N] copies of sc (dyn_fused<true>)
     double* hyp;         // [6][G] exp(std_*)  order: att, def, ha, aa, hd, ad
     const double* z;
     double* potential;
@@ -896,6 +900,7 @@ struct DynFx {
 // Everything it reads was produced by other workgroups of this launch: L1-bypassing loads, all of
 // them requested before the first is used (a dependent chain of such loads is ~1 us each).
 // `jac_corr`: softplus(z_corr) + softplus(-z_corr), worked out long before.
+template <bool BIG = false>
 __device__ __forceinline__ void final_fused(const DynArgs& A, const Bounds& b, double jac_corr, int lane) {
     const DynLayout& L = A.L;
     const int G = L.G, K = L.K;
@@ -908,7 +913,12 @@ __device__ __forceinline__ void final_fused(const DynArgs& A, const Bounds& b, d
     for (int j = 0; j < 6; ++j) hyp[j] = dc::ld_sc1(&A.hyp[j * G + g]);
 #pragma unroll
     for (int j = 0; j < 10; ++j) gs[j] = dc::ld_sc1(&A.gsum[j * G + g]);
-    const double r_md = dc::ld_sc1(&A.red[R_MD]), r_l = dc::ld_sc1(&A.red[R_L]), r_u = dc::ld_sc1(&A.sc[SC_U]);
+    double r_u = dc::ld_sc1(&A.sc[SC_U]);
+    if (BIG) {   // (the value's fixture part: summed over the copies, lanes 0..15 hold one each)
+        r_u = lane < SC_GROUPS ? dc::ld_sc1(A.grp + (size_t)lane * SC_N + SC_U) : 0.0;
+        r_u = dc::wave_sum_f64(r_u);
+    }
+    const double r_md = dc::ld_sc1(&A.red[R_MD]), r_l = dc::ld_sc1(&A.red[R_L]);
     const int o_mean[4] = {L.o_mha, L.o_maa, L.o_mhd, L.o_mad};
     const int o_std[6] = {L.o_s_att, L.o_s_def, L.o_s_ha, L.o_s_aa, L.o_s_hd, L.o_s_ad};
 #pragma unroll
@@ -947,6 +957,8 @@ __device__ __forceinline__ void final_fused(const DynArgs& A, const Bounds& b, d
         for (int j = 0; j < 10; ++j) A.gsum[j * G + g] = 0.0;
     }
     if (lane < SC_N) A.sc[lane] = 0.0;
+    if (BIG)
+        for (int k = lane; k < SC_GROUPS * SC_N; k += 64) A.grp[k] = 0.0;
     if (lane < R_N) A.red[lane] = 0.0;
     for (int k = lane; k < 2 * K; k += 64) A.cov[k] = 0.0;
     Lg = dc::wave_sum_f64(Lg);
@@ -994,7 +1006,7 @@ constexpr int FUSED_BIG_UNROLL = 4;   // fixtures of a thread in flight per roun
 // adjoints, which are sums of these (big_adjoint)
 constexpr int R_N8 = 8;
 __host__ __device__ inline size_t fused_big_lds_bytes(int T, int rate_cap, bool stage_fx) {
-    return ((size_t)T * (P_N + R_N8) + (stage_fx ? 3 : 2) * (size_t)rate_cap) * 8;
+    return ((size_t)T * (2 * P_N + R_N8) + (stage_fx ? 3 : 2) * (size_t)rate_cap) * 8;
 }
 __host__ __device__ inline unsigned long long pack_fixture(unsigned int h, unsigned int a, unsigned int x, unsigned int y,
                                                            unsigned int nv) {
@@ -1003,14 +1015,17 @@ __host__ __device__ inline unsigned long long pack_fixture(unsigned int h, unsig
 }
 // adjoint j (A_*) of a team from its eight role sums r = {Hh, Ha, Hh_n, Ha_n, Ah, Aa, Ah_n, Aa_n}
 // (H/A: the team was home / away; h/a: d/d eta_home / eta_away; _n: at a neutral venue)
-__device__ __forceinline__ double big_adjoint(const double* r, int j) {
+// (role sum w of team t at r[w * stride]: the LDS tables of the sliced form are role-major / entry-major, [w][T] --
+// team-major rows of 6 or 8 doubles put every team's word w on the same few LDS banks, and the random
+// gathers and atomics of a wave's 64 fixtures then queue on them)
+__device__ __forceinline__ double big_adjoint(const double* r, int stride, int j) {
     switch (j) {
-        case A_ATT:  return (r[0] + r[2]) + (r[5] + r[7]);
-        case A_DEF:  return -((r[1] + r[3]) + (r[4] + r[6]));
+        case A_ATT:  return (r[0] + r[2 * stride]) + (r[5 * stride] + r[7 * stride]);
+        case A_DEF:  return -((r[stride] + r[3 * stride]) + (r[4 * stride] + r[6 * stride]));
         case A_HATT: return r[0];
-        case A_ADEF: return -r[4];
-        case A_AATT: return r[5];
-        default:     return -r[1];   // A_HDEF
+        case A_ADEF: return -r[4 * stride];
+        case A_AATT: return r[5 * stride];
+        default:     return -r[stride];   // A_HDEF
     }
 }
 template <bool BIG>
@@ -1018,9 +1033,9 @@ __global__ __launch_bounds__(FUSED_DYN_BLOCK) void dyn_fused(DynArgs A) {
     constexpr int WAVES = FUSED_DYN_BLOCK / 64;
     extern __shared__ double big_lds[];   // BIG: cells [T][P_N] | accumulators [T][A_N] | rates [cap][2]
     __shared__ double lsum[WAVES][10][64];
-    __shared__ unsigned long long shm[3 * WAVES];
+    __shared__ unsigned long long shm[3 * (WAVES > SC_GROUPS ? WAVES : SC_GROUPS)];
     __shared__ double shr[2 * WAVES];
-    __shared__ int s_ok, s_last, s_bad;
+    __shared__ int s_ok, s_last, s_bad, s_slow;
     const DynLayout& L = A.L;
     const int G = L.G, T = L.T, K = L.K;
     const double* z = A.z;
@@ -1057,7 +1072,9 @@ __global__ __launch_bounds__(FUSED_DYN_BLOCK) void dyn_fused(DynArgs A) {
         }
     }
     double* const lcell = big_lds;
-    double* const lacc = lcell + (size_t)T * P_N;                    // [T][R_N8]
+    // (entry-major: lcell / lexp [P_N][T], lacc [R_N8][T] -- see big_adjoint)
+    double* const lexp = lcell + (size_t)T * P_N;                    // exp(+-record), see phase 2
+    double* const lacc = lexp + (size_t)T * P_N;
     double* const lrate = lacc + (size_t)T * R_N8;                   // [cap][2]
     unsigned long long* const lfx = reinterpret_cast<unsigned long long*>(lrate + 2 * (size_t)A.rate_cap);   // [cap]
     auto load_fx = [&](long long i) {
@@ -1076,7 +1093,7 @@ __global__ __launch_bounds__(FUSED_DYN_BLOCK) void dyn_fused(DynArgs A) {
     const double z_mha = z[L.o_mha + g], z_maa = z[L.o_maa + g], z_mhd = z[L.o_mhd + g], z_mad = z[L.o_mad + g];
     const double hat = z[L.o_hat + c], aat = z[L.o_aat + c], hdf = z[L.o_hdf + c], adf = z[L.o_adf + c];
     const double z_corr = z[L.o_corr];
-    if (tid == 0) s_bad = 0;
+    if (tid == 0) s_bad = s_slow = 0;
     __syncthreads();  // (the loads above are in flight; s_bad is set by whoever gives up waiting for a cell)
     double att0 = 0.0, def0 = z[L.o_md];
     for (int k = 0; k < K; ++k) {
@@ -1208,15 +1225,29 @@ __global__ __launch_bounds__(FUSED_DYN_BLOCK) void dyn_fused(DynArgs A) {
                         const int kk = k0 + j * FUSED_DYN_BLOCK + tid;
                         u[j] = dc::ld_sc1(src + (kk < nw ? kk : nw - 1));
                     }
+                    // A rate is exp(attack-type record of one team - defence-type record of the other): the
+                    // exponentials are taken here, once per record (6T per workgroup), and a fixture's rates
+                    // are PRODUCTS of two of them -- the two exp per fixture were half of phase 2's
+                    // instructions, and the per-fixture float64 work is what bounds this kernel (1e6 fixtures x
+                    // ~400 instructions = 10 us of the whole chip's vector issue).  Records beyond +-300
+                    // (where a factor alone could overflow although the rate does not): the exact form.
+                    bool far = false;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const int kk = k0 + j * FUSED_DYN_BLOCK + tid;
-                        if (kk < nw) lcell[kk] = u[j];
+                        if (kk >= nw) continue;
+                        const int tt = kk / P_N, which = kk - tt * P_N;
+                        const bool attack_type = which == P_AH || which == P_AA || which == P_ATT;
+                        lcell[which * T + tt] = u[j];
+                        lexp[which * T + tt] = dc::lean::exp(attack_type ? u[j] : -u[j]);
+                        far = far || fabs(u[j]) > 300.0;
                     }
+                    if (far) s_slow = 1;
                 }
                 for (int k = tid; k < T * R_N8; k += FUSED_DYN_BLOCK) lacc[k] = 0.0;
             }
             __syncthreads();
+            const bool slow = s_slow != 0;
             for (int base = 0; base < n_mine; base += FUSED_DYN_BLOCK * FUSED_BIG_UNROLL) {
                 unsigned long long w[FUSED_BIG_UNROLL];
 #pragma unroll
@@ -1231,11 +1262,15 @@ __global__ __launch_bounds__(FUSED_DYN_BLOCK) void dyn_fused(DynArgs A) {
                     const int fh = (int)(w[j] & 0xFFFF), fa = (int)(w[j] >> 16) & 0xFFFF;
                     const int fx = (int)(w[j] >> 32) & 0xFF, fy = (int)(w[j] >> 40) & 0xFF;
                     const bool nvf = (w[j] >> 48) & 1;
-                    const double* Ph = lcell + fh * P_N;
-                    const double* Pa = lcell + fa * P_N;
-                    const double eh = Ph[nvf ? P_ATT : P_AH] - Pa[nvf ? P_DEF : P_BA];
-                    const double ea = Pa[nvf ? P_ATT : P_AA] - Ph[nvf ? P_DEF : P_BH];
-                    const double lh = dc::lean::exp(eh), la = dc::lean::exp(ea);
+                    const int oh_att = (nvf ? P_ATT : P_AH) * T + fh, oa_def = (nvf ? P_DEF : P_BA) * T + fa;
+                    const int oa_att = (nvf ? P_ATT : P_AA) * T + fa, oh_def = (nvf ? P_DEF : P_BH) * T + fh;
+                    const double eh = lcell[oh_att] - lcell[oa_def];
+                    const double ea = lcell[oa_att] - lcell[oh_def];
+                    double lh = lexp[oh_att] * lexp[oa_def], la = lexp[oa_att] * lexp[oh_def];
+                    if (slow) {   // (workgroup-uniform)
+                        lh = dc::lean::exp(eh);
+                        la = dc::lean::exp(ea);
+                    }
                     lrate[2 * k] = lh;
                     lrate[2 * k + 1] = la;
                     Ui_big += fx * eh - lh + fy * ea - la;
@@ -1275,7 +1310,10 @@ __global__ __launch_bounds__(FUSED_DYN_BLOCK) void dyn_fused(DynArgs A) {
         if (tid < 3) {
             unsigned long long m = 0;
             for (int w = 0; w < WAVES; ++w) m = shm[w * 3 + tid] > m ? shm[w * 3 + tid] : m;
-            if (m) atomicMax(&scu[SC_MAXP + tid], m);
+            // (BIG: into this workgroup's copy of the words -- ~250 atomics on one address are served one after
+            // another at the memory side, ~35 ns each, and the loads behind barrier 2 queue behind them)
+            unsigned long long* dst = BIG ? reinterpret_cast<unsigned long long*>(A.grp + (size_t)(blockIdx.x % SC_GROUPS) * SC_N) : scu;
+            if (m) atomicMax(&dst[SC_MAXP + tid], m);
         }
     }
     DYN_STAMP(4);
@@ -1306,7 +1344,24 @@ __global__ __launch_bounds__(FUSED_DYN_BLOCK) void dyn_fused(DynArgs A) {
 
     // ---- phase 3: value + adjoint
     Bounds b;
-    b.M = dc::ld_sc1(&A.sc[SC_MAXP]); b.Lh = dc::ld_sc1(&A.sc[SC_MAXH]); b.La = dc::ld_sc1(&A.sc[SC_MAXA]);
+    if (BIG) {   // the maxima over the copies: one load per lane, folded through LDS
+        static_assert(SC_MAXH == SC_MAXP + 1 && SC_MAXA == SC_MAXP + 2, "maxima in a row");
+        if (tid < 3 * SC_GROUPS) {
+            const int g_ = tid / 3, j_ = tid - 3 * g_;
+            shm[tid] = (unsigned long long)__double_as_longlong(dc::ld_sc1(A.grp + (size_t)g_ * SC_N + SC_MAXP + j_));
+        }
+        __syncthreads();
+        unsigned long long mx[3] = {0ull, 0ull, 0ull};
+#pragma unroll
+        for (int g_ = 0; g_ < SC_GROUPS; ++g_)
+#pragma unroll
+            for (int j_ = 0; j_ < 3; ++j_) mx[j_] = shm[3 * g_ + j_] > mx[j_] ? shm[3 * g_ + j_] : mx[j_];
+        b.M = __longlong_as_double((long long)mx[0]);
+        b.Lh = __longlong_as_double((long long)mx[1]);
+        b.La = __longlong_as_double((long long)mx[2]);
+    } else {
+        b.M = dc::ld_sc1(&A.sc[SC_MAXP]); b.Lh = dc::ld_sc1(&A.sc[SC_MAXH]); b.La = dc::ld_sc1(&A.sc[SC_MAXA]);
+    }
     b.q = q; b.dq = dq; b.sq = sq;
     b.UB = b.M > 1.0 ? 1.0 / b.M : 1.0;
     b.LB = -1.0 / fmax(b.Lh, b.La);
@@ -1341,7 +1396,7 @@ __global__ __launch_bounds__(FUSED_DYN_BLOCK) void dyn_fused(DynArgs A) {
                         const double arg = 1.0 + b.rho * cc;
                         if (arg > 0.0) {
                             Ui += dc::lean::log(arg);
-                            const double uu = cc / arg;
+                            const double uu = cc * dc::lean::rcp(arg);
                             ui += uu;
                             if (x == 0) gh += b.rho * uu;
                             if (y == 0) ga += b.rho * uu;
@@ -1356,19 +1411,19 @@ __global__ __launch_bounds__(FUSED_DYN_BLOCK) void dyn_fused(DynArgs A) {
                     if (lh * la == b.M) atomicMax(&scu[SC_IDXP], key);
                     if (lh == b.Lh) atomicMax(&scu[SC_IDXQ], key);
                     if (la == b.La) atomicMax(&scu[SC_IDXR], key);
-                    double* Rh = lacc + fh * R_N8 + 2 * nvi;        // home side: {Hh, Ha} or {Hh_n, Ha_n}
-                    double* Ra = lacc + fa * R_N8 + 4 + 2 * nvi;    // away side: {Ah, Aa} or {Ah_n, Aa_n}
+                    double* Rh = lacc + (2 * nvi) * T + fh;        // home side: {Hh, Ha} or {Hh_n, Ha_n}
+                    double* Ra = lacc + (4 + 2 * nvi) * T + fa;    // away side: {Ah, Aa} or {Ah_n, Aa_n}
                     atomicAdd(&Rh[0], gh);
-                    atomicAdd(&Rh[1], ga);
+                    atomicAdd(&Rh[T], ga);
                     atomicAdd(&Ra[0], gh);
-                    atomicAdd(&Ra[1], ga);
+                    atomicAdd(&Ra[T], ga);
                 }
             }
             __syncthreads();
             if (n_mine > 0)
                 for (int k = tid; k < T * A_N; k += FUSED_DYN_BLOCK) {
                     const int tt = k / A_N, j = k - tt * A_N;
-                    const double v = big_adjoint(lacc + tt * R_N8, j);
+                    const double v = big_adjoint(lacc + tt, T, j);
                     if (v != 0.0) atomicAdd(&A.acc[(size_t)gi * T * A_N + k], v);
                 }
         }
@@ -1427,7 +1482,8 @@ __global__ __launch_bounds__(FUSED_DYN_BLOCK) void dyn_fused(DynArgs A) {
         if (tid < 2) {
             double v = 0.0;
             for (int w = 0; w < WAVES; ++w) v += shr[w * 2 + tid];
-            if (v != 0.0) atomicAdd(&A.sc[tid == 0 ? SC_U : SC_GRHO], v);
+            double* dst = BIG ? A.grp + (size_t)(blockIdx.x % SC_GROUPS) * SC_N : A.sc;
+            if (v != 0.0) atomicAdd(&dst[tid == 0 ? SC_U : SC_GRHO], v);
         }
     }
     DYN_STAMP(6);
@@ -1452,7 +1508,17 @@ __global__ __launch_bounds__(FUSED_DYN_BLOCK) void dyn_fused(DynArgs A) {
 #pragma unroll
         for (int j = 0; j < A_N; ++j) G6[j] = dc::ld_sc1(&Ac[j]);
     }
-    b.G_rho = dc::ld_sc1(&A.sc[SC_GRHO]);
+    if (BIG) {
+        double part[SC_GROUPS];
+#pragma unroll
+        for (int g_ = 0; g_ < SC_GROUPS; ++g_) part[g_] = dc::ld_sc1(A.grp + (size_t)g_ * SC_N + SC_GRHO);
+        double sum = 0.0;
+#pragma unroll
+        for (int g_ = 0; g_ < SC_GROUPS; ++g_) sum += part[g_];
+        b.G_rho = sum;
+    } else {
+        b.G_rho = dc::ld_sc1(&A.sc[SC_GRHO]);
+    }
     // (all three packed fixtures with the accumulators, in one round of loads: behind the
     // comparisons that pick two of them each was a dependent round trip of its own)
     const unsigned long long keyP = __hip_atomic_load(&scu[SC_IDXP], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1575,7 +1641,7 @@ __global__ __launch_bounds__(FUSED_DYN_BLOCK) void dyn_fused(DynArgs A) {
         return;
     }
     if (BIG) tree_reset(A.tickets);   // (everyone is past every barrier)
-    if (wave == 0) final_fused(A, b, jac_corr, lane);
+    if (wave == 0) final_fused<BIG>(A, b, jac_corr, lane);
     DYN_STAMP(9);
     DYN_STAMP_FLUSH;
 }

@@ -134,10 +134,16 @@ __device__ inline dcd::SigSite sig_site_lean(double zr) {
 
 // BLOCK threads of ONE workgroup; SC1: the accumulators and scratch words were produced by other
 // workgroups of THIS launch (neu_big's last-arriving workgroup): L1-bypassing loads
+#ifdef DC_STAMPS
+#define EPI_STAMP(k) do { if (threadIdx.x == 0 && epi_stamp) epi_stamp[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define EPI_STAMP(k) do { } while (0)
+#endif
 template <int BLOCK, bool SC1>
-__device__ __forceinline__ void epilogue_body(const NeuArgs& A, double* sums) {
+__device__ __forceinline__ void epilogue_body(const NeuArgs& A, double* sums, unsigned long long* epi_stamp = nullptr) {
     constexpr int NEU_EPI = BLOCK;
     const NeuLayout& L = A.L;
+    EPI_STAMP(0);
     const int T = L.T, K = L.K;
     const int tid = threadIdx.x;
     const double* z = A.F.z;
@@ -181,6 +187,7 @@ __device__ __forceinline__ void epilogue_body(const NeuArgs& A, double* sums) {
         q[0] = ss.v; q[1] = ss.dv; q[2] = ss.log_v; q[3] = ss.log_1mv; q[4] = ss.sig; q[5] = ss.sp_sum;
     }
     __syncthreads();
+    EPI_STAMP(1);
     const double* su_ = scal + 6;       // u site
     const double* sc_ = scal + 12;      // corr_coef_raw site
     dcd::Bounds b;
@@ -198,6 +205,7 @@ __device__ __forceinline__ void epilogue_body(const NeuArgs& A, double* sums) {
     __shared__ dcd::Coupling C;
     __shared__ dcd::CouplingFix CF[2];
     dcd::build_coupling<SC1>(A.F, b, &C, CF, tid, SC1 ? pre_idx : nullptr);
+    EPI_STAMP(2);
     const int cn = C.n;
     auto coupled = [&](int cell, int which, double base) {
         double v = base;
@@ -218,11 +226,22 @@ __device__ __forceinline__ void epilogue_body(const NeuArgs& A, double* sums) {
         double G6[dcd::A_N];
 #pragma unroll
         for (int j = 0; j < dcd::A_N; ++j) G6[j] = t == tid ? pG[j] : SC1 ? dc::ld_sc1(&Ac[j]) : Ac[j];
-        bool hit = false;  // (at most three fixtures' teams carry a bounds adjoint)
-        for (int e = 0; e < cn; ++e) hit = hit || (C.cell[e] == t && C.which[e] < dcd::A_N);
-        if (hit) {
+        {   // (at most three fixtures' teams carry a bounds adjoint: ONE pass over the table, every LDS read of it
+            // independent of the others -- entry by entry behind a search per adjoint, these reads were a chain
+            // of ~120 dependent LDS round trips: 9 of the epilogue's 15 us)
+            double adj[dcd::A_N];
 #pragma unroll
-            for (int j = 0; j < dcd::A_N; ++j) G6[j] = coupled(t, j, G6[j]);
+            for (int j = 0; j < dcd::A_N; ++j) adj[j] = 0.0;
+#pragma unroll
+            for (int e = 0; e < 18; ++e) {
+                const bool mine = e < cn && C.cell[e] == t;
+                const int wh = C.which[e];
+                const double v = C.val[e];
+#pragma unroll
+                for (int j = 0; j < dcd::A_N; ++j) adj[j] += (mine && wh == j) ? v : 0.0;
+            }
+#pragma unroll
+            for (int j = 0; j < dcd::A_N; ++j) G6[j] += adj[j];
         }
         const double G_att = G6[dcd::A_ATT], G_def = G6[dcd::A_DEF], G_hat = G6[dcd::A_HATT],
                      G_adf = G6[dcd::A_ADEF], G_aat = G6[dcd::A_AATT], G_hdf = G6[dcd::A_HDEF];
@@ -251,6 +270,7 @@ __device__ __forceinline__ void epilogue_body(const NeuArgs& A, double* sums) {
             atomicAdd(&sums[NEU_SUMS + K + k], xv * G_def);
         }
     }
+    EPI_STAMP(3);
     // wave sums by DPP (same-address LDS atomics from many lanes serialise badly), then one
     // LDS atomic per wave and value
     if ((tid & ~63) < T) {
@@ -261,6 +281,7 @@ __device__ __forceinline__ void epilogue_body(const NeuArgs& A, double* sums) {
         }
     }
     __syncthreads();
+    EPI_STAMP(4);
 
     for (int k = tid; k < 2 * K; k += NEU_EPI) {  // covariate coefficients ~ N(0,1)
         const int o = k < K ? L.o_bA + k : L.o_bD + k - K;
@@ -341,16 +362,25 @@ __global__ __launch_bounds__(NEU_EPI) void neu_epilogue(NeuArgs A) {
 //      6T + C global float64 atomics per workgroup
 //   -- arrival ticket: the last workgroup runs the epilogue (epilogue_body, L1-bypassing loads) and puts
 //      the scratch and the counters back to zero for the next launch
-constexpr int NEU_BIG_BLOCK = 1024;
+constexpr int NEU_BIG_BLOCK = 512;    // (1024 threads leave 128 VGPRs per lane: the epilogue alone wants 254 -- 118 spilled, its
+                                      // team loop and phase 3 ran at the speed of scratch memory)
+constexpr int NEU_BIG_GROUPS = 16;   // copies of the global scratch (see neu_big)
+#ifdef DC_STAMPS  // diagnostic build: thread 0 of the LAST workgroup overwrites grad[o_sat + 0..15] with the 100 MHz
+                  // clock at points of its way through the launch (tools/neutral_big_stamps.py)
+#define NEU_STAMP(k) do { if (threadIdx.x == 0) nstamp_[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define NEU_STAMP(k) do { } while (0)
+#endif
 __host__ __device__ inline size_t big_lds_bytes(const NeuLayout& L, long long rate_cap) {
-    return ((size_t)L.T * (dcd::P_N + dcd::A_N) + (size_t)L.C + 4 * (size_t)rate_cap + NEU_SUMS + 2 * (size_t)L.K + 2) * 8;
+    return ((size_t)L.T * (2 * dcd::P_N + 2 * dcd::A_N) + 2 * (size_t)L.C + dcd::SC_N + 4 * (size_t)rate_cap + NEU_SUMS +
+            2 * (size_t)L.K + 2) * 8;
 }
 __global__ __launch_bounds__(NEU_BIG_BLOCK) void neu_big(NeuArgs A) {
     constexpr int WAVES = NEU_BIG_BLOCK / 64;
     extern __shared__ __attribute__((aligned(16))) double big_lds[];   // fixtures [cap] (16 B) | rates [cap][2] | cells [T][P_N] | accumulators [T][A_N] + [C] | epilogue sums
-    __shared__ unsigned long long shm[3 * WAVES];
+    __shared__ unsigned long long shm[3 * (WAVES > NEU_BIG_GROUPS ? WAVES : NEU_BIG_GROUPS)];
     __shared__ double shr[2 * WAVES];
-    __shared__ int s_ok, s_last;
+    __shared__ int s_ok, s_last, s_slow;
     const NeuLayout& L = A.L;
     const dcd::DynArgs& F = A.F;
     const int T = L.T, K = L.K, C = L.C;
@@ -360,15 +390,32 @@ __global__ __launch_bounds__(NEU_BIG_BLOCK) void neu_big(NeuArgs A) {
     FusedFixture* const lfx = reinterpret_cast<FusedFixture*>(big_lds);   // (16-byte aligned: first)
     double* const lrate = big_lds + 2 * (size_t)F.rate_cap;
     double* const lcell = lrate + 2 * (size_t)F.rate_cap;
-    double* const lacc = lcell + (size_t)T * dcd::P_N;   // [T][A_N] then [C]
+    double* const lexp = lcell + (size_t)T * dcd::P_N;   // [T][P_N]: exp(+-record) -- a rate is a product of two
+    double* const lacc = lexp + (size_t)T * dcd::P_N;    // [T][A_N] then [C]
     double* const lconf = lacc + (size_t)T * dcd::A_N;
-    double* const sums = lconf + C;
-    unsigned long long* scu = reinterpret_cast<unsigned long long*>(F.sc);
+    double* const lred = lconf + C;                      // [scratch_n]: the copies of the global scratch, summed
+    double* const sums = lred + F.scratch_n;
+    // Global scratch: NEU_BIG_GROUPS copies of acc | sc | cacc, workgroup b adds into copy b % GROUPS -- hundreds
+    // of atomics on ONE address are served one after another at the memory side (~35 ns each: 256
+    // workgroups x one maximum = 9 us, and the loads that follow queue behind them), 16 per address are not
+    // felt.  The arg-extremal indices (rare, one per wave at most) all go to copy 0.
+    const int grp = (int)(blockIdx.x % NEU_BIG_GROUPS);
+    double* const gacc = F.acc + (size_t)grp * F.scratch_n;
+    double* const gsc = gacc + (size_t)T * dcd::A_N;
+    double* const gcacc = gsc + dcd::SC_N;
+    unsigned long long* scu = reinterpret_cast<unsigned long long*>(F.sc);      // copy 0: the indices
+    unsigned long long* gscu = reinterpret_cast<unsigned long long*>(gsc);
     const unsigned int failed = __hip_atomic_load(F.tickets + dcd::TK_FAIL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef DC_STAMPS
+    unsigned long long nstamp_[16] = {};
+#endif
+    NEU_STAMP(0);
     const long long share = (F.n + nb - 1) / nb;
     const long long i_lo = (long long)blockIdx.x * share < F.n ? (long long)blockIdx.x * share : F.n;
     const long long i_hi = i_lo + share < F.n ? i_lo + share : F.n;
 
+    if (tid == 0) s_slow = 0;
+    __syncthreads();
     // ---- this workgroup's fixtures into LDS (one 16-byte record each, every load in flight before the first
     // store: read from memory round by round, each round of phases 2 and 3 waited a memory latency)
     const int n_mine = (int)(i_hi - i_lo);
@@ -390,6 +437,7 @@ __global__ __launch_bounds__(NEU_BIG_BLOCK) void neu_big(NeuArgs A) {
             }
         }
     }
+    NEU_STAMP(1);
     // ---- cells of every team, accumulators to zero
     {
         const double e_att = dc::lean::exp(z[L.o_s_att]), e_def = dc::lean::exp(z[L.o_s_def]),
@@ -410,17 +458,27 @@ __global__ __launch_bounds__(NEU_BIG_BLOCK) void neu_big(NeuArgs A) {
             const double hdf = m_hd + e_hd * z[L.o_hdf + t];
             const double adf = m_ad + e_ad * z[L.o_adf + t];
             double* P = lcell + (size_t)t * dcd::P_N;
-            P[dcd::P_AH] = att + hat;
-            P[dcd::P_AA] = att + aat;
-            P[dcd::P_BH] = def + hdf;
-            P[dcd::P_BA] = def + adf;
-            P[dcd::P_ATT] = att;
-            P[dcd::P_DEF] = def;
+            double* E = lexp + (size_t)t * dcd::P_N;
+            const double rec[dcd::P_N] = {att + hat, att + aat, def + hdf, def + adf, att, def};
+            static_assert(dcd::P_AH == 0 && dcd::P_AA == 1 && dcd::P_BH == 2 && dcd::P_BA == 3 && dcd::P_ATT == 4 &&
+                          dcd::P_DEF == 5, "record order");
+            bool far = false;
+#pragma unroll
+            for (int j = 0; j < dcd::P_N; ++j) {
+                P[j] = rec[j];
+                // (attack-type entries enter a rate with +, defence-type ones with -; beyond +-300 a factor alone
+                // could overflow although the rate does not: the workgroup then takes exp of the difference)
+                E[j] = dc::lean::exp((j == dcd::P_AH || j == dcd::P_AA || j == dcd::P_ATT) ? rec[j] : -rec[j]);
+                far = far || fabs(rec[j]) > 300.0;
+            }
+            if (far) s_slow = 1;
         }
         for (int k = tid; k < T * dcd::A_N + C; k += NEU_BIG_BLOCK) lacc[k] = 0.0;
     }
     __syncthreads();
+    const bool slow = s_slow != 0 || C != 0;   // (confederation strengths shift the exponent per fixture: exact form)
 
+    NEU_STAMP(2);
     // ---- phase 2: rates, Poisson part of the value, maxima
     double Ui = 0.0;
     {
@@ -430,16 +488,20 @@ __global__ __launch_bounds__(NEU_BIG_BLOCK) void neu_big(NeuArgs A) {
             const int h = f.h, a = f.a, x = f.x, y = f.y;
             const bool nvf = f.nv != 0;
             const double wi = (double)f.w;
-            const double* Ph = lcell + h * dcd::P_N;
-            const double* Pa = lcell + a * dcd::P_N;
-            double eh = Ph[nvf ? dcd::P_ATT : dcd::P_AH] - Pa[nvf ? dcd::P_DEF : dcd::P_BA];
-            double ea = Pa[nvf ? dcd::P_ATT : dcd::P_AA] - Ph[nvf ? dcd::P_DEF : dcd::P_BH];
+            const int oh_att = h * dcd::P_N + (nvf ? dcd::P_ATT : dcd::P_AH), oa_def = a * dcd::P_N + (nvf ? dcd::P_DEF : dcd::P_BA);
+            const int oa_att = a * dcd::P_N + (nvf ? dcd::P_ATT : dcd::P_AA), oh_def = h * dcd::P_N + (nvf ? dcd::P_DEF : dcd::P_BH);
+            double eh = lcell[oh_att] - lcell[oa_def];
+            double ea = lcell[oa_att] - lcell[oh_def];
             if (C) {  // bpl/neutral_dixon_coles_WC.py:188-203
                 const double d = F.cs[f.hc] - F.cs[f.ac];
                 eh += d;
                 ea -= d;
             }
-            const double lh = dc::lean::exp(eh), la = dc::lean::exp(ea);
+            double lh = lexp[oh_att] * lexp[oa_def], la = lexp[oa_att] * lexp[oh_def];
+            if (slow) {   // (workgroup-uniform)
+                lh = dc::lean::exp(eh);
+                la = dc::lean::exp(ea);
+            }
             lrate[2 * k] = lh;
             lrate[2 * k + 1] = la;
             Ui += wi * (x * eh - lh + y * ea - la);
@@ -457,9 +519,10 @@ __global__ __launch_bounds__(NEU_BIG_BLOCK) void neu_big(NeuArgs A) {
         if (tid < 3) {
             unsigned long long m = 0;
             for (int w = 0; w < WAVES; ++w) m = shm[w * 3 + tid] > m ? shm[w * 3 + tid] : m;
-            if (m) atomicMax(&scu[dcd::SC_MAXP + tid], m);
+            if (m) atomicMax(&gscu[dcd::SC_MAXP + tid], m);
         }
     }
+    NEU_STAMP(3);
     dcd::tree_arrive(F.tickets, dcd::TB_2, blockIdx.x, nb);
     // (in the barrier's shadow: corr_coef_raw's sigmoid)
     double q, dq, sq;
@@ -475,22 +538,47 @@ __global__ __launch_bounds__(NEU_BIG_BLOCK) void neu_big(NeuArgs A) {
         if (blockIdx.x == 0 && tid == 0) F.potential[0] = __builtin_nan("");
     };
     if (!dcd::tree_wait(F.tickets, dcd::TB_2, failed, &s_ok, F.fault)) { give_up(); return; }
+    NEU_STAMP(4);
 
     // ---- phase 3: tau terms, adjoints
     {
-        const double M = dc::ld_sc1(&F.sc[dcd::SC_MAXP]), Lh = dc::ld_sc1(&F.sc[dcd::SC_MAXH]),
-                     La = dc::ld_sc1(&F.sc[dcd::SC_MAXA]);
+        // the three maxima: over the copies (one load per lane of wave 0, folded through LDS)
+        static_assert(dcd::SC_MAXH == dcd::SC_MAXP + 1 && dcd::SC_MAXA == dcd::SC_MAXP + 2, "maxima in a row");
+        if (tid < 3 * NEU_BIG_GROUPS) {
+            const int g_ = tid / 3, j_ = tid - 3 * g_;
+            shm[tid] = (unsigned long long)__double_as_longlong(
+                dc::ld_sc1(F.acc + (size_t)g_ * F.scratch_n + (size_t)T * dcd::A_N + dcd::SC_MAXP + j_));
+        }
+        __syncthreads();
+        unsigned long long mx[3] = {0ull, 0ull, 0ull};
+#pragma unroll
+        for (int g_ = 0; g_ < NEU_BIG_GROUPS; ++g_)
+#pragma unroll
+            for (int j_ = 0; j_ < 3; ++j_) mx[j_] = shm[3 * g_ + j_] > mx[j_] ? shm[3 * g_ + j_] : mx[j_];
+        const double M = __longlong_as_double((long long)mx[0]), Lh = __longlong_as_double((long long)mx[1]),
+                     La = __longlong_as_double((long long)mx[2]);
         const double UB = M > 1.0 ? 1.0 / M : 1.0;
         const double LB = -1.0 / fmax(Lh, La);
         const double rho = LB + q * (UB - LB);
         (void)dq;
+        NEU_STAMP(8);
         double ui = 0.0;
-        for (int base = 0; base < n_mine; base += NEU_BIG_BLOCK) {  // (wave-uniform trip count)
-            const int k = base + tid;
+        // Each WAVE takes a contiguous part of the slice, 64 fixtures per step: consecutive steps of a wave mostly
+        // stay inside one (venue, home, away) run, whose adjoints it then carries in registers (one partial sum
+        // per lane) and adds ONCE, when the run ends -- a DPP sum and a set of LDS atomics per step were 1.1 us
+        // per step and workgroup
+        const int per_wave = (n_mine + WAVES - 1) / WAVES;
+        const int w0 = wave * per_wave < n_mine ? wave * per_wave : n_mine;
+        const int w1 = w0 + per_wave < n_mine ? w0 + per_wave : n_mine;
+        unsigned long long run_key = ~0ull;          // (no fixture packs to this: bits 49.. are zero)
+        double run_h = 0.0, run_a = 0.0;             // this lane's share of the carried run's sums
+        for (int base = w0; base < w1; base += 64) {  // (wave-uniform trip count)
+            const int k = base + lane;
             const long long i = i_lo + k;
-            const bool active = k < n_mine;
+            const bool active = k < w1;
             int h = 0, a = 0, nv = 0, hcv = 0, acv = 0;
             double gh = 0.0, ga = 0.0;
+            bool hitP = false, hitQ = false, hitR = false;
             if (active) {
                 const FusedFixture f = lfx[k];
                 h = f.h; a = f.a; nv = f.nv; hcv = f.hc; acv = f.ac;
@@ -504,7 +592,7 @@ __global__ __launch_bounds__(NEU_BIG_BLOCK) void neu_big(NeuArgs A) {
                     const double arg = 1.0 + rho * cc;
                     if (arg > 0.0) {
                         Ui += wi * dc::lean::log(arg);
-                        const double uu = cc / arg;
+                        const double uu = cc * dc::lean::rcp(arg);
                         ui += wi * uu;
                         if (x == 0) gh += rho * uu;
                         if (y == 0) ga += rho * uu;
@@ -516,40 +604,118 @@ __global__ __launch_bounds__(NEU_BIG_BLOCK) void neu_big(NeuArgs A) {
                 ga *= wi;
                 // arg-extremal fixtures: smallest index among those attaining the maximum
                 // (stored as ~0 - i under atomicMax, so the zeroed word means "none")
-                if (lh * la == M) atomicMax(&scu[dcd::SC_IDXP], ~0ull - (unsigned long long)i);
-                if (lh == Lh) atomicMax(&scu[dcd::SC_IDXQ], ~0ull - (unsigned long long)i);
-                if (la == La) atomicMax(&scu[dcd::SC_IDXR], ~0ull - (unsigned long long)i);
+                hitP = lh * la == M;
+                hitQ = lh == Lh;
+                hitR = la == La;
+            }
+            // arg-extremal fixtures: smallest index among those attaining the maximum (stored as ~0 - i under
+            // atomicMax, so the zeroed word means "none").  One atomic per wave and maximum, from its lowest
+            // lane that attains it: the fixtures are sorted by (venue, home, away), every fixture of the
+            // extremal run ties, and a thousand same-address atomics are served one after another at the memory
+            // side (the last workgroup spent 15 us in this phase at N = 1e6)
+            {
+                const unsigned long long bP = __ballot(hitP), bQ = __ballot(hitQ), bR = __ballot(hitR);
+                if (bP && lane == __ffsll((long long)bP) - 1) atomicMax(&scu[dcd::SC_IDXP], ~0ull - (unsigned long long)i);
+                if (bQ && lane == __ffsll((long long)bQ) - 1) atomicMax(&scu[dcd::SC_IDXQ], ~0ull - (unsigned long long)i);
+                if (bR && lane == __ffsll((long long)bR) - 1) atomicMax(&scu[dcd::SC_IDXR], ~0ull - (unsigned long long)i);
             }
             const unsigned long long am = __ballot(active);
             if (am == 0ull) continue;
-            const int first = __ffsll((long long)am) - 1;
-            const int k_h = __shfl(h, first, 64), k_a = __shfl(a, first, 64), k_nv = __shfl(nv, first, 64),
-                      k_hc = __shfl(hcv, first, 64), k_ac = __shfl(acv, first, 64);
-            const bool same = !active || (h == k_h && a == k_a && nv == k_nv && hcv == k_hc && acv == k_ac);
-            const bool uniform = __all(same);
-            if (uniform) {
-                dc::wave_sum2_f64(gh, ga);
-                h = k_h; a = k_a; nv = k_nv; hcv = k_hc; acv = k_ac;
-            }
-            if (uniform ? lane == first : active) {
-                double* Ah = lacc + h * dcd::A_N;
-                double* Aa = lacc + a * dcd::A_N;
-                atomicAdd(&Ah[dcd::A_ATT], gh);
-                atomicAdd(&Aa[dcd::A_DEF], -gh);
-                atomicAdd(&Aa[dcd::A_ATT], ga);
-                atomicAdd(&Ah[dcd::A_DEF], -ga);
-                if (!nv) {
-                    atomicAdd(&Ah[dcd::A_HATT], gh);
-                    atomicAdd(&Aa[dcd::A_ADEF], -gh);
-                    atomicAdd(&Aa[dcd::A_AATT], ga);
-                    atomicAdd(&Ah[dcd::A_HDEF], -ga);
+            // The fixtures are sorted by (venue, home, away[, confederations]): a wave's 64 consecutive ones
+            // are one run or a few.  Per run: the sums by DPP, ONE set of LDS atomics from its first lane --
+            // 64 lanes adding to the same two teams' words are served one after another by the LDS (the few
+            // waves per workgroup that straddle a run boundary cost more than all the others together).
+            auto add_adjoints = [&](unsigned long long kk, double sh, double sa) {
+                const int h_ = (int)(kk >> 33) & 0xFFFF, a_ = (int)(kk >> 17) & 0xFFFF, hc_ = (int)(kk >> 8) & 0xFF,
+                          ac_ = (int)kk & 0xFF;
+                const bool nv_ = (kk >> 16) & 1;
+                double* Ah = lacc + h_ * dcd::A_N;
+                double* Aa = lacc + a_ * dcd::A_N;
+                atomicAdd(&Ah[dcd::A_ATT], sh);
+                atomicAdd(&Aa[dcd::A_DEF], -sh);
+                atomicAdd(&Aa[dcd::A_ATT], sa);
+                atomicAdd(&Ah[dcd::A_DEF], -sa);
+                if (!nv_) {
+                    atomicAdd(&Ah[dcd::A_HATT], sh);
+                    atomicAdd(&Aa[dcd::A_ADEF], -sh);
+                    atomicAdd(&Aa[dcd::A_AATT], sa);
+                    atomicAdd(&Ah[dcd::A_HDEF], -sa);
                 }
                 if (C) {
-                    atomicAdd(&lconf[hcv], gh - ga);
-                    atomicAdd(&lconf[acv], ga - gh);
+                    atomicAdd(&lconf[hc_], sh - sa);
+                    atomicAdd(&lconf[ac_], sa - sh);
+                }
+            };
+            auto flush_run = [&]() {   // (wave-uniform)
+                if (run_key == ~0ull) return;
+                double sh = run_h, sa = run_a;
+                dc::wave_sum2_f64(sh, sa);
+                if (lane == 0) add_adjoints(run_key, sh, sa);
+                run_key = ~0ull;
+                run_h = run_a = 0.0;
+            };
+            const unsigned long long key = ((unsigned long long)h << 33) | ((unsigned long long)a << 17) |
+                                           ((unsigned long long)(nv != 0) << 16) | ((unsigned long long)hcv << 8) |
+                                           (unsigned long long)acv;
+            // (the active lanes are a prefix of the wave: lane 0 is active here)
+            const unsigned long long k0 = ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(key >> 32)) << 32) |
+                                          (unsigned int)__builtin_amdgcn_readfirstlane((int)key);
+            if (__all(!active || key == k0)) {   // one run in this step
+                if (k0 != run_key) {
+                    flush_run();
+                    run_key = k0;
+                }
+                run_h += gh;   // (zero on the inactive lanes)
+                run_a += ga;
+                continue;
+            }
+            flush_run();
+            // a step that straddles runs: per run the sums by DPP and one set of atomics from its first lane (64
+            // lanes adding to the same two teams' words are served one after another by the LDS)
+            const unsigned long long prev = __shfl_up(key, 1, 64);
+            const bool head = active && (lane == 0 || key != prev);
+            unsigned long long rest = __ballot(head);
+            if (__popcll(rest) <= 8) {
+                while (rest) {   // (wave-uniform)
+                    const int l0 = __ffsll((long long)rest) - 1;
+                    rest &= rest - 1;
+                    const int l1 = rest ? __ffsll((long long)rest) - 1 : 64;
+                    const bool in = active && lane >= l0 && lane < l1;
+                    double sh = in ? gh : 0.0, sa = in ? ga : 0.0;
+                    dc::wave_sum2_f64(sh, sa);
+                    if (lane == l0) add_adjoints(key, sh, sa);
+                }
+            } else if (active) {   // short runs (many pairs, few fixtures each): every lane for itself
+                add_adjoints(key, gh, ga);
+            }
+        }
+        if (run_key != ~0ull) {   // (wave-uniform) the run this wave was still carrying
+            double sh = run_h, sa = run_a;
+            dc::wave_sum2_f64(sh, sa);
+            if (lane == 0) {
+                const unsigned long long kk = run_key;
+                const int h_ = (int)(kk >> 33) & 0xFFFF, a_ = (int)(kk >> 17) & 0xFFFF, hc_ = (int)(kk >> 8) & 0xFF,
+                          ac_ = (int)kk & 0xFF;
+                const bool nv_ = (kk >> 16) & 1;
+                double* Ah = lacc + h_ * dcd::A_N;
+                double* Aa = lacc + a_ * dcd::A_N;
+                atomicAdd(&Ah[dcd::A_ATT], sh);
+                atomicAdd(&Aa[dcd::A_DEF], -sh);
+                atomicAdd(&Aa[dcd::A_ATT], sa);
+                atomicAdd(&Ah[dcd::A_DEF], -sa);
+                if (!nv_) {
+                    atomicAdd(&Ah[dcd::A_HATT], sh);
+                    atomicAdd(&Aa[dcd::A_ADEF], -sh);
+                    atomicAdd(&Aa[dcd::A_AATT], sa);
+                    atomicAdd(&Ah[dcd::A_HDEF], -sa);
+                }
+                if (C) {
+                    atomicAdd(&lconf[hc_], sh - sa);
+                    atomicAdd(&lconf[ac_], sa - sh);
                 }
             }
         }
+        NEU_STAMP(9);
         double both[2] = {Ui, ui};
         dc::wave_sumN_f64(both);
         if (lane == 0) {
@@ -560,29 +726,73 @@ __global__ __launch_bounds__(NEU_BIG_BLOCK) void neu_big(NeuArgs A) {
         if (tid < 2) {
             double v = 0.0;
             for (int w = 0; w < WAVES; ++w) v += shr[w * 2 + tid];
-            if (v != 0.0) atomicAdd(&F.sc[tid == 0 ? dcd::SC_U : dcd::SC_GRHO], v);
+            if (v != 0.0) atomicAdd(&gsc[tid == 0 ? dcd::SC_U : dcd::SC_GRHO], v);
         }
         for (int k = tid; k < T * dcd::A_N; k += NEU_BIG_BLOCK) {
             const double v = lacc[k];
-            if (v != 0.0) atomicAdd(&F.acc[k], v);
+            if (v != 0.0) atomicAdd(&gacc[k], v);
         }
         for (int k = tid; k < C; k += NEU_BIG_BLOCK) {
             const double v = lconf[k];
-            if (v != 0.0) atomicAdd(&F.cacc[k], v);
+            if (v != 0.0) atomicAdd(&gcacc[k], v);
+        }
+        // (the maxima travel to the epilogue in LDS: the last workgroup has them like every other)
+        if (tid == 0) {
+            lred[(size_t)T * dcd::A_N + dcd::SC_MAXP] = M;
+            lred[(size_t)T * dcd::A_N + dcd::SC_MAXH] = Lh;
+            lred[(size_t)T * dcd::A_N + dcd::SC_MAXA] = La;
         }
     }
     // ---- arrive (atomics drained); the last workgroup runs the epilogue
+    NEU_STAMP(5);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) s_last = dcd::tree_arrive_one(F.tickets, dcd::TB_FINAL, blockIdx.x, nb, false);
     __syncthreads();
     if (!s_last) return;
     dcd::tree_reset(F.tickets);   // everyone is past the barrier: the counters go back to zero for the next launch
-    epilogue_body<NEU_BIG_BLOCK, true>(A, sums);
+    NEU_STAMP(6);
+    // the copies of the scratch, summed into LDS (every load of a thread in flight at once); the epilogue
+    // then reads LDS only.  Words: acc | sc (maxima: put there above; SC_U, SC_GRHO: sums; indices: copy 0) | cacc
+    {
+        const int o_sc = T * dcd::A_N;
+        for (int k = tid; k < (int)F.scratch_n; k += NEU_BIG_BLOCK) {
+            const int j = k - o_sc;
+            const bool is_max = j >= dcd::SC_MAXP && j <= dcd::SC_MAXA, is_idx = j >= dcd::SC_IDXP && j <= dcd::SC_IDXR;
+            double v[NEU_BIG_GROUPS];
+#pragma unroll
+            for (int g_ = 0; g_ < NEU_BIG_GROUPS; ++g_) v[g_] = dc::ld_sc1(F.acc + (size_t)g_ * F.scratch_n + k);
+            double sum = 0.0;
+#pragma unroll
+            for (int g_ = 0; g_ < NEU_BIG_GROUPS; ++g_) sum += v[g_];
+            if (is_idx) lred[k] = v[0];          // (bit patterns of the indices: copy 0 only)
+            else if (!is_max) lred[k] = sum;
+        }
+    }
+    __syncthreads();
+    NeuArgs E = A;
+    E.F.acc = lred;
+    E.F.sc = lred + (size_t)T * dcd::A_N;
+    E.F.cacc = E.F.sc + dcd::SC_N;
+#ifdef DC_STAMPS
+    __shared__ unsigned long long epi_st[8];
+    epilogue_body<NEU_BIG_BLOCK, false>(E, sums, epi_st);
+#else
+    epilogue_body<NEU_BIG_BLOCK, false>(E, sums);
+#endif
+    NEU_STAMP(7);
+#ifdef DC_STAMPS
+    __syncthreads();
+    if (tid == 0) {
+        for (int k = 0; k < 8 && k < T; ++k) F.grad[L.o_sat + k] = (double)nstamp_[k];
+        for (int k = 0; k < 5 && 8 + k < T; ++k) F.grad[L.o_sat + 8 + k] = (double)epi_st[k];
+        for (int k = 0; k < 2 && 13 + k < T; ++k) F.grad[L.o_sat + 13 + k] = (double)nstamp_[8 + k];
+    }
+#endif
     // everything this launch accumulated is read: back to zero for the next one (plain stores: the words are
     // next touched by the NEXT launch's atomics, and the kernel boundary writes them back first)
     __syncthreads();
-    for (size_t k = tid; k < F.scratch_n; k += NEU_BIG_BLOCK) F.acc[k] = 0.0;
+    for (size_t k = tid; k < F.scratch_n * NEU_BIG_GROUPS; k += NEU_BIG_BLOCK) F.acc[k] = 0.0;
 }
 
 // ---- the whole evaluation in ONE workgroup (one workgroup per chain), everything in LDS.
