@@ -217,6 +217,7 @@ __device__ __forceinline__ void epilogue_body(const NeuArgs& A, double* sums, un
                  s_ad = scal[5];
     const double u = su_[0], du = su_[1], su = su_[4];
     const double rp = 2.0 * u - 1.0, vv = 1.0 - rp * rp, log_vv = dc::lean::log(vv);
+    const double ivv = dc::lean::rcp(vv);   // (one reciprocal: a float64 division is ~30 dependent instructions)
 
     double loc[NEU_SUMS];
 #pragma unroll
@@ -248,21 +249,21 @@ __device__ __forceinline__ void epilogue_body(const NeuArgs& A, double* sums, un
         const bool first = t == tid;
         const double sa = first ? pz[0] : z[L.o_sat + t], sd = first ? pz[1] : z[L.o_sdt + t];
         const double e = sd - rp * sa;
-        grad[L.o_sat + t] = -(s_att * G_att - sa + rp * e / vv);
-        grad[L.o_sdt + t] = -(s_def * G_def - e / vv);
+        grad[L.o_sat + t] = -(s_att * G_att - sa + rp * e * ivv);
+        grad[L.o_sdt + t] = -(s_def * G_def - e * ivv);
         const double hat = first ? pz[2] : z[L.o_hat + t], aat = first ? pz[3] : z[L.o_aat + t],
                      hdf = first ? pz[4] : z[L.o_hdf + t], adf = first ? pz[5] : z[L.o_adf + t];
         grad[L.o_hat + t] = -(s_ha * G_hat - hat);
         grad[L.o_aat + t] = -(s_aa * G_aat - aat);
         grad[L.o_hdf + t] = -(s_hd * G_hdf - hdf);
         grad[L.o_adf + t] = -(s_ad * G_adf - adf);
-        loc[0] += e * sa / vv - rp * e * e / (vv * vv) + rp / vv;
+        loc[0] += e * sa * ivv - rp * e * e * (ivv * ivv) + rp * ivv;
         loc[1] += sa * G_att;
         loc[2] += sd * G_def;
         loc[3] += G_def;
         loc[4] += G_hat; loc[5] += G_aat; loc[6] += G_hdf; loc[7] += G_adf;
         loc[8] += hat * G_hat; loc[9] += aat * G_aat; loc[10] += hdf * G_hdf; loc[11] += adf * G_adf;
-        loc[12] += -0.5 * sa * sa - HALF_LOG_2PI - 0.5 * e * e / vv - 0.5 * log_vv - HALF_LOG_2PI
+        loc[12] += -0.5 * sa * sa - HALF_LOG_2PI - 0.5 * e * e * ivv - 0.5 * log_vv - HALF_LOG_2PI
                    - 0.5 * (hat * hat + aat * aat + hdf * hdf + adf * adf) - 4.0 * HALF_LOG_2PI;
         for (int k = 0; k < K; ++k) {
             const double xv = A.F.xs[(size_t)t * K + k];
@@ -274,10 +275,10 @@ __device__ __forceinline__ void epilogue_body(const NeuArgs& A, double* sums, un
     // wave sums by DPP (same-address LDS atomics from many lanes serialise badly), then one
     // LDS atomic per wave and value
     if ((tid & ~63) < T) {
+        dc::wave_sumN_f64(loc);   // (the thirteen chains interleaved step by step, not one after another)
+        if ((tid & 63) == 0) {
 #pragma unroll
-        for (int i = 0; i < NEU_SUMS; ++i) {
-            const double v = dc::wave_sum_f64(loc[i]);
-            if ((tid & 63) == 0) atomicAdd(&sums[i], v);
+            for (int i = 0; i < NEU_SUMS; ++i) atomicAdd(&sums[i], loc[i]);
         }
     }
     __syncthreads();

@@ -164,9 +164,14 @@ int bplhip_set_fixtures_neutral(bplhip_ctx* ctx, int64_t n, int32_t n_teams,
  *   "persistent_kernel" 1 (default) = one resident chain of the basic / extended model runs its
  *            leapfrogs INSIDE one launch (the streaming workgroups poll the next position);
  *            0 = one launch per leapfrog.
- *   "fused_small" 1 (default) = neutral / dynamic evaluations small enough for it run as ONE
- *            launch (neutral: one workgroup per chain, everything in LDS; dynamic: phases behind
- *            grid barriers); 0 = always the multi-launch path.
+ *   "fused_small" 1 (default) = neutral / dynamic evaluations run as ONE launch: small ones on
+ *            one workgroup per chain with everything in LDS (neutral) / one workgroup per four
+ *            teams with phases behind grid barriers (dynamic), larger ones sliced over all CUs
+ *            (a slice of the fixtures per workgroup, tree barriers) while the slices fit the LDS;
+ *            0 = always the multi-launch path.
+ *   "dyn_big_wgs" 0 (default) = the sliced single launch uses one workgroup per CU, and the
+ *            dynamic model takes it past 1024 fixtures per team workgroup; > 0 = that many
+ *            workgroups, and the dynamic model takes the sliced form whatever its size.
  *   "dense_pairs" 1 (default) = a complete pair table (every ordered pair h != a present) of 8192
  *            pairs or more takes the rho bounds from the top two table entries per role
  *            (O(teams)); 0 = always walk the pair table.

@@ -13,6 +13,8 @@ python tools/stamps.py > $OUT/stamps_timeline.txt 2>&1
 python tools/stamps.py nuts >> $OUT/stamps_timeline.txt 2>&1
 NUTS_K=5 python tools/stamps.py nuts >> $OUT/stamps_timeline.txt 2>&1
 python tools/dynamic_stamps.py > $OUT/dynamic_timeline.txt 2>&1
+BIGN=1e6 python tools/dynamic_stamps.py > $OUT/dynamic_big_stamps.txt 2>&1
+python tools/neutral_big_stamps.py > $OUT/neutral_big_stamps.txt 2>&1
 python tools/neutral_phases.py > $OUT/neutral_phases.txt 2>&1
 TEAMS=100 python tools/stamps.py basic > $OUT/stamps_teams100.txt 2>&1
 TEAMS=200 python tools/stamps.py basic > $OUT/stamps_teams200.txt 2>&1
@@ -20,7 +22,7 @@ python tools/n_sweep.py > $OUT/n_sweep.txt 2>&1
 python tools/batched_bench.py > $OUT/batched_chains_vec.txt 2>&1
 VEC=0 CHAINS=8,64 python tools/batched_bench.py > $OUT/batched_chains_gridy.txt 2>&1
 CHAINS=4,8,16,32,64 python tools/lockstep_bench.py > $OUT/lockstep_chains.txt 2>&1
-python tools/dynamic_bench.py > $OUT/dynamic_model.txt 2>&1
+SWEEP=1 python tools/dynamic_bench.py > $OUT/dynamic_model.txt 2>&1
 python tools/predict_bench.py > $OUT/predict.txt 2>&1
 python tools/neutral_bench.py > $OUT/neutral_model.txt 2>&1
 python tools/small_n_bench.py > $OUT/small_n.txt 2>&1

@@ -10,7 +10,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-for CASE in basic c3 c3w t100 t200 nuts vec64 dyn_c4 neutral predict predict_venue; do
+for CASE in basic c3 c3w t100 t200 nuts vec64 dyn_c4 dyn_1e6 neutral neutral_1e6 predict predict_venue; do
   D=$OUT/$CASE; mkdir -p $D
   rocprofv3 --kernel-trace --stats --output-format csv -d $D/trace -- python3 $ROOT/tools/kernel_cases.py $CASE > $D/trace.log 2>&1
   echo "$CASE trace exit $?"

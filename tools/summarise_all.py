@@ -48,7 +48,7 @@ for case_dir in sorted(glob.glob(os.path.join(d, "*/"))):
         hbm = (2 * f + w) if f is not None and w is not None else None
         alg = meta.get("algorithmic_bytes_per_launch")
         need = meta.get("library_copy_bytes_per_launch")
-        main = any(s in name for s in ("dc_eval", "dc_vec_stream", "dyn_pass", "dyn_fused", "neu_fused", "predict_score_grid"))
+        main = any(s in name for s in ("dc_eval", "dc_vec_stream", "dyn_pass", "dyn_fused", "neu_fused", "neu_big", "predict_score_grid"))
         fa = alg / 1e3 / avg / PEAK if (alg and main) else None
         fn = need / 1e3 / avg / PEAK if (need and main) else None
         rows.append({"case": case, "kernel": name, "calls": int(r["Calls"]), "avg_us": avg, "min_us": mn,
