@@ -115,3 +115,51 @@ def test_single_launch_models_repeat(hip_ctx):
         torch.cuda.synchronize()
         assert ((U - U0).abs() <= 1e-12 * U0.abs()).all()
         assert float((g - g0).abs().max()) <= 1e-11 * float(g0.abs().max())
+
+
+def test_sliced_single_launches_repeat(hip_ctx):
+    """The single launches sliced over all CUs (dyn_fused<true>, dcn::neu_big: tree barriers, a counted cell
+    hand-off, copies of the scratch words, scratch and counters cleared by the launch's last workgroup):
+    thousands of back-to-back launches agree to rounding (float64 atomics land in arbitrary order), raise no
+    fault and leave scratch and counters clean for the next one -- which the four-launch path, run right after
+    on the same context, confirms from the other side."""
+    import torch
+
+    def soak(rounds, replays, tol_u, tol_g):
+        z = torch.tensor(np.random.RandomState(7).uniform(-0.3, 0.3, (8, hip_ctx.dim)), dtype=torch.float64,
+                         device=hip_ctx.device)
+        U = torch.zeros(8, dtype=torch.float64, device=hip_ctx.device)
+        g = torch.zeros_like(z)
+        hip_ctx.logp_grad_graph(16, z, U, g, replays=1)
+        torch.cuda.synchronize()
+        U0, g0 = U.clone(), g.clone()
+        assert torch.isfinite(U0).all() and torch.isfinite(g0).all()
+        for _ in range(rounds):
+            U.zero_()
+            g.zero_()
+            hip_ctx.logp_grad_graph(16, z, U, g, replays=replays)
+            torch.cuda.synchronize()
+            assert ((U - U0).abs() <= tol_u * U0.abs()).all()
+            assert float((g - g0).abs().max()) <= tol_g * float(g0.abs().max())
+        hip_ctx.set_option("fused_small", 0)   # the same points through the multi-launch path
+        try:
+            U4, g4, _ = hip_ctx.logp_grad(z)
+        finally:
+            hip_ctx.set_option("fused_small", 1)
+        assert ((U4 - U0).abs() <= 1e-9 * U0.abs()).all()
+        assert float((g4 - g0).abs().max()) <= 1e-9 * float(g0.abs().max())
+
+    rs = np.random.RandomState(5)
+    Tn, G, n = 100, 50, 300_000
+    h = rs.randint(0, Tn, n)
+    a = (h + 1 + rs.randint(0, Tn - 1, n)) % Tn
+    hip_ctx.set_fixtures_dynamic(h, a, rs.poisson(1.5, n), rs.poisson(1.2, n), rs.randint(0, G, n),
+                                 (rs.rand(n) < 0.1).astype(np.uint8), Tn, G)
+    soak(4, 40, 1e-12, 1e-11)    # 4 x 40 x 16 = 2560 launches of dyn_fused<true>
+
+    T, n = 20, 300_000
+    h = rs.randint(0, T, n)
+    a = (h + 1 + rs.randint(0, T - 1, n)) % T
+    hip_ctx.set_fixtures_neutral(h, a, rs.poisson(1.4, n), rs.poisson(1.1, n), rs.randint(0, 2, n), T,
+                                 weights=rs.uniform(0.2, 3.0, n).astype(np.float32))
+    soak(4, 40, 1e-12, 1e-11)    # 2560 launches of neu_big
