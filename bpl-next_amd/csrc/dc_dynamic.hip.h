@@ -1391,26 +1391,31 @@ __global__ __launch_bounds__(FUSED_DYN_BLOCK) void dyn_fused(DynArgs A) {
                     const int nvi = (int)(w[j] >> 48) & 1;
                     const double lh = rl[j][0], la = rl[j][1];
                     double gh = x - lh, ga = y - la;
+                    // (the fixture phases are bound by instruction issue, and most of this loop's instructions were
+                    // control flow: ONE branch around the tau term, selects inside it; ONE around the three
+                    // arg-extremal tests)
                     if (x <= 1 && y <= 1) {
                         const double cc = x == 0 ? (y == 0 ? -lh * la : lh) : (y == 0 ? la : -1.0);
                         const double arg = 1.0 + b.rho * cc;
-                        if (arg > 0.0) {
-                            Ui += dc::lean::log(arg);
-                            const double uu = cc * dc::lean::rcp(arg);
-                            ui += uu;
-                            if (x == 0) gh += b.rho * uu;
-                            if (y == 0) ga += b.rho * uu;
-                        } else {
-                            Ui += log(0.0);  // -inf (tol = 0, bpl/_util.py:42)
-                        }
+                        const bool pos = arg > 0.0;
+                        const double safe = pos ? arg : 1.0;
+                        const double lg = dc::lean::log(safe);
+                        const double uu = pos ? cc * dc::lean::rcp(safe) : 0.0;
+                        Ui += pos ? lg : -__builtin_inf();   // log(0) = -inf (tol = 0, bpl/_util.py:42)
+                        ui += uu;
+                        gh += x == 0 ? b.rho * uu : 0.0;
+                        ga += y == 0 ? b.rho * uu : 0.0;
                     }
-                    const long long i = i_lo + k;
-                    const unsigned long long key =
-                        ((unsigned long long)(0x1FFFFFFF - i) << 35) | ((unsigned long long)gi << 25) |
-                        ((unsigned long long)fh << 13) | ((unsigned long long)fa << 1) | (unsigned long long)nvi;
-                    if (lh * la == b.M) atomicMax(&scu[SC_IDXP], key);
-                    if (lh == b.Lh) atomicMax(&scu[SC_IDXQ], key);
-                    if (la == b.La) atomicMax(&scu[SC_IDXR], key);
+                    const double lp = lh * la;
+                    if (lp == b.M || lh == b.Lh || la == b.La) {   // (rare)
+                        const long long i = i_lo + k;
+                        const unsigned long long key =
+                            ((unsigned long long)(0x1FFFFFFF - i) << 35) | ((unsigned long long)gi << 25) |
+                            ((unsigned long long)fh << 13) | ((unsigned long long)fa << 1) | (unsigned long long)nvi;
+                        if (lp == b.M) atomicMax(&scu[SC_IDXP], key);
+                        if (lh == b.Lh) atomicMax(&scu[SC_IDXQ], key);
+                        if (la == b.La) atomicMax(&scu[SC_IDXR], key);
+                    }
                     double* Rh = lacc + (2 * nvi) * T + fh;        // home side: {Hh, Ha} or {Hh_n, Ha_n}
                     double* Ra = lacc + (4 + 2 * nvi) * T + fa;    // away side: {Ah, Aa} or {Ah_n, Aa_n}
                     atomicAdd(&Rh[0], gh);
