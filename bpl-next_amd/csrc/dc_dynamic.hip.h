@@ -841,6 +841,7 @@ __device__ __forceinline__ bool grid_wait(unsigned int* tickets, int which, unsi
 // lines 0..15 group counters, 16 the top counter, 17..32 the flags; put back to zero by the launch's last
 // workgroup (tree_reset).
 constexpr int TREE_FAN = 16, TREE_LINES = 2 * TREE_FAN + 1, TREE_WORDS = TREE_LINES * 16, TREE_BASE = 64;
+constexpr unsigned int TREE_FLAT_MAX = 32;   // up to this many arrivals go to the top counter directly
 enum { TB_1 = 0, TB_2, TB_3, TB_FINAL, TB_N };
 constexpr size_t TICKET_BYTES = (size_t)(TREE_BASE + TB_N * TREE_WORDS) * 4;
 __device__ __forceinline__ unsigned int* tree_word(unsigned int* tickets, int b, int line) {
@@ -849,12 +850,15 @@ __device__ __forceinline__ unsigned int* tree_word(unsigned int* tickets, int b,
 // One thread.  Arrival `idx` of `n`; true for the arrival that completes the barrier.
 __device__ __forceinline__ bool tree_arrive_one(unsigned int* tickets, int b, unsigned int idx, unsigned int n,
                                                 bool set_flags) {
-    const unsigned int gs = (n + TREE_FAN - 1) / TREE_FAN;   // arrivals per group
-    const unsigned int grp = idx / gs, ngrp = (n + gs - 1) / gs;
-    const unsigned int mine = n - grp * gs < gs ? n - grp * gs : gs;
-    if (__hip_atomic_fetch_add(tree_word(tickets, b, (int)grp), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != mine - 1)
-        return false;
-    if (__hip_atomic_fetch_add(tree_word(tickets, b, TREE_FAN), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != ngrp - 1)
+    if (n > TREE_FLAT_MAX) {   // (few arrivals: one level -- a second counter is a second memory-side round trip)
+        const unsigned int gs = (n + TREE_FAN - 1) / TREE_FAN;   // arrivals per group
+        const unsigned int grp = idx / gs;
+        const unsigned int mine = n - grp * gs < gs ? n - grp * gs : gs;
+        if (__hip_atomic_fetch_add(tree_word(tickets, b, (int)grp), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != mine - 1)
+            return false;
+        n = (n + gs - 1) / gs;   // the groups arrive at the top counter
+    }
+    if (__hip_atomic_fetch_add(tree_word(tickets, b, TREE_FAN), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != n - 1)
         return false;
     if (set_flags)
         for (int f = 0; f < TREE_FAN; ++f)
