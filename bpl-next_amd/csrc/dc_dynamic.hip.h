@@ -22,6 +22,9 @@
 //                 reduced over the workgroup's teams in LDS, then ONE global atomic per entry;
 //                 the last-arriving workgroup (ticket) finishes the per-gameweek
 //                 hyper-parameters, coefficients, scalars and the potential
+// ... or, whenever the shapes allow it, ONE launch with these four as phases (dyn_fused, further down):
+// <false> one workgroup per four teams (config 4, 19 us), <true> a gameweek's slice of the fixtures per
+// workgroup on every CU with tree barriers (any N while a slice fits the LDS: 34.5 us at N = 1e6, four launches 67).
 // Roofline: HBM-bound stream of 9 B per fixture (u16,u16,u8,u8,u16,u8) + gathers from an
 // L2-resident cell table; at config-4 size (N = 2500) it is launch-latency bound.
 // Mathematics: SURVEY.md Appendix A.5 (+ Appendix A.1-A.3 for the shared pieces).
