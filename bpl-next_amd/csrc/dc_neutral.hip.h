@@ -139,8 +139,11 @@ __device__ inline dcd::SigSite sig_site_lean(double zr) {
 #else
 #define EPI_STAMP(k) do { } while (0)
 #endif
-template <int BLOCK, bool SC1>
-__device__ __forceinline__ void epilogue_body(const NeuArgs& A, double* sums, unsigned long long* epi_stamp = nullptr) {
+// LDSACC (neu_big): A.F.acc is this workgroup's LDS copy -- the bounds' adjoint entries are added into it by one
+// lane each instead of being searched by every team
+template <int BLOCK, bool SC1, bool LDSACC = false>
+__device__ __forceinline__ void epilogue_body(const NeuArgs& A, double* sums, unsigned long long* epi_stamp = nullptr,
+                                              double* lds_acc = nullptr) {
     constexpr int NEU_EPI = BLOCK;
     const NeuLayout& L = A.L;
     EPI_STAMP(0);
@@ -207,6 +210,12 @@ __device__ __forceinline__ void epilogue_body(const NeuArgs& A, double* sums, un
     dcd::build_coupling<SC1>(A.F, b, &C, CF, tid, SC1 ? pre_idx : nullptr);
     EPI_STAMP(2);
     const int cn = C.n;
+    if (LDSACC) {   // (one entry per lane; build_coupling ends with a barrier)
+        if (tid < cn && C.which[tid] < dcd::A_N)
+            atomicAdd(&lds_acc[C.cell[tid] * dcd::A_N + C.which[tid]], C.val[tid]);   // (the LDS array itself: through
+                                                                                       // A.F.acc it is a generic pointer)
+        __syncthreads();
+    }
     auto coupled = [&](int cell, int which, double base) {
         double v = base;
         for (int e = 0; e < cn; ++e)
@@ -226,8 +235,8 @@ __device__ __forceinline__ void epilogue_body(const NeuArgs& A, double* sums, un
         const double* Ac = A.F.acc + (size_t)t * dcd::A_N;
         double G6[dcd::A_N];
 #pragma unroll
-        for (int j = 0; j < dcd::A_N; ++j) G6[j] = t == tid ? pG[j] : SC1 ? dc::ld_sc1(&Ac[j]) : Ac[j];
-        {   // (at most three fixtures' teams carry a bounds adjoint: ONE pass over the table, every LDS read of it
+        for (int j = 0; j < dcd::A_N; ++j) G6[j] = LDSACC ? Ac[j] : t == tid ? pG[j] : SC1 ? dc::ld_sc1(&Ac[j]) : Ac[j];
+        if (!LDSACC) {   // (at most three fixtures' teams carry a bounds adjoint: ONE pass over the table, every LDS read of it
             // independent of the others -- entry by entry behind a search per adjoint, these reads were a chain
             // of ~120 dependent LDS round trips: 9 of the epilogue's 15 us)
             double adj[dcd::A_N];
@@ -777,9 +786,9 @@ __global__ __launch_bounds__(NEU_BIG_BLOCK) void neu_big(NeuArgs A) {
     E.F.cacc = E.F.sc + dcd::SC_N;
 #ifdef DC_STAMPS
     __shared__ unsigned long long epi_st[8];
-    epilogue_body<NEU_BIG_BLOCK, false>(E, sums, epi_st);
+    epilogue_body<NEU_BIG_BLOCK, false, true>(E, sums, epi_st, lred);
 #else
-    epilogue_body<NEU_BIG_BLOCK, false>(E, sums);
+    epilogue_body<NEU_BIG_BLOCK, false, true>(E, sums, nullptr, lred);
 #endif
     NEU_STAMP(7);
 #ifdef DC_STAMPS
