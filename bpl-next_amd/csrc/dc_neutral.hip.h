@@ -143,7 +143,7 @@ __device__ inline dcd::SigSite sig_site_lean(double zr) {
 // lane each instead of being searched by every team
 template <int BLOCK, bool SC1, bool LDSACC = false>
 __device__ __forceinline__ void epilogue_body(const NeuArgs& A, double* sums, unsigned long long* epi_stamp = nullptr,
-                                              double* lds_acc = nullptr) {
+                                              double* lds_acc = nullptr, const double* pre_scal = nullptr) {
     constexpr int NEU_EPI = BLOCK;
     const NeuLayout& L = A.L;
     EPI_STAMP(0);
@@ -179,14 +179,16 @@ __device__ __forceinline__ void epilogue_body(const NeuArgs& A, double* sums, un
     // scalar sites first, in parallel lanes of one wave (a float64 libm call costs ~1 us of
     // dependent instructions: they must not run one after another on one lane):
     //   lanes 0..5 exp(std sites) | lanes 6, 7 sigmoid sites u, corr_coef_raw
-    __shared__ double scal[6 + 2 * 6];
-    if (tid < 6) {
+    __shared__ double scal_own[6 + 2 * 6];
+    const double* scal = LDSACC ? pre_scal : scal_own;   // (neu_big: worked out in its barrier's shadow, by every workgroup)
+    if (LDSACC) {
+    } else if (tid < 6) {
         const int o = tid == 0 ? L.o_s_att : tid == 1 ? L.o_s_def : tid == 2 ? L.o_s_ha
                     : tid == 3 ? L.o_s_aa : tid == 4 ? L.o_s_hd : L.o_s_ad;
-        scal[tid] = dc::lean::exp(z[o]);
+        scal_own[tid] = dc::lean::exp(z[o]);
     } else if (tid < 8) {
         const dcd::SigSite ss = sig_site_lean(z[tid == 6 ? L.o_u : L.o_corr]);
-        double* q = scal + 6 + (tid - 6) * 6;
+        double* q = scal_own + 6 + (tid - 6) * 6;
         q[0] = ss.v; q[1] = ss.dv; q[2] = ss.log_v; q[3] = ss.log_1mv; q[4] = ss.sig; q[5] = ss.sp_sum;
     }
     __syncthreads();
@@ -391,6 +393,7 @@ __global__ __launch_bounds__(NEU_BIG_BLOCK) void neu_big(NeuArgs A) {
     __shared__ unsigned long long shm[3 * (WAVES > NEU_BIG_GROUPS ? WAVES : NEU_BIG_GROUPS)];
     __shared__ double shr[2 * WAVES];
     __shared__ int s_ok, s_last, s_slow;
+    __shared__ double s_scal[6 + 2 * 6];
     const NeuLayout& L = A.L;
     const dcd::DynArgs& F = A.F;
     const int T = L.T, K = L.K, C = L.C;
@@ -534,7 +537,17 @@ __global__ __launch_bounds__(NEU_BIG_BLOCK) void neu_big(NeuArgs A) {
     }
     NEU_STAMP(3);
     dcd::tree_arrive(F.tickets, dcd::TB_2, blockIdx.x, nb);
-    // (in the barrier's shadow: corr_coef_raw's sigmoid)
+    // (in the barrier's shadow: the scalar sites for the epilogue, whichever workgroup will run it -- lanes 0..5
+    // exp(std sites) | lanes 6, 7 the sigmoid sites u, corr_coef_raw; and corr_coef_raw's sigmoid for phase 3)
+    if (tid < 6) {
+        const int o = tid == 0 ? L.o_s_att : tid == 1 ? L.o_s_def : tid == 2 ? L.o_s_ha
+                    : tid == 3 ? L.o_s_aa : tid == 4 ? L.o_s_hd : L.o_s_ad;
+        s_scal[tid] = dc::lean::exp(z[o]);
+    } else if (tid < 8) {
+        const dcd::SigSite ss = sig_site_lean(z[tid == 6 ? L.o_u : L.o_corr]);
+        double* qq = s_scal + 6 + (tid - 6) * 6;
+        qq[0] = ss.v; qq[1] = ss.dv; qq[2] = ss.log_v; qq[3] = ss.log_1mv; qq[4] = ss.sig; qq[5] = ss.sp_sum;
+    }
     double q, dq, sq;
     {
         const double z_corr = z[L.o_corr];
@@ -786,9 +799,9 @@ __global__ __launch_bounds__(NEU_BIG_BLOCK) void neu_big(NeuArgs A) {
     E.F.cacc = E.F.sc + dcd::SC_N;
 #ifdef DC_STAMPS
     __shared__ unsigned long long epi_st[8];
-    epilogue_body<NEU_BIG_BLOCK, false, true>(E, sums, epi_st, lred);
+    epilogue_body<NEU_BIG_BLOCK, false, true>(E, sums, epi_st, lred, s_scal);
 #else
-    epilogue_body<NEU_BIG_BLOCK, false, true>(E, sums, nullptr, lred);
+    epilogue_body<NEU_BIG_BLOCK, false, true>(E, sums, nullptr, lred, s_scal);
 #endif
     NEU_STAMP(7);
 #ifdef DC_STAMPS
