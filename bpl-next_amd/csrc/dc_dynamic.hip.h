@@ -604,12 +604,6 @@ __global__ __launch_bounds__(BACK_BLOCK) void dyn_back(DynArgs A) {
     __shared__ CouplingFix CF[2];
     build_coupling(A, b, &C, CF, threadIdx.x);
     const int cn = C.n;
-    auto coupled = [&](int cell, int which, double base) {
-        double v = base;
-        for (int e = 0; e < cn; ++e)
-            if (C.cell[e] == cell && C.which[e] == which) v += C.val[e];
-        return v;
-    };
     double* gs = lds_sums ? lgs : A.gsum;  // (LDS atomics here, one global atomic per entry below)
     double carry_a = 0.0, carry_d = 0.0, Lloc = 0.0;
     const int nchunk = t < T ? (G + 63) / 64 : 0;  // (a wave without a team only joins the barriers)
@@ -621,11 +615,22 @@ __global__ __launch_bounds__(BACK_BLOCK) void dyn_back(DynArgs A) {
         double G6[A_N];
 #pragma unroll
         for (int j = 0; j < A_N; ++j) G6[j] = on ? Ac[j] : 0.0;
-        bool hit = false;  // (at most three fixtures' cells carry a bounds adjoint)
-        for (int e = 0; e < cn; ++e) hit = hit || C.cell[e] == c;
-        if (hit && on) {
+        {   // (at most three fixtures' cells carry a bounds adjoint: ONE pass over the table, every LDS read of it
+            // independent of the others -- behind a search per adjoint these reads were a chain of ~120 dependent
+            // LDS round trips, the larger part of this kernel's time: see dcn::epilogue_body)
+            double adj[A_N];
 #pragma unroll
-            for (int j = 0; j < A_N; ++j) G6[j] = coupled(c, j, G6[j]);
+            for (int j = 0; j < A_N; ++j) adj[j] = 0.0;
+#pragma unroll
+            for (int e = 0; e < 18; ++e) {
+                const bool mine = on && e < cn && C.cell[e] == c;
+                const int wh = C.which[e];
+                const double v = C.val[e];
+#pragma unroll
+                for (int j = 0; j < A_N; ++j) adj[j] += (mine && wh == j) ? v : 0.0;
+            }
+#pragma unroll
+            for (int j = 0; j < A_N; ++j) G6[j] += adj[j];
         }
         const double ga_ = A.random_walk ? G6[A_ATT] : 0.0;
         const double gd_ = A.random_walk ? G6[A_DEF] : 0.0;
