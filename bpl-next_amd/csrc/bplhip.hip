@@ -166,6 +166,8 @@ struct bplhip_ctx {
     bool dyn_attr_set = false;
     std::map<GraphKey, hipGraphExec_t> graphs;
     hipStream_t cap_stream = nullptr;
+    bool capturing = false;   // between hipStreamBeginCapture and hipStreamEndCapture on cap_stream: nothing
+                              // may allocate, free or synchronise (capture_launches)
 
     ~bplhip_ctx() {
         for (auto& kv : graphs) (void)hipGraphExecDestroy(kv.second);
@@ -705,13 +707,26 @@ int launch_vec_t(bplhip_ctx* c, const dc::EvalArgs& A, int chains, hipStream_t s
 }
 // nuts != nullptr: lock-step device NUTS; chain c's state at nuts + c*nuts_stride, and
 // z / pot / grad / aux point into chain 0's state (strides = nuts_stride)
+// select the partition for `chains` chains and size its hand-off buffer.  Growing it is a hipMalloc
+// (+ hipFree): not allowed while a stream of this thread is capturing -- whoever captures launches of
+// the vectorised kernel sizes it first (round 3 did not: every sampler run with more chains than
+// gridy_max_chains on a fresh context failed inside the chunk graph's capture).
+int prepare_vec(bplhip_ctx* c, int chains) {
+    c->vp = &c->vps[chains <= 8 ? 0 : (chains <= 23 ? 1 : 2)];
+    if (chains > c->vp->slab_chains) {
+        if (c->capturing)
+            return fail(c, BPLHIP_ESTATE, "dc_vec: hand-off buffer for %d chains not sized before the capture", chains);
+        HIP_TRY(c, c->vp->d_hbuf.ensure((size_t)chains * vec_hb_stride(c) * sizeof(double)));
+        c->vp->slab_chains = chains;
+    }
+    return BPLHIP_OK;
+}
 int launch_eval_vec(bplhip_ctx* c, int chains, const double* z, double* pot, double* grad,
                     double* aux, hipStream_t s, double* nuts = nullptr, int nuts_stride = 0,
                     int nuts_depth = 0, const nd::Persist* persist = nullptr) {
-    c->vp = &c->vps[chains <= 8 ? 0 : (chains <= 23 ? 1 : 2)];
-    if (chains > c->vp->slab_chains) {
-        HIP_TRY(c, c->vp->d_hbuf.ensure((size_t)chains * vec_hb_stride(c) * sizeof(double)));
-        c->vp->slab_chains = chains;
+    {
+        const int prc = prepare_vec(c, chains);
+        if (prc != BPLHIP_OK) return prc;
     }
     dc::EvalArgs A = eval_args(c, chains, z, pot, grad, aux);
     if (nuts) {
@@ -784,6 +799,38 @@ SparseSlabs build_sparse_slabs(const std::vector<uint16_t>& hs, const std::vecto
 void drop_graphs(bplhip_ctx* c) {  // (declared above ensure_slabs)
     for (auto& kv : c->graphs) (void)hipGraphExecDestroy(kv.second);
     c->graphs.clear();
+}
+
+// Capture what `enqueue(stream)` launches into an executable graph.  A capture is an optimisation,
+// never a requirement: whatever goes wrong inside it (a launch path that wanted to allocate, an API
+// the runtime refuses while capturing, an instantiation failure) ends the capture, clears the
+// runtime's error state and returns nullptr with BPLHIP_OK -- the caller then enqueues the same
+// launches one by one.  Callers run the launches ONCE un-captured first, so that everything a launch
+// path sizes or sets lazily (buffers, function attributes, occupancy queries) is settled.
+template <class F>
+int capture_launches(bplhip_ctx* c, F&& enqueue, hipGraphExec_t* out) {
+    *out = nullptr;
+    if (!c->cap_stream) HIP_TRY(c, hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking));
+    if (hipStreamBeginCapture(c->cap_stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+        (void)hipGetLastError();
+        return BPLHIP_OK;
+    }
+    c->capturing = true;
+    const bool dyn_clean = c->dyn_scratch_clean;
+    const int crc = enqueue(c->cap_stream);
+    c->capturing = false;
+    hipGraph_t g = nullptr;
+    const hipError_t e = hipStreamEndCapture(c->cap_stream, &g);
+    hipGraphExec_t ge = nullptr;
+    if (crc == BPLHIP_OK && e == hipSuccess && g && hipGraphInstantiate(&ge, g, nullptr, nullptr, 0) == hipSuccess) {
+        (void)hipGraphDestroy(g);
+        *out = ge;
+        return BPLHIP_OK;
+    }
+    if (g) (void)hipGraphDestroy(g);
+    (void)hipGetLastError();
+    c->dyn_scratch_clean = dyn_clean;   // (a captured memset never ran)
+    return BPLHIP_OK;
 }
 
 }  // namespace
@@ -1054,6 +1101,10 @@ static int bplhip_set_fixtures_impl(bplhip_ctx* c, int model_kind, int64_t n, in
             for (int cidx = 0; cidx < ncol; ++cidx) expect[cidx] = sp.col_off[cidx + 1] - sp.col_off[cidx];
             for (int w = 0; w < ep.n_wg; ++w)
                 for (int j = 0; j < dc::N_SCAL; ++j) expect[ncol + (w % dc::GA_SHARDS) * dc::N_SCAL + j] += 1;
+            for (int e : expect)
+                if (e > 255)
+                    return fail(c, BPLHIP_EUNSUPPORTED,
+                                "set_fixtures: %d workgroups feed one accumulator row (the row's counter holds 255)", e);
             HIP_TRY(c, ep.d_ga_expect.ensure(expect.size() * 4));
             HIP_TRY(c, hipMemcpy(ep.d_ga_expect.p, expect.data(), expect.size() * 4, hipMemcpyHostToDevice));
         }
@@ -1209,7 +1260,9 @@ int bplhip_set_option(bplhip_ctx* c, const char* name, int value) {
         return BPLHIP_OK;
     }
     if (n == "max_wg") {  // takes effect at the next bplhip_set_fixtures
-        if (value < 1 || value > 1024) return fail(c, BPLHIP_EINVAL, "max_wg out of range [1,1024]");
+        // (an accumulator row counts its contributions in 8 bits, dc::GA_COUNT_SHIFT: with few teams every
+        // workgroup adds to every row)
+        if (value < 1 || value > 255) return fail(c, BPLHIP_EINVAL, "max_wg out of range [1,255]");
         c->opt_max_wg = value;
         return BPLHIP_OK;
     }
@@ -1563,31 +1616,33 @@ static int bplhip_logp_grad_graph_impl(bplhip_ctx* c, int32_t count, int32_t n_z
         return fail(c, BPLHIP_EINVAL, "logp_grad_graph: bad argument");
     HIP_TRY(c, hipSetDevice(c->device));
     const GraphKey key{count, n_z, z, potential, grad};
-    auto it = c->graphs.find(key);
-    if (it == c->graphs.end()) {
-        if (!c->cap_stream) HIP_TRY(c, hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking));
-        const int D = bplhip_latent_dim(c);
-        HIP_TRY(c, hipStreamBeginCapture(c->cap_stream, hipStreamCaptureModeThreadLocal));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int D = bplhip_latent_dim(c);
+    auto enqueue = [&](hipStream_t st) -> int {
         int rc = BPLHIP_OK;
         for (int i = 0; i < count && rc == BPLHIP_OK; ++i) {
             const int j = i % n_z;
-            rc = launch_eval(c, 1, z + (size_t)j * D, potential + j, grad + (size_t)j * D,
-                             nullptr, c->cap_stream);
+            rc = launch_eval(c, 1, z + (size_t)j * D, potential + j, grad + (size_t)j * D, nullptr, st);
         }
-        hipGraph_t g = nullptr;
-        hipError_t e = hipStreamEndCapture(c->cap_stream, &g);
-        if (rc != BPLHIP_OK) {
-            if (g) (void)hipGraphDestroy(g);
-            return rc;
-        }
-        HIP_TRY(c, e);
+        return rc;
+    };
+    auto it = c->graphs.find(key);
+    if (it == c->graphs.end()) {
+        // one un-captured evaluation first: whatever the launch path sets up lazily happens outside the capture
+        int rc = launch_eval(c, 1, z, potential, grad, nullptr, s);
+        if (rc != BPLHIP_OK) return rc;
         hipGraphExec_t ge = nullptr;
-        e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
-        (void)hipGraphDestroy(g);
-        HIP_TRY(c, e);
+        rc = capture_launches(c, enqueue, &ge);
+        if (rc != BPLHIP_OK) return rc;
+        if (!ge) {  // no graph on this runtime: the same launches, one by one
+            for (int r = 0; r < replays; ++r) {
+                rc = enqueue(s);
+                if (rc != BPLHIP_OK) return rc;
+            }
+            return BPLHIP_OK;
+        }
         it = c->graphs.emplace(key, ge).first;
     }
-    hipStream_t s = static_cast<hipStream_t>(stream);
     for (int r = 0; r < replays; ++r) HIP_TRY(c, hipGraphLaunch(it->second, s));
     return BPLHIP_OK;
 }
@@ -2141,19 +2196,13 @@ int run_chains_persistent(bplhip_ctx* c, hipStream_t s, const nuts::Config& nc, 
         ~ExecGuard() { if (e) (void)hipGraphExecDestroy(e); }
     } chunk_graph;
     if (!looped && c->opt_chunk_graph) {
-        if (!c->cap_stream) HIP_TRY(c, hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking));
-        HIP_TRY(c, hipStreamBeginCapture(c->cap_stream, hipStreamCaptureModeThreadLocal));
-        const int crc = enqueue_leapfrogs(c->cap_stream, chunk);
-        hipGraph_t g = nullptr;
-        const hipError_t e = hipStreamEndCapture(c->cap_stream, &g);
-        if (crc != BPLHIP_OK) {
-            if (g) (void)hipGraphDestroy(g);
-            return crc;
-        }
-        HIP_TRY(c, e);
-        const hipError_t e2 = hipGraphInstantiate(&chunk_graph.e, g, nullptr, nullptr, 0);
-        (void)hipGraphDestroy(g);
-        HIP_TRY(c, e2);
+        // one un-captured leapfrog first: the launch path sizes its buffers and sets its function
+        // attributes outside the capture (it advances the chains like any other leapfrog)
+        rc = enqueue_leapfrogs(s, 1);
+        if (rc != BPLHIP_OK) return rc;
+        steps_done += 1.0;
+        rc = capture_launches(c, [&](hipStream_t st) { return enqueue_leapfrogs(st, chunk); }, &chunk_graph.e);
+        if (rc != BPLHIP_OK) return rc;   // (no graph is not an error: the loop below enqueues launch by launch)
     }
     while (!all_done) {
         if (steps_done > max_steps)

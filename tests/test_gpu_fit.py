@@ -296,6 +296,59 @@ def test_lockstep_chains_match_single_chains(hip_ctx, persistent):
     hip_ctx.set_option("persistent_nuts", 1)
 
 
+@pytest.mark.parametrize("nch", [33, 64])
+def test_many_chains_on_a_fresh_context(nch):
+    """More chains than `gridy_max_chains` (32) share the chain-vectorised kernel, whose launches a
+    chunk captures into a hipGraph.  On a FRESH context nothing has sized that kernel's hand-off
+    buffer yet (round 3: the capture failed with "operation not permitted when stream is
+    capturing" and `fit(num_chains=64)` raised).  Same keys through bplhip_nuts_run, chain by chain:
+    same trees, first draws to 1e-5 (reference: mcmc_kwargs={"num_chains": ...},
+    bpl/dixon_coles.py:101-106)."""
+    from bpl._ffi import MODEL_BASIC, HipContext, default_nuts_cfg
+
+    fx = cases.fixtures("dummy")
+    cfg = default_nuts_cfg()
+    cfg.num_warmup, cfg.num_samples, cfg.step_size = 0, 4, 0.02
+    cfg.adapt_step_size = cfg.adapt_mass_matrix = 0
+    keys = [(0, 101 + c) for c in range(nch)]
+    z0 = np.random.RandomState(5).uniform(-0.2, 0.2, (nch, 45))
+    runs = {}
+    for graph in (1, 0):   # the chunk as a replayed graph, and launch by launch: the same chains
+        ctx = HipContext(0)
+        try:
+            ctx.set_option("chunk_graph", graph)
+            ctx.set_fixtures(MODEL_BASIC, fx.home_idx.astype(np.uint16), fx.away_idx.astype(np.uint16),
+                             fx.home_goals.astype(np.uint8), fx.away_goals.astype(np.uint8), 20)
+            runs[graph] = ctx.nuts_run_chains(cfg, keys, z0)     # first call on this context
+            if graph:
+                singles = [ctx.nuts_run(cfg, keys[c], z0[c]) for c in range(nch)]
+        finally:
+            ctx.close()
+    for c in range(nch):
+        dm, sm = runs[1][c]
+        d1, s1 = singles[c]
+        assert sm["num_steps"][:3].tolist() == s1["num_steps"][:3].tolist(), c
+        assert np.abs(dm[:3] - d1[:3]).max() < 1e-5, c
+        assert np.abs(sm["potential_energy"][:3] - s1["potential_energy"][:3]).max() < 1e-4
+        assert np.array_equal(dm, runs[0][c][0]), c   # graph replay == launch by launch, bit for bit
+    assert np.abs(runs[1][0][0] - runs[1][nch - 1][0]).max() > 1e-3
+
+
+def test_fit_forty_chains(dummy_data):
+    """fit(mcmc_kwargs={"num_chains": 40}) on a fresh context (every fit makes its own): adapted
+    chains through the chain-vectorised sampler; shapes, chain-major order, healthy statistics."""
+    m = DixonColesMatchPredictor().fit(dummy_data, random_state=11, num_warmup=150, num_samples=25,
+                                       mcmc_kwargs={"num_chains": 40})
+    assert m.attack.shape == (1000, 20) and m.corr_coef.shape == (1000,)
+    assert np.isfinite(m.attack).all() and np.isfinite(m.corr_coef).all()
+    assert m.mcmc_info_["num_chains"] == 40 and m.mcmc_info_["divergences"] <= 10
+    acc = m.mcmc_info_["accept_prob"].reshape(40, 25).mean(1)
+    assert (acc > 0.5).all()
+    # distinct chains, one posterior: chain means scatter by their Monte-Carlo error only
+    cm = m.home_advantage.reshape(40, 25).mean(1)
+    assert cm.std() > 1e-4 and cm.std() < 0.1
+
+
 def test_fit_num_chains_lockstep_vs_sequential(dummy_data):
     """fit(mcmc_kwargs={"num_chains": 4}): the lock-step default and chain_method="sequential"
     sample the same posterior (shapes, chain-major order, means within Monte-Carlo error)."""
