@@ -42,17 +42,20 @@ def _wall_clock_seed() -> int:
 
 
 def _fingerprint(arrays) -> tuple:
-    """Cheap identity of a set of posterior arrays: object, shape, the sum and a strided sample of
-    the values -- an in-place edit (`model.attack[:, j] = ...`) changes it, a recycled `id` does
-    not fake it."""
+    """Identity of a set of posterior arrays BY CONTENT: shape, dtype and a 128-bit hash of the whole
+    buffer -- any in-place edit (`model.attack[:, j] = ...`, a swap of two columns) changes it, and
+    neither a recycled `id` nor a temporary made by `np.asarray` enters it.  blake2b runs at ~1 GB/s: 0.6 ms
+    for the four [1000, 20] tables of a league fit (the dynamic class hashes one gameweek's slices).
+    Plain Python values (the dynamic class's gameweek) are part of the stamp as they are."""
+    import hashlib
+
     out = []
     for a in arrays:
-        if a is None:
-            out.append(None)
+        if a is None or isinstance(a, (int, float, str, bool)):
+            out.append(a)
             continue
-        a = np.asarray(a)
-        flat = a.reshape(-1)
-        out.append((id(a), a.shape, float(flat.sum()), flat[:: max(1, flat.size // 1024)].tobytes()))
+        a = np.ascontiguousarray(a)
+        out.append((a.shape, a.dtype.str, hashlib.blake2b(memoryview(a).cast("B"), digest_size=16).digest()))
     return tuple(out)
 
 

@@ -208,14 +208,20 @@ class DynamicNeutralDixonColesMatchPredictor(PosteriorOnDevice):
     # ---- predict side: the tables of ONE gameweek through the venue-aware device kernels
     # (csrc/dc_predict.hip.h, the same entry points the neutral-venue classes use)
     _VENUE_TABLES = ("attack", "defence", "home_attack", "away_attack", "home_defence", "away_defence")
-    _predict_gameweek = None
+    _predict_gameweek = None   # the gameweek whose tables the device holds (part of the upload stamp, a plain int)
 
     def _posterior_arrays(self):
-        return tuple(getattr(self, nm) for nm in self._VENUE_TABLES) + (self.corr_coef, np.asarray(self._predict_gameweek))
+        g = self._predict_gameweek
+        return tuple(getattr(self, nm)[:, g, :] for nm in self._VENUE_TABLES) + (self.corr_coef, int(g))
 
     def _upload_posterior(self, ctx):
         g = self._predict_gameweek
         ctx.predict_set_posterior_venue(*(getattr(self, nm)[:, g, :] for nm in self._VENUE_TABLES), self.corr_coef)
+
+    def __getstate__(self):
+        state = super().__getstate__()
+        state.pop("_predict_gameweek", None)   # (a cache key of the device side, not model state)
+        return state
 
     def _week(self, gameweek: Optional[int]) -> int:
         g = self.num_gameweeks - 1 if gameweek is None else int(gameweek)

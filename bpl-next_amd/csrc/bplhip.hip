@@ -91,6 +91,8 @@ struct bplhip_ctx {
     DevBuf d_h, d_a, d_x, d_y, d_w, d_pairs, d_xs, d_cA, d_cD, d_cH, d_tickets, d_debug, d_xsf, d_hbuf;
     DevBuf d_gacc;  // accumulator rows of dc_eval's hand-off (dc::GA_ROW)
     DevBuf d_pairw; // per unique pair: sum of weights, of w x, of w y (data only; dc::EvalArgs::pairw)
+    DevBuf d_pairc; // per unique pair: weight of its (0,0), (1,0), (0,1) fixtures (dc::ill_pass)
+    double w11 = 0.0;  // weight of all (1,1) fixtures
     // fault word: host memory mapped into the device.  A kernel whose bounded wait expires ORs its
     // code in (dc::raise_fault); every entry point looks at it on the way in and on the way out
     // (consume_fault), so a timed-out hand-off becomes BPLHIP_EHIP + a message instead of NaN outputs
@@ -199,7 +201,8 @@ int fail(bplhip_ctx* c, int code, const char* fmt, ...) {
 
 constexpr size_t LDS_LIMIT = 160 * 1024;
 
-int zo_stride_of(const dc::Layout& L) { return (dc::ZO_HDR + L.D + 3 * L.T + 1) & ~1; }
+// the prior workgroup's record: header | gz[D] | eps[3T] | (dc_vec) the ill-conditioned classes' sums [3T + 4]
+int zo_stride_of(const dc::Layout& L) { return (dc::zo_ill_off(L.D, L.T) + dc::zo_ill_len(L.T) + 1) & ~1; }
 
 // dc_eval's hand-off buffer holds the prior workgroup's record only (the fixture sums travel
 // through the accumulator rows, d_gacc)
@@ -565,6 +568,8 @@ dc::EvalArgs eval_args(bplhip_ctx* c, int chains, const double* z, double* pot, 
     A.tiles_per_wave = c->ep->tpw;
     A.pairs = c->d_pairs.as<const uint32_t>();
     A.pairw = c->d_pairw.as<const double>();
+    A.pairc = c->d_pairc.as<const double>();
+    A.w11 = c->w11;
     A.P = c->P;
     A.dense_pairs = c->opt_dense_pairs && c->pairs_complete && c->P >= dc::DENSE_MIN_PAIRS;
     A.xs = c->L.K ? c->d_xs.as<const double>() : nullptr;
@@ -998,6 +1003,8 @@ static int bplhip_set_fixtures_impl(bplhip_ctx* c, int model_kind, int64_t n, in
     if (weights) ws.reserve(hs.capacity());
     std::vector<uint32_t> pairs;
     std::vector<double> pairw;  // [P][4]: sum w | sum w x | sum w y | 0  (for the prior workgroup's corrections)
+    std::vector<double> pairc;  // [P][4]: weight of the pair's (0,0) | (1,0) | (0,1) fixtures | 0  (dc::ill_pass)
+    double w11 = 0.0;
     std::vector<double> cA(T, 0.0), cD(T, 0.0), cH(T, 0.0);
     double lgsum = 0.0;
     auto pad_run = [&]() {
@@ -1017,6 +1024,7 @@ static int bplhip_set_fixtures_impl(bplhip_ctx* c, int model_kind, int64_t n, in
             if (!pairs.empty()) pad_run();
             pairs.push_back(pk);
             pairw.insert(pairw.end(), {0.0, 0.0, 0.0, 0.0});
+            pairc.insert(pairc.end(), {0.0, 0.0, 0.0, 0.0});
         }
         hs.push_back(h[i]);
         as.push_back(a[i]);
@@ -1035,6 +1043,10 @@ static int bplhip_set_fixtures_impl(bplhip_ctx* c, int model_kind, int64_t n, in
             pw[0] += wi;
             pw[1] += wi * x[i];
             pw[2] += wi * y[i];
+            if (x[i] <= 1 && y[i] <= 1) {   // score classes of bpl/_util.py:58-91
+                if (x[i] == 1 && y[i] == 1) w11 += wi;
+                else pairc[pairc.size() - 4 + (x[i] == 1 ? 1 : (y[i] == 1 ? 2 : 0))] += wi;
+            }
         }
         lgsum += wi * (std::lgamma((double)x[i] + 1.0) + std::lgamma((double)y[i] + 1.0));
     }
@@ -1123,6 +1135,9 @@ static int bplhip_set_fixtures_impl(bplhip_ctx* c, int model_kind, int64_t n, in
     }
     HIP_TRY(c, c->d_pairw.ensure(std::max<size_t>(pairw.size(), 4) * 8));
     HIP_TRY(c, hipMemcpy(c->d_pairw.p, pairw.data(), pairw.size() * 8, hipMemcpyHostToDevice));
+    HIP_TRY(c, c->d_pairc.ensure(std::max<size_t>(pairc.size(), 4) * 8));
+    HIP_TRY(c, hipMemcpy(c->d_pairc.p, pairc.data(), pairc.size() * 8, hipMemcpyHostToDevice));
+    c->w11 = w11;
     HIP_TRY(c, c->d_pairs.ensure(pairs.size() * 4));
     HIP_TRY(c, hipMemcpyAsync(c->d_pairs.p, pairs.data(), pairs.size() * 4,
                               hipMemcpyHostToDevice, s));

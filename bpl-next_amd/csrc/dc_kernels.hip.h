@@ -135,6 +135,8 @@ enum {
     ZO_PP, ZO_PQ, ZO_PR,  // arg-extremal pairs (home | away<<16, as double)
     ZO_FLAGS,             // bit0 P home clipped, bit1 P away clipped, bit2 Q, bit3 R
     ZO_PAIRC,             // per-pair value corrections (float32 rate-product rounding, clipped-rate log term)
+    ZO_RHOF,              // (double)rho_f32: what every streaming workgroup used
+    ZO_ILL,               // != 0: some (pair, class) has a float32 tau argument below TAU_ILL (ill_pass)
     ZO_HDR = 24
 };
 
@@ -150,6 +152,8 @@ struct EvalArgs {
     int active_waves;       // waves of a workgroup that own tiles (the first ones)
     const uint32_t* pairs;  // [P] unique (home | away<<16)
     const double* pairw;    // [P][4] per pair, data only: sum of weights | sum w x | sum w y | 0
+    const double* pairc;    // [P][4] per pair, data only: weight of its (0,0) | (1,0) | (0,1) fixtures | 0  (ill_pass)
+    double w11;             // weight of all (1,1) fixtures
     int dense_pairs;  // 1: every ordered pair h != a is present -- the maxima over pairs are separable (O(T))
     int P;
     const double* xs;       // [T,K] standardised covariates (float64) or nullptr
@@ -779,6 +783,10 @@ __device__ __forceinline__ void build_tables_f32(const Layout& L, const double* 
                                                  int tid, const TeamZ& first, const F32Scalars& s) {
     build_tables_f32_x<EXT, SC1, SMALLT>(L, z, XsFromF32{xsf, L.K}, tabH, tabA, tid, first, s);
 }
+// tau argument of one score class in float32, and the threshold below which a class is left to the
+// tail workgroup's float64 pass (class_terms, ill_pass)
+constexpr float TAU_ILL = 1.0f / 64.0f;
+__device__ __forceinline__ float class_arg(float rho, float c) { return fmaf(rho, c, 1.0f); }
 // rho in float32 from the three float32 maxima (identical code in stream and prior)
 __device__ __forceinline__ float rho_f32(float mP, float mQ, float mR, float q) {
     const float ub = mP > 1.0f ? __builtin_amdgcn_rcpf(mP) : 1.0f;
@@ -942,6 +950,132 @@ __device__ __forceinline__ void pair_maxima_f32(const EvalArgs& A, const float2*
     *oP = mP;
     *oQ = mQ;
     *oR = mR;
+}
+
+// ---- ill-conditioned tau classes in float64 (round 4; see class_terms).  Runs ONLY when the prior part
+// raised ZO_ILL (rho within ~1/64 of one of its bounds, relative to the extremal rate:
+// |corr_coef_raw| > 4.1 -- never during init_to_uniform(2), rarely on a trajectory); everybody else
+// pays a uniform branch on one LDS word.  Not tuned: every thread walks pairs p = tid, tid + BLOCK, ...
+// of the pair table, takes the two teams' float32 table entries (the prior part's LDS copies: the bits
+// the streaming workgroups built, hence the same "t < TAU_ILL" decisions) and, for the classes they
+// left out, adds from the exact float64 rates
+//     value   W log(1 + rho c)                      -> red[0]   (-inf when 1 + rho c <= 0: tol = 0 -> red[3])
+//     dL/drho W c / t                               -> red[2]   (G_rho: bounds' adjoint, corr_coef_raw)
+//     -dL/d eta  = -rho W c / t  per side           -> slots[3T], as flush_run files a lane's sums
+// The epilogue books first-order table / rho corrections (eps, ZO_DRHO) on everything that sits in its
+// columns; the exact parts have no such error, so what it will book for them goes into red[1] with
+// the opposite sign.  slots / red: LDS, zeroed by the caller, a barrier in between; ends with a barrier.
+template <bool EXT>
+__device__ void ill_core(const EvalArgs& A, const float2* tabH, const float2* tabA, const double* tru,
+                         double rho, float rho_f, double* slots, double* red) {
+    const int T = A.L.T;
+    const int tid = threadIdx.x;
+    double val = 0.0, cancel = 0.0, su = 0.0;
+    bool neg_inf = false;
+    auto eps_of = [&](double tv, float tabv) {   // log(true / table entry), as prior_body files it
+        const double r = (tv - (double)tabv) / (double)tabv;
+        return fabs(r) < 1e-4 ? r - 0.5 * r * r : 0.0;
+    };
+#pragma unroll 1
+    for (int p = tid; p < A.P; p += BLOCK) {
+        const uint32_t pr = A.pairs[p];
+        const int h = pr & 0xFFFFu, a = pr >> 16;
+        const float2 th = tabH[h], ta = tabA[a];
+        float lhf = th.x * ta.y, laf = ta.x * th.y;   // (lane_uniform)
+        bool ch = false, ca = false;
+        if (EXT) {
+            ch = lhf > (float)RATE_CLIP;
+            ca = laf > (float)RATE_CLIP;
+            lhf = ch ? (float)RATE_CLIP : lhf;
+            laf = ca ? (float)RATE_CLIP : laf;
+        }
+        const unsigned int illm = (class_arg(rho_f, -lhf * laf) >= TAU_ILL ? 0u : 1u) |
+                                  (class_arg(rho_f, laf) >= TAU_ILL ? 0u : 2u) |
+                                  (class_arg(rho_f, lhf) >= TAU_ILL ? 0u : 4u);
+        if (illm == 0u) continue;
+        // exact rates (the clip DECISION is the streaming workgroups', as everywhere: the same float32 bits)
+        const double lh = ch ? RATE_CLIP : tru[h] * tru[2 * T + a], la = ca ? RATE_CLIP : tru[T + a] * tru[2 * T + h];
+        double dh = 0.0, da = 0.0;   // what the lanes would have put into rsh / rsa
+#pragma unroll 1
+        for (int cls = 0; cls < 3; ++cls) {   // (0,0) | (1,0) | (0,1)
+            if (!((illm >> cls) & 1u)) continue;
+            const double W = A.pairc[4 * (size_t)p + cls];
+            if (!(W > 0.0)) continue;
+            const double c = cls == 0 ? -lh * la : (cls == 1 ? la : lh);
+            const double t = fma(rho, c, 1.0);
+            if (!(t > 0.0)) {   // log(clip(t, 0)) = -inf, derivative 0 (bpl/_util.py:42); NaN propagates
+                if (t <= 0.0) neg_inf = true;
+                else val += t;
+                continue;
+            }
+            const double u = c * lean::rcp(t);
+            val += W * lean::log(t);
+            su += W * u;
+            if (cls != 1 && !ch) dh -= rho * W * u;   // d/d eta_home: (0,0) and (0,1)
+            if (cls != 2 && !ca) da -= rho * W * u;   // d/d eta_away: (0,0) and (1,0)
+        }
+        if (dh != 0.0) {
+            atomicAdd(&slots[h], dh);
+            atomicAdd(&slots[2 * T + h], dh);
+            atomicAdd(&slots[T + a], dh);
+            cancel += dh * (eps_of(tru[h], th.x) + eps_of(tru[2 * T + a], ta.y));
+        }
+        if (da != 0.0) {
+            atomicAdd(&slots[a], da);
+            atomicAdd(&slots[T + h], da);
+            cancel += da * (eps_of(tru[T + a], ta.x) + eps_of(tru[2 * T + h], th.y));
+        }
+    }
+    if (tid == 0 && !(class_arg(rho_f, -1.0f) >= TAU_ILL) && A.w11 > 0.0) {   // (1,1): the same for every pair
+        const double t = 1.0 - rho;
+        if (t > 0.0) {
+            val += A.w11 * lean::log(t);
+            su -= A.w11 * lean::rcp(t);
+        } else if (t <= 0.0) {
+            neg_inf = true;
+        } else {
+            val += t;
+        }
+    }
+    if (val != 0.0) atomicAdd(&red[0], val);
+    if (cancel != 0.0) atomicAdd(&red[1], cancel);
+    if (su != 0.0) atomicAdd(&red[2], su);
+    if (neg_inf) red[3] = 1.0;
+    __syncthreads();
+}
+// what the tail does with the result: value and rho-derivative into the record / the SU column
+__device__ __forceinline__ void ill_apply(double* zoL, double* col, int ncol, double val, double cancel, double su,
+                                          bool neg_inf) {
+    const double add = val + cancel - su * zoL[ZO_DRHO];
+    zoL[ZO_PAIRC] = neg_inf ? -__builtin_inf() : zoL[ZO_PAIRC] + add;
+    col[ncol + 2] += su;
+}
+// dc_eval's tail workgroup: the prior part's tables are still in LDS (prior_smem), the columns take the
+// slot sums directly
+template <bool EXT>
+__device__ void ill_pass_lds(const EvalArgs& A, double* zoL, double* col, double* scratch, char* prior_smem) {
+    const int T = A.L.T;
+    const float2* tabH = reinterpret_cast<const float2*>(prior_smem);
+    const float2* tabA = tabH + tab_len(T);
+    const double* tru = reinterpret_cast<const double*>(tabA + tab_len(T));
+    double* red = scratch + 8;
+    if (threadIdx.x < 4) red[threadIdx.x] = 0.0;
+    __syncthreads();
+    ill_core<EXT>(A, tabH, tabA, tru, zoL[ZO_RHO], (float)zoL[ZO_RHOF], col, red);
+    if (threadIdx.x == 0) ill_apply(zoL, col, 3 * T, red[0], red[1], red[2], red[3] != 0.0);
+    __syncthreads();
+}
+// dc_vec: the prior workgroups are not the tail (a launch of its own): they file the result behind the
+// record -- [zo_ill_off, +3T) slot sums | value | cancel | su | -inf seen -- and the tail adds it
+__host__ __device__ inline int zo_ill_off(int D, int T) { return (ZO_HDR + D + 3 * T + 1) & ~1; }
+__host__ __device__ inline int zo_ill_len(int T) { return 3 * T + 4; }
+__device__ __forceinline__ void ill_add_filed(const EvalArgs& A, double* zoL, double* col) {
+    const int T = A.L.T, ncol = 3 * T;
+    const double* ill = zoL + zo_ill_off(A.L.D, T);
+    for (int i = threadIdx.x; i < ncol; i += BLOCK) col[i] += ill[i];
+    __syncthreads();
+    if (threadIdx.x == 0) ill_apply(zoL, col, ncol, ill[ncol], ill[ncol + 1], ill[ncol + 2], ill[ncol + 3] != 0.0);
+    __syncthreads();
 }
 
 // ---------------------------------------------------------------- prior workgroup
@@ -1414,6 +1548,8 @@ __device__ void prior_body(const EvalArgs& A, int chain, char* smem, double* zo_
         pQ = (uint32_t)__builtin_amdgcn_readlane((int)q1, bQ ? __ffsll((long long)bQ) - 1 : 0);
         pR = (uint32_t)__builtin_amdgcn_readlane((int)q2, bR ? __ffsll((long long)bR) - 1 : 0);
     }
+    double ill_flag = 0.0, rho_keep = 0.0;
+    float rhof_keep = 0.f;
     if (tid == 0) {
         unsigned int flags = 0;
         if (CLIP) {
@@ -1440,6 +1576,16 @@ __device__ void prior_body(const EvalArgs& A, int chain, char* smem, double* zo_
         zput(&zo[ZO_LB], LB);
         zput(&zo[ZO_RHO], rho);
         zput(&zo[ZO_DRHO], rho - (double)rho_f);
+        zput(&zo[ZO_RHOF], (double)rho_f);
+        {   // the smallest float32 tau argument of each class over ALL pairs (rounding is monotone: it sits
+            // at the class's extremal c, i.e. at the float32 maxima): any below TAU_ILL?
+            const bool fine = class_arg(rho_f, -fP) >= TAU_ILL && class_arg(rho_f, fQ) >= TAU_ILL &&
+                              class_arg(rho_f, fR) >= TAU_ILL && class_arg(rho_f, -1.0f) >= TAU_ILL;
+            zput(&zo[ZO_ILL], fine ? 0.0 : 1.0);
+            ill_flag = fine ? 0.0 : 1.0;
+            rho_keep = rho;
+            rhof_keep = rho_f;
+        }
         zput(&zo[ZO_M], M);
         zput(&zo[ZO_LH], Lh);
         zput(&zo[ZO_LA], La);
@@ -1456,6 +1602,28 @@ __device__ void prior_body(const EvalArgs& A, int chain, char* smem, double* zo_
                                  (1.0 - 2.0 * sc[14])));
         }
         zput(&zo[ZO_LZ], Lz + v[0]);
+    }
+    if (!TO_LDS) {
+        // dc_vec: this workgroup is not the tail (a launch of its own, without these tables): the
+        // ill-conditioned tau classes (class_terms, ill_core) are worked out here and filed behind the
+        // record.  One more barrier on a workgroup that is not the launch's critical path.
+        if (tid == 0) {
+            sc[34] = ill_flag;
+            sc[35] = rho_keep;
+            sc[36] = (double)rhof_keep;
+        }
+        __syncthreads();
+        if (sc[34] != 0.0) {   // (uniform)
+            double* slots = par;          // att | def | ha: nothing reads them any more
+            double* red = scratch;        // (free: block_sum is done)
+            for (int i = tid; i < 3 * T; i += BLOCK) slots[i] = 0.0;
+            if (tid < 4) red[tid] = 0.0;
+            __syncthreads();
+            ill_core<CLIP>(A, tabH, tabA, tru, sc[35], (float)sc[36], slots, red);
+            double* ill = zo + zo_ill_off(D, T);
+            for (int i = tid; i < 3 * T; i += BLOCK) zput(&ill[i], slots[i]);
+            if (tid < 4) zput(&ill[3 * T + tid], red[tid]);
+        }
     }
 }
 
@@ -1971,6 +2139,7 @@ __device__ void tail_body(const EvalArgs& A, int chain, char* smem) {
     }
     __syncthreads();
     DC_STAMP(9);
+    if (zoL[ZO_ILL] != 0.0) ill_add_filed(A, zoL, col);   // (uniform; rare: see class_terms, prior_body)
     // STAGED <=> T <= 64 (host): the two epilogues never meet in one instantiation (code size
     // matters at ~9 us per launch)
     if (STAGED) {  // lane = team: four waves, one output group each, no LDS traffic
@@ -2196,6 +2365,9 @@ __device__ __forceinline__ bool tail_acc(const EvalArgs& A, int chain, char* sme
         ga_rearm(ga + (size_t)(ncol + (lane & 15) * N_SCAL + (lane >> 4)) * GA_ROW);
     }
     DC_STAMP(9);
+    if (zoL[ZO_ILL] != 0.0)   // (uniform; rare: see class_terms.  The prior part's LDS sits behind the tail's arrays)
+        ill_pass_lds<EXT>(A, zoL, col, scratch,
+                          smem + ((acc_tail_lds_bytes(T, D, K, A.zo_stride, SMALLT && NUTS) + 15) & ~(size_t)15));
     if (SMALLT) {  // lane = team: four waves, one output group each, no LDS traffic
         if (NUTS) {  // the idle waves' shares of the leaf preparation (see LEAF_WAVE)
             if (!small && wave >= 4) {
@@ -2312,14 +2484,22 @@ __device__ __forceinline__ ScoreMasks score_masks(uint32_t x, uint32_t y) {
 // |U - U_float64| left (7e-3; tools: the emulation in profiles/r03/parity_errors.txt).  The rounding
 // is known exactly: 1 - t is exact near 1, so one more fma gives r = (1 + rho c) - t, and
 // log2(1 + rho c) = log2 t + r / t / ln 2 to first order -- three instructions per class and lane.
+// (round 4) ILL-CONDITIONED CLASSES.  Near a bound of rho one of the arguments goes to 0 (tol = 0,
+// bpl/_util.py:42,58-85): log t and c / t amplify the float32 roundings of rho and of the rates by
+// 1 / t and 1 / t^2 -- 1e-6 from a bound the value was off by O(1) and the gradient, a difference of
+// two terms of 1e6 (the direct one and the bounds' adjoint), by more than its size.  A class whose
+// float32 argument is below TAU_ILL contributes NOTHING here; the tail workgroup adds it in float64 from
+// the exact rates (ill_pass: a data-only table holds every pair's class weights).  The decision is taken
+// on the same float32 bits there (same tables, same rho_f32, this same expression) and, being
+// monotone in c, is known for ALL pairs from the three float32 maxima: ZO_ILL.  Also covers t <= 0
+// (the float64 side returns the -inf of the reference's log(clip(., 0))).
 __device__ __forceinline__ void class_terms(float rho, float c, float* l2, float* u) {
-    const float t = fmaf(rho, c, 1.0f);
+    const float t = class_arg(rho, c);
     const float it = __builtin_amdgcn_rcpf(t);
     const float r = fmaf(rho, c, 1.0f - t);
-    const bool pos = t > 0.0f;
-    // log(clip(., 0)): -inf at 0 (tol = 0, bpl/_util.py:42)
-    *l2 = pos ? fmaf(r * it, 1.44269504088896341f, __log2f(t)) : -__builtin_inff();
-    *u = pos ? c * it : 0.0f;
+    const bool ok = t >= TAU_ILL;   // (false for NaN as well: the Poisson part carries it)
+    *l2 = ok ? fmaf(r * it, 1.44269504088896341f, __log2f(t)) : 0.0f;
+    *u = ok ? c * it : 0.0f;
 }
 
 // All fixtures of a lane are one pair (h, a): the library pads every pair's run to a multiple

@@ -557,8 +557,11 @@ __global__ __launch_bounds__(NEU_BIG_BLOCK) void neu_big(NeuArgs A) {
         q = sq < dc::SIG_LO ? dc::SIG_LO : sq > dc::SIG_HI ? dc::SIG_HI : sq;
         dq = (sq < dc::SIG_LO || sq > dc::SIG_HI) ? 0.0 : sq * (1.0 - sq);
     }
-    auto give_up = [&]() {
-        if (blockIdx.x == 0 && tid == 0) F.potential[0] = __builtin_nan("");
+    auto give_up = [&]() {   // a bounded wait expired: NaN outputs (the header's promise), potential AND gradient
+        if (blockIdx.x == 0) {
+            if (tid == 0) F.potential[0] = __builtin_nan("");
+            for (int i = tid; i < L.D; i += NEU_BIG_BLOCK) F.grad[i] = __builtin_nan("");
+        }
     };
     if (!dcd::tree_wait(F.tickets, dcd::TB_2, failed, &s_ok, F.fault)) { give_up(); return; }
     NEU_STAMP(4);

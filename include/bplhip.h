@@ -175,8 +175,20 @@ int bplhip_set_fixtures_neutral(bplhip_ctx* ctx, int64_t n, int32_t n_teams,
  *   "dense_pairs" 1 (default) = a complete pair table (every ordered pair h != a present) of 8192
  *            pairs or more takes the rho bounds from the top two table entries per role
  *            (O(teams)); 0 = always walk the pair table.
- *   "max_wg" streaming workgroups per evaluation (default 255: with the prior workgroup
- *            one per CU); applies at the next bplhip_set_fixtures
+ *   "max_wg" streaming workgroups per evaluation, 1..255 (default 255: with the prior workgroup
+ *            one per CU; an accumulator row counts its contributors in 8 bits); applies at the next
+ *            bplhip_set_fixtures
+ *   "gridy_max_chains" 32 (default) = bplhip_nuts_run_chains keeps up to this many chains as grid.y
+ *            copies of the single-chain NUTS-aware launch; more share the chain-vectorised kernel
+ *   "vec_min_chains" 32 (default) = bplhip_logp_grad_batched takes the chain-vectorised kernel
+ *            (dc_vec: the fixtures are read once per 8 chains) from this many chains on; 0 = never
+ *   "vec_tiles_per_wave" 0 (default) = the chain-vectorised partitions scale with the chain count
+ *            (1x / 2x / 4x the single-chain tiles per wave); > 0 = this many; next bplhip_set_fixtures
+ *   "chunk_graph" 1 (default) = a persistent sampler replays its chunk of 256 leapfrog launches as
+ *            ONE hipGraph (falls back to plain launches by itself if a capture fails); 0 = always
+ *            launch by launch
+ *   "debug_raise_fault" test hook: ORs `value` into the context's fault word, as a kernel whose
+ *            bounded wait expired would (the next entry point returns BPLHIP_EHIP)
  *   "active_waves" waves per workgroup that own tiles: 0 (default) = automatic -- short
  *            streams get a second partition with 4 of 8 waves owning tiles, used while the
  *            launch's workgroups still find a CU each; 1..8 = one fixed partition; applies
@@ -310,11 +322,16 @@ int bplhip_predict_score_grid(bplhip_ctx* ctx, int64_t m, const uint16_t* home_i
 /* The same three entry points for the venue-aware rate form of the neutral-venue family:
  * `_calculate_expected_goals` of bpl/neutral_dixon_coles.py:399-423 (four per-team offsets that
  * are switched off at neutral venues), bpl/neutral_dixon_coles_WC.py:385-424 (plus the difference
- * of the two sides' confederation strengths) and bpl/dynamic_dixon_coles.py:336-361 (the tables of
- * one gameweek):
+ * of the two sides' confederation strengths) and, for the dynamic class, the rates of its MODEL,
+ * bpl/dynamic_dixon_coles.py:220-231, on the tables of one gameweek:
  *   on = 1 - neutral_venue,  dc = confederation_strength[home_conf] - confederation_strength[away_conf]
  *   log home rate = attack[h] - defence[a] + on (home_attack[h] - away_defence[a]) + dc
  *   log away rate = attack[a] - defence[h] + on (away_attack[a] - home_defence[h]) - dc
+ * (A DELIBERATE DEVIATION for the dynamic class: upstream's own predict-time
+ * `_calculate_expected_goals`, bpl/dynamic_dixon_coles.py:336-361, differs from the model it was fitted
+ * with -- "+ on away_defence[a]" in the home rate, "- on away_attack[a] - on home_defence[h]" in the away
+ * rate -- and indexes no gameweek (the class is unfinished upstream).  Predictions
+ * here use the rates the likelihood used.)
  * set_posterior_venue: six HOST f64[s,t] tables, confederation_strength HOST f64[s,n_conf] or NULL
  * with n_conf = 0, corr_coef f64[s].  Queries: neutral_venue HOST u8[m] (required), home_conf /
  * away_conf HOST u16[m] exactly when the posterior has confederations (else NULL).  A context holds

@@ -190,6 +190,7 @@ def likelihood_and_adjoint(
     home_adv: np.ndarray,  # [T] (basic: the scalar broadcast to T)
     q: float,  # constrained corr_coef_raw in (0,1)
     clip_rates: bool,
+    ties: str = "split",
 ):
     """Poisson + tau part of L, and dL/d(attack, defence, home_adv[T], q).
 
@@ -237,6 +238,45 @@ def likelihood_and_adjoint(
     Lh, La = lam_h[iQ], lam_a[iR]
     LB = -1.0 / max(Lh, La)
     rho = LB + q * (UB - LB)
+    # Where the extrema are attained.  bpl/_util.py:23-30 takes them with jnp.min / jnp.max, whose
+    # derivative at a tie is split EVENLY over the tied entries (jax's reduce-min/-max JVP divides the
+    # indicator of the attained positions by their count) -- over tied fixtures inside min_i / max_i, and
+    # half / half between the two entries of jnp.array([min_i 1/(lh la), 1]) and of
+    # jnp.array([max_i -1/lh, max_i -1/la]).  ties="split" (default) restates that.  Ties are exact
+    # floating-point equalities: z = 0 (every rate 1), or teams with identical parameters.  The product
+    # path keeps ONE arg-extremal pair, the smallest (home, away) key -- another element of the same
+    # subdifferential; ties="first_pair" restates THAT (tests compare gradients at tied points with it;
+    # U, rho and the bounds do not depend on the rule).
+    wP = np.zeros(fx.n)   # d UB / d (1 / (lh la))_i ... as weights over fixtures
+    wQ = np.zeros(fx.n)   # d LB / d (-1 / lh)_i
+    wR = np.zeros(fx.n)   # d LB / d (-1 / la)_i
+    tP, tQ, tR = prod == M, lam_h == Lh, lam_a == La
+    tied = False
+    if ties == "split":
+        shareP = 1.0 if M > 1.0 else (0.5 if M == 1.0 else 0.0)
+        wP[tP] = shareP / tP.sum()
+        shareQ = 1.0 if Lh > La else (0.5 if Lh == La else 0.0)
+        wQ[tQ] = shareQ / tQ.sum()
+        wR[tR] = (1.0 - shareQ) / tR.sum()
+    elif ties == "first_pair":
+        key = (h.astype(np.int64) << 16) + a.astype(np.int64)   # the product's pair table is sorted by (home, away)
+
+        def first(mask):
+            idx = np.flatnonzero(mask)
+            return idx[np.argmin(key[idx])]
+
+        if M > 1.0:
+            wP[first(tP)] = 1.0
+        if Lh >= La:
+            wQ[first(tQ)] = 1.0
+        else:
+            wR[first(tR)] = 1.0
+    else:
+        raise ValueError(ties)
+    # (more than one PAIR attains an extremum that matters, or two branches tie)
+    npairs = lambda mask: len(set(zip(h[mask].tolist(), a[mask].tolist())))
+    tied = bool((M >= 1.0 and npairs(tP) > 1) or M == 1.0 or Lh == La or
+                (Lh >= La and npairs(tQ) > 1) or (La >= Lh and npairs(tR) > 1))
 
     # tau (bpl/_util.py:58-91), tol = 0
     c00 = (x == 0) & (y == 0)
@@ -268,6 +308,20 @@ def likelihood_and_adjoint(
     dT_drho[c01] = lam_h[c01] * inv[c01]
     dT_drho[c11] = -inv[c11]
     G_rho = float(np.sum(w * dT_drho))
+    # Conditioning of the tau part (test infrastructure: the gates of tests/test_gpu_parity.py follow it).
+    # A relative perturbation d of the product rho*c moves log(1 + rho c) by |rho c| / t * d and its
+    # derivative rho c / t by |rho c| / t^2 * d (t = 1 + rho c): near a bound of rho (t -> 0,
+    # bpl/_util.py:58-70 with tol = 0) float32 inputs cannot hold more than that.  The product path
+    # therefore works classes with t < 1/64 out in float64 (dc_kernels.hip.h, TAU_ILL): the amplification
+    # of its float32 part is capped there, and cond_val / cond_grad are the capped sums.
+    rc = np.where(low & ~clipped_tau, np.abs(arg - 1.0), 0.0)
+    cond_val_raw = float(np.sum(w * rc * inv))          # uncapped: what float64 arithmetic itself feels
+    cond_grad_raw = float(max(np.bincount(h, w * rc * inv * inv, fx.n_teams).max(),
+                              np.bincount(a, w * rc * inv * inv, fx.n_teams).max()))
+    amp = np.minimum(inv, 64.0)
+    cond_val = float(np.sum(w * rc * amp))
+    per_fix = w * rc * amp * amp
+    cond_grad = float(max(np.bincount(h, per_fix, fx.n_teams).max(), np.bincount(a, per_fix, fx.n_teams).max()))
 
     # total adjoint wrt lam (before rho coupling)
     bar_lh = dP_dlh + w * dT_dlh
@@ -275,13 +329,10 @@ def likelihood_and_adjoint(
     # rho = LB + q (UB - LB): d rho/d UB = q, d rho/d LB = 1-q
     #   UB = 1/M (M>1): dUB/d lam_h[P] = -lam_a[P]/M^2, dUB/d lam_a[P] = -lam_h[P]/M^2
     #   LB = -1/max(Lh,La): dLB/d lam[arg] = 1/lam^2
-    if M > 1.0:
-        bar_lh[iP] += G_rho * q * (-lam_a[iP] / (M * M))
-        bar_la[iP] += G_rho * q * (-lam_h[iP] / (M * M))
-    if Lh >= La:
-        bar_lh[iQ] += G_rho * (1.0 - q) / (Lh * Lh)
-    else:
-        bar_la[iR] += G_rho * (1.0 - q) / (La * La)
+    bar_lh += G_rho * q * wP * (-lam_a / (prod * prod))
+    bar_la += G_rho * q * wP * (-lam_h / (prod * prod))
+    bar_lh += G_rho * (1.0 - q) * wQ / (lam_h * lam_h)
+    bar_la += G_rho * (1.0 - q) * wR / (lam_a * lam_a)
 
     g_h = bar_lh * dlh  # dL/d eta_h
     g_a = bar_la * dla
@@ -299,6 +350,12 @@ def likelihood_and_adjoint(
         "rho": rho,
         "LB": LB,
         "UB": UB,
+        "cond_val": cond_val,
+        "cond_grad": cond_grad,
+        "cond_val_raw": cond_val_raw,
+        "cond_grad_raw": cond_grad_raw,
+        "tau_min": float(np.min(np.where(low, arg, 1.0))),
+        "tied": tied,
     }
 
 
@@ -323,7 +380,7 @@ def _halfnormal_exp_site(zs: float):
     return s, lp, -s * s + 1.0
 
 
-def potential_and_grad(model: int, fx: Fixtures, z: np.ndarray):
+def potential_and_grad(model: int, fx: Fixtures, z: np.ndarray, ties: str = "split"):
     """U(z) = -log p(z, data) in unconstrained space, and dU/dz (float64).
 
     Returns (U, grad[D], aux) with aux = {rho, LB, UB, attack, defence,
@@ -354,7 +411,7 @@ def potential_and_grad(model: int, fx: Fixtures, z: np.ndarray):
         L += float(np.sum(_normal_lp(a_dec, 0.0, 1.0)))
         L += float(np.sum(_normal_lp(d_dec, 0.0, 1.0)))
 
-        lik = likelihood_and_adjoint(fx, attack, defence, ha, q, clip_rates=False)
+        lik = likelihood_and_adjoint(fx, attack, defence, ha, q, clip_rates=False, ties=ties)
         L += lik["L"]
         ga, gd, gh = lik["g_attack"], lik["g_defence"], lik["g_home_adv"]
 
@@ -403,7 +460,7 @@ def potential_and_grad(model: int, fx: Fixtures, z: np.ndarray):
         L += float(np.sum(-0.5 * e * e / v - 0.5 * math.log(v) - HALF_LOG_2PI))
         L += float(np.sum(_normal_lp(ha_dec, 0.0, 1.0)))
 
-        lik = likelihood_and_adjoint(fx, attack, defence, ha, q, clip_rates=True)
+        lik = likelihood_and_adjoint(fx, attack, defence, ha, q, clip_rates=True, ties=ties)
         L += lik["L"]
         ga, gd, gh = lik["g_attack"], lik["g_defence"], lik["g_home_adv"]
 
@@ -431,6 +488,12 @@ def potential_and_grad(model: int, fx: Fixtures, z: np.ndarray):
         "defence": defence,
         "home_advantage": aux_ha,
         "corr_coef": lik["rho"],
+        "cond_val": lik["cond_val"],
+        "cond_grad": lik["cond_grad"],
+        "cond_val_raw": lik["cond_val_raw"],
+        "cond_grad_raw": lik["cond_grad_raw"],
+        "tau_min": lik["tau_min"],
+        "tied": lik["tied"],
     }
     return -L, -g, aux
 

@@ -30,6 +30,9 @@ GOLDEN_CASES = [
     (O.MODEL_EXTENDED, "dummy_cov"),
     (O.MODEL_EXTENDED, "dummy_w"),
     (O.MODEL_EXTENDED, "timed_w"),
+    # "the N=1e5 synthetic of section 8d" (the fixtures are data too: 0.2 MB each)
+    (O.MODEL_BASIC, "league_1e5"),
+    (O.MODEL_EXTENDED, "league_1e5"),
 ]
 
 
@@ -37,16 +40,25 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     for model, name in GOLDEN_CASES:
         fx = cases.fixtures(name)
-        pts = cases.z_points(model, fx)
-        zs, Us, gs, rhos, lbs, ubs, atts, dfns, has = [], [], [], [], [], [], [], [], []
+        # SURVEY.md section 8c's list: z = 0, RandomState(7).uniform(-.5, .5), 8 further random points, the
+        # UB-branch point, the rate-clip point (extended), rho 1e-2 / 1e-4 / 1e-6 from each of its bounds
+        pts = cases.golden_points(model, fx)
+        zs, Us, gs, rhos, lbs, ubs, atts, dfns, has, cvs, cgs = [], [], [], [], [], [], [], [], [], [], []
+        gfp, tied = [], []
         for _, z in pts:
-            U, g, aux = O.potential_and_grad(model, fx, z)
+            U, g, aux = O.potential_and_grad(model, fx, z)   # the reference's tie rule (even split)
             zs.append(z)
             Us.append(U)
             gs.append(g)
+            # the product's element of the subdifferential where extremal rates tie (z = 0; clipped rates):
+            # one arg-extremal pair, the smallest (home, away) key -- see dc_oracle.likelihood_and_adjoint
+            gfp.append(O.potential_and_grad(model, fx, z, ties="first_pair")[1])
+            tied.append(aux["tied"])
             rhos.append(aux["rho"])
             lbs.append(aux["LB"])
             ubs.append(aux["UB"])
+            cvs.append(aux["cond_val"])
+            cgs.append(aux["cond_grad"])
             atts.append(aux["attack"])
             dfns.append(aux["defence"])
             has.append(np.broadcast_to(aux["home_advantage"], (fx.n_teams,)))
@@ -64,9 +76,14 @@ def main():
             z=np.stack(zs),
             U=np.array(Us),
             grad=np.stack(gs),
+            grad_first_pair=np.stack(gfp),
+            tied=np.array(tied),
             rho=np.array(rhos),
             LB=np.array(lbs),
             UB=np.array(ubs),
+            # conditioning of the tau term at each point (cases.u_tolerance_cond / g_tolerance_cond)
+            cond_val=np.array(cvs),
+            cond_grad=np.array(cgs),
             # deterministic sites at each point
             attack=np.stack(atts),
             defence=np.stack(dfns),
@@ -74,6 +91,34 @@ def main():
         )
         print(f"wrote m{model}_{name}.npz  ({len(pts)} points, N={fx.n})")
     neutral_golden()
+    dynamic_golden()
+
+
+def dynamic_golden():
+    """Dynamic (time-varying) model, BASELINE config 4's model at a small size (7 teams x 5 gameweeks,
+    300 fixtures, 3 covariates; oracle/dc_dynamic_oracle.py small_recipe): both walk settings."""
+    import dc_dynamic_oracle as DO
+
+    fx = DO.small_recipe(k=3)
+    D = DO.latent_dim(fx.n_gameweeks, fx.n_teams, fx.k)
+    sl = DO.site_slices(fx.n_gameweeks, fx.n_teams, fx.k)
+    # (no z = 0: every rate ties there, and which arg-extremal fixture carries the bounds' adjoint is a
+    # convention of this float64 path, not of a reference -- the class is unfinished upstream, SURVEY App. D)
+    zs = [np.random.RandomState(s).uniform(-sc, sc, D) for s, sc in ((7, 0.3), (2, 0.3), (3, 0.3), (4, 1.0))]
+    zs[1][sl["mean_home_attack"]] = 1.2
+    out = {}
+    for rw in (1, 0):
+        res = [DO.potential_and_grad(fx, z, bool(rw)) for z in zs]
+        out[f"U_rw{rw}"] = np.array([r[0] for r in res])
+        out[f"grad_rw{rw}"] = np.stack([r[1] for r in res])
+        out[f"rho_rw{rw}"] = np.array([r[2]["rho"] for r in res])
+    np.savez_compressed(
+        os.path.join(OUT, "m2_small_cov.npz"), model=2,
+        home_idx=fx.home_idx.astype(np.uint16), away_idx=fx.away_idx.astype(np.uint16),
+        home_goals=fx.home_goals.astype(np.uint8), away_goals=fx.away_goals.astype(np.uint8),
+        gameweek=fx.gameweek.astype(np.uint16), neutral=fx.neutral.astype(np.uint8),
+        n_teams=fx.n_teams, n_gameweeks=fx.n_gameweeks, covariates=fx.covariates, z=np.stack(zs), **out)
+    print(f"wrote m2_small_cov.npz  ({len(zs)} points x 2 walk settings, N={fx.n})")
 
 
 def neutral_golden():

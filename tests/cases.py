@@ -83,6 +83,80 @@ def z_points(model, fx, n_random=3):
     return pts
 
 
+def _corr_slot(model, fx):
+    K = fx.k if model == O.MODEL_EXTENDED else 0
+    return O.site_slices(model, fx.n_teams, K)["corr_coef_raw"].start
+
+
+def near_bound_points(model, fx, distances=(1e-2, 1e-4, 1e-6)):
+    """Latent points whose correlation coefficient sits a given ABSOLUTE distance from one of its
+    bounds (bpl/_util.py:17-31: rho = LB + sigmoid(corr_coef_raw) (UB - LB)): there one of the tau
+    arguments of bpl/_util.py:58-85 -- 1 - rho lh la at the arg-max pair (upper bound, UB = 1/M),
+    1 - rho (upper bound, UB = 1), 1 + rho lh / 1 + rho la at the largest rate (lower bound) -- is the
+    distance times O(1), and its log and reciprocal amplify every rounding of rho and of the rates
+    (tol = 0, bpl/_util.py:42).  SURVEY.md section 8c asks for such a point ("rho within 1e-6 of a bound").
+    The bounds do not depend on corr_coef_raw, so it is solved for: q = (rho - LB) / (UB - LB).
+    Three bases: M > 1 (UB = 1/M binds), every rate < 1 (UB = 1: the (1,1) term), and the lower bound."""
+    D = O.latent_dim(model, fx.n_teams, fx.k if model == O.MODEL_EXTENDED else 0)
+    sl = O.site_slices(model, fx.n_teams, fx.k if model == O.MODEL_EXTENDED else 0)
+    ic = _corr_slot(model, fx)
+    ha = "home_advantage" if model == O.MODEL_BASIC else "mean_home_advantage"
+    pts = []
+    for base, side in (("M", "ub"), ("1", "ub"), ("L", "lb")):
+        z = np.random.RandomState(31).uniform(-0.5, 0.5, D)
+        if base == "M":
+            z[sl[ha]] = 1.0                 # M = max lh la > 1
+        elif base == "1":
+            z[sl["mean_defence"]] = 1.6     # every rate < 1: UB = 1
+            z[sl[ha]] = 0.0
+            for site in ("attack_coefficients", "defence_coefficients"):
+                if site in sl:
+                    z[sl[site]] *= 0.1
+        _, _, aux = O.potential_and_grad(model, fx, z)
+        LB, UB = aux["LB"], aux["UB"]
+        assert base == "L" or (UB < 1.0) == (base == "M"), (base, UB)
+        for d in distances:
+            q = 1.0 - d / (UB - LB) if side == "ub" else d / (UB - LB)
+            zz = z.copy()
+            zz[ic] = np.log(q) - np.log1p(-q)
+            pts.append((f"{side}{base}-{d:.0e}", zz))
+    return pts
+
+
+def golden_points(model, fx):
+    """SURVEY.md section 8c's list: z = 0, RandomState(7).uniform(-.5, .5), 8 further seeded random points,
+    the UB-branch point, (extended) a rate-clip point, and rho 1e-2 / 1e-4 / 1e-6 from each bound."""
+    D = O.latent_dim(model, fx.n_teams, fx.k if model == O.MODEL_EXTENDED else 0)
+    pts = [("zero", np.zeros(D))] + z_points(model, fx)
+    pts += [(f"r{s}", np.random.RandomState(1000 + s).uniform(-0.7, 0.7, D)) for s in range(8)]
+    return pts + near_bound_points(model, fx)
+
+
+EPS32 = 2.0 ** -24   # unit roundoff of float32
+
+
+def u_tolerance_cond(n_fixtures, U, aux):
+    """u_tolerance + what the CONDITIONING of the tau term allows the float32 part of the kernel.
+    Its per-fixture inputs are float32: rho, and the rates as products of two float32 table entries.  The
+    first-order effect of the table and rho roundings on U is removed exactly (DESIGN.md section 4
+    "Numerics"), the rounding of 1 + rho c itself is carried (class_terms); what is left per low-score
+    fixture is the three roundings of the products lh = t t', la = t t', c = lh la -- a relative error
+    <= 3 EPS32 of rho c, i.e. 3 EPS32 |rho c| / t in log t.  Classes with t < 1/64 never see float32 (the
+    tail workgroup's float64 pass, ill_core), so the amplification 1 / t is capped at 64:
+        |dU| <= u_tolerance(N, U) + 4 EPS32 cond_val,   cond_val = sum_i w_i |rho c_i| min(1 / t_i, 64)
+    (oracle/dc_oracle.py).  Away from the bounds the second term is < 2 % of the first; 1e-6 from a bound it
+    is < 30 % of it -- round 3's kernel was off by O(1) there and was gated at 2e-2 |U|."""
+    return u_tolerance(n_fixtures, U) + 4.0 * EPS32 * aux["cond_val"]
+
+
+def g_tolerance_cond(g, aux):
+    """|dgrad|_inf gate: 5e-7 |grad|_inf + 1e-7 (float32 tables) + the conditioning of the tau term's
+    derivative rho c / t, which a relative input error d moves by |rho c| / t^2 d:
+    8 EPS32 cond_grad, cond_grad = the largest per-team sum of w |rho c| min(1 / t, 64)^2 (capped as above;
+    the chain rule to z multiplies by std = O(1) factors, which the 8 covers)."""
+    return 5e-7 * np.abs(g).max() + 1e-7 + 8.0 * EPS32 * aux["cond_grad"]
+
+
 def u_tolerance(n_fixtures, U):
     """The stated bound on |U_hip - U_float64| for the float32-table kernels (models 0 / 1):
     TWICE the tolerance SURVEY.md section 8c asks for,  2 (1e-6 sqrt(N) + 1e-9 |U|)  (+ 1e-9): 9e-3 at

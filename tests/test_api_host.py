@@ -71,6 +71,19 @@ def test_in_place_edit_reaches_the_device(dummy_data):
     assert p1 > p0 + 0.05
     model.attack = model.attack - 0.0  # reassignment
     assert model.predict_outcome_proba("0", "1")["home_win"][0] == pytest.approx(p1, abs=1e-12)
+    # an edit that keeps every sum and touches two elements only (round 3 stamped the sum and a strided
+    # sample: a swap like this one went unnoticed and predictions used the stale upload)
+    uploads = []
+    real = model._upload_posterior
+    model._upload_posterior = lambda ctx: (uploads.append(1), real(ctx))[1]
+    model.predict_outcome_proba("0", "1")
+    assert not uploads                                   # nothing changed: no re-upload
+    i, j = model._teams_dict["0"], model._teams_dict["1"]
+    model.attack[3, i], model.attack[3, j] = model.attack[3, j], model.attack[3, i]
+    model.predict_outcome_proba("0", "1")
+    assert uploads == [1]
+    model.predict_outcome_proba(["0"], ["1"])            # list arguments make no new stamp
+    assert uploads == [1]
     model.invalidate_predict_cache()
     assert model._uploaded is None
 

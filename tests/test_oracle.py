@@ -113,9 +113,46 @@ def test_golden_vectors():
             assert U == pytest.approx(float(d["U"][i]), rel=1e-12), f
             assert np.abs(g - d["grad"][i]).max() <= 1e-11 * np.abs(g).max(), f
             assert aux["rho"] == pytest.approx(float(d["rho"][i]), abs=1e-13)
+            assert aux["cond_val"] == pytest.approx(float(d["cond_val"][i]), rel=1e-9)
+            if not d["tied"][i]:   # the two tie rules differ at ties only (fixtures of one pair: to rounding)
+                assert np.abs(d["grad"][i] - d["grad_first_pair"][i]).max() <= \
+                    1e-13 * np.abs(g).max() + 64 * 2.0 ** -53 * aux["cond_grad_raw"]
+            # the C restatement: another float64 program (libm's exp instead of numpy's, another summation
+            # order).  At the points 1e-4 / 1e-6 from a bound of rho the tau term amplifies the last bits of
+            # the rates by 1 / t in the value and 1 / t^2 in the gradient: 64 ulp of the uncapped conditioning
+            eps64 = 64 * 2.0 ** -53
             Uc, gc, _ = OC.potential_and_grad(cf, d["z"][i])
-            assert Uc == pytest.approx(float(d["U"][i]), rel=1e-12)
-            assert np.abs(gc - d["grad"][i]).max() <= 1e-11 * np.abs(g).max()
+            assert abs(Uc - float(d["U"][i])) <= 1e-12 * abs(U) + eps64 * aux["cond_val_raw"], (f, i)
+            if not d["tied"][i]:   # (the C restatement keeps the first tied FIXTURE: a third element of the subdifferential)
+                assert np.abs(gc - d["grad"][i]).max() <= 1e-11 * np.abs(g).max() + eps64 * aux["cond_grad_raw"], (f, i)
+            gf = O.potential_and_grad(model, fx, d["z"][i], ties="first_pair")[1]
+            assert np.abs(gf - d["grad_first_pair"][i]).max() <= 1e-11 * np.abs(g).max()
+
+
+def test_tie_rule_at_zero_matches_autograd():
+    """z = 0: every rate is exactly 1, so every fixture attains every extremum of bpl/_util.py:23-30 and both
+    two-entry min / max tie as well.  jnp.min / jnp.max split the derivative evenly over tied entries;
+    torch.amin / amax / minimum / maximum (oracle/dc_torch_ref.py, the literal transcription) do the same, and
+    the hand-derived adjoint restates it (ties="split", the default).  ties="first_pair" -- what the product
+    computes -- is a different element of the subdifferential there and the same gradient everywhere else."""
+    import dc_torch_ref as TR
+
+    for model, name in [(O.MODEL_BASIC, "dummy"), (O.MODEL_BASIC, "ragged_777"), (O.MODEL_EXTENDED, "dummy_cov"),
+                        (O.MODEL_EXTENDED, "timed_w")]:
+        fx = cases.fixtures(name)
+        D = O.latent_dim(model, fx.n_teams, fx.k if model == O.MODEL_EXTENDED else 0)
+        z = np.zeros(D)
+        U, g, aux = O.potential_and_grad(model, fx, z)
+        Ut, gt = TR.potential_and_grad(model, fx, z)[:2]
+        assert aux["tied"]
+        assert U == pytest.approx(Ut, rel=1e-14)
+        assert np.abs(g - gt).max() <= 1e-12 * np.abs(g).max()
+        U1, g1, _ = O.potential_and_grad(model, fx, z, ties="first_pair")
+        assert U1 == U and np.abs(g1 - g).max() > 0.5
+        z = np.random.RandomState(3).uniform(-0.5, 0.5, D)
+        # (fixtures of ONE pair always tie: an even split over them sums to the one-hot, up to rounding)
+        ga, gb = O.potential_and_grad(model, fx, z)[1], O.potential_and_grad(model, fx, z, ties="first_pair")[1]
+        assert np.abs(ga - gb).max() <= 1e-13 * np.abs(ga).max()
 
 
 def test_tau_clip_returns_inf_and_zero_adjoint():

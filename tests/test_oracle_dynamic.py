@@ -51,3 +51,18 @@ def test_config4_recipe_shapes():
         m = fx.gameweek == w
         assert m.sum() == 50
         assert len(set(fx.home_idx[m]) | set(fx.away_idx[m])) == 100
+
+
+def test_golden_vectors():
+    """tests/golden/m2_small_cov.npz (oracle/make_golden.py) is reproduced by the oracle as it stands."""
+    import os
+
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "m2_small_cov.npz"))
+    fx = DO.DynFixtures(d["home_idx"], d["away_idx"], d["home_goals"], d["away_goals"], d["gameweek"],
+                        d["neutral"], int(d["n_teams"]), int(d["n_gameweeks"]), covariates=d["covariates"])
+    for rw in (1, 0):
+        for i in range(d["z"].shape[0]):
+            U, g, aux = DO.potential_and_grad(fx, d["z"][i], bool(rw))
+            assert abs(U - d[f"U_rw{rw}"][i]) <= 1e-12 * abs(U)
+            assert np.abs(g - d[f"grad_rw{rw}"][i]).max() <= 1e-11 * np.abs(g).max()
+            assert abs(aux["rho"] - d[f"rho_rw{rw}"][i]) <= 1e-13
