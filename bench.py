@@ -82,8 +82,13 @@ def cpu_baseline(h, a, x, y, n_teams, zs, budget_s, with_torch=True):
     cf = OC.CFixtures(O.MODEL_BASIC, fx)
     ncpu = OC.max_threads()
     sweep = {}
-    share = budget_s * 0.6 / 8
-    for nt in sorted({1, max(1, ncpu // 8), max(1, ncpu // 4), max(1, ncpu // 2), ncpu}):
+    # (round 4: 1/16 and 3/16 of the threads join the sweep -- on the 128-thread box the best count was 16 with
+    # 32 already half of it, so the optimum could sit at 8 or 24 -- and the best count is timed once more
+    # with OMP_WAIT_POLICY=passive, in a process of its own: the policy is read when the runtime starts)
+    counts = sorted({1, max(1, ncpu // 16), max(1, ncpu // 8), max(1, 3 * ncpu // 16), max(1, ncpu // 4),
+                     max(1, ncpu // 2), ncpu})
+    share = budget_s * 0.6 / (2 * len(counts))
+    for nt in counts:
         port = OC.CpuPort(cf, nt)
         port.eval_many(zs, 8)  # warm (thread team, caches)
         rates = []
@@ -113,6 +118,24 @@ def cpu_baseline(h, a, x, y, n_teams, zs, budget_s, with_torch=True):
         "threads_sweep": {str(nt): [round(r[0], 1) for r in sweep[nt]] for nt in sweep},
         "repeat_spread": max(r[0] for r in sweep[best]) / v - 1.0,
     }
+    try:   # passive wait policy at the best thread count (a fresh OpenMP runtime: a child process)
+        import subprocess
+
+        child = (
+            "import sys, time, numpy as np; sys.path[:0] = [%r, %r]\n"
+            "import bench, dc_oracle as O, dc_oracle_c as OC\n"
+            "h, a, x, y = bench.synthetic_league(%d, %d)\n"
+            "cf = OC.CFixtures(O.MODEL_BASIC, O.Fixtures(h, a, x, y, %d))\n"
+            "zs = np.random.RandomState(7).uniform(-0.5, 0.5, (64, cf.dim if hasattr(cf, 'dim') else 2 * %d + 5))\n"
+            "port = OC.CpuPort(cf, %d); port.eval_many(zs, 8)\n"
+            "k = %d; t0 = time.perf_counter(); port.eval_many(zs, k); print(k / (time.perf_counter() - t0))\n"
+        ) % (ROOT, os.path.join(ROOT, "oracle"), len(h), n_teams, n_teams, n_teams, best,
+             max(64, int(v * budget_s * 0.05)))
+        env = dict(os.environ, OMP_WAIT_POLICY="passive")
+        r = subprocess.run([sys.executable, "-c", child], env=env, capture_output=True, text=True, timeout=120)
+        out["passive_wait"] = {"threads": best, "value": float(r.stdout.strip().splitlines()[-1]), "unit": "evals/s"}
+    except Exception as e:  # pylint: disable=broad-except
+        out["passive_wait"] = {"error": f"{type(e).__name__}: {e}"[:200]}
     # the float64 checker (round 1's baseline), all threads and one
     chk = {}
     for label, nt in (("all", ncpu), ("one", 1)):
@@ -291,9 +314,10 @@ def main():
 
     extra = {}
     if rank == 0 and not args.no_insitu and world == 1:
-        # in situ: leapfrogs/s of a real NUTS chain on the same data (short, bounded)
+        # in situ: leapfrogs/s of a real NUTS chain on the same data -- SURVEY.md section 8d's 500 + 500
+        # (about 2 s at N = 1e6: ~290 leapfrogs per transition)
         cfg = default_nuts_cfg()
-        cfg.num_warmup, cfg.num_samples = 150, 100
+        cfg.num_warmup, cfg.num_samples = 500, 500
         _, st = ctx.nuts_run(cfg, prng_key(42))
         extra["insitu_leapfrogs_per_s"] = st["total_leapfrogs"] / st["wall_seconds"]
         extra["insitu_leapfrogs"] = st["total_leapfrogs"]

@@ -110,6 +110,7 @@ struct bplhip_ctx {
     DevBuf d_zb;    // persistent evaluation kernel: the next position as tagged granules
     unsigned int loop_tag = 0;  // tags handed out so far (a launch of k steps takes k + 1 of them)
     int opt_persistent_kernel = 1;  // 1: a single chain's leapfrogs run inside one resident launch
+    int opt_persist_spec = 1;       // ... and the next position is published before the leaf is booked (dc::tail_waves)
     int opt_dense_pairs = 1;        // 1: complete pair tables take the separable (O(teams)) bounds
     bool pairs_complete = false;
     int opt_fused_small = 1;        // 1: neutral / dynamic evaluations that fit one CU's LDS run as one launch
@@ -632,7 +633,8 @@ int launch_eval(bplhip_ctx* c, int chains, const double* z, double* pot, double*
 bool loop_ok(const bplhip_ctx* c) {
     if (c->dynamic || c->neutral || !c->opt_persistent_kernel) return false;
     const bplhip_ctx::EvalPart& ep = c->parts[0];
-    return ep.staged && ep.n_wg + 1 <= c->n_cu && ctx_lds_bytes(c, true) <= 64 * 1024;
+    // (the leaf's vectors live in registers / LDS lanes there: two elements per lane at most)
+    return ep.staged && ep.n_wg + 1 <= c->n_cu && ctx_lds_bytes(c, true) <= 64 * 1024 && c->L.D <= 128;
 }
 template <bool W, bool C, int LNE>
 int launch_loop_l(bplhip_ctx* c, const dc::EvalArgs& A, hipStream_t s) {
@@ -648,7 +650,7 @@ template <bool W, bool C>
 int launch_loop_t(bplhip_ctx* c, const dc::EvalArgs& A, hipStream_t s) {
     // the leaf's vectors in registers: one element per lane up to 64 latent entries, two up to 128
     // (the extended model: 3T + 2K + 7); beyond, the LDS-staged leaf of the one-element kernel
-    if (C && c->L.D > 64 && c->L.D <= 128) return launch_loop_l<W, C, 2>(c, A, s);
+    if (c->L.D > 64) return launch_loop_l<W, C, 2>(c, A, s);
     return launch_loop_l<W, C, 1>(c, A, s);
 }
 int launch_eval_loop(bplhip_ctx* c, double* ns, int nuts_depth, const nd::Persist* persist, int steps,
@@ -668,6 +670,7 @@ int launch_eval_loop(bplhip_ctx* c, double* ns, int nuts_depth, const nd::Persis
     A.nuts_max_depth = nuts_depth;
     A.persist = persist;
     A.persist_steps = steps;
+    A.persist_spec = c->opt_persist_spec;
     A.zg = c->d_zb.as<unsigned long long>();
     const bool clip = c->L.model == dc::MODEL_EXTENDED;
     if (c->weighted) return clip ? launch_loop_t<true, true>(c, A, s) : launch_loop_t<true, false>(c, A, s);
@@ -1268,6 +1271,10 @@ int bplhip_set_option(bplhip_ctx* c, const char* name, int value) {
     if (n == "vec_tiles_per_wave") {  // 0 = by chain count; takes effect at the next bplhip_set_fixtures
         if (value < 0 || value > 4096) return fail(c, BPLHIP_EINVAL, "vec_tiles_per_wave out of range");
         c->opt_vec_tpw = value;
+        return BPLHIP_OK;
+    }
+    if (n == "persist_spec") {  // persistent kernel: the next position before the leaf (1) or after it (0)
+        c->opt_persist_spec = value != 0;
         return BPLHIP_OK;
     }
     if (n == "chunk_graph") {  // persistent chains: a chunk of leapfrogs as one replayed hipGraph (1) or launch by launch (0)

@@ -200,6 +200,7 @@ struct EvalArgs {
     // granules {float32 z_i, tag}, tag = tag_base + 1 + step (the host hands out tag ranges that
     // never repeat, so a granule of an earlier launch can never look current)
     int persist_steps;
+    int persist_spec;        // 1: the next position is published before the leaf is booked (tail_waves, defer_out)
     unsigned int tag_base;
     unsigned long long* zg;  // [chains][D] granules
     const int* ga_expect;    // [ga_rows(T)] contributions every accumulator row receives per evaluation (static)
@@ -651,6 +652,13 @@ __host__ __device__ inline size_t prior_lds_bytes(int T) {
     b += 3 * (size_t)T * 8;                                // att, def, ha (double)
     b += (40 + WAVES * 8 + WAVES * 8) * 8;                 // scalars, scratch, argmax
     return b;
+}
+// persistent kernel: the state of the leaf being booked one step behind its evaluation, parked in LDS by each
+// of the two leaf waves (dc_eval_loop, leaf_window_*): header words [64] | invM, zn, r_half, r_sum, sl_r,
+// sr_r [64 lanes each, per 64 elements] | the leaf's rng words [8]
+constexpr int LEAF_PARK_VECS = 6;
+__host__ __device__ inline size_t leaf_park_doubles(int D) {
+    return 64 + (size_t)LEAF_PARK_VECS * 64 * ((D + 63) / 64) + 8;
 }
 __host__ __device__ inline size_t acc_tail_lds_bytes(int T, int D, int K, int zo_stride, bool stage);
 __host__ __device__ inline size_t eval_lds_bytes(int T, int D, int K, int zo_stride, bool stage) {
@@ -1187,6 +1195,16 @@ __device__ void prior_body(const EvalArgs& A, int chain, char* smem, double* zo_
     else
         build_tables_f32<CLIP>(L, z, A.xsf, tabH, tabA, tid, load_team_z<CLIP>(L, z, min(tid, T - 1)), fs);
 
+    // DEFER (small leagues: wave 6 holds no pair and wave 7 is the team-sum wave): the scalar priors and
+    // the cells' rounding errors -- which nothing in the cells reads -- sit behind the cells' barrier, on
+    // those two waves, beside the pair walk.
+    const bool defer = sums_on_wave && (two_each || 6 * 64 >= A.P);
+    // (Round 4 tried to shorten the two phases in front of the pair walk, twice, and kept neither: (a) no
+    // first phase at all, every cell thread working its exp(std) out itself -- three more exp in front of each
+    // cell's own cost more than the barrier saved: cells done at 1.94 us instead of 1.68 in a plain launch;
+    // (b) the sigmoid sites' chains moved beside the cells -- the first phase is no shorter without them
+    // (0.84 against 0.80 us in the persistent kernel: it is argument reloads, the position's LDS reads and the
+    // float32 tables), and the cells got 0.2 us slower next to the chains.  A/B on one box, tools/ab_libs.py.)
     // ---- z-only scalars, one transcendental chain per wave, in parallel
     //   0 s_a  1 s_d  2 s_h  3..8 corr site  9..14 u site
     if (tid == 0) sc[0] = lean::exp(z[L.o_sa]);
@@ -1210,11 +1228,8 @@ __device__ void prior_body(const EvalArgs& A, int chain, char* smem, double* zo_
 
     // ---- scalar priors + Jacobians (L = log density) and their gradient: one lane of wave 1,
     // while wave 0 builds the cells below (only the team sums v[] are still missing at the end).
-    // DEFER (small leagues: wave 6 holds no pair and wave 7 is the team-sum wave): both
-    // this chain and the cells' rounding errors -- which nothing in here reads -- move behind the cells'
-    // barrier, onto those two waves, beside the pair walk: the barrier then waits for the cells' exp
-    // alone (it waited 0.56 us for either of the two, the other waves 0.4 us for them)
-    const bool defer = sums_on_wave && (two_each || 6 * 64 >= A.P);
+    // (DEFER, above: behind the cells' barrier, so that it waits for the cells' exp alone -- it waited
+    // 0.56 us for either of the two, the other waves 0.4 us for them)
     // (not deferred: the chain sits on a wave that builds no cells -- wave 6 up to 128 teams, wave 7 up to
     // 149; on wave 1 it ran in FRONT of that wave's cells, 0.5 us of the phase at 100 teams)
     const int lz_tid = defer || 3 * T <= 6 * 64 ? 6 * 64 : (3 * T <= 7 * 64 ? 7 * 64 : 64);
@@ -1649,6 +1664,35 @@ __device__ __forceinline__ void publish_fin(unsigned long long* zg, int D, int l
     for (int i = lane; i < D; i += 64) st_granule(&zg[i], 0.f, fin_tag);
 }
 
+// persistent chains: a subtree is complete (the doubling's last leaf, a U-turn, a divergence): the leaf
+// wave combines the trees, adapts / stores the draw when the transition ends, and starts the next
+// doubling or transition -- from a position only memory holds.  Called by the whole workgroup behind a
+// barrier that follows the leaf's two halves; `pub_tag` != 0: publish that position (or FIN) for the
+// streaming workgroups.  *fin_flag = 1 when the chain has finished.
+__device__ __forceinline__ void subtree_complete(const EvalArgs& A, int chain, double* fin_flag, double* zn_lds,
+                                                 unsigned int pub_tag) {
+    const int D = A.L.D;
+    const int t = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double* ns = nuts_of(A, chain);
+    if (wave == RNG_WAVE) nd::wave_mem_sync();   // (the other half's stores, before the leaf wave reads them)
+    __syncthreads();
+    if (wave == LEAF_WAVE) {
+        __builtin_amdgcn_s_dcache_inv();   // (the advance reads chain state with uniform addresses)
+        nd::persist_advance(ns, *A.persist, chain, t);
+        if (zn_lds)   // (rare: the new doubling / transition starts from a position only memory holds)
+            for (int i = t; i < D; i += 64) zn_lds[i] = nd::vec(ns, D, nd::V_ZN)[i];
+        if (pub_tag != 0u) {  // a new doubling / transition starts somewhere else -- or nowhere
+            const bool fin = (ns + A.persist->pd_off)[nd::P_ALLDONE] != 0.0;
+            if (fin) {
+                publish_fin(A.zg + (size_t)chain * D, D, t, A.tag_base + 1u + (unsigned int)A.persist_steps);
+                if (t == 0) *fin_flag = 1.0;
+            } else {
+                publish_z(A.zg + (size_t)chain * D, nd::vec(ns, D, nd::V_ZN), D, t, pub_tag);
+            }
+        }
+    }
+}
+
 // Per-team epilogue for T <= 64: lane t owns team t, sums are DPP wave reductions, adds and
 // FMAs only.  A single wave issues a dependent instruction every ~5 cycles, so the work is
 // split by OUTPUT GROUP over four waves that never need each other's results:
@@ -1661,12 +1705,13 @@ __device__ __forceinline__ void publish_fin(unsigned long long* zg, int D, int l
 // everywhere but in the persistent kernel, which takes 2 for 64 < D <= 128 (the extended model with
 // 20 teams: D = 67 .. 77) instead of staging the leaf's vectors in LDS -- a single resident chain
 // has the registers, and the staged leaf was 1.0 us slower per leapfrog.
-template <bool NUTS, bool EXT, int LNE>
+// LOOP (the persistent kernel): outputs only -- its loop books the leaf itself (leaf_window_*, dc_eval_loop)
+template <bool NUTS, bool EXT, int LNE, bool LOOP = false>
 __device__ void tail_waves(const EvalArgs& A, int chain, const double* zoL, const double* cL,
                            const double* zL, const double* col, const double* xsL,
                            double* gradL, const nd::LeafState<LNE>& leaf1, double* stg,
-                           unsigned int pub_tag = 0u /* persistent kernel: tag of the NEXT step */,
-                           double* zn_lds = nullptr /* persistent kernel: the LDS copy of the position */) {
+                           unsigned int pub_tag = 0u /* tag of the NEXT step */,
+                           double* zn_lds = nullptr /* the LDS copy of the position */) {
     const Layout& L = A.L;
     const int T = L.T, K = L.K, D = L.D;
     const int t = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1674,7 +1719,7 @@ __device__ void tail_waves(const EvalArgs& A, int chain, const double* zoL, cons
     double* grad = grad_of(A, chain);
     constexpr bool nuts = NUTS;
     auto put = [&](int o, double v) {
-        grad[o] = v;
+        if (!LOOP) grad[o] = v;   // (the persistent kernel's leaf reads the LDS copy; nobody reads V_GRAD there)
         if (nuts) gradL[o] = v;
     };
     const double* gz = zoL + ZO_HDR;
@@ -1799,7 +1844,7 @@ __device__ void tail_waves(const EvalArgs& A, int chain, const double* zoL, cons
         }
     }
     DC_STAMP(14);
-    if (nuts) {  // device-resident NUTS: the leaf wave finishes the leapfrog and books the leaf
+    if (nuts && !LOOP) {  // device-resident NUTS: the leaf wave finishes the leapfrog and books the leaf
         const bool small = D <= 64 * LNE;  // LNE vector elements per lane: registers; else LDS (stg)
         nd::LeafState<LNE> lf1 = leaf1;
         double* ns = nuts_of(A, chain);
@@ -1838,23 +1883,7 @@ __device__ void tail_waves(const EvalArgs& A, int chain, const double* zoL, cons
         // then see the other half's stores -- release + barrier, acquire in persist_advance
         __syncthreads();
         if (gradL[D + 5] == 0.0) return;  // (uniform)
-        if (wave == RNG_WAVE) nd::wave_mem_sync();
-        __syncthreads();
-        if (wave == LEAF_WAVE) {
-            __builtin_amdgcn_s_dcache_inv();   // (the advance reads chain state with uniform addresses)
-            nd::persist_advance(ns, *A.persist, chain, t);
-            if (zn_lds)   // (rare: the new doubling / transition starts from a position only memory holds)
-                for (int i = t; i < D; i += 64) zn_lds[i] = nd::vec(ns, D, nd::V_ZN)[i];
-            if (pub_tag != 0u) {  // a new doubling / transition starts somewhere else -- or nowhere
-                const bool fin = (ns + A.persist->pd_off)[nd::P_ALLDONE] != 0.0;
-                if (fin) {
-                    publish_fin(A.zg + (size_t)chain * D, D, t, A.tag_base + 1u + (unsigned int)A.persist_steps);
-                    if (t == 0) gradL[D + 6] = 1.0;
-                } else {
-                    publish_z(A.zg + (size_t)chain * D, nd::vec(ns, D, nd::V_ZN), D, t, pub_tag);
-                }
-            }
-        }
+        subtree_complete(A, chain, gradL + D + 6, zn_lds, pub_tag);
     }
 }
 
@@ -2167,8 +2196,8 @@ __device__ void tail_body(const EvalArgs& A, int chain, char* smem) {
 // so the shard sums are 16-lane DPP row sums.
 __host__ __device__ inline size_t acc_tail_lds_bytes(int T, int D, int K, int zo_stride, bool stage) {
     size_t d = (size_t)zo_stride + 3 * (size_t)T + D + (3 * (size_t)T + N_SCAL + 4) + WAVES * 8 +
-               (size_t)T * xs_staged_k(K) + (size_t)D + 8 +
-               (stage && D > 64 ? (size_t)nd::LEAF_STAGE_VECS * D : 0);
+               (size_t)T * xs_staged_k(K) + 2 * ((size_t)D + 8) +
+               (stage && D > 64 ? (size_t)nd::LEAF_STAGE_VECS * D : 0) + (stage ? 2 * leaf_park_doubles(D) + 8 : 0);
     return d * 8 + 16;
 }
 // Everything the tail needs that does NOT depend on the streaming workgroups is requested by
@@ -2205,12 +2234,13 @@ __device__ __forceinline__ void tail_preload_static(const EvalArgs& A, int chain
 template <bool SMALLT, bool NUTS, bool ZL = false, int LNE>
 __device__ __forceinline__ void tail_preload(const EvalArgs& A, int chain, TailPre& P,
                                              nd::LeafState<LNE>& leaf1,
-                                             double (&bigv)[nd::LEAF_STAGE_LOADS], bool static_done = false) {
+                                             double (&bigv)[nd::LEAF_STAGE_LOADS], bool static_done = false,
+                                             bool want_leaf = true) {
     const Layout& L = A.L;
     const int D = L.D;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (!static_done) tail_preload_static<ZL>(A, chain, P);
-    if (NUTS && SMALLT) {
+    if (NUTS && SMALLT && want_leaf) {
         double* ns = nuts_of(A, chain);
         if (D <= 64 * LNE) {
             if (wave == LEAF_WAVE || wave == RNG_WAVE)
@@ -2285,8 +2315,8 @@ __device__ __forceinline__ bool tail_acc(const EvalArgs& A, int chain, char* sme
     double* col = zL + D;                               // [3T + N_SCAL + 4] reduced sums
     double* scratch = col + ncol + N_SCAL + 4;          // [WAVES*8]
     double* xsL = scratch + WAVES * 8;                  // [T*K] when K <= 16
-    double* gradL = xsL + (size_t)T * xs_staged_k(K);   // [D+8] grad | U | aux (NUTS hand-over)
-    double* stg = gradL + D + 8;                        // [7*D] NUTS leaf vectors when D > 64
+    double* gradL = xsL + (size_t)T * xs_staged_k(K);   // [2][D+8] grad | U | aux (NUTS hand-over; the persistent kernel alternates)
+    double* stg = gradL + 2 * (D + 8);                  // [7*D] NUTS leaf vectors when D > 64
     DC_STAMP(7);
 
     const bool small = D <= 64 * LNE;
@@ -2392,11 +2422,172 @@ __device__ __forceinline__ int* acc_tail_flag(const EvalArgs& A, char* smem) {
     const Layout& L = A.L;
     return reinterpret_cast<int*>(reinterpret_cast<double*>(smem) + A.zo_stride + 3 * L.T + L.D + (3 * L.T + N_SCAL + 4));
 }
+// the persistent kernel's parked leaf states and flags (behind the leaf's staging vectors)
+__device__ __forceinline__ double* acc_tail_park(const EvalArgs& A, char* smem, bool stage) {
+    const Layout& L = A.L;
+    return reinterpret_cast<double*>(smem) + A.zo_stride + 3 * L.T + L.D + (3 * L.T + N_SCAL + 4) + WAVES * 8 +
+           (size_t)L.T * xs_staged_k(L.K) + 2 * ((size_t)L.D + 8) +
+           (stage && L.D > 64 ? (size_t)nd::LEAF_STAGE_VECS * L.D : 0);
+}
 // where tail_acc keeps its NUTS hand-over block gradL (grad | U | aux | sub_done | finished)
 __device__ __forceinline__ double* acc_tail_gradL(const EvalArgs& A, char* smem) {
     const Layout& L = A.L;
     return reinterpret_cast<double*>(smem) + A.zo_stride + 3 * L.T + L.D + (3 * L.T + N_SCAL + 4) + WAVES * 8 +
            (size_t)L.T * xs_staged_k(L.K);
+}
+
+// ------------------------------------------------------------ persistent kernel: the tail of one step
+// Round 4: THE LEAF IS BOOKED ONE STEP BEHIND ITS EVALUATION.  While a subtree goes on, the next leapfrog
+// starts at zn + eps M^-1 (r_half - eps g): one fma chain per element once the gradient exists, whereas the
+// leaf's decisions (energy, U-turn test, multinomial transition) only matter when they END the subtree.
+// Whether the subtree is complete after a leaf is known from the header (num + 1 == S_MAX: that leaf is
+// booked at once, the sequential path); otherwise only a U-turn or a divergence ends it -- about once per
+// transition.  So the leaf wave publishes the next position right behind the epilogue's barrier, and the
+// leaf itself is booked during the NEXT step's wait for the accumulator rows and its epilogue, on the two
+// waves that idle there (LEAF_WAVE: leaf_window_moves, across the barrier that ends the wait; RNG_WAVE:
+// leaf_window_weights, beside the epilogue).  Its state is not re-read from memory: each leaf wave
+// forwards its registers (nd::leaf_forward_*) and parks them in LDS across the prior part.  A step was
+//   prior 3.1 + wait 0.9 + sums 0.25 + epilogue 1.1 + leaf 0.8-1.0 + publish 0.25 us
+// with the streaming workgroups done at 2.9 (profiles/r03/stamps_timeline.txt); the leaf and its
+// publish leave that chain.  When the leaf of step s - 1 turns out to have ended its subtree, evaluation s
+// -- consumed by then: no drain -- is simply dropped and the chain moves on from where it really is.
+// (First tried with the leaf inside the next PRIOR part's first phase: that phase is 0.8 us, the leaf
+// 1.3 us + 0.6 us of store drain in front of the phase's barrier -- 8.8 us per step instead of 7.5.)
+enum { LF_SUBDONE = 0, LF_FIN = 1, LF_SPEC = 2, LF_N = 8 };
+template <int LNE>
+__device__ __forceinline__ void leaf_park(double* pk, const nd::LeafState<LNE>& S, int t, bool with_rng) {
+    pk[t] = S.hv;
+#pragma unroll
+    for (int e = 0; e < LNE; ++e) {
+        double* v = pk + 64 + (size_t)e * LEAF_PARK_VECS * 64 + t;
+        v[0] = S.invM[e]; v[64] = S.zn[e]; v[128] = S.r[e]; v[192] = S.rs[e]; v[256] = S.sl_r[e]; v[320] = S.sr_r[e];
+    }
+    if (with_rng && t == 0) {
+        double* w = pk + 64 + (size_t)LNE * LEAF_PARK_VECS * 64;
+        w[0] = (double)S.nhi; w[1] = (double)S.nlo; w[2] = (double)S.u_take;
+    }
+}
+template <int LNE>
+__device__ __forceinline__ nd::LeafState<LNE> leaf_unpark(const double* pk, int t, bool with_rng) {
+    nd::LeafState<LNE> S;
+    S.hv = pk[t];
+#pragma unroll
+    for (int e = 0; e < LNE; ++e) {
+        const double* v = pk + 64 + (size_t)e * LEAF_PARK_VECS * 64 + t;
+        S.invM[e] = v[0]; S.zn[e] = v[64]; S.r[e] = v[128]; S.rs[e] = v[192]; S.sl_r[e] = v[256]; S.sr_r[e] = v[320];
+    }
+    if (with_rng) {
+        const double* w = pk + 64 + (size_t)LNE * LEAF_PARK_VECS * 64;
+        S.nhi = (uint32_t)w[0]; S.nlo = (uint32_t)w[1]; S.u_take = (float)w[2];
+    }
+    return S;
+}
+struct WorkgroupSync {
+    __device__ __forceinline__ void operator()(bool) const { __syncthreads(); }
+};
+// LEAF_WAVE, in place of polling a row it does not own: the previous step's leaf (gradient and potential in
+// gL_prev), the workgroup's barrier in the middle (after the decisions, before the stores)
+template <int LNE>
+__device__ __forceinline__ void leaf_window_moves(const EvalArgs& A, int chain, const double* gL_prev, double* pk,
+                                                  double* flags, int t) {
+    const int D = A.L.D;
+    nd::LeafState<LNE> S = leaf_unpark<LNE>(pk, t, false);
+    nd::leaf_prepare<false>(S);
+    const bool done = nd::leaf_moves(nuts_of(A, chain), D, A.nuts_max_depth, t, gL_prev, S, (double*)nullptr,
+                                     WorkgroupSync());
+    if (t == 0) flags[LF_SUBDONE] = done ? 1.0 : 0.0;
+    if (!done) {   // the subtree goes on: this wave's copy of the next leaf's state
+        nd::leaf_forward_moves(S, D, t, gL_prev);
+        leaf_park<LNE>(pk, S, t, false);
+    }
+}
+// RNG_WAVE, likewise (dc_eval's tail polls the scalar rows on this wave; here another idle wave does):
+// the other half of that leaf, then the next leaf's random numbers
+template <int LNE>
+__device__ __forceinline__ void leaf_window_weights(const EvalArgs& A, int chain, const double* gL_prev, double* pk,
+                                                    int t) {
+    const int D = A.L.D;
+    nd::LeafState<LNE> S = leaf_unpark<LNE>(pk, t, true);
+    const nd::LeafWeights W = nd::leaf_weights(nuts_of(A, chain), D, t, gL_prev, S, WorkgroupSync());
+    nd::leaf_forward_weights(S, D, t, gL_prev, W);
+    nd::leaf_rng(S.hv, &S.nhi, &S.nlo, &S.u_take);
+    leaf_park<LNE>(pk, S, t, true);
+}
+// One step's wait + epilogue in the persistent kernel (T <= 64, D <= 64 LNE).  `prev`: the previous step's
+// leaf is still to be booked (its state parked, its gradient in the other gradL buffer); otherwise leaf1 is
+// this step's leaf as prefetched from memory, and is parked here.  false: the bounded wait expired.
+template <bool EXT, int LNE>
+__device__ __forceinline__ bool loop_tail(const EvalArgs& A, int chain, char* smem,
+                                          const nd::LeafState<LNE>& leaf1, int* okflag, int set, bool prev) {
+    const Layout& L = A.L;
+    const int T = L.T, K = L.K, D = L.D;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ncol = 3 * T;
+    double* zoL = reinterpret_cast<double*>(smem);
+    double* cL = zoL + A.zo_stride;
+    double* zL = cL + ncol;
+    double* col = zL + D;
+    double* scratch = col + ncol + N_SCAL + 4;
+    double* xsL = scratch + WAVES * 8;
+    double* gradL0 = xsL + (size_t)T * xs_staged_k(K);
+    double* gL_cur = gradL0 + (size_t)set * (D + 8);
+    const double* gL_prev = gradL0 + (size_t)(set ^ 1) * (D + 8);
+    double* pkL = acc_tail_park(A, smem, true);
+    double* pkR = pkL + leaf_park_doubles(D);
+    double* flags = pkR + leaf_park_doubles(D);
+    const bool xs_staged = K > 0 && K <= 16;
+    long long* ga = A.gacc + ((size_t)chain * 2 + set) * ga_set_words(T);
+    // (T <= 64: the team rows are waves 0..2's; the scalar rows go to wave SCAL_WAVE here -- in dc_eval's tail
+    // they are the last wave's, which is RNG_WAVE)
+    constexpr int SCAL_WAVE = 5;
+    static_assert(SCAL_WAVE != LEAF_WAVE && SCAL_WAVE != RNG_WAVE && SCAL_WAVE >= 3, "an idle wave");
+    if (wave == LEAF_WAVE && prev) {
+        leaf_window_moves<LNE>(A, chain, gL_prev, pkL, flags, lane);   // (the barrier below is inside)
+    } else if (wave == RNG_WAVE && prev) {
+        leaf_window_weights<LNE>(A, chain, gL_prev, pkR, lane);        // (likewise)
+    } else {
+        // poll this thread's row until every workgroup that feeds it has added (tail_acc); the other set --
+        // the next step's, re-armed one step ago -- must read all zero in the same round of loads
+        GaWords w0;
+        const int row = wave == SCAL_WAVE ? ncol + (lane & 15) * N_SCAL + (lane >> 4) : min(tid, ncol - 1);
+        const size_t ro = (size_t)row * GA_ROW;
+        const bool ok = ga_take_row(ga + ro, A.ga_expect[row], &w0,
+                                    A.gacc + ((size_t)chain * 2 + (set ^ 1)) * ga_set_words(T) + ro);
+        if (wave != SCAL_WAVE) {
+            if (tid < ncol) col[tid] = ga_value(w0);
+        } else {  // scalar rows: sum the shards
+            double v = ga_value(w0);
+            v += dpp_f64<0xB1>(0.0, v);
+            v += dpp_f64<0x4E>(0.0, v);
+            v += dpp_f64<0x124>(0.0, v);
+            v += dpp_f64<0x128>(0.0, v);
+            if ((lane & 15) == 0) col[ncol + (lane >> 4)] = v;
+        }
+        if (!ok && lane == 0) *okflag = 0;
+        if (wave == LEAF_WAVE) {   // (!prev: this step's leaf came from memory)
+            leaf_park<LNE>(pkL, leaf1, lane, false);
+            if (lane == 0) flags[LF_SUBDONE] = 0.0;
+        }
+        __syncthreads();
+    }
+    DC_STAMP(8);
+    if (*okflag == 0) return false;
+    if (wave == SCAL_WAVE) {
+        ga_rearm(ga + (size_t)(ncol + (lane & 15) * N_SCAL + (lane >> 4)) * GA_ROW);
+    } else if (tid < ncol) {
+        ga_rearm(ga + (size_t)tid * GA_ROW);
+    }
+    DC_STAMP(9);
+    if (zoL[ZO_ILL] != 0.0)   // (uniform; rare: see class_terms)
+        ill_pass_lds<EXT>(A, zoL, col, scratch, smem + ((acc_tail_lds_bytes(T, D, K, A.zo_stride, true) + 15) & ~(size_t)15));
+    tail_waves<true, EXT, LNE, true>(A, chain, zoL, cL, zL, col, xs_staged ? xsL : nullptr, gL_cur, leaf1, nullptr);
+    if (wave == RNG_WAVE && !prev) {   // this step's leaf came from memory: its random numbers, parked
+        nd::LeafState<LNE> S = leaf1;
+        nd::leaf_rng(S.hv, &S.nhi, &S.nlo, &S.u_take);
+        leaf_park<LNE>(pkR, S, lane, true);
+    }
+    DC_STAMP(10);
+    return true;
 }
 
 // ------------------------------------------------------------ per-lane fixture math
@@ -2978,6 +3169,13 @@ __global__ DC_LAUNCH_BOUNDS void dc_eval_loop(EvalArgs A) {
         if (xs_staged)
             for (int i = tid; i < T * L.K; i += BLOCK) xsL[i] = A.xs[i];
         __syncthreads();
+        // (round 4: the leaf is booked one step behind its evaluation -- see loop_tail)
+        bool prev = false;   // the previous step's leaf is still to be booked
+        double* gradL0 = acc_tail_gradL(A, smem);
+        double* pkL = acc_tail_park(A, smem, true);
+        double* pkR = pkL + leaf_park_doubles(L.D);
+        double* flags = pkR + leaf_park_doubles(L.D);
+        if (tid < LF_N) flags[tid] = 0.0;
         for (int s = 0; s < steps; ++s) {
             DC_STAMP(0);
             // (no scalar-cache invalidate here any more: what changes between steps is read through
@@ -2985,26 +3183,26 @@ __global__ DC_LAUNCH_BOUNDS void dc_eval_loop(EvalArgs A) {
             // and an invalidate made the kernel-argument reloads below miss, 0.3 us per step; the one
             // path that reads state with uniform addresses, the chain advance, invalidates for itself)
             if (tid == 0) *acc_tail_flag(A, smem) = 1;   // (in front of the prior part's first barrier)
+            const bool last = s + 1 == steps;
+            const unsigned int next_tag = last ? 0u : A.tag_base + 2u + (unsigned int)s;   // evaluation s + 1's
+            double* gL_cur = gradL0 + (size_t)(s & 1) * (L.D + 8);
             prior_body<CLIP, true, false, true>(reload_args(), chain, smem + tail_bytes, reinterpret_cast<double*>(smem),
                                                 zL, cL, xs_staged ? xsL : nullptr);
             DC_STAMP(4);
             TailPre pre;
             nd::LeafState<LNE> leaf1{};
             double bigv[nd::LEAF_STAGE_LOADS];
-            // (requesting the leaf's state in FRONT of the prior part, so that the barrier below has nothing to
-            // wait for, was measured neutral -- +1 % at N = 1e6, -1.5 % at 1e5 -- for 20 more registers)
-            tail_preload<STAGED, NUTS, true>(reload_args(), chain, pre, leaf1, bigv);
+            // (a leaf that follows a booked-behind one takes its state from LDS, not from memory)
+            tail_preload<STAGED, NUTS, true>(reload_args(), chain, pre, leaf1, bigv, false, !prev);
             __syncthreads();
             DC_STAMP(6);
-            const bool last = s + 1 == steps;
-            bool done;
+            bool ok;
             {
                 const EvalArgs B = reload_args();
-                // (the last step of the launch publishes nothing: the next launch starts from V_ZN)
-                done = tail_acc<STAGED, NUTS, CLIP, true>(B, chain, smem, pre, leaf1, bigv, acc_tail_flag(B, smem),
-                                                          last ? 0u : A.tag_base + 2u + (unsigned int)s, s & 1, true);
+                ok = loop_tail<CLIP, LNE>(B, chain, smem, leaf1, acc_tail_flag(B, smem), s & 1, prev);
             }
-            if (!done) {  // bounded wait expired: end the launch for everybody, poison the outputs
+            __syncthreads();   // the outputs of evaluation s are in gL_cur; the previous leaf is booked
+            if (!ok || *acc_tail_flag(A, smem) == 0) {  // a bounded wait expired: end the launch for everybody, poison the outputs
                 if (wave == LEAF_WAVE) publish_fin(zg, L.D, lane, fin_tag);
                 if (tid == 0) {
                     *pot_of(A, chain) = __builtin_nan("");
@@ -3012,9 +3210,57 @@ __global__ DC_LAUNCH_BOUNDS void dc_eval_loop(EvalArgs A) {
                 }
                 return;
             }
-            __syncthreads();  // (also: this step's LDS is dead, the next prior may overwrite it)
             DC_STAMP(5);
-            if (acc_tail_gradL(A, smem)[L.D + 6] != 0.0) return;  // the chain finished (FIN is out)
+            bool complete = prev && flags[LF_SUBDONE] != 0.0;   // the previous leaf ended its subtree: evaluation s is void
+            prev = false;
+            if (!complete) {
+                // ---- this step's leaf (parked by both leaf waves): does the subtree go on after it?
+                if (wave == LEAF_WAVE) {
+                    const double hv = pkL[lane];
+                    const int num = (int)nd::hdr_word(hv, nd::H_S_NUM);
+                    const bool spec = A.persist_spec && next_tag != 0u && num + 1 < (int)nd::hdr_word(hv, nd::H_S_MAX);
+                    if (spec) {   // yes unless it turns or diverges: the next position goes out NOW
+                        const double eps = nd::hdr_word(hv, nd::H_EPS) * nd::hdr_word(hv, nd::H_DIR);
+#pragma unroll
+                        for (int e = 0; e < LNE; ++e) {
+                            const int i = lane + 64 * e;
+                            const double* v = pkL + 64 + (size_t)e * LEAF_PARK_VECS * 64 + lane;
+                            if (i < L.D) zL[i] = nd::leaf_next_position(v[64], v[0], v[128], eps, gL_cur[i]);
+                        }
+                    }
+                    if (lane == 0) flags[LF_SPEC] = spec ? 1.0 : 0.0;
+                    // (the granules go out behind the LDS stores, and this wave joins the barrier below WITHOUT
+                    // waiting for them: __syncthreads() would hold the whole workgroup for the write-through
+                    // stores' round trip, 0.7 us -- 6.88 -> 7.64 in the stamped step.  Its next full barrier is
+                    // the prior part's first, by when they have landed.)
+                    if (spec) publish_z(zg, zL, L.D, lane, next_tag);
+                    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                } else {
+                    __syncthreads();   // (the next position and the decision are in LDS)
+                }
+                if (flags[LF_SPEC] != 0.0) {
+                    prev = true;   // booked during the next step's wait and epilogue
+                    continue;
+                }
+                // ---- the sequential path: this leaf completes its subtree by count (or the launch ends here)
+                if (wave == LEAF_WAVE) {
+                    nd::LeafState<LNE> S = leaf_unpark<LNE>(pkL, lane, false);
+                    nd::leaf_prepare<false>(S);
+                    const bool sub_done = nd::leaf_moves(nuts_of(A, chain), L.D, A.nuts_max_depth, lane, gL_cur, S, zL);
+                    if (lane == 0) flags[LF_SUBDONE] = sub_done ? 1.0 : 0.0;
+                    if (next_tag != 0u && !sub_done) publish_z(zg, zL, L.D, lane, next_tag);
+                } else if (wave == RNG_WAVE) {
+                    const nd::LeafState<LNE> S = leaf_unpark<LNE>(pkR, lane, true);
+                    (void)nd::leaf_weights(nuts_of(A, chain), L.D, lane, gL_cur, S);
+                }
+                __syncthreads();
+                complete = flags[LF_SUBDONE] != 0.0;
+            }
+            if (complete) {
+                subtree_complete(reload_args(), chain, flags + LF_FIN, zL, next_tag);
+                __syncthreads();
+                if (flags[LF_FIN] != 0.0) return;  // the chain finished (FIN is out)
+            }
             if (last && ld_sc1(&(nuts_of(A, chain) + A.persist->pd_off)[nd::P_ALLDONE]) != 0.0) return;
         }
         return;

@@ -392,13 +392,20 @@ __device__ __forceinline__ void leaf_moves_header(double* ns, double hv, int new
 }
 
 // S needs hv, invM, zn, r (half-stepped) and the rng fields
-template <int LEAF_NE>
-__device__ inline void leaf_weights(double* ns, int D, int lane, const double* gL,
-                                    const LeafState<LEAF_NE>& S) {
+struct NoSync {
+    __device__ __forceinline__ void operator()(bool) const {}
+};
+// SYNC: called once between the decisions and the stores, with leaf_moves' verdict (subtree complete) -- the
+// persistent kernel books a leaf on waves of their own across one of the workgroup's barriers
+// (dc_kernels.hip.h leaf_window_*)
+template <int LEAF_NE, class SYNC = NoSync>
+__device__ inline LeafWeights leaf_weights(double* ns, int D, int lane, const double* gL,
+                                           const LeafState<LEAF_NE>& S, const SYNC sync = SYNC()) {
     const double eps = hdr_word(S.hv, H_EPS) * hdr_word(S.hv, H_DIR);
     double r[LEAF_NE], g[LEAF_NE];
     const LeafEnergy E = leaf_energy(S, D, lane, gL, eps, r, g);
     const LeafWeights W = leaf_weigh(S.hv, (int)hdr_word(S.hv, H_S_NUM), E.delta, S.u_take);
+    sync(false);
     if (W.take) {
         double* sp_z = vec(ns, D, V_SP_Z); double* sp_g = vec(ns, D, V_SP_G);
 #pragma unroll
@@ -408,12 +415,21 @@ __device__ inline void leaf_weights(double* ns, int D, int lane, const double* g
         }
     }
     if (lane == 0) leaf_weights_header(ns, gL, D, W, E.e_new, S.nhi, S.nlo);
+    return W;
 }
 
+// where the next leapfrog starts while the subtree goes on: the expressions of leaf_energy / leaf_moves
+// (second half step of this leaf, first half step of the next, full position step), for the caller that
+// publishes the position BEFORE the leaf is booked (dc_kernels.hip.h tail_waves, defer_out)
+__device__ __forceinline__ double leaf_next_position(double zn, double invM, double r_half, double eps, double g) {
+    const double r = r_half - 0.5 * eps * g;
+    const double rn = r - 0.5 * eps * g;
+    return zn + eps * invM * rn;
+}
 // S fully prefetched and prepared; returns (wave uniform) whether the subtree is complete
-template <int LEAF_NE>
+template <int LEAF_NE, class SYNC = NoSync>
 __device__ inline bool leaf_moves(double* ns, int D, int max_depth, int lane, const double* gL,
-                                  const LeafState<LEAF_NE>& S, double* zn_lds = nullptr) {
+                                  const LeafState<LEAF_NE>& S, double* zn_lds = nullptr, const SYNC sync = SYNC()) {
     const double hv = S.hv;
     const double h_eps = hdr_word(hv, H_EPS), h_dir = hdr_word(hv, H_DIR);
     const double eps = h_eps * h_dir;
@@ -456,6 +472,7 @@ __device__ inline bool leaf_moves(double* ns, int D, int max_depth, int lane, co
     const int new_num = num + 1;
     const bool done = turning || div_leaf || new_num >= (int)hdr_word(hv, H_S_MAX);
 
+    sync(done);
     // ---- (D) stores
     double* p_zn = vec(ns, D, V_ZN); double* p_rh = vec(ns, D, V_RH); double* p_rsum = vec(ns, D, V_S_RSUM);
     double* sl_z = vec(ns, D, V_SL_Z); double* sl_r = vec(ns, D, V_SL_R); double* sl_g = vec(ns, D, V_SL_G);
@@ -484,6 +501,54 @@ __device__ inline bool leaf_moves(double* ns, int D, int max_depth, int lane, co
     }
     if (lane == 0) leaf_moves_header(ns, hv, new_num, div_leaf, turning, done);
     return done;
+}
+
+// ---- the NEXT leaf's state from this one's, in registers (persistent kernel: while a subtree goes on,
+// what leaf_prefetch would load after leaf_moves / leaf_weights have stored is known already -- V_ZN,
+// V_RH, V_S_RSUM, V_SL_R / V_SR_R and the header words each half reads).  Same expressions as the stores
+// of leaf_moves (r, rn, z_next, rs) and of the two header writers, hence the same bits.  Each of the two
+// leaf waves forwards ITS copy: the words the other half writes and this one never reads stay stale.
+__device__ __forceinline__ double hdr_patch(double hv, int lane, int k, double v) { return lane == k ? v : hv; }
+template <int LEAF_NE>
+__device__ __forceinline__ void leaf_forward_moves(LeafState<LEAF_NE>& S, int D, int lane, const double* gL) {
+    const double h_dir = hdr_word(S.hv, H_DIR);
+    const double eps = hdr_word(S.hv, H_EPS) * h_dir;
+    const bool going_right = h_dir > 0.0;
+    const int num = (int)hdr_word(S.hv, H_S_NUM);
+    const bool wl = num == 0 || !going_right, wr = num == 0 || going_right;
+#pragma unroll
+    for (int e = 0; e < LEAF_NE; ++e) {
+        const int i = lane + 64 * e;
+        const double g = i < D ? gL[i] : 0.0;
+        const double r = S.r[e] - 0.5 * eps * g;
+        const double rn = r - 0.5 * eps * g;
+        S.zn[e] = S.zn[e] + eps * S.invM[e] * rn;
+        S.rs[e] = num == 0 ? r : S.rs[e] + r;
+        S.r[e] = rn;
+        if (wl) S.sl_r[e] = r;
+        if (wr) S.sr_r[e] = r;
+    }
+    S.hv = hdr_patch(hdr_patch(S.hv, lane, H_S_NUM, (double)(num + 1)), lane, H_EVALS, hdr_word(S.hv, H_EVALS) + 1.0);
+}
+template <int LEAF_NE>
+__device__ __forceinline__ void leaf_forward_weights(LeafState<LEAF_NE>& S, int D, int lane, const double* gL,
+                                                     const LeafWeights& W) {
+    const double eps = hdr_word(S.hv, H_EPS) * hdr_word(S.hv, H_DIR);
+    const int num = (int)hdr_word(S.hv, H_S_NUM);
+#pragma unroll
+    for (int e = 0; e < LEAF_NE; ++e) {
+        const int i = lane + 64 * e;
+        const double g = i < D ? gL[i] : 0.0;
+        const double r = S.r[e] - 0.5 * eps * g;
+        const double rn = r - 0.5 * eps * g;
+        S.zn[e] = S.zn[e] + eps * S.invM[e] * rn;
+        S.r[e] = rn;
+    }
+    double hv = hdr_patch(S.hv, lane, H_S_NUM, (double)(num + 1));
+    hv = hdr_patch(hv, lane, H_S_WEIGHT, W.w_sub);
+    hv = hdr_patch(hv, lane, H_S_SUMACC, W.sum_acc);
+    hv = hdr_patch(hv, lane, H_KEY_HI, (double)S.nhi);
+    S.hv = hdr_patch(hv, lane, H_KEY_LO, (double)S.nlo);
 }
 
 // both halves on one wave (the leaf as its own launch: kp_leaf)

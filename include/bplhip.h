@@ -164,6 +164,9 @@ int bplhip_set_fixtures_neutral(bplhip_ctx* ctx, int64_t n, int32_t n_teams,
  *   "persistent_kernel" 1 (default) = one resident chain of the basic / extended model runs its
  *            leapfrogs INSIDE one launch (the streaming workgroups poll the next position);
  *            0 = one launch per leapfrog.
+ *   "persist_spec" 1 (default) = inside that resident launch the next position goes out as soon as
+ *            the gradient exists and the leaf is booked beside the next step's prior part (a U-turn or
+ *            divergence -- once per transition -- discards one evaluation); 0 = leaf first, then publish
  *   "fused_small" 1 (default) = neutral / dynamic evaluations run as ONE launch: small ones on
  *            one workgroup per chain with everything in LDS (neutral) / one workgroup per four
  *            teams with phases behind grid barriers (dynamic), larger ones sliced over all CUs

@@ -69,6 +69,37 @@ def test_persistent_kernel_chain_repeats(hip_ctx):
     assert s3["total_leapfrogs"] == s1["total_leapfrogs"] and np.array_equal(d1, d3)
 
 
+@pytest.mark.parametrize("extended", [False, True])
+def test_leaf_one_step_behind_is_bitwise_neutral(hip_ctx, extended):
+    """Inside the persistent kernel the next position goes out from the epilogue and the leaf is booked one
+    step behind its evaluation, from forwarded registers (option persist_spec, default 1; dc_eval_loop).
+    Same draws, bit for bit, as with the leaf booked first and its state re-read from memory (0) -- through
+    warm-up (trees that end by U-turn: the dropped evaluation), adaptation and the launch boundaries of a
+    chain of several thousand leapfrogs; 45 and 77 latent entries (one and two elements per leaf lane)."""
+    from bpl._ffi import MODEL_BASIC, MODEL_EXTENDED, default_nuts_cfg
+
+    h, a, x, y = _league(100_000)
+    cov = None
+    if extended:
+        cov = np.random.RandomState(0).normal(size=(20, 5))
+        cov = (cov - cov.mean(0)) / cov.std(0)
+    hip_ctx.set_fixtures(MODEL_EXTENDED if extended else MODEL_BASIC, h, a, x, y, 20, covariates_std=cov)
+    cfg = default_nuts_cfg()
+    cfg.num_warmup, cfg.num_samples = 120, 60
+    runs = {}
+    try:
+        for spec in (1, 0):
+            hip_ctx.set_option("persist_spec", spec)
+            runs[spec] = hip_ctx.nuts_run(cfg, (0, 23))
+    finally:
+        hip_ctx.set_option("persist_spec", 1)
+    (d1, s1), (d0, s0) = runs[1], runs[0]
+    assert s1["total_leapfrogs"] == s0["total_leapfrogs"] > 3000
+    assert np.array_equal(d1, d0)
+    assert np.array_equal(s1["potential_energy"], s0["potential_energy"])
+    assert np.array_equal(s1["num_steps"], s0["num_steps"])
+
+
 def test_single_launch_models_repeat(hip_ctx):
     """Neutral-venue kernel: bit-identical repeats (fixed gather order).  Dynamic kernel (data-flagged
     cell records, two grid barriers, self-clearing scratch): thousands of back-to-back launches agree

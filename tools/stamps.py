@@ -60,7 +60,8 @@ def run_nuts(n=1_000_000):
     if k > 0:
         cov = np.random.RandomState(0).normal(size=(20, k)); cov = (cov - cov.mean(0)) / cov.std(0)
     w = np.exp(-np.linspace(5.0, 0.0, n)).astype(np.float32) if os.environ.get("NUTS_W") else None
-    c = HipContext(0); c.set_fixtures(MODEL_BASIC if k < 0 else MODEL_EXTENDED, h, a, x, y, 20, weights=w, covariates_std=cov)
+    c = HipContext(0); c.set_option("persist_spec", int(os.environ.get("PERSIST_SPEC", "1")))
+    c.set_fixtures(MODEL_BASIC if k < 0 else MODEL_EXTENDED, h, a, x, y, 20, weights=w, covariates_std=cov)
     lib = c._lib
     lib.bplhip_debug_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int]; lib.bplhip_debug_stamps.restype = C.c_int
     nwg = lib.bplhip_debug_stamps(c._h, None, 0)
@@ -81,10 +82,12 @@ def run_nuts(n=1_000_000):
     last = int(np.argmax(st[:, 10]))
     print("  tail WG", last, " ".join(f"{nm}={rel[last, k]:.2f}" for k, nm in [(6, "ticket"), (7, "tail:start"), (8, "tail:loads"), (9, "tail:colsums"), (14, "outputs"), (13, "leaf:prepared"), (12, "leaf:start"), (11, "moves:end"), (15, "weights:end"), (5, "published (persistent kernel)")]))
     print("  (persistent kernel: a step's record; entry = the step's start in that workgroup; tail WG entry=%.2f)" % rel[0, 0])
+    print("  tail WG raw slots (us since its step start): " + " ".join(f"{k}:{(st[0, k] - st[0, 0]) * 0.01:.2f}" for k in range(16)))
     pw = (buf[nwg * 16: (nwg + 1) * 16].astype(np.int64) - st[:, 0].min()) * 0.01
     print("  prior part, thread 0 after the bounds barrier (team sums read | records read | combined | arg-pairs | record written): " + " ".join(f"{v:.2f}" for v in pw[:5]))
     print("  prior part, per wave, arrival at the barrier that ends the bounds: " + " ".join(f"{v:.2f}" for v in pw[8:]))
     print("  seq (thread 0): " + " ".join(f"{v:.2f}" for v in pw[:4]))
+    print("  deferred leaf (hook) since the tail WG's step start: begin %.2f prepared %.2f moves done %.2f" % tuple((buf[nwg * 16 + k].astype(np.int64) - st[0, 0]) * 0.01 for k in range(3)))
     c.close()
 
 if len(sys.argv) > 1 and sys.argv[1] == "nuts":
