@@ -711,7 +711,7 @@ __global__ __launch_bounds__(BACK_BLOCK) void dyn_back(DynArgs A) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
-        const unsigned int k = __hip_atomic_fetch_add(A.tickets + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned int k = __hip_atomic_fetch_add(A.tickets + 1, 1u, DC_ARRIVE_RET_ORDER, __HIP_MEMORY_SCOPE_AGENT);
         s_last = k == gridDim.x - 1;
         if (s_last) __hip_atomic_store(A.tickets + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -816,7 +816,7 @@ enum { TK_FINAL = 1, TK_B1 = 2, TK_B2 = 3, TK_B3 = 4, TK_FAIL = 5 };
 __device__ __forceinline__ void grid_arrive(unsigned int* ctr) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's stores and atomics are in L2
     __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(ctr, 1u, DC_ARRIVE_ORDER, __HIP_MEMORY_SCOPE_AGENT);
 }
 // false: the other workgroups did not arrive within the spin limit, or an earlier launch gave up
 // (`failed`: the sticky TK_FAIL word as read at kernel entry).  A launch that gives up leaves the
@@ -827,7 +827,7 @@ __device__ __forceinline__ bool grid_wait(unsigned int* tickets, int which, unsi
     if (threadIdx.x == 0) {
         unsigned int spins = 0;
         bool ok = failed == 0;
-        while (ok && __hip_atomic_load(tickets + which, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < n) {
+        while (ok && __hip_atomic_load(tickets + which, DC_POLL_ORDER, __HIP_MEMORY_SCOPE_AGENT) < n) {
             if (++spins >= GRID_SPIN_LIMIT) ok = false;
             __builtin_amdgcn_s_sleep(1);
         }
@@ -862,15 +862,15 @@ __device__ __forceinline__ bool tree_arrive_one(unsigned int* tickets, int b, un
         const unsigned int gs = (n + TREE_FAN - 1) / TREE_FAN;   // arrivals per group
         const unsigned int grp = idx / gs;
         const unsigned int mine = n - grp * gs < gs ? n - grp * gs : gs;
-        if (__hip_atomic_fetch_add(tree_word(tickets, b, (int)grp), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != mine - 1)
+        if (__hip_atomic_fetch_add(tree_word(tickets, b, (int)grp), 1u, DC_ARRIVE_RET_ORDER, __HIP_MEMORY_SCOPE_AGENT) != mine - 1)
             return false;
         n = (n + gs - 1) / gs;   // the groups arrive at the top counter
     }
-    if (__hip_atomic_fetch_add(tree_word(tickets, b, TREE_FAN), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != n - 1)
+    if (__hip_atomic_fetch_add(tree_word(tickets, b, TREE_FAN), 1u, DC_ARRIVE_RET_ORDER, __HIP_MEMORY_SCOPE_AGENT) != n - 1)
         return false;
     if (set_flags)
         for (int f = 0; f < TREE_FAN; ++f)
-            __hip_atomic_store(tree_word(tickets, b, TREE_FAN + 1 + f), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(tree_word(tickets, b, TREE_FAN + 1 + f), 1u, DC_ARRIVE_ORDER, __HIP_MEMORY_SCOPE_AGENT);
     return true;
 }
 __device__ __forceinline__ void tree_arrive(unsigned int* tickets, int b, unsigned int idx, unsigned int n) {
@@ -885,7 +885,7 @@ __device__ __forceinline__ bool tree_wait(unsigned int* tickets, int b, unsigned
         unsigned int spins = 0;
         bool ok = failed == 0;
         const unsigned int* flag = tree_word(tickets, b, TREE_FAN + 1 + (int)(blockIdx.x % TREE_FAN));
-        while (ok && __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+        while (ok && __hip_atomic_load(flag, DC_POLL_ORDER, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
             if (++spins >= GRID_SPIN_LIMIT) ok = false;
             __builtin_amdgcn_s_sleep(1);
         }
@@ -1619,7 +1619,7 @@ __global__ __launch_bounds__(FUSED_DYN_BLOCK) void dyn_fused(DynArgs A) {
         if (BIG) {
             s_last = tree_arrive_one(A.tickets, TB_FINAL, blockIdx.x, nb, false);
         } else {
-            const unsigned int k = __hip_atomic_fetch_add(A.tickets + TK_FINAL, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned int k = __hip_atomic_fetch_add(A.tickets + TK_FINAL, 1u, DC_ARRIVE_RET_ORDER, __HIP_MEMORY_SCOPE_AGENT);
             s_last = k == nb - 1;
             if (s_last) {  // everyone is past every barrier: the counters go back to zero for the next launch
                 __hip_atomic_store(A.tickets + TK_FINAL, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

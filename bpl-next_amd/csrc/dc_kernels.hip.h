@@ -216,6 +216,24 @@ enum : unsigned int {
     FAULT_LOOP_GRANULES = 4u,   // dc_eval_loop: the next position never arrived
     FAULT_DYN_BARRIER = 8u,     // dyn_fused: a grid barrier / a cell record timed out
 };
+// ---- memory ordering of the cross-workgroup hand-offs (round 4: the A/B VERDICT r03 asked for).
+// Shipped: every arrival atomic and every polling load is RELAXED at agent scope; what orders a
+// producer's data against its arrival is the hardware itself -- the data is either the atomic's own target
+// (accumulator rows, data-tagged granules and records: nothing to order) or went out as write-through
+// stores that the wave waits for (s_waitcnt vmcnt(0): acknowledged by the memory side) before it issues
+// the arrival.  -DDC_STRICT_ORDER=1 builds the formal version instead: RELEASE on the arrivals, ACQUIRE on
+// the pollers (on gfx950 a release at agent scope is buffer_wbl2 + s_waitcnt in front of the atomic, an
+// acquire buffer_inv behind the load).  A/B of the two libraries on one box: profiles/r04/ab_strict_order.txt,
+// DESIGN.md section 4 ("Memory ordering").
+#ifndef DC_STRICT_ORDER
+#define DC_STRICT_ORDER 0
+#endif
+#define DC_ARRIVE_ORDER (DC_STRICT_ORDER ? __ATOMIC_RELEASE : __ATOMIC_RELAXED)
+#define DC_POLL_ORDER (DC_STRICT_ORDER ? __ATOMIC_ACQUIRE : __ATOMIC_RELAXED)
+#define DC_ARRIVE_RET_ORDER (DC_STRICT_ORDER ? __ATOMIC_ACQ_REL : __ATOMIC_RELAXED)   // the last arriver goes on to read
+__device__ __forceinline__ void poll_acquired() {   // behind a polling load written in asm
+    if (DC_STRICT_ORDER) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
 __device__ __forceinline__ void raise_fault(unsigned int* fault, unsigned int code) {
     if (fault) (void)__hip_atomic_fetch_or(fault, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
@@ -556,10 +574,20 @@ __device__ __forceinline__ void ga_add(long long* row, double v /* in units of 2
     } else {
         h = rint(v * (1.0 / (GA_HI_UNIT * GA_LO_SCALE)));  // |h| < 2^50
         r = fma(-h, GA_HI_UNIT * GA_LO_SCALE, v);          // exact, |r| <= 2^43
-        if (h != 0.0)
+        if (h != 0.0) {
             (void)__hip_atomic_fetch_add(row + 1, exact_i64(h), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // (round 4) The reader takes a complete COUNT in the lo word as proof that every hi
+            // contribution has landed.  What orders the two atomics is the hardware: both target ONE 16-byte
+            // granule of one line, i.e. one memory channel, and a wave's requests to a channel are served in
+            // issue order; the memory model does not promise it.  A release fence between them was tried
+            // (thinking this branch rare -- it is not: at N = 1e6 a workgroup's per-team sums exceed the lo
+            // word's 2^43 units, so most adds come through here): dc_eval 5.8 -> 7.3 us, the persistent chain
+            // 7.3 -> 9.9 us per leapfrog (profiles/r04/ab_strict_order.txt).  Kept relaxed; the guard is
+            // empirical: the wild-region parity tests and the bit-identical soak run through this branch.
+            if (DC_STRICT_ORDER) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        }
     }
-    (void)__hip_atomic_fetch_add(row, exact_i64(r) + GA_BIAS + (1ll << GA_COUNT_SHIFT), __ATOMIC_RELAXED,
+    (void)__hip_atomic_fetch_add(row, exact_i64(r) + GA_BIAS + (1ll << GA_COUNT_SHIFT), DC_ARRIVE_ORDER,
                                  __HIP_MEMORY_SCOPE_AGENT);
 }
 struct GaWords {
@@ -2283,6 +2311,7 @@ __device__ __forceinline__ bool ga_take_row(const long long* row, int expect, Ga
         if (ok) break;
         __builtin_amdgcn_s_sleep(1);
     }
+    poll_acquired();
     return ok;
 }
 // (Tried and measured slower, twice -- profiles/r03/stamps_early_poll.txt: polling the rows EARLY,
