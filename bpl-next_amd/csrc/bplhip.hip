@@ -104,6 +104,7 @@ struct bplhip_ctx {
     int dyn_fused_blocks_per_cu = -1;  // occupancy of dyn_fused (queried once)
     long long dyn_max_gw = 0;          // fixtures of the largest gameweek (dyn_fused<true> sizes its LDS by it)
     int opt_dyn_big_wgs = 0;           // dyn_fused<true>: workgroups aimed for (0: one per CU)
+    int opt_dyn_gather = 1;            // dyn_fused<false>: adjoint records + gather (1) or float64 atomics into the cells (0)
     size_t dyn_big_lds = 0;            // ... the LDS size its cached occupancy belongs to
     int dyn_big_blocks_per_cu = 0;
     bool dyn_big_attr_set = false, neu_big_attr_set = false;
@@ -166,6 +167,8 @@ struct bplhip_ctx {
     int opt_debug_stop = 0;         // diagnostic build only
     DevBuf dd_gwoff, dd_tick;  // dynamic model: first fixture of each gameweek; arrival counters
     DevBuf dd_fx8;             // dynamic model: one packed word per fixture (dcd::pack_fixture), dyn_fused<true>
+    DevBuf dd_fadj, dd_inc_off, dd_inc;   // dyn_fused<false>: per-fixture adjoint records + the cells' incidence lists
+    bool dyn_gather = false;   // every cell's list is short enough for the gathering phase 4
     bool dyn_attr_set = false;
     std::map<GraphKey, hipGraphExec_t> graphs;
     hipStream_t cap_stream = nullptr;
@@ -325,6 +328,10 @@ int launch_eval_dynamic(bplhip_ctx* c, int chains, const double* z, double* pot,
         A.gw_off = c->dd_gwoff.as<const int>();
         A.tickets = c->dd_tick.as<unsigned int>();
         A.fault = c->d_fault;
+        A.gather = c->dyn_gather && c->opt_dyn_gather;
+        A.fadj = c->dd_fadj.as<double>();
+        A.inc_off = c->dd_inc_off.as<const int>();
+        A.inc = c->dd_inc.as<const unsigned int>();
         const int team_blocks = (L.T + dcd::BACK_BLOCK / 64 - 1) / (dcd::BACK_BLOCK / 64);
         // one launch when every workgroup is resident and a wave spans all gameweeks
         // (and a workgroup's share of the fixtures is a few rounds of its threads)
@@ -1273,6 +1280,11 @@ int bplhip_set_option(bplhip_ctx* c, const char* name, int value) {
         c->opt_vec_tpw = value;
         return BPLHIP_OK;
     }
+    if (n == "dyn_gather") {  // dynamic model's small single launch: per-fixture adjoint records gathered by the cells (1) / atomics (0)
+        c->opt_dyn_gather = value != 0;
+        drop_graphs(c);
+        return BPLHIP_OK;
+    }
     if (n == "persist_spec") {  // persistent kernel: the next position before the leaf (1) or after it (0)
         c->opt_persist_spec = value != 0;
         return BPLHIP_OK;
@@ -1568,6 +1580,33 @@ static int bplhip_set_fixtures_dynamic_impl(bplhip_ctx* c, int64_t n, int32_t n_
     for (int64_t i = 0; i < n; ++i) fx8[i] = dcd::pack_fixture(h[i], a[i], x[i], y[i], nv[i]);
     HIP_TRY(c, c->dd_fx8.ensure(n * 8));
     HIP_TRY(c, hipMemcpyAsync(c->dd_fx8.p, fx8.data(), n * 8, hipMemcpyHostToDevice, s));
+    {   // incidence lists of the cells (gameweek, team) over the sorted fixtures: dyn_fused<false>'s gather
+        std::vector<int> off(GT + 1, 0);
+        for (int64_t i = 0; i < n; ++i) {
+            off[(size_t)g[i] * n_teams + h[i] + 1] += 1;
+            off[(size_t)g[i] * n_teams + a[i] + 1] += 1;
+        }
+        int longest = 0;
+        for (size_t cidx = 0; cidx < GT; ++cidx) {
+            longest = std::max(longest, off[cidx + 1]);
+            off[cidx + 1] += off[cidx];
+        }
+        c->dyn_gather = longest <= dcd::GATHER_MAX_INCIDENT && n < (1ll << 30);
+        if (c->dyn_gather) {
+            std::vector<unsigned int> inc(std::max<size_t>(2 * (size_t)n, 1));
+            std::vector<int> fill(off.begin(), off.end() - 1);
+            for (int64_t i = 0; i < n; ++i) {   // (fixture order within a list: ascending, the summation order)
+                const unsigned int venue = nv[i] ? 1u << 30 : 0u;
+                inc[fill[(size_t)g[i] * n_teams + h[i]]++] = (unsigned int)i | venue;
+                inc[fill[(size_t)g[i] * n_teams + a[i]]++] = (unsigned int)i | venue | (1u << 31);
+            }
+            HIP_TRY(c, c->dd_inc_off.ensure(off.size() * 4));
+            HIP_TRY(c, c->dd_inc.ensure(inc.size() * 4));
+            HIP_TRY(c, c->dd_fadj.ensure((size_t)n * 16));
+            HIP_TRY(c, hipMemcpy(c->dd_inc_off.p, off.data(), off.size() * 4, hipMemcpyHostToDevice));
+            HIP_TRY(c, hipMemcpy(c->dd_inc.p, inc.data(), inc.size() * 4, hipMemcpyHostToDevice));
+        }
+    }
     HIP_TRY(c, c->dd_cells.ensure(GT * dcd::P_N * 8));
     HIP_TRY(c, c->dd_acc.ensure(dcd::scratch_doubles(n_gameweeks, n_teams, k) * 8));
     // the single-launch kernel finds its scratch zeroed and its cell records armed (and leaves them so):

@@ -132,6 +132,15 @@ struct DynArgs {
     int rate_cap;            // dyn_fused<true>: fixtures whose rates a workgroup's LDS holds (>= its slice)
     const unsigned long long* fx8;   // dyn_fused<true>: one word per fixture {h:16, a:16, x:8, y:8, venue:8} (pack_fixture)
     int stage_fx;            // dyn_fused<true>: 1 = the slice's words are copied into LDS in front of phase 2
+    // dyn_fused<false>, round 4: the adjoints travel as ONE 16-byte record per fixture {dL/d eta_home,
+    // dL/d eta_away} (write-through store) instead of 8 float64 atomics per fixture into the cells'
+    // accumulators, and phase 4 GATHERS: a cell's lane walks the fixtures it takes part in (host-built
+    // incidence lists, the gameweek-sorted fixture order).  Fixed summation order (bit-reproducible),
+    // 40 KB of stores at BASELINE config 4 where the atomics were 20 000 x 64 B at the memory side.
+    int gather;              // 1: taken (every cell's list is short: host, GATHER_MAX_INCIDENT)
+    double* fadj;            // [n][2]
+    const int* inc_off;      // [G*T + 1]
+    const unsigned int* inc; // [2n] fixture | away side << 31 | neutral venue << 30
     DynLayout L;
 };
 
@@ -804,6 +813,7 @@ __device__ void final_body(const DynArgs& A, double* shl, const Bounds* known) {
 // Cross-workgroup data travels write-through / L1-bypassing (sc1); the barriers are an
 // agent-scope counter each, polled by one lane with a bounded spin.
 constexpr int FUSED_DYN_BLOCK = 256;
+constexpr int GATHER_MAX_INCIDENT = 16;   // longest incidence list a cell's lane walks (dyn_fused<false>, gather)
 constexpr int FUSED_DYN_MAX_G = 64, FUSED_DYN_MAX_T = 1024;
 constexpr unsigned int GRID_SPIN_LIMIT = 1u << 22;
 // "not written yet" in a cell record: a quiet NaN no arithmetic produces (computed NaNs are stored as
@@ -1476,6 +1486,10 @@ __global__ __launch_bounds__(FUSED_DYN_BLOCK) void dyn_fused(DynArgs A) {
             if (lh * la == b.M) atomicMax(&scu[SC_IDXP], key);
             if (lh == b.Lh) atomicMax(&scu[SC_IDXQ], key);
             if (la == b.La) atomicMax(&scu[SC_IDXR], key);
+            if (A.gather) {   // (uniform) one record per fixture; the cells gather (phase 4)
+                dc::st_sc1_x2(A.fadj + 2 * i, gh, ga);
+                continue;
+            }
             double* Ah = A.acc + (size_t)(f.g * T + f.h) * A_N;
             double* Aa = A.acc + (size_t)(f.g * T + f.a) * A_N;
             atomicAdd(&Ah[A_ATT], gh);
@@ -1504,6 +1518,9 @@ __global__ __launch_bounds__(FUSED_DYN_BLOCK) void dyn_fused(DynArgs A) {
         }
     }
     DYN_STAMP(6);
+    // (the adjoint records went out through inline-asm stores the compiler does not count: wait for them by hand
+    // before the arrival -- the hardware counter covers them)
+    if (!BIG && A.gather) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (BIG) tree_arrive(A.tickets, TB_3, blockIdx.x, nb);
     else grid_arrive(A.tickets + TK_B3);
     // (third shadow: log-density of this wave's cell sites -- log(1 - rho'^2) = log(4 u (1-u)) --
@@ -1520,7 +1537,34 @@ __global__ __launch_bounds__(FUSED_DYN_BLOCK) void dyn_fused(DynArgs A) {
 
     // ---- phase 4: this wave's team again
     double G6[A_N];
-    {
+    if (!BIG && A.gather) {
+        // this cell's fixtures, in list order: {dL/d eta_home, dL/d eta_away} of each, booked by the side the
+        // team plays (the signs and the venue switch of the atomics' path above); all of a round's loads in
+        // flight together (up to GATHER_MAX_INCIDENT entries: host)
+#pragma unroll
+        for (int j = 0; j < A_N; ++j) G6[j] = 0.0;
+        const int e0 = on ? A.inc_off[c] : 0, e1 = on ? A.inc_off[c + 1] : 0;
+        for (int eb = e0; __ballot(eb < e1) != 0ull; eb += 4) {
+            unsigned int w[4];
+            dc::double2_t v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) w[u] = A.inc[eb + u < e1 ? eb + u : (e1 > e0 ? e1 - 1 : 0)];
+            dc::ld_sc1_x2_4(A.fadj + 2 * (size_t)(w[0] & 0x3FFFFFFFu), A.fadj + 2 * (size_t)(w[1] & 0x3FFFFFFFu),
+                            A.fadj + 2 * (size_t)(w[2] & 0x3FFFFFFFu), A.fadj + 2 * (size_t)(w[3] & 0x3FFFFFFFu), v);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (eb + u >= e1) continue;
+                const bool away = w[u] >> 31, fnv = (w[u] >> 30) & 1u;
+                const double gh = v[u].x, ga = v[u].y;
+                G6[A_ATT] += away ? ga : gh;
+                G6[A_DEF] -= away ? gh : ga;
+                if (!fnv) {
+                    if (away) { G6[A_AATT] += ga; G6[A_ADEF] -= gh; }
+                    else { G6[A_HATT] += gh; G6[A_HDEF] -= ga; }
+                }
+            }
+        }
+    } else {
         const double* Ac = A.acc + (size_t)c * A_N;
 #pragma unroll
         for (int j = 0; j < A_N; ++j) G6[j] = dc::ld_sc1(&Ac[j]);
@@ -1643,9 +1687,11 @@ __global__ __launch_bounds__(FUSED_DYN_BLOCK) void dyn_fused(DynArgs A) {
         // (plain stores: these words are next touched by the NEXT launch, and a kernel boundary
         // writes them back; write-through stores here were waited for by the kernel's completion)
         static_assert(A_N == 6 && P_N == 6, "three 16-byte stores each");
-        dc::double2_t* Az = reinterpret_cast<dc::double2_t*>(A.acc + (size_t)c * A_N);
-        const dc::double2_t zero2 = {0.0, 0.0};
-        Az[0] = zero2; Az[1] = zero2; Az[2] = zero2;
+        if (BIG || !A.gather) {   // (the gathering form never touched them)
+            dc::double2_t* Az = reinterpret_cast<dc::double2_t*>(A.acc + (size_t)c * A_N);
+            const dc::double2_t zero2 = {0.0, 0.0};
+            Az[0] = zero2; Az[1] = zero2; Az[2] = zero2;
+        }
         // ... and its cell record armed again (every reader is past phase 3: barrier 3)
         const double empty = __longlong_as_double((long long)CELL_EMPTY);
         dc::double2_t* P2 = reinterpret_cast<dc::double2_t*>(A.cells + (size_t)c * P_N);

@@ -553,6 +553,19 @@ __device__ __forceinline__ void st_sc1(double* p, double v) {
 // allocator reuses them at once) would change what is stored -- found as cell records that
 // depended on how the stored expression was written.
 typedef double double2_t __attribute__((ext_vector_type(2)));
+// the matching L1-bypassing 16-byte load (the wait is part of it, as in ga_load)
+__device__ __forceinline__ double2_t ld_sc1_x2(const double* p) {
+    double2_t v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+// four of them in ONE round trip
+__device__ __forceinline__ void ld_sc1_x2_4(const double* p0, const double* p1, const double* p2, const double* p3,
+                                            double2_t (&v)[4]) {
+    asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %5, off sc1\n\t"
+                 "global_load_dwordx4 %2, %6, off sc1\n\tglobal_load_dwordx4 %3, %7, off sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]) : "v"(p0), "v"(p1), "v"(p2), "v"(p3) : "memory");
+}
 __device__ __forceinline__ void st_sc1_x2(double* p, double a, double b) {
     double2_t v = {a, b};
     asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 2" ::"v"(p), "v"(v) : "memory");

@@ -16,6 +16,7 @@ def big(N=1_000_000, T=100, G=50, seed=5):
     return h, a, rs.poisson(1.5, N), rs.poisson(1.2, N), np.sort(rs.randint(0, G, N)), np.zeros(N, int)
 
 c = HipContext(0)
+c.set_option('dyn_gather', int(os.environ.get('DYN_GATHER', '1')))   # 0: float64 atomics into the cells (round 3)
 CASES = [("config4 N=2500", config4(), 0, 1), ("N=1e6", big(), 0, 1)]
 if os.environ.get('SWEEP', '0') == '1':   # the sliced single launch at other grid sizes, and the four-launch path
     CASES += [(f"N=1e6 wgs={w}", big(), w, 1) for w in (128, 384, 512, 768)] + [("N=1e6 four launches", big(), 0, 0)]
