@@ -122,14 +122,17 @@ struct bplhip_ctx {
     int opt_max_wg = 255;  // streaming workgroups (+1 prior workgroup = one per CU)
     int opt_active_waves = 0;  // waves per workgroup that own tiles (0 = automatic, see set_fixtures)
     int opt_persistent_nuts = 1;  // bplhip_nuts_run_chains: whole chains on the device (0: lock step)
-    int opt_vec_min_chains = 32;  // batched calls with at least this many chains use dc_vec (0: never);
-                                  // fewer run as grid.y copies of the single-chain launch (62
-                                  // workgroups per chain at N = 1e6: measured faster up to ~31)
-    int opt_gridy_max_chains = 32;  // persistent chains: grid.y copies of the NUTS-aware launch up to here
+    int opt_vec_min_chains = 8;   // batched calls with at least this many chains use dc_vec (0: never);
+                                  // fewer run as grid.y copies of the single-chain launch (62 workgroups per
+                                  // chain at N = 1e6).  Round 4: 8 (was 32) -- with the chain arithmetic done per
+                                  // run dc_vec takes 10.4 us for 8 chains against 11.3 for the copies
+    int opt_gridy_max_chains = 8;   // persistent chains: grid.y copies of the NUTS-aware launch up to here (was 32:
+                                    // 16 chains 698k -> 921k leapfrogs/s, 32 chains 986k -> 1.22M through dc_vec;
+                                    // 8 chains stay with the copies, 582k against 474k: profiles/r04/lockstep_gridy.txt)
     int opt_vec_tpw = 0;         // > 0: force this many tiles per wave for every chain count
     // chain-vectorised partitions (dc_vec.hip.h): fewer, fatter workgroups the more chains
     // share a launch (the per-workgroup prologue builds 8 chains' tables); each has its
-    // own sparse-slab structure.  vps[0..2]: 1x / 2x / 4x the single-chain tiles per wave,
+    // own sparse-slab structure.  vps[0..2]: 1x / 2x / 3x the single-chain tiles per wave,
     // used for <= 8 / <= 23 / more chains; vp = the one selected for the current launch.
     struct VecPart {
         bool ok = false, staged = true;
@@ -727,7 +730,22 @@ int launch_vec_t(bplhip_ctx* c, const dc::EvalArgs& A, int chains, hipStream_t s
 // the vectorised kernel sizes it first (round 3 did not: every sampler run with more chains than
 // gridy_max_chains on a fresh context failed inside the chunk graph's capture).
 int prepare_vec(bplhip_ctx* c, int chains) {
-    c->vp = &c->vps[chains <= 8 ? 0 : (chains <= 23 ? 1 : 2)];
+    // The thinnest partition whose grid still fits the chip in (about) one round -- groups x workgroups + one
+    // prior workgroup per chain <= CUs: tiles per wave set the launch's length as long as nobody queues behind
+    // another workgroup (measured, N = 1e6, us per launch at 1x / 2x / 3x / 4x tiles per wave: 8 chains 10.4 /
+    // 12.9 / 14.6 / 15.8, 32 chains 12.7 / 13.2 / 14.5 / 16.1, 64 chains 17.0 / 16.3 / 14.9 / 16.3, 128 chains
+    // 21.7 / 22.3 / 19.0 / 21.7, 256 chains 32.8 / 30.1 / 30.0 / 31.6: profiles/r04/vec_tiles_per_wave.txt.
+    // Round 3 took 1x / 2x / 4x by chain count alone: 4x at 32 and at 64 chains).
+    {
+        const int groups = (chains + dc::CB - 1) / dc::CB;
+        int pi = 2;
+        for (int k = 0; k < 3; ++k)
+            if ((long long)groups * c->vps[k].n_wg + chains <= c->n_cu + c->n_cu / 8) {   // (a few workgroups over: still one round)
+                pi = k;
+                break;
+            }
+        c->vp = &c->vps[pi];
+    }
     if (chains > c->vp->slab_chains) {
         if (c->capturing)
             return fail(c, BPLHIP_ESTATE, "dc_vec: hand-off buffer for %d chains not sized before the capture", chains);
@@ -1200,7 +1218,7 @@ static int bplhip_set_fixtures_impl(bplhip_ctx* c, int model_kind, int64_t n, in
         c->vp = &vp;  // (the LDS helpers below read the current partition)
         vp.ok = false;
         vp.slab_chains = 0;
-        vp.tpw = c->opt_vec_tpw > 0 ? std::max(tpw, c->opt_vec_tpw) : tpw << pi;
+        vp.tpw = c->opt_vec_tpw > 0 ? std::max(tpw, c->opt_vec_tpw) : tpw * (pi + 1);   // (1x / 2x / 3x: prepare_vec)
         const int vwaves = (n_tiles + vp.tpw - 1) / vp.tpw;
         vp.n_wg = (vwaves + dc::WAVES - 1) / dc::WAVES;
         const SparseSlabs vs = build_sparse_slabs(hs, as, n_lanefix, T, vp.tpw * dc::WAVES, vp.n_wg);

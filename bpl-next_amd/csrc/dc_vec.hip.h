@@ -223,77 +223,57 @@ __global__ __launch_bounds__(BLOCK) void dc_vec_stream(EvalArgs A) {
         if (lane == 0) rhoL[b] = rho_f32(mP, mQ, mR, fs.q);
         __syncthreads();
     }
-    float rho[CB], l11[CB], u11[CB];
-#pragma unroll
-    for (int b = 0; b < CB; ++b) {
-        rho[b] = rhoL[b];
-        class_terms(rho[b], -1.0f, &l11[b], &u11[b]);
-    }
-
-    // ---- 2. stream the fixtures, all chains per lane
-    double dV[CB], dSU[CB];  // per lane: ln2*SLOG - SLAM - CLIPC, and SU
-#pragma unroll
-    for (int b = 0; b < CB; ++b) dV[b] = dSU[b] = 0.0;
+    // ---- 2. stream the fixtures.  Round 4: the chain-dependent arithmetic is done PER RUN, not per lane.
+    // A lane's fixtures are one (home, away) pair (runs are padded to the lane width) and a tile of 64 lanes
+    // holds one or two pairs at N = 1e6, so the rates and the three tau terms of a chain were worked out 64
+    // times per tile with the same inputs -- 8 chains x (2 LDS gathers + 3 rcp + 3 log2 + ~35 other
+    // operations) per lane, 4.6 us per tile and wave, 200+ registers and spills.  Everything a chain's
+    // sums need from the fixtures is LINEAR in the lane's seven class sums (weights of the (0,0) / (1,0) /
+    // (0,1) / (1,1) scorelines, of all fixtures, of the goals on either side), with coefficients that
+    // depend on (run, chain) only.  So: classify per lane (shared by the chains, as before), add the seven
+    // sums over the lanes of the run (DPP, chain independent), and let LANE b work chain b's terms out ONCE
+    // from the run's totals -- the eight chains side by side on eight lanes.  The fixtures are still
+    // streamed and classified on every evaluation; what changed is how often a transcendental is taken.
+    const int myb = lane < CB ? lane : CB - 1;   // the chain this lane works for (lanes 8.. shadow chain 7)
+    const float my_rho = rhoL[myb];
+    float my_l11, my_u11;
+    class_terms(my_rho, -1.0f, &my_l11, &my_u11);
+    const float2* myH = tab + (size_t)(2 * myb) * tl;
+    const float2* myA = myH + tl;
+    double dV = 0.0, dSU = 0.0;   // lane b < CB: chain b's  ln2*SLOG - SLAM - CLIPC  and SU of this wave
     const uint32_t sentinel = (uint32_t)T;
+    auto run_terms = [&](const LaneClass& tot) {   // one run's totals -> chain `myb`'s sums and accumulators
+        const ChainOut o = chain_terms<CLIP>(tot, my_rho, myH, myA, my_l11, my_u11);
+        if (lane < CB) {
+            double v = fma((double)LN2, (double)o.slog, -o.slam);
+            if (CLIP) v -= (double)o.sclip;
+            dV += v;
+            dSU += (double)o.su;
+            flush_run(acc + (size_t)lane * accn, T1, tot.key, o.rsh, o.rsa);
+        }
+    };
     while (tile < tile_end) {
         // (unconditional prefetch: the last round re-requests its own tile and drops it)
         LaneData nxt = load_lane<WEIGHTED>(A, (size_t)min(tile + 1, tile_end - 1) * 64 + lane);
-
-        float prs[CB], pra[CB];  // the lane's last run stays pending (merges across lanes)
-        uint32_t pkey = sentinel | (sentinel << 16);
-#pragma unroll
-        for (int b = 0; b < CB; ++b) prs[b] = pra[b] = 0.f;
-        uint32_t rem = LANE_FIX >= 32 ? 0xFFFFFFFFu : (1u << (LANE_FIX & 31)) - 1u;
-        do {
-            const bool act = rem != 0;
-            const LaneClass lc = classify<WEIGHTED>(cur, rem, sentinel);
-            const bool more = rem != 0;  // further runs in this lane: this one is complete
-#pragma unroll
-            for (int b = 0; b < CB; ++b) {
-                const float2* tH = tab + (size_t)(2 * b) * tl;
-                const ChainOut o = chain_terms<CLIP>(lc, rho[b], tH, tH + tl, l11[b], u11[b]);
-                double v = fma((double)LN2, (double)o.slog, -o.slam);
-                if (CLIP) v -= (double)o.sclip;
-                dV[b] += v;
-                dSU[b] += (double)o.su;
-                prs[b] = act ? o.rsh : prs[b];
-                pra[b] = act ? o.rsa : pra[b];
-            }
-            pkey = act ? lc.key : pkey;
-            if (more) {  // (rare) a finished run inside the lane goes straight to LDS
-#pragma unroll
-                for (int b = 0; b < CB; ++b)
-                    flush_run(acc + (size_t)b * accn, T1, pkey, prs[b], pra[b]);
-            }
-        } while (__ballot(rem != 0) != 0ull);
-
-        // ---- per-(home,away) run sums across the wave: DPP, then float64 LDS accumulators
-        const uint32_t kprev = prev_lane_u32(pkey, ~pkey);
-        const unsigned long long heads = __ballot(kprev != pkey);  // lane 0 always a head
-        const int nruns = __popcll(heads);
-        if (nruns <= RUN_LOOP_MAX) {
-            unsigned long long hd = heads;
-            while (hd) {
-                const int first = __ffsll((long long)hd) - 1;
-                hd &= hd - 1;
-                const int stop = hd ? __ffsll((long long)hd) - 1 : 64;
-                const bool in = lane >= first && lane < stop;
-                const uint32_t kk = (uint32_t)__builtin_amdgcn_readlane((int)pkey, first);
-                float sh[CB], sa[CB];
-#pragma unroll
-                for (int b = 0; b < CB; ++b) {
-                    sh[b] = in ? prs[b] : 0.f;
-                    sa[b] = in ? pra[b] : 0.f;
-                    wave_sum2_f32(sh[b], sa[b]);
-                }
-                // lane b adds chain b's run sums
-                const float vh = pick_chain(sh, lane), va = pick_chain(sa, lane);
-                if (lane < CB) flush_run(acc + (size_t)lane * accn, T1, kk, vh, va);
-            }
-        } else {  // many short runs: every lane adds its own sums
-#pragma unroll
-            for (int b = 0; b < CB; ++b)
-                flush_run(acc + (size_t)b * accn, T1, pkey, prs[b], pra[b]);
+        uint32_t rem = 0;
+        const LaneClass lc = classify<WEIGHTED>(cur, rem, sentinel);   // (one run per lane)
+        const uint32_t kprev = prev_lane_u32(lc.key, ~lc.key);
+        unsigned long long hd = __ballot(kprev != lc.key);  // lane 0 always a head
+        while (hd) {   // the tile's runs, one after the other (one or two at N = 1e6; up to 64 in a tiny league)
+            const int first = __ffsll((long long)hd) - 1;
+            hd &= hd - 1;
+            const int stop = hd ? __ffsll((long long)hd) - 1 : 64;
+            const bool in = lane >= first && lane < stop;
+            LaneClass tot;
+            tot.key = (uint32_t)__builtin_amdgcn_readlane((int)lc.key, first);
+            float a0 = in ? lc.n00 : 0.f, a1 = in ? lc.n10 : 0.f, a2 = in ? lc.n01 : 0.f, a3 = in ? lc.n11 : 0.f;
+            float a4 = in ? lc.nall : 0.f, a5 = in ? lc.sx : 0.f, a6 = in ? lc.sy : 0.f;
+            wave_sum2_f32(a0, a1);
+            wave_sum2_f32(a2, a3);
+            wave_sum2_f32(a4, a5);
+            a6 = wave_sum_f32(a6);
+            tot.n00 = a0; tot.n10 = a1; tot.n01 = a2; tot.n11 = a3; tot.nall = a4; tot.sx = a5; tot.sy = a6;
+            run_terms(tot);
         }
         // (see dc_eval: keeps the compiler from consuming the prefetched words at issue time)
         asm volatile("" : "+v"(nxt.hw[0]), "+v"(nxt.aw[0]), "+v"(nxt.xw[0]), "+v"(nxt.yw[0]));
@@ -302,17 +282,9 @@ __global__ __launch_bounds__(BLOCK) void dc_vec_stream(EvalArgs A) {
     }
 
     // ---- 3. workgroup reduction of the scalars, then the slabs of all chains
-    static_assert(CB % 2 == 0, "two chains' sums per written-out reduction");
-#pragma unroll
-    for (int b = 0; b < CB; b += 2) {   // (four chains of DPP steps at a time: one after the other they were 1.6 us)
-        double q[4] = {dV[b], dSU[b], dV[b + 1], dSU[b + 1]};
-        wave_sum4_f64(q);
-        if (lane == 0) {
-            red[(wave * CB + b) * 2 + 0] = q[0];
-            red[(wave * CB + b) * 2 + 1] = q[1];
-            red[(wave * CB + b + 1) * 2 + 0] = q[2];
-            red[(wave * CB + b + 1) * 2 + 1] = q[3];
-        }
+    if (lane < CB) {   // (lane b holds chain b's sums of this wave: nothing to reduce)
+        red[(wave * CB + lane) * 2 + 0] = dV;
+        red[(wave * CB + lane) * 2 + 1] = dSU;
     }
     __syncthreads();
     const int cnt = o1 - o0;

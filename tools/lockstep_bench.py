@@ -16,7 +16,7 @@ for sd in (42, 43):
     print(f"single chain seed {sd} (device tree): {st['total_leapfrogs'] / st['wall_seconds']:10.0f} leapfrogs/s "
           f"({st['total_leapfrogs']} in {st['wall_seconds']:.3f} s) eps {st['final_step_size']:.2e}", flush=True)
 c.set_option('persistent_nuts', int(os.environ.get('PERSIST', '1')))
-c.set_option('gridy_max_chains', int(os.environ.get('GRIDY', '32')))
+if os.environ.get('GRIDY'): c.set_option('gridy_max_chains', int(os.environ['GRIDY']))   # (default: the library's, 8)
 for C in [int(v) for v in os.environ.get('CHAINS', '2,4,8,16,32,64').split(',')]:
     res = c.nuts_run_chains(cfg, [(0, 42 + i) for i in range(C)])
     leap = sum(r[1]['total_leapfrogs'] for r in res); wall = res[0][1]['wall_seconds']
