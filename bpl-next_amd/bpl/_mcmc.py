@@ -107,6 +107,24 @@ def run_mcmc(
     thinning = int(mcmc_kwargs.get("thinning", 1))
     if num_chains < 1 or thinning < 1:
         raise ValueError("num_chains and thinning must be >= 1")
+    # numpyro's MCMC takes these too; none is silently ignored here (round 3 accepted and dropped them):
+    #   postprocess_fn  the map from unconstrained draws to the sites of `get_samples()`: the library's own
+    #                   (bplhip_constrain + the closed-form transforms below) is the only one there is
+    #   jit_model_args  a compilation knob of the JAX path; nothing is traced here, either value is a no-op
+    #   extra_fields    (MCMC.run) per-draw sampler statistics: every one this sampler keeps is returned in
+    #                   `info` anyway; the names asked for are checked against them and echoed back
+    if mcmc_kwargs.get("postprocess_fn") is not None:
+        raise NotImplementedError("postprocess_fn: the device sampler constrains its draws itself "
+                                  "(bplhip_constrain); transform the returned samples instead")
+    extra = tuple(run_kwargs.get("extra_fields") or ())
+    known = {"potential_energy", "accept_prob", "mean_accept_prob", "adapt_state.step_size", "step_size",
+             "num_steps", "diverging", "energy"}
+    bad = [f for f in extra if f not in known]
+    if bad:
+        raise ValueError(f"extra_fields {bad} are not collected by this sampler; available: {sorted(known - {'energy'})}")
+    if "energy" in extra:
+        raise ValueError("extra_fields 'energy' (the Hamiltonian of the proposal) is not kept per draw; "
+                         "'potential_energy' is")
 
     hg = np.asarray(home_goals)
     ag = np.asarray(away_goals)
@@ -196,6 +214,8 @@ def run_mcmc(
         }
         for i, nm in enumerate(stat_names):
             info[nm] = stats[:, :, i].reshape(-1)
+        alias = {"adapt_state.step_size": "step_size", "mean_accept_prob": "accept_prob"}
+        info["extra_fields"] = {f: info[alias.get(f, f)] for f in extra}
         return samples, info
     finally:
         close = getattr(ctx, "close", None)

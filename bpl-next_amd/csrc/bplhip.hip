@@ -165,6 +165,10 @@ struct bplhip_ctx {
     dcn::NeuLayout NL{};
     DevBuf dd_gw, dd_nv, dd_cells, dd_acc, dd_hyp, dd_hc, dd_ac;
     DevBuf dd_fpack, dd_sched, dd_slot_off;  // single-launch neutral kernel (dcn::neu_fused)
+    std::vector<unsigned long long> neu_keys;   // neu_big: the sorted fixtures' run keys (host copy: run counts per wave)
+    int neu_runs_nb = -1;                       // ... the grid size the cached answer belongs to
+    bool neu_runs_ok = false;
+    int opt_neu_runs = 1;                       // neu_big: per-run arithmetic (1) / per-fixture (0)
     bool neu_fusable = false;
     int neu_slots = 0;
     int opt_debug_stop = 0;         // diagnostic build only
@@ -537,6 +541,27 @@ int launch_eval_neutral(bplhip_ctx* c, int chains, const double* z, double* pot,
                     }
                     F.rate_cap = (int)cap;
                     A.fxp = c->dd_fpack.as<const dcn::FusedFixture>();
+                    if (c->neu_runs_nb != nbig) {   // per-run arithmetic: every wave's part must fit its run table
+                        constexpr int WV = dcn::NEU_BIG_BLOCK / 64;
+                        bool ok = (long long)c->neu_keys.size() == c->n &&
+                                  (size_t)WV * dcn::NEU_RUNS_MAX * dcn::NEU_RUN_W <= 2 * (size_t)cap;
+                        for (int b = 0; ok && b < nbig; ++b) {
+                            const long long i_lo = std::min<long long>((long long)b * cap, c->n), i_hi = std::min<long long>(i_lo + cap, c->n);
+                            const long long n_mine = i_hi - i_lo, per_wave = (n_mine + WV - 1) / WV;
+                            for (int w = 0; ok && w < WV; ++w) {
+                                const long long w0 = std::min<long long>(w * per_wave, n_mine), w1 = std::min<long long>(w0 + per_wave, n_mine);
+                                int runs = 0;
+                                // (a wave counts a run per step-aligned piece as well: one per key change, plus one where a
+                                // 64-fixture step that straddles runs ends inside a run -- bounded by twice the key changes + 1)
+                                for (long long i = w0; i < w1; ++i)
+                                    runs += i == w0 || c->neu_keys[i_lo + i] != c->neu_keys[i_lo + i - 1];
+                                ok = 2 * runs + 1 <= dcn::NEU_RUNS_MAX;
+                            }
+                        }
+                        c->neu_runs_ok = ok;
+                        c->neu_runs_nb = nbig;
+                    }
+                    A.runs = c->neu_runs_ok && c->opt_neu_runs;
                     hipLaunchKernelGGL(dcn::neu_big, dim3(nbig), dim3(dcn::NEU_BIG_BLOCK), lds, s, A);
                     HIP_TRY(c, hipGetLastError());
                     continue;
@@ -1298,6 +1323,11 @@ int bplhip_set_option(bplhip_ctx* c, const char* name, int value) {
         c->opt_vec_tpw = value;
         return BPLHIP_OK;
     }
+    if (n == "neu_runs") {  // neutral model's sliced single launch: per-run arithmetic (1) / per fixture (0)
+        c->opt_neu_runs = value != 0;
+        drop_graphs(c);
+        return BPLHIP_OK;
+    }
     if (n == "dyn_gather") {  // dynamic model's small single launch: per-fixture adjoint records gathered by the cells (1) / atomics (0)
         c->opt_dyn_gather = value != 0;
         drop_graphs(c);
@@ -1481,8 +1511,11 @@ static int bplhip_set_fixtures_neutral_impl(bplhip_ctx* c, int64_t n, int32_t n_
             HIP_TRY(c, hipMemcpy(c->dd_slot_off.p, slot_off.data(), slot_off.size() * 4, hipMemcpyHostToDevice));
         }
     }
+    c->neu_keys.clear();
+    c->neu_runs_nb = -1;
     if (!c->neu_fusable) {  // dcn::neu_big streams the same 16-byte records
         std::vector<dcn::FusedFixture> pack(n);
+        c->neu_keys.resize(n);
         for (int64_t i = 0; i < n; ++i) {
             dcn::FusedFixture f{};
             f.h = h[i]; f.a = a[i]; f.x = x[i]; f.y = y[i]; f.nv = nv[i];
@@ -1490,6 +1523,8 @@ static int bplhip_set_fixtures_neutral_impl(bplhip_ctx* c, int64_t n, int32_t n_
             f.ac = n_conf ? acv[i] : 0;
             f.w = weights ? w[i] : 1.0f;
             pack[i] = f;
+            c->neu_keys[i] = ((unsigned long long)f.h << 33) | ((unsigned long long)f.a << 17) |
+                             ((unsigned long long)(f.nv != 0) << 16) | ((unsigned long long)f.hc << 8) | (unsigned long long)f.ac;
         }
         HIP_TRY(c, c->dd_fpack.ensure(pack.size() * sizeof(dcn::FusedFixture)));
         HIP_TRY(c, hipMemcpy(c->dd_fpack.p, pack.data(), pack.size() * sizeof(dcn::FusedFixture), hipMemcpyHostToDevice));

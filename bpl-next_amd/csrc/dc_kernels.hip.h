@@ -228,6 +228,9 @@ enum : unsigned int {
 #ifndef DC_STRICT_ORDER
 #define DC_STRICT_ORDER 0
 #endif
+#ifndef DC_ILL_CALL   // (diagnostic builds: 0 compiles the float64 pass of the ill-conditioned tau classes out)
+#define DC_ILL_CALL 1
+#endif
 #define DC_ARRIVE_ORDER (DC_STRICT_ORDER ? __ATOMIC_RELEASE : __ATOMIC_RELAXED)
 #define DC_POLL_ORDER (DC_STRICT_ORDER ? __ATOMIC_ACQUIRE : __ATOMIC_RELAXED)
 #define DC_ARRIVE_RET_ORDER (DC_STRICT_ORDER ? __ATOMIC_ACQ_REL : __ATOMIC_RELAXED)   // the last arriver goes on to read
@@ -2209,7 +2212,7 @@ __device__ void tail_body(const EvalArgs& A, int chain, char* smem) {
     }
     __syncthreads();
     DC_STAMP(9);
-    if (zoL[ZO_ILL] != 0.0) ill_add_filed(A, zoL, col);   // (uniform; rare: see class_terms, prior_body)
+    if (DC_ILL_CALL && zoL[ZO_ILL] != 0.0) ill_add_filed(A, zoL, col);   // (uniform; rare: see class_terms, prior_body)
     // STAGED <=> T <= 64 (host): the two epilogues never meet in one instantiation (code size
     // matters at ~9 us per launch)
     if (STAGED) {  // lane = team: four waves, one output group each, no LDS traffic
@@ -2437,7 +2440,7 @@ __device__ __forceinline__ bool tail_acc(const EvalArgs& A, int chain, char* sme
         ga_rearm(ga + (size_t)(ncol + (lane & 15) * N_SCAL + (lane >> 4)) * GA_ROW);
     }
     DC_STAMP(9);
-    if (zoL[ZO_ILL] != 0.0)   // (uniform; rare: see class_terms.  The prior part's LDS sits behind the tail's arrays)
+    if (DC_ILL_CALL && zoL[ZO_ILL] != 0.0)   // (uniform; rare: see class_terms.  The prior part's LDS sits behind the tail's arrays)
         ill_pass_lds<EXT>(A, zoL, col, scratch,
                           smem + ((acc_tail_lds_bytes(T, D, K, A.zo_stride, SMALLT && NUTS) + 15) & ~(size_t)15));
     if (SMALLT) {  // lane = team: four waves, one output group each, no LDS traffic
@@ -2620,7 +2623,7 @@ __device__ __forceinline__ bool loop_tail(const EvalArgs& A, int chain, char* sm
         ga_rearm(ga + (size_t)tid * GA_ROW);
     }
     DC_STAMP(9);
-    if (zoL[ZO_ILL] != 0.0)   // (uniform; rare: see class_terms)
+    if (DC_ILL_CALL && zoL[ZO_ILL] != 0.0)   // (uniform; rare: see class_terms)
         ill_pass_lds<EXT>(A, zoL, col, scratch, smem + ((acc_tail_lds_bytes(T, D, K, A.zo_stride, true) + 15) & ~(size_t)15));
     tail_waves<true, EXT, LNE, true>(A, chain, zoL, cL, zL, col, xs_staged ? xsL : nullptr, gL_cur, leaf1, nullptr);
     if (wave == RNG_WAVE && !prev) {   // this step's leaf came from memory: its random numbers, parked

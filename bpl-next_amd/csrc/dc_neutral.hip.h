@@ -73,7 +73,11 @@ struct NeuArgs {
     dcd::DynArgs F;   // fixtures, cells, scratch (acc | sc), z / potential / grad / aux
     NeuLayout L;
     const FusedFixture* fxp;   // neu_big: the fixtures again, one 16-byte record each (weight 1 when unweighted)
+    int runs;                  // neu_big: 1 = per-run arithmetic (the host checked the run tables' capacity)
 };
+// neu_big, round 4: a wave's table of the (venue, home, away[, confederations]) runs of its part of the slice
+constexpr int NEU_RUNS_MAX = 32;   // runs per wave (host: max over the waves' parts, else the per-fixture form)
+constexpr int NEU_RUN_W = 10;      // key | first fixture | W, WX, WY, W00, W10, W01, W11 | spare
 
 // ---- per team: constrained sites -> cell record (dcd::P_*)
 __global__ __launch_bounds__(256) void neu_cells(NeuArgs A) {
@@ -492,11 +496,134 @@ __global__ __launch_bounds__(NEU_BIG_BLOCK) void neu_big(NeuArgs A) {
     const bool slow = s_slow != 0 || C != 0;   // (confederation strengths shift the exponent per fixture: exact form)
 
     NEU_STAMP(2);
+    // ---- Round 4: PER-RUN ARITHMETIC (A.runs).  The fixtures are sorted by (venue, home, away[, confederations])
+    // and every fixture of a run has the same rates and the same four tau arguments: per fixture the kernel spent
+    // ~20 float64 operations on the rates and ~50 (a log and a reciprocal for a third of them) on the adjoints --
+    // phases 2 and 3 were 3.1 + 5.2 us of a 26.7 us launch, bound by float64 issue.  What the value and the
+    // adjoints need from a run's fixtures is LINEAR in seven sums (the weights of all its fixtures, of their goals
+    // on either side, of its (0,0) / (1,0) / (0,1) / (1,1) scorelines).  So a wave walks its part of the slice once,
+    // adds those seven per lane while a step stays inside one run (as it carried the adjoints before), reduces them
+    // at the run's end and files one record per run; then LANE r works run r out -- rates, Poisson part and
+    // maxima in front of the barrier, tau terms and adjoints behind it (its rates stay in registers).  The
+    // fixtures are still streamed and classified on every evaluation.  (dc_vec got the same treatment: DESIGN.md 4a.)
+    const int per_wave_r = (n_mine + WAVES - 1) / WAVES;
+    const int rw0 = wave * per_wave_r < n_mine ? wave * per_wave_r : n_mine;
+    const int rw1 = rw0 + per_wave_r < n_mine ? rw0 + per_wave_r : n_mine;
+    double* const myruns = lrate + (size_t)wave * NEU_RUNS_MAX * NEU_RUN_W;
+    int n_runs = 0;                      // (wave-uniform)
+    unsigned long long r_key = 0ull;     // lane r < n_runs: its run
+    long long r_first = 0;
+    double rW = 0.0, rWX = 0.0, rWY = 0.0, rW00 = 0.0, rW10 = 0.0, rW01 = 0.0, rW11 = 0.0, r_lh = 0.0, r_la = 0.0;
+    if (A.runs) {
+        unsigned long long run_key = ~0ull;
+        long long run_first = 0;
+        double sv[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        auto file_run = [&](unsigned long long kk, long long first, double (&t)[7]) {   // (wave-uniform call, totals in every lane)
+            if (lane == 0 && n_runs < NEU_RUNS_MAX) {
+                double* R = myruns + (size_t)n_runs * NEU_RUN_W;
+                R[0] = __longlong_as_double((long long)kk);
+                R[1] = __longlong_as_double(first);
+#pragma unroll
+                for (int j = 0; j < 7; ++j) R[2 + j] = t[j];
+            }
+            ++n_runs;
+        };
+        auto flush_carried = [&]() {
+            if (run_key == ~0ull) return;
+            dc::wave_sumN_f64(sv);
+            file_run(run_key, run_first, sv);
+            run_key = ~0ull;
+#pragma unroll
+            for (int j = 0; j < 7; ++j) sv[j] = 0.0;
+        };
+        for (int base = rw0; base < rw1; base += 64) {   // (wave-uniform trip count)
+            const int k = base + lane;
+            const bool active = k < rw1;
+            unsigned long long key = 0ull;
+            double cv[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+            if (active) {
+                const FusedFixture f = lfx[k];
+                const int x = f.x, y = f.y;
+                const double wi = (double)f.w;
+                key = ((unsigned long long)f.h << 33) | ((unsigned long long)f.a << 17) |
+                      ((unsigned long long)(f.nv != 0) << 16) | ((unsigned long long)f.hc << 8) | (unsigned long long)f.ac;
+                cv[0] = wi; cv[1] = wi * x; cv[2] = wi * y;
+                const bool low = x <= 1 && y <= 1;
+                cv[3] = low && x == 0 && y == 0 ? wi : 0.0;
+                cv[4] = low && x == 1 && y == 0 ? wi : 0.0;
+                cv[5] = low && x == 0 && y == 1 ? wi : 0.0;
+                cv[6] = low && x == 1 && y == 1 ? wi : 0.0;
+            }
+            // (the active lanes are a prefix of the wave: lane 0 is active here)
+            const unsigned long long k0 = ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(key >> 32)) << 32) |
+                                          (unsigned int)__builtin_amdgcn_readfirstlane((int)key);
+            if (__all(!active || key == k0)) {   // one run in this step
+                if (k0 != run_key) {
+                    flush_carried();
+                    run_key = k0;
+                    run_first = i_lo + base;
+                }
+#pragma unroll
+                for (int j = 0; j < 7; ++j) sv[j] += cv[j];
+                continue;
+            }
+            flush_carried();
+            // a step that straddles runs: one record per run of the step
+            const unsigned long long prev = __shfl_up(key, 1, 64);
+            unsigned long long rest = __ballot(active && (lane == 0 || key != prev));
+            while (rest) {   // (wave-uniform)
+                const int l0 = __ffsll((long long)rest) - 1;
+                rest &= rest - 1;
+                const int l1 = rest ? __ffsll((long long)rest) - 1 : 64;
+                const bool in = active && lane >= l0 && lane < l1;
+                double t[7];
+#pragma unroll
+                for (int j = 0; j < 7; ++j) t[j] = in ? cv[j] : 0.0;
+                dc::wave_sumN_f64(t);
+                const unsigned long long kk = ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)(key >> 32), l0) << 32) |
+                                              (unsigned int)__builtin_amdgcn_readlane((int)key, l0);
+                file_run(kk, i_lo + base + l0, t);
+            }
+        }
+        flush_carried();
+        if (n_runs > NEU_RUNS_MAX) n_runs = NEU_RUNS_MAX;   // (cannot happen: the host counted)
+        if (lane < n_runs) {
+            const double* R = myruns + (size_t)lane * NEU_RUN_W;
+            r_key = (unsigned long long)__double_as_longlong(R[0]);
+            r_first = __double_as_longlong(R[1]);
+            rW = R[2]; rWX = R[3]; rWY = R[4]; rW00 = R[5]; rW10 = R[6]; rW01 = R[7]; rW11 = R[8];
+        }
+    }
     // ---- phase 2: rates, Poisson part of the value, maxima
     double Ui = 0.0;
     {
         double mP = 0.0, mH = 0.0, mA = 0.0;
-        for (int k = tid; k < n_mine; k += NEU_BIG_BLOCK) {
+        if (A.runs && lane < n_runs) {   // lane r: run r
+            const int h = (int)(r_key >> 33) & 0xFFFF, a = (int)(r_key >> 17) & 0xFFFF, hc_ = (int)(r_key >> 8) & 0xFF,
+                      ac_ = (int)r_key & 0xFF;
+            const bool nvf = (r_key >> 16) & 1;
+            const int oh_att = h * dcd::P_N + (nvf ? dcd::P_ATT : dcd::P_AH), oa_def = a * dcd::P_N + (nvf ? dcd::P_DEF : dcd::P_BA);
+            const int oa_att = a * dcd::P_N + (nvf ? dcd::P_ATT : dcd::P_AA), oh_def = h * dcd::P_N + (nvf ? dcd::P_DEF : dcd::P_BH);
+            double eh = lcell[oh_att] - lcell[oa_def];
+            double ea = lcell[oa_att] - lcell[oh_def];
+            if (C) {  // bpl/neutral_dixon_coles_WC.py:188-203
+                const double d = F.cs[hc_] - F.cs[ac_];
+                eh += d;
+                ea -= d;
+            }
+            double lh = lexp[oh_att] * lexp[oa_def], la = lexp[oa_att] * lexp[oh_def];
+            if (slow) {   // (workgroup-uniform)
+                lh = dc::lean::exp(eh);
+                la = dc::lean::exp(ea);
+            }
+            r_lh = lh;
+            r_la = la;
+            Ui += rWX * eh - rW * lh + rWY * ea - rW * la;
+            mP = lh * la;
+            mH = lh;
+            mA = la;
+        }
+        for (int k = tid; !A.runs && k < n_mine; k += NEU_BIG_BLOCK) {
             const FusedFixture f = lfx[k];
             const int h = f.h, a = f.a, x = f.x, y = f.y;
             const bool nvf = f.nv != 0;
@@ -596,9 +723,54 @@ __global__ __launch_bounds__(NEU_BIG_BLOCK) void neu_big(NeuArgs A) {
         const int per_wave = (n_mine + WAVES - 1) / WAVES;
         const int w0 = wave * per_wave < n_mine ? wave * per_wave : n_mine;
         const int w1 = w0 + per_wave < n_mine ? w0 + per_wave : n_mine;
+        if (A.runs && lane < n_runs) {   // ---- lane r: run r's tau terms and adjoints, from its seven sums
+            const double lh = r_lh, la = r_la;
+            double gh = rWX - rW * lh, ga = rWY - rW * la;
+            auto cls = [&](double Wc, double cc, bool to_h, bool to_a) {
+                if (!(Wc > 0.0)) return;
+                const double arg = 1.0 + rho * cc;
+                if (arg > 0.0) {
+                    Ui += Wc * dc::lean::log(arg);
+                    const double uu = cc * dc::lean::rcp(arg);
+                    ui += Wc * uu;
+                    if (to_h) gh += rho * Wc * uu;
+                    if (to_a) ga += rho * Wc * uu;
+                } else {
+                    Ui += Wc * log(0.0);  // -inf (tol = 0, bpl/_util.py:42)
+                }
+            };
+            cls(rW00, -lh * la, true, true);
+            cls(rW10, la, false, true);
+            cls(rW01, lh, true, false);
+            cls(rW11, -1.0, false, false);
+            // arg-extremal fixtures: the smallest index among those attaining a maximum -- the run's first fixture
+            // (a run cut by a wave or workgroup boundary proposes each piece's first: the maximum of ~0 - i keeps the smallest)
+            if (lh * la == M) atomicMax(&scu[dcd::SC_IDXP], ~0ull - (unsigned long long)r_first);
+            if (lh == Lh) atomicMax(&scu[dcd::SC_IDXQ], ~0ull - (unsigned long long)r_first);
+            if (la == La) atomicMax(&scu[dcd::SC_IDXR], ~0ull - (unsigned long long)r_first);
+            const unsigned long long kk = r_key;
+            const int h_ = (int)(kk >> 33) & 0xFFFF, a_ = (int)(kk >> 17) & 0xFFFF, hc_ = (int)(kk >> 8) & 0xFF, ac_ = (int)kk & 0xFF;
+            const bool nv_ = (kk >> 16) & 1;
+            double* Ah = lacc + h_ * dcd::A_N;
+            double* Aa = lacc + a_ * dcd::A_N;
+            atomicAdd(&Ah[dcd::A_ATT], gh);
+            atomicAdd(&Aa[dcd::A_DEF], -gh);
+            atomicAdd(&Aa[dcd::A_ATT], ga);
+            atomicAdd(&Ah[dcd::A_DEF], -ga);
+            if (!nv_) {
+                atomicAdd(&Ah[dcd::A_HATT], gh);
+                atomicAdd(&Aa[dcd::A_ADEF], -gh);
+                atomicAdd(&Aa[dcd::A_AATT], ga);
+                atomicAdd(&Ah[dcd::A_HDEF], -ga);
+            }
+            if (C) {
+                atomicAdd(&lconf[hc_], gh - ga);
+                atomicAdd(&lconf[ac_], ga - gh);
+            }
+        }
         unsigned long long run_key = ~0ull;          // (no fixture packs to this: bits 49.. are zero)
         double run_h = 0.0, run_a = 0.0;             // this lane's share of the carried run's sums
-        for (int base = w0; base < w1; base += 64) {  // (wave-uniform trip count)
+        for (int base = w0; !A.runs && base < w1; base += 64) {  // (wave-uniform trip count)
             const int k = base + lane;
             const long long i = i_lo + k;
             const bool active = k < w1;

@@ -172,6 +172,12 @@ int bplhip_set_fixtures_neutral(bplhip_ctx* ctx, int64_t n, int32_t n_teams,
  *            teams with phases behind grid barriers (dynamic), larger ones sliced over all CUs
  *            (a slice of the fixtures per workgroup, tree barriers) while the slices fit the LDS;
  *            0 = always the multi-launch path.
+ *   "dyn_gather" 1 (default) = the dynamic model's small single launch hands the adjoints over as one
+ *            16-byte record per fixture and gathers them per cell (host-built incidence lists; taken when no
+ *            cell takes part in more than 16 fixtures); 0 = float64 atomics into the cells' accumulators
+ *   "neu_runs" 1 (default) = the neutral model's sliced single launch works rates, tau terms and adjoints
+ *            out once per (venue, home, away) run from seven sums over the run's fixtures (taken when every
+ *            wave's part of the slice holds at most 15 runs); 0 = per fixture
  *   "dyn_big_wgs" 0 (default) = the sliced single launch uses one workgroup per CU, and the
  *            dynamic model takes it past 1024 fixtures per team workgroup; > 0 = that many
  *            workgroups, and the dynamic model takes the sliced form whatever its size.

@@ -183,3 +183,20 @@ def test_add_new_team(dummy_data):
     assert np.all(model.predict_outcome_proba("new", "0")["home_win"] > 0)
     with pytest.raises(ValueError):
         model.add_new_team("new")
+
+
+def test_mcmc_keywords_are_checked_not_dropped(dummy_data):
+    """numpyro's MCMC(...) / MCMC.run(...) keywords the device sampler cannot honour raise; the ones it can are
+    validated before any device work (round 3 accepted `postprocess_fn` / `extra_fields` and ignored them)."""
+    from bpl import _mcmc
+    from bpl._ffi import MODEL_BASIC
+
+    args = (MODEL_BASIC, np.zeros(2, np.uint16), np.ones(2, np.uint16), [1, 0], [0, 2], 2)
+    with pytest.raises(NotImplementedError):
+        _mcmc.run_mcmc(*args, mcmc_kwargs={"postprocess_fn": lambda z: z}, context_factory=lambda i: None)
+    with pytest.raises(ValueError, match="extra_fields"):
+        _mcmc.run_mcmc(*args, run_kwargs={"extra_fields": ("no_such_field",)}, context_factory=lambda i: None)
+    with pytest.raises(ValueError, match="energy"):
+        _mcmc.run_mcmc(*args, run_kwargs={"extra_fields": ("energy",)}, context_factory=lambda i: None)
+    with pytest.raises(TypeError):
+        _mcmc.run_mcmc(*args, mcmc_kwargs={"no_such_keyword": 1}, context_factory=lambda i: None)

@@ -58,4 +58,11 @@ r1 = c.nuts_run_chains(cfg, seeds); r2 = c.nuts_run_chains(cfg, seeds)
 same = all(np.array_equal(p[0], q[0]) for p, q in zip(r1, r2))
 print(f"8 persistent chains twice: identical draws = {same}; leapfrogs {sum(p[1]['total_leapfrogs'] for p in r1)}")
 assert same
+# ... and through the chain-vectorised kernel (more chains than gridy_max_chains: the chunk hipGraph of dc_vec launches)
+seeds = [(0, 300 + i) for i in range(40)]
+cfg.num_warmup, cfg.num_samples = 100, 30
+r1 = c.nuts_run_chains(cfg, seeds); r2 = c.nuts_run_chains(cfg, seeds)
+same = all(np.array_equal(p[0], q[0]) for p, q in zip(r1, r2))
+print(f"40 chains through dc_vec twice: identical draws = {same}; leapfrogs {sum(p[1]['total_leapfrogs'] for p in r1)}")
+assert same
 print("soak ok")
