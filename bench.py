@@ -386,10 +386,10 @@ def main():
                 "frac_traffic": (traffic / per_eval_us / 1e3 / HBM_PEAK_GBS) if traffic else None,
                 "duration_note": "HIP events around the replayed graph divided by its evaluations: kernel "
                                  "duration plus the dependent-launch gap; rocprofv3's per-kernel average "
-                                 "(profiles/r03/kernels.md) is the duration alone",
+                                 "(profiles/r04/kernels.md) is the duration alone",
                 "regime": "latency bound at this size (an empty kernel in the same graph is 2.06 us of the "
                           "~5.9 us launch); the same kernel reaches ~83% of peak at N=1e7 and ~205% "
-                          "(algorithmic) at N=1e8: profiles/r03/n_sweep.txt",
+                          "(algorithmic) at N=1e8: profiles/r04/n_sweep.txt",
             },
         }
         out.update(extra)

@@ -122,10 +122,10 @@ struct bplhip_ctx {
     int opt_max_wg = 255;  // streaming workgroups (+1 prior workgroup = one per CU)
     int opt_active_waves = 0;  // waves per workgroup that own tiles (0 = automatic, see set_fixtures)
     int opt_persistent_nuts = 1;  // bplhip_nuts_run_chains: whole chains on the device (0: lock step)
-    int opt_vec_min_chains = 8;   // batched calls with at least this many chains use dc_vec (0: never);
+    int opt_vec_min_chains = 12;  // batched calls with at least this many chains use dc_vec (0: never);
                                   // fewer run as grid.y copies of the single-chain launch (62 workgroups per
-                                  // chain at N = 1e6).  Round 4: 8 (was 32) -- with the chain arithmetic done per
-                                  // run dc_vec takes 10.4 us for 8 chains against 11.3 for the copies
+                                  // chain at N = 1e6).  Round 4: 12 (was 32) -- with the chain arithmetic done per
+                                  // run dc_vec takes 10.5 us for 8 or 16 chains, the copies 9.2 for 8 and 13.8 for 16
     int opt_gridy_max_chains = 8;   // persistent chains: grid.y copies of the NUTS-aware launch up to here (was 32:
                                     // 16 chains 698k -> 921k leapfrogs/s, 32 chains 986k -> 1.22M through dc_vec;
                                     // 8 chains stay with the copies, 582k against 474k: profiles/r04/lockstep_gridy.txt)

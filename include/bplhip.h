@@ -189,7 +189,7 @@ int bplhip_set_fixtures_neutral(bplhip_ctx* ctx, int64_t n, int32_t n_teams,
  *            bplhip_set_fixtures
  *   "gridy_max_chains" 8 (default) = bplhip_nuts_run_chains keeps up to this many chains as grid.y
  *            copies of the single-chain NUTS-aware launch; more share the chain-vectorised kernel
- *   "vec_min_chains" 8 (default) = bplhip_logp_grad_batched takes the chain-vectorised kernel
+ *   "vec_min_chains" 12 (default) = bplhip_logp_grad_batched takes the chain-vectorised kernel
  *            (dc_vec: the fixtures are read once per 8 chains) from this many chains on; 0 = never
  *   "vec_tiles_per_wave" 0 (default) = the chain-vectorised partitions scale with the chain count
  *            (1x / 2x / 3x the single-chain tiles per wave, the thinnest whose grid fits the chip in one round); > 0 = this many; next bplhip_set_fixtures

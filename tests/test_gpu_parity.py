@@ -36,7 +36,7 @@ def _run(ctx, model, fx, zs):
     Ub, gb, auxb = ctx.logp_grad(z)
     ctx.set_option("vec_min_chains", 1)      # chain-vectorised kernel (dc_vec.hip.h)
     Uv, gv, auxv = ctx.logp_grad(z)
-    ctx.set_option("vec_min_chains", 8)
+    ctx.set_option("vec_min_chains", 12)
     return outs, (Ub.cpu().numpy(), gb.cpu().numpy(), auxb.cpu().numpy()), \
         (Uv.cpu().numpy(), gv.cpu().numpy(), auxv.cpu().numpy())
 
@@ -208,7 +208,7 @@ def test_chain_vectorised_matches_single(hip_ctx, name, model, chains):
     hip_ctx.set_option("vec_min_chains", 1)
     U1, g1, _ = hip_ctx.logp_grad(z)
     U2, g2, _ = hip_ctx.logp_grad(z)
-    hip_ctx.set_option("vec_min_chains", 8)
+    hip_ctx.set_option("vec_min_chains", 12)
     assert torch.equal(U1, U2) and torch.equal(g1, g2)
 
 
@@ -260,7 +260,7 @@ def test_graph_replay_matches_direct(hip_ctx):
     z = torch.tensor(zs, dtype=torch.float64, device=hip_ctx.device)
     hip_ctx.set_option("vec_min_chains", 0)  # direct = 8 single-chain launches (grid.y)
     Ud, gd, _ = hip_ctx.logp_grad(z)
-    hip_ctx.set_option("vec_min_chains", 8)
+    hip_ctx.set_option("vec_min_chains", 12)
     U = torch.zeros(8, dtype=torch.float64, device=hip_ctx.device)
     g = torch.zeros_like(z)
     hip_ctx.logp_grad_graph(16, z, U, g, replays=3)
@@ -291,7 +291,7 @@ def test_graph_survives_slab_growth(hip_ctx):
     try:
         Ub, gb, _ = hip_ctx.logp_grad(z)  # 8 chains as grid.y copies: the slabs grow
     finally:
-        hip_ctx.set_option("vec_min_chains", 8)
+        hip_ctx.set_option("vec_min_chains", 12)
     assert torch.equal(Ub, Ud) and torch.equal(gb, gd)
     U.zero_()
     g.zero_()
@@ -476,7 +476,7 @@ def test_launch_partitions_agree(hip_ctx):
             aux = torch.zeros((6, 4), dtype=torch.float64, device=hip_ctx.device)
             hip_ctx.set_option("vec_min_chains", 0)                               # grid.y copies
             hip_ctx.logp_grad(z, U, g, aux)
-            hip_ctx.set_option("vec_min_chains", 8)
+            hip_ctx.set_option("vec_min_chains", 12)
             got = (U1.cpu().numpy()[0], g1.cpu().numpy(), U.cpu().numpy(), g.cpu().numpy())
             assert abs(got[2][0] - got[0]) <= 1e-12 * abs(got[0])
             if ref is None:
@@ -488,7 +488,7 @@ def test_launch_partitions_agree(hip_ctx):
             assert np.abs(got[3] - ref[3]).max() <= 1e-10 * np.abs(ref[3]).max()
     finally:
         hip_ctx.set_option("active_waves", 0)
-        hip_ctx.set_option("vec_min_chains", 8)
+        hip_ctx.set_option("vec_min_chains", 12)
 
 
 def test_hand_off_timeout_is_reported_not_silent(hip_ctx):
