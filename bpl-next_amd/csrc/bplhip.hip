@@ -276,7 +276,10 @@ int launch_eval_n(bplhip_ctx* c, const dc::EvalArgs& A, int chains, hipStream_t 
         HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(dc::dc_eval<W, C, S, N>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
-    hipLaunchKernelGGL((dc::dc_eval<W, C, S, N>), grid, block, lds, s, A);
+    // (the leading arguments are the ones gfx950 preloads into SGPRs: dc_eval)
+    hipLaunchKernelGGL((dc::dc_eval<W, C, S, N>), grid, block, lds, s, A.z, A.h, A.a, A.x, A.y,
+                       (int)(A.L.T | (A.L.K << 16)), A.n_tiles, (int)(A.tiles_per_wave | (A.active_waves << 16)),
+                       A.z_stride, A);
     HIP_TRY(c, hipGetLastError());
     return BPLHIP_OK;
 }

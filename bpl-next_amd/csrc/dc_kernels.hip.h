@@ -2674,6 +2674,16 @@ __device__ __forceinline__ void load_lane_weights(const EvalArgs& A, size_t o, L
         for (int j = 0; j < LANE_FIX; ++j) L.wj[j] = 1.0f;
     }
 }
+// indices and goals from bare pointers (dc_eval's first tile: pointers that arrive in preloaded SGPRs)
+__device__ __forceinline__ LaneData load_lane_p(const uint32_t* ph, const uint32_t* pa, const uint32_t* px,
+                                                const uint32_t* py, size_t o) {
+    LaneData L;
+    L.hw[0] = ph[o];
+    L.aw[0] = pa[o];
+    load_words<XWORDS>(px + o * XWORDS, L.xw);
+    load_words<XWORDS>(py + o * XWORDS, L.yw);
+    return L;
+}
 // indices and goals only (WITH_WEIGHTS = false: the caller requests the weights later)
 template <bool WEIGHTED, bool WITH_WEIGHTS = true>
 __device__ __forceinline__ LaneData load_lane(const EvalArgs& A, size_t o /* tile*64 + lane */) {
@@ -2851,9 +2861,11 @@ __device__ __forceinline__ T* as_global(T* p) {
 }
 // A fresh copy of the kernel's (single, by-value) argument from the kernarg segment.  The
 // pointer is made opaque so the scalar loads stay where the copy is taken.
+// OFF: bytes of kernel arguments in front of the EvalArgs block (dc_eval: the preloaded ones, EVAL_PRE_BYTES)
+template <int OFF = 0>
 __device__ __forceinline__ EvalArgs reload_args() {
     typedef const __attribute__((address_space(4))) uint32_t* kptr;
-    kptr src = (kptr)__builtin_amdgcn_kernarg_segment_ptr();
+    kptr src = (kptr)__builtin_amdgcn_kernarg_segment_ptr() + OFF / 4;
     asm volatile("" : "+s"(src));
     constexpr int NW = (int)(sizeof(EvalArgs) / 4);
     static_assert(sizeof(EvalArgs) % 4 == 0, "EvalArgs is copied word by word");
@@ -2876,14 +2888,24 @@ __device__ __forceinline__ EvalArgs reload_args() {
 #else
 #define DC_LAUNCH_BOUNDS __launch_bounds__(BLOCK)
 #endif
+// Round 4: KERNEL-ARGUMENT PRELOAD.  Everything the first loads of a workgroup need -- the position, the
+// four fixture arrays, the sizes that locate its tile and the latent layout (a function of the team and
+// covariate counts) -- comes as 14 dwords of plain leading arguments, which gfx950 delivers in SGPRs at wave
+// launch (-mllvm -amdgpu-kernarg-preload-count=14, bpl-next_amd/csrc/Makefile): the position's and the tile's
+// loads issue at once instead of behind the scalar loads of the 400-byte EvalArgs block (a miss every launch:
+// the kernarg segment is fresh), i.e. one dependent memory latency less at the head of EVERY workgroup.
+// (The block itself still follows; reload_args<EVAL_PRE_BYTES>() finds it behind these.)
+constexpr int EVAL_PRE_BYTES = 56;   // 5 pointers + 4 ints
 template <bool WEIGHTED, bool CLIP, bool STAGED, bool NUTS>
-__global__ DC_LAUNCH_BOUNDS void dc_eval(EvalArgs A) {
+__global__ DC_LAUNCH_BOUNDS void dc_eval(const double* pz, const uint32_t* ph, const uint32_t* pa, const uint32_t* px,
+                                         const uint32_t* py, int tk /* T | K << 16 */, int p_tiles,
+                                         int tw_aw /* tiles per wave | active waves << 16 */, int p_zstride, EvalArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const Layout& L = A.L;
+    const Layout L = make_layout(CLIP ? MODEL_EXTENDED : MODEL_BASIC, tk & 0xFFFF, tk >> 16);
     const int T = L.T, T1 = T + 1;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int chain = blockIdx.y;
-    const double* z = z_of(A, chain);
+    const double* z = pz + (size_t)chain * p_zstride;
 #ifdef DC_STAMPS
     const unsigned long long t_entry = __builtin_amdgcn_s_memrealtime();
     const unsigned long long c_entry = __builtin_amdgcn_s_memtime();
@@ -2911,8 +2933,14 @@ __global__ DC_LAUNCH_BOUNDS void dc_eval(EvalArgs A) {
         if (NUTS && nuts_done != 0.0) return;
         const size_t tail_bytes = (acc_tail_lds_bytes(T, L.D, L.K, A.zo_stride, STAGED && NUTS) + 15) & ~(size_t)15;
         TailPre pre;
-        tail_preload_static(A, chain, pre);
-        prior_body<CLIP, true, !STAGED>(A, chain, smem + tail_bytes, reinterpret_cast<double*>(smem));
+        // (the position and the layout as the preloaded arguments give them: the prior part's first loads do
+        // not wait for the argument block either)
+        EvalArgs Ap = A;
+        Ap.L = L;
+        Ap.z = pz;
+        Ap.z_stride = p_zstride;
+        tail_preload_static(Ap, chain, pre);
+        prior_body<CLIP, true, !STAGED>(Ap, chain, smem + tail_bytes, reinterpret_cast<double*>(smem));
         DC_STAMP(4);
         // The tail reads its arguments from the kernarg segment again (scalar loads behind an
         // opaque pointer): kept live in SGPRs from the kernel entry they were spilled.
@@ -2920,11 +2948,11 @@ __global__ DC_LAUNCH_BOUNDS void dc_eval(EvalArgs A) {
         // the scalar cache, and nothing is held in SGPRs across the polling loop.)
         nd::LeafState<1> leaf1{};            // D <= 64: the leaf's vectors in registers (waves 4, 5)
         double bigv[nd::LEAF_STAGE_LOADS];   // D > 64: waves 4..7 stage one 64-element slice each
-        tail_preload<STAGED, NUTS>(reload_args(), chain, pre, leaf1, bigv, true);
+        tail_preload<STAGED, NUTS>(reload_args<EVAL_PRE_BYTES>(), chain, pre, leaf1, bigv, true);
         if (tid == 0) *acc_tail_flag(A, smem) = 1;
         __syncthreads();
         DC_STAMP(5);
-        const EvalArgs B = reload_args();
+        const EvalArgs B = reload_args<EVAL_PRE_BYTES>();
         // (tail_acc waits for the rows itself: every thread polls the row it will read)
         if (!tail_acc<STAGED, NUTS, CLIP>(B, chain, smem, pre, leaf1, bigv, acc_tail_flag(B, smem))) {
             // the streaming workgroups never arrived (bounded wait): poison the outputs
@@ -2945,8 +2973,6 @@ __global__ DC_LAUNCH_BOUNDS void dc_eval(EvalArgs A) {
         // are unconditional (indices clamped) wherever possible: behind a branch the compiler can
         // no longer count how many younger loads may stay outstanding and waits for all of them,
         // and a load that a branch also zeroes is waited for on the spot.
-        uint32_t pr0 = 0;
-        if (tid < A.P) pr0 = A.pairs[tid];
         const TeamZ tz0 = load_team_z<CLIP>(L, z, min(tid, T - 1));
         const F32Scalars fs = f32_scalars<CLIP>(L, z);
         // (basic model: every read of z is above, so a compiler barrier can pin them in front of
@@ -2954,15 +2980,19 @@ __global__ DC_LAUNCH_BOUNDS void dc_eval(EvalArgs A) {
         // With covariates z is read again in the table loop, and behind a barrier those reads
         // would stop being scalar loads.)
         if (!CLIP) asm volatile("" ::: "memory");
-        const int gw = wgi * A.active_waves + wave;
-        int tile = wave < A.active_waves ? gw * A.tiles_per_wave : A.n_tiles;
-        const int tile_end = min(tile + A.tiles_per_wave, A.n_tiles);
+        const int p_tpw = tw_aw & 0xFFFF, p_aw = tw_aw >> 16;
+        const int gw = wgi * p_aw + wave;
+        int tile = wave < p_aw ? gw * p_tpw : p_tiles;
+        const int tile_end = min(tile + p_tpw, p_tiles);
         // (a wave without tiles loads the last one and never uses it)
         // (the weights of a time-weighted tile -- 8 KB per wave -- are requested AFTER the table
         // loads: vector loads return in order, and behind them the covariate rows of the tables
         // waited 1.7 us for HBM)
-        const size_t lane0 = (size_t)min(tile, A.n_tiles - 1) * 64 + lane;
-        LaneData cur = load_lane<WEIGHTED, false>(A, lane0);
+        const size_t lane0 = (size_t)min(tile, p_tiles - 1) * 64 + lane;
+        LaneData cur = load_lane_p(ph, pa, px, py, lane0);
+        // (what follows reads the argument block: the loads above do not wait for it)
+        uint32_t pr0 = 0;
+        if (tid < A.P) pr0 = A.pairs[tid];
         const int o0 = A.wg_off[wgi], o1 = A.wg_off[wgi + 1];  // static sparse-slab slots
         // (unconditional, index clamped: a load into a register that a branch also zeroes made the
         // compiler wait for it -- and, in order, for the whole tile -- right here)

@@ -38,7 +38,7 @@ struct Layout {
     int o_corr, o_md, o_sa, o_sd;
 };
 
-inline Layout make_layout(int model, int T, int K) {
+DC_HD Layout make_layout(int model, int T, int K) {
     Layout L{};
     L.model = model;
     L.T = T;

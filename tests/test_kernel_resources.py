@@ -38,7 +38,8 @@ def kernels(tmp_path_factory):
 
 def _eval_name(weighted, clip, staged, nuts):
     b = lambda v: "Lb1E" if v else "Lb0E"
-    return f"_ZN2dc7dc_evalI{b(weighted)}{b(clip)}{b(staged)}{b(nuts)}EEvNS_8EvalArgsE"
+    # (round 4: five pointers and four ints in front of the argument block -- the ones gfx950 preloads into SGPRs)
+    return f"_ZN2dc7dc_evalI{b(weighted)}{b(clip)}{b(staged)}{b(nuts)}EEvPKdPKjS4_S4_S4_iiiiNS_8EvalArgsE"
 
 
 def test_every_eval_variant_is_built(kernels):
