@@ -112,6 +112,7 @@ struct bplhip_ctx {
     unsigned int loop_tag = 0;  // tags handed out so far (a launch of k steps takes k + 1 of them)
     int opt_persistent_kernel = 1;  // 1: a single chain's leapfrogs run inside one resident launch
     int opt_persist_spec = 1;       // ... and the next position is published before the leaf is booked (dc::tail_waves)
+    int opt_pair_order = -1;        // fixture layout: 0 (home, away) order, 1 Z-order over (home, away), -1: Z-order past 64 teams
     int opt_dense_pairs = 1;        // 1: complete pair tables take the separable (O(teams)) bounds
     bool pairs_complete = false;
     int opt_fused_small = 1;        // 1: neutral / dynamic evaluations that fit one CU's LDS run as one launch
@@ -1047,6 +1048,27 @@ static int bplhip_set_fixtures_impl(bplhip_ctx* c, int model_kind, int64_t n, in
     std::sort(order.begin(), order.end());
 
     const int T = n_teams;
+    // Leagues of more than 64 teams: the FIXTURES are laid out along the Z-order curve over (home, away)
+    // instead (the pair table below keeps the (home, away) order: its index is the tie rule of the bounds).
+    // A workgroup's contiguous slice then covers ~sqrt(its pairs) home teams x as many away teams, and adds
+    // into that many accumulator rows; in (home, away) order a slice is one home team against everybody --
+    // ~3T row adds per workgroup, and every workgroup of the grid adding into the same away-side rows, one
+    // after the other at the memory side.  Runs of one pair stay contiguous either way.
+    const bool z_order = c->opt_pair_order == 1 || (c->opt_pair_order < 0 && T > 64);
+    std::vector<uint64_t> forder;
+    if (z_order) {
+        auto spread = [](uint32_t v) {  // 16 bits -> every other bit of 32
+            v = (v | (v << 8)) & 0x00FF00FFu;
+            v = (v | (v << 4)) & 0x0F0F0F0Fu;
+            v = (v | (v << 2)) & 0x33333333u;
+            v = (v | (v << 1)) & 0x55555555u;
+            return v;
+        };
+        forder.resize(n);
+        for (int64_t i = 0; i < n; ++i)
+            forder[i] = ((uint64_t)((spread(h[i]) << 1) | spread(a[i])) << 32) | (uint64_t)(uint32_t)i;
+        std::sort(forder.begin(), forder.end());
+    }
     // Every pair's run is padded to a multiple of LANE_FIX with NULL fixtures (same pair,
     // goals (255, 255), weight 0): a lane never straddles a pair boundary.  Then the whole
     // array is padded to the tile size with the sentinel team T (zero table entries).
@@ -1073,22 +1095,32 @@ static int bplhip_set_fixtures_impl(bplhip_ctx* c, int model_kind, int64_t n, in
             if (weights) ws.push_back(0.0f);
         }
     };
+    {   // the fixture arrays, in layout order
+        const std::vector<uint64_t>& lay = z_order ? forder : order;
+        uint32_t last_pk = 0;
+        for (int64_t r = 0; r < n; ++r) {
+            const uint32_t i = (uint32_t)lay[r];
+            const uint32_t pk = (uint32_t)h[i] | ((uint32_t)a[i] << 16);
+            if (r > 0 && pk != last_pk) pad_run();
+            last_pk = pk;
+            hs.push_back(h[i]);
+            as.push_back(a[i]);
+            xs8.push_back(x[i]);
+            ys8.push_back(y[i]);
+            is_null.push_back(0);
+            if (weights) ws.push_back(w[i]);
+        }
+    }
+    // the pair table and the host-side sums, in (home, away) order
     for (int64_t r = 0; r < n; ++r) {
         const uint32_t i = (uint32_t)order[r];
         const uint32_t pk = (uint32_t)h[i] | ((uint32_t)a[i] << 16);
         if (pairs.empty() || pairs.back() != pk) {
-            if (!pairs.empty()) pad_run();
             pairs.push_back(pk);
             pairw.insert(pairw.end(), {0.0, 0.0, 0.0, 0.0});
             pairc.insert(pairc.end(), {0.0, 0.0, 0.0, 0.0});
         }
-        hs.push_back(h[i]);
-        as.push_back(a[i]);
-        xs8.push_back(x[i]);
-        ys8.push_back(y[i]);
-        is_null.push_back(0);
         const double wi = weights ? (double)w[i] : 1.0;
-        if (weights) ws.push_back(w[i]);
         cA[h[i]] += wi * x[i];
         cA[a[i]] += wi * y[i];
         cD[a[i]] += wi * x[i];
@@ -1299,6 +1331,11 @@ int bplhip_set_option(bplhip_ctx* c, const char* name, int value) {
 #endif
     if (n == "debug_raise_fault") {  // test hook: raise the fault word as a timed-out kernel would
         if (c->h_fault) __atomic_fetch_or(c->h_fault, (unsigned int)value, __ATOMIC_RELAXED);
+        return BPLHIP_OK;
+    }
+    if (n == "pair_order") {   // takes effect at the next set_fixtures
+        if (value < -1 || value > 1) return fail(c, BPLHIP_EINVAL, "set_option: pair_order is -1, 0 or 1");
+        c->opt_pair_order = value;
         return BPLHIP_OK;
     }
     if (n == "dense_pairs") {  // 0: the rho bounds always walk the pair table

@@ -472,7 +472,11 @@ __device__ __forceinline__ double wave_max_f64(double v) {  // v >= 0  (written 
 // Workgroup sum of NV doubles (all threads get the totals).  scratch: WAVES*NV doubles.
 // (The unrolled serial combine is one round of independent LDS reads; a lane-parallel read +
 // second DPP reduction measured slower.)
-template <int NV>
+// a barrier for LDS traffic alone: __syncthreads() also waits for the wave's outstanding global stores (a memory
+// round trip when write-through stores have just been issued)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// LDS_ONLY: see lds_barrier (tail_general: the rows' re-arming stores and the gradient's are in flight)
+template <int NV, bool LDS_ONLY = false>
 __device__ __forceinline__ void block_sum(double (&v)[NV], double* scratch, int tid) {
     const int lane = tid & 63, wave = tid >> 6;
     if constexpr (NV >= 4) {   // (four chains of DPP steps at a time: wave_reduce.hip.h)
@@ -491,12 +495,12 @@ __device__ __forceinline__ void block_sum(double (&v)[NV], double* scratch, int 
 #pragma unroll
         for (int i = 0; i < NV; ++i) v[i] = wave_sum_f64(v[i]);
     }
-    __syncthreads();
+    if (LDS_ONLY) lds_barrier(); else __syncthreads();
     if (lane == 0) {
 #pragma unroll
         for (int i = 0; i < NV; ++i) scratch[wave * NV + i] = v[i];
     }
-    __syncthreads();
+    if (LDS_ONLY) lds_barrier(); else __syncthreads();
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         double s = 0.0;
@@ -647,6 +651,25 @@ __device__ __forceinline__ void ga_load4(const long long* r0, const long long* r
                  : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3) : "v"(r0), "v"(r1), "v"(r2), "v"(r3) : "memory");
     w[0].lo = v0.x; w[0].hi = v0.y; w[1].lo = v1.x; w[1].hi = v1.y;
     w[2].lo = v2.x; w[2].hi = v2.y; w[3].lo = v3.x; w[3].hi = v3.y;
+}
+__device__ __forceinline__ void ga_load3(const long long* r0, const long long* r1, const long long* r2,
+                                         GaWords (&w)[4]) {
+    typedef long long i64x2 __attribute__((ext_vector_type(2)));
+    i64x2 v0, v1, v2;
+    asm volatile("global_load_dwordx4 %0, %3, off sc1\n\tglobal_load_dwordx4 %1, %4, off sc1\n\t"
+                 "global_load_dwordx4 %2, %5, off sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(v0), "=&v"(v1), "=&v"(v2) : "v"(r0), "v"(r1), "v"(r2) : "memory");
+    w[0].lo = v0.x; w[0].hi = v0.y; w[1].lo = v1.x; w[1].hi = v1.y; w[2].lo = v2.x; w[2].hi = v2.y;
+    w[3] = w[0];
+}
+__device__ __forceinline__ void ga_load2rows(const long long* r0, const long long* r1, GaWords (&w)[4]) {
+    typedef long long i64x2 __attribute__((ext_vector_type(2)));
+    i64x2 v0, v1;
+    asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %3, off sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(v0), "=&v"(v1) : "v"(r0), "v"(r1) : "memory");
+    w[0].lo = v0.x; w[0].hi = v0.y; w[1].lo = v1.x; w[1].hi = v1.y;
+    w[2] = w[0];
+    w[3] = w[0];
 }
 __device__ __forceinline__ int ga_count(const GaWords& w) { return (int)((unsigned long long)w.lo >> GA_COUNT_SHIFT); }
 __device__ __forceinline__ bool ga_is_zero(const GaWords& w) { return (w.lo | w.hi) == 0; }
@@ -855,7 +878,7 @@ __device__ __forceinline__ float rho_f32(float mP, float mQ, float mR, float q) 
 // O(T) instead of O(pairs) per workgroup: at T = 200 the walks were 6 us of every streaming workgroup
 // and 13.5 us (float64, with arg-pairs) of the prior workgroup.  Taken from DENSE_MIN_PAIRS pairs on
 // (more than 90 teams): below, a few pairs per thread are the cheaper walk (measured at 48 and 64 teams).
-constexpr int DENSE_MIN_PAIRS = 8192;
+constexpr int DENSE_MIN_PAIRS = 4096;   // (round 4: from 8192 -- every complete table past 64 teams; 80 teams walked theirs in 10.4 us, 100 teams took 8.3)
 // the largest and the second largest entry (of a different team) of ONE per-team array, with
 // their teams: lanes stride over the teams, then two wave maxima.  get(t): team t's value (> 0).
 // Teams: -1 when there is none.  Results wave-uniform.
@@ -870,13 +893,22 @@ template <class F, class Get>
 __device__ __forceinline__ Top2<F> wave_top2(int T, int lane, Get get) {
     F a1 = (F)0, a2 = (F)0;
     int j1 = -1, j2 = -1;
-    for (int t = lane; t < T; t += 64) {
-        const F v = get(t);
-        const bool first = v > a1, second = !first && v > a2;
-        a2 = first ? a1 : second ? v : a2;
-        j2 = first ? j1 : second ? t : j2;
-        a1 = first ? v : a1;
-        j1 = first ? t : j1;
+    // (four teams per lane and round, all of them requested before the first is looked at -- index clamped, the
+    // repeat does not take part: one team per trip was two dependent LDS round trips per trip, 0.17 us each
+    // at 200 teams; the trip count is wave uniform)
+    for (int b = 0; b < T; b += 256) {
+        F v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = get(min(b + 64 * k + lane, T - 1));
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int t = b + 64 * k + lane;
+            const bool first = t < T && v[k] > a1, second = t < T && !first && v[k] > a2;
+            a2 = first ? a1 : second ? v[k] : a2;
+            j2 = first ? j1 : second ? t : j2;
+            a1 = first ? v[k] : a1;
+            j1 = first ? t : j1;
+        }
     }
     Top2<F> R;
     R.m1 = wave_max_pos(a1);
@@ -909,23 +941,42 @@ constexpr int DENSE_ARRAYS = 5;
 // LDS record each, one barrier, then every thread evaluates the three candidates.  false: a rate
 // reaches the clip -- the clipped product is not separable, the caller walks the pairs.
 // rec: 5 x 4 floats (m1, m2, i1, i2 as bit patterns).
-template <bool CLIP>
+// PRIOR (the prior part, whose waves 0..4 take the float64 arrays at the same time): the float32 arrays go
+// to waves 5 (0, 1), 6 (2, 3) and 7 (4) -- one after the other on waves 0..4 the two precisions were 2.6 us
+// of that workgroup at 200 teams.
+struct NoHook {
+    __device__ __forceinline__ void operator()() const {}
+};
+// AFTER: called by every wave right behind the barrier (the prior part past 64 teams: the rows' early poll)
+template <bool CLIP, bool PRIOR = false, class AFTER = NoHook>
 __device__ __forceinline__ bool dense_maxima_f32(int T, const float2* tabH, const float2* tabA, float* rec,
-                                                 int tid, float* oP, float* oQ, float* oR) {
-    const int lane = tid & 63, wave = tid >> 6;
-    if (wave < DENSE_ARRAYS) {
+                                                 int tid, float* oP, float* oQ, float* oR,
+                                                 unsigned long long* dbg = nullptr, AFTER after = AFTER()) {
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (uniform branches below)
+    auto job = [&](int j) {
         const Top2<float> R = wave_top2<float>(T, lane, [&](int t) {
             const float2 th = tabH[t], ta = tabA[t];
-            return wave == 0 ? th.x : wave == 1 ? ta.x : wave == 2 ? th.y : wave == 3 ? th.x * th.y : ta.x * ta.y;
+            return j == 0 ? th.x : j == 1 ? ta.x : j == 2 ? th.y : j == 3 ? th.x * th.y : ta.x * ta.y;
         });
         if (lane == 0) {
-            rec[wave * 4 + 0] = R.m1;
-            rec[wave * 4 + 1] = R.m2;
-            rec[wave * 4 + 2] = __int_as_float(R.i1);
-            rec[wave * 4 + 3] = __int_as_float(R.i2);
+            rec[j * 4 + 0] = R.m1;
+            rec[j * 4 + 1] = R.m2;
+            rec[j * 4 + 2] = __int_as_float(R.i1);
+            rec[j * 4 + 3] = __int_as_float(R.i2);
         }
+    };
+    if (!PRIOR) {
+        if (wave < DENSE_ARRAYS) job(wave);
+    } else if (wave >= DENSE_ARRAYS) {
+        static_assert(WAVES == 8 && DENSE_ARRAYS == 5, "float32 arrays 0..4 on waves 5, 5, 6, 6, 7");
+        job(2 * (wave - DENSE_ARRAYS));
+        if (wave < WAVES - 1) job(2 * (wave - DENSE_ARRAYS) + 1);
     }
+#ifdef DC_STAMPS
+    if (PRIOR && lane == 0 && dbg) dbg[wave] = __builtin_amdgcn_s_memrealtime();
+#endif
     __syncthreads();
+    after();
     // (all twenty record words in ONE round of LDS reads: read where they are used -- inside the
     // branches of dense_pair_max -- each one was waited for on its own)
     float rv[DENSE_ARRAYS * 4];
@@ -1180,10 +1231,21 @@ __device__ __forceinline__ SigSite sig_site(double zc) {
 // ... and, with it, the static per-team sums (c_lds = cA | cD | cH) and, when they fit, the
 // standardised covariates (xs_lds, null otherwise): the tail's LDS copies, filled once per launch --
 // per step they were a round of global loads at the head of the critical path
-template <bool CLIP, bool TO_LDS = false, bool DENSE = false, bool Z_LDS = false>
-__device__ void prior_body(const EvalArgs& A, int chain, char* smem, double* zo_lds = nullptr,
+struct NoEntryLoads {
+    __device__ __forceinline__ void operator()() const {}
+};
+// ENTRY_LOADS: the caller's own data-only loads (dc_eval past 64 teams: tail_preload_static), issued BEHIND the
+// position's -- vector loads return in order, and in front of them those loads of cold data held the tables back
+// (the prior part's first barrier at 1.8 us with 200 teams, the streaming workgroups' at 1.05)
+// EARLY: the caller's poll of the accumulator rows (dc_eval past 64 teams: tail_poll_early), called by every wave
+// as soon as the bounds' top-two records are out -- the waves that do not go on to the record have nothing left
+// to do but the float32 candidates nobody reads from them.  Returns whether it was called (complete pair tables).
+template <bool CLIP, bool TO_LDS = false, bool DENSE = false, bool Z_LDS = false, class ENTRY_LOADS = NoEntryLoads,
+          class EARLY = NoHook>
+__device__ bool prior_body(const EvalArgs& A, int chain, char* smem, double* zo_lds = nullptr,
                            const double* z_lds = nullptr, const double* c_lds = nullptr,
-                           const double* xs_lds = nullptr) {
+                           const double* xs_lds = nullptr, ENTRY_LOADS entry_loads = ENTRY_LOADS(),
+                           EARLY early = EARLY()) {
     const Layout& L = A.L;
     const int T = L.T, K = L.K, D = L.D;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1211,11 +1273,23 @@ __device__ void prior_body(const EvalArgs& A, int chain, char* smem, double* zo_
     // bound, and with a pair per thread on eight waves two of them shared every SIMD.
     // (Not the extended model: its walk is the heavier part -- clip branches, the clipped lanes'
     // corrections -- and two of those per lane cost more than the shared SIMDs: 9.0 against 8.8 us.)
+    constexpr bool MAYBE_BIG = DENSE || !TO_LDS;
+    constexpr bool Z_FIRST = DENSE && !Z_LDS;   // (dc_eval past 64 teams)
+    TeamZ tz_first{};
+    F32Scalars fs_first{};
+    if (Z_FIRST) {
+        tz_first = load_team_z<CLIP>(L, z, min(tid, T - 1));
+        fs_first = f32_scalars<CLIP>(L, z);
+        asm volatile("" ::: "memory");   // (keeps what follows behind them)
+    }
     const bool two_each = !CLIP && A.P <= BLOCK;
     const int pfirst = two_each ? 2 * tid : tid;
     uint32_t pr0 = 0, pr1 = 0;
     double pw0[3] = {0.0, 0.0, 0.0}, pw1[3] = {0.0, 0.0, 0.0};
-    if (pfirst < A.P) {
+    // (a complete pair table past 64 teams takes the separable bounds: no pair is walked.  Should a rate reach the
+    // clip the walk takes its first pair from the table like the others.)
+    const bool no_walk = DENSE && A.dense_pairs;
+    if (!no_walk && pfirst < A.P) {
         pr0 = A.pairs[pfirst];
         pw0[0] = A.pairw[4 * (size_t)pfirst]; pw0[1] = A.pairw[4 * (size_t)pfirst + 1]; pw0[2] = A.pairw[4 * (size_t)pfirst + 2];
     }
@@ -1224,8 +1298,19 @@ __device__ void prior_body(const EvalArgs& A, int chain, char* smem, double* zo_
         pw1[0] = A.pairw[4 * (size_t)pfirst + 4]; pw1[1] = A.pairw[4 * (size_t)pfirst + 5]; pw1[2] = A.pairw[4 * (size_t)pfirst + 6];
     }
     // the team-sum wave (see below) requests its inputs now: its loads queue behind nothing
-    const bool sums_on_wave = T <= 64;
+    // (MAYBE_BIG: instantiations that can see more than 64 teams -- dc_eval's STAGED one and the persistent
+    // kernel's cannot, and keep no trace of the other form)
+    const bool sums_on_wave = !MAYBE_BIG || T <= 64;
     double pre[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    if (MAYBE_BIG && !sums_on_wave && tid < T) {
+        // larger leagues: the team sums follow the bounds' barrier, one team per thread up to BLOCK teams; their
+        // inputs are requested here with everything else (behind that barrier they were a memory round trip
+        // in front of the sums; requested just ahead of the bounds, the bounds' loops waited for them)
+        pre[0] = A.cA[tid]; pre[1] = A.cD[tid]; pre[2] = A.cH[tid];
+        pre[3] = z[CLIP ? L.o_sat + tid : L.o_adec + tid];
+        pre[4] = z[CLIP ? L.o_sdt + tid : L.o_ddec + tid];
+        pre[5] = CLIP ? z[L.o_hadec + tid] : 0.0;
+    }
     if (sums_on_wave && wave == WAVES - 1 && lane < T) {
         if (Z_LDS) { pre[0] = c_lds[lane]; pre[1] = c_lds[T + lane]; pre[2] = c_lds[2 * T + lane]; }
         else { pre[0] = A.cA[lane]; pre[1] = A.cD[lane]; pre[2] = A.cH[lane]; }
@@ -1233,11 +1318,12 @@ __device__ void prior_body(const EvalArgs& A, int chain, char* smem, double* zo_
         pre[4] = z[CLIP ? L.o_sdt + lane : L.o_ddec + lane];
         pre[5] = CLIP ? z[L.o_hadec + lane] : 0.0;
     }
-    const F32Scalars fs = f32_scalars<CLIP>(L, z);
+    entry_loads();
+    const F32Scalars fs = Z_FIRST ? fs_first : f32_scalars<CLIP>(L, z);
     if (Z_LDS && xs_lds != nullptr)
         build_tables_f32_x<CLIP>(L, z, XsFromF64{xs_lds, K}, tabH, tabA, tid, load_team_z<CLIP>(L, z, min(tid, T - 1)), fs);
     else
-        build_tables_f32<CLIP>(L, z, A.xsf, tabH, tabA, tid, load_team_z<CLIP>(L, z, min(tid, T - 1)), fs);
+        build_tables_f32<CLIP>(L, z, A.xsf, tabH, tabA, tid, Z_FIRST ? tz_first : load_team_z<CLIP>(L, z, min(tid, T - 1)), fs);
 
     // DEFER (small leagues: wave 6 holds no pair and wave 7 is the team-sum wave): the scalar priors and
     // the cells' rounding errors -- which nothing in the cells reads -- sit behind the cells' barrier, on
@@ -1251,15 +1337,20 @@ __device__ void prior_body(const EvalArgs& A, int chain, char* smem, double* zo_
     // float32 tables), and the cells got 0.2 us slower next to the chains.  A/B on one box, tools/ab_libs.py.)
     // ---- z-only scalars, one transcendental chain per wave, in parallel
     //   0 s_a  1 s_d  2 s_h  3..8 corr site  9..14 u site
-    if (tid == 0) sc[0] = lean::exp(z[L.o_sa]);
-    if (tid == 64) sc[1] = lean::exp(z[L.o_sd]);
-    if (tid == 128) sc[2] = CLIP ? lean::exp(z[L.o_sh]) : 0.0;
-    if (tid == 192) {
+    // (past 64 teams the first waves build the float32 tables, one team per thread: the chains go to the last
+    // waves -- up to 192 teams those build none)
+    const bool chains_last = MAYBE_BIG && !sums_on_wave;
+    const int ct0 = chains_last ? 3 * 64 : 0, ct1 = chains_last ? 4 * 64 : 64, ct2 = chains_last ? 5 * 64 : 128,
+              ct3 = chains_last ? 6 * 64 : 192, ct4 = chains_last ? 7 * 64 : 256;
+    if (tid == ct0) sc[0] = lean::exp(z[L.o_sa]);
+    if (tid == ct1) sc[1] = lean::exp(z[L.o_sd]);
+    if (tid == ct2) sc[2] = CLIP ? lean::exp(z[L.o_sh]) : 0.0;
+    if (tid == ct3) {
         const SigSite s = sig_site(z[L.o_corr]);
         sc[3] = s.v; sc[4] = s.dv; sc[5] = s.log_v; sc[6] = s.log_1mv; sc[7] = s.jac;
         sc[8] = s.sig;
     }
-    if (tid == 256 && CLIP) {
+    if (tid == ct4 && CLIP) {
         const SigSite s = sig_site(z[L.o_u]);
         sc[9] = s.v; sc[10] = s.dv; sc[11] = s.log_v; sc[12] = s.log_1mv; sc[13] = s.jac;
         sc[14] = s.sig;
@@ -1276,7 +1367,15 @@ __device__ void prior_body(const EvalArgs& A, int chain, char* smem, double* zo_
     // 0.56 us for either of the two, the other waves 0.4 us for them)
     // (not deferred: the chain sits on a wave that builds no cells -- wave 6 up to 128 teams, wave 7 up to
     // 149; on wave 1 it ran in FRONT of that wave's cells, 0.5 us of the phase at 100 teams)
-    const int lz_tid = defer || 3 * T <= 6 * 64 ? 6 * 64 : (3 * T <= 7 * 64 ? 7 * 64 : 64);
+    // SLACK (leagues past 64 teams with a complete pair table, round 4): the bounds are ten top-two jobs on the
+    // eight waves (below) -- waves 5 and 6 take two float32 arrays each, 1.5 us at 200 teams, everybody else one --
+    // and the waves with one job spend their wait on what used to be phases of their own: the scalar priors (this
+    // lane's serial chain ran on wave 1 in front of its cells: 0.5 us of that phase) go to wave 7 in front of its
+    // job, the team sums (a phase of 0.6 us behind the bounds' barrier) to the waves that own the teams, behind
+    // their float64 job, as wave sums the one thread that needs them adds up.
+    const bool dense_in = DENSE && A.dense_pairs;
+    const bool slack = MAYBE_BIG && !sums_on_wave && dense_in;
+    const int lz_tid = slack ? 7 * 64 : defer || 3 * T <= 6 * 64 ? 6 * 64 : (3 * T <= 7 * 64 ? 7 * 64 : 64);
     double Lz = 0.0;
     auto scalar_priors = [&]() {
         const double zsa = z[L.o_sa], zsd = z[L.o_sd];
@@ -1309,7 +1408,7 @@ __device__ void prior_body(const EvalArgs& A, int chain, char* smem, double* zo_
         zput(&zo[ZO_SD], s_d);
         zput(&zo[ZO_SH], s_h);
     };
-    if (!defer && tid == lz_tid) scalar_priors();
+    if (!defer && !slack && tid == lz_tid) scalar_priors();
     // eps = log(true/table) = log1p(r), r = (true - table)/table, |r| ~ 1e-7
     auto put_eps = [&](int j, int t, double tv) {
         const float tabv = j == 0 ? tabH[t].x : (j == 1 ? tabA[t].x : tabH[t].y);
@@ -1429,7 +1528,8 @@ __device__ void prior_body(const EvalArgs& A, int chain, char* smem, double* zo_
             const bool ch = CLIP && lhf > (float)RATE_CLIP, ca = CLIP && laf > (float)RATE_CLIP;
             if (valid) {
                 const double ph = (double)th.x * (double)ta.y, pa = (double)ta.x * (double)th.y;  // exact
-                pairc += pW * ((ch ? 0.0 : (double)lhf - ph) + (ca ? 0.0 : (double)laf - pa));
+                // (DENSE = dc_eval past 64 teams: its lanes take the exact products themselves, lane_uniform<EXACT>)
+                if (!DENSE) pairc += pW * ((ch ? 0.0 : (double)lhf - ph) + (ca ? 0.0 : (double)laf - pa));
                 // (a clipped lane hands the tail its goal sum as "raw" accumulator -- that cancels the goal
                 // count in the gradient -- and the tail's first-order table correction then books
                 // - (sum w k) eps for it, which a clipped rate does not have: put it back)
@@ -1468,11 +1568,15 @@ __device__ void prior_body(const EvalArgs& A, int chain, char* smem, double* zo_
     // reductions below then see uniform values (zero from the other waves)
     float dPf = 0.f, dQf = 0.f, dRf = 0.f;
     double* rec64 = scratch;  // [5][4] (free until block_sum)
-    const bool dense_in = DENSE && A.dense_pairs;
+    double* wsum = scratch + 32;   // [WAVES][2] (SLACK: the waves' team sums)
+    if (slack && tid == lz_tid) scalar_priors();
     if (dense_in && wave < DENSE_ARRAYS) {
+        const int job = __builtin_amdgcn_readfirstlane(wave);
+        // 0 AH | 1 AA | 2 BD | 3 AH * BD | 4 AA * BD  (x * 1.0 is exact)
+        const double* first = tru + (job == 1 || job == 4 ? T : job == 2 ? 2 * T : 0);
         const Top2<double> R = wave_top2<double>(T, lane, [&](int t) {
-            const double ah = tru[t], aa = tru[T + t], bd = tru[2 * T + t];
-            return wave == 0 ? ah : wave == 1 ? aa : wave == 2 ? bd : wave == 3 ? ah * bd : aa * bd;
+            const double x = first[t], bd = tru[2 * T + t];
+            return x * (job >= 3 ? bd : 1.0);
         });
         if (lane == 0) {
             rec64[wave * 4 + 0] = R.m1;
@@ -1481,7 +1585,29 @@ __device__ void prior_body(const EvalArgs& A, int chain, char* smem, double* zo_
             rec64[wave * 4 + 3] = (double)R.i2;
         }
     }
-    const bool dense = dense_in && dense_maxima_f32<CLIP>(T, tabH, tabA, redm, tid, &dPf, &dQf, &dRf);  // (barrier inside)
+    if (slack) {
+        if (wave * 64 < T || T > BLOCK) {   // (wave uniform)
+            if (tid < T) team_term(tid, pre[0], pre[1], pre[2], pre[3], pre[4], pre[5]);
+            for (int t = tid + BLOCK; t < T; t += BLOCK)
+                team_term(t, A.cA[t], A.cD[t], A.cH[t], z[CLIP ? L.o_sat + t : L.o_adec + t],
+                          z[CLIP ? L.o_sdt + t : L.o_ddec + t], CLIP ? z[L.o_hadec + t] : 0.0);
+            double s0 = v[0], s1 = v[1];
+            wave_sum2_f64(s0, s1);
+            if (lane == 0) {
+                wsum[2 * wave] = s0;
+                wsum[2 * wave + 1] = s1;
+            }
+        } else if (lane == 0) {
+            wsum[2 * wave] = 0.0;
+            wsum[2 * wave + 1] = 0.0;
+        }
+    }
+#ifdef DC_STAMPS
+    unsigned long long* dense_dbg = A.debug && blockIdx.y == 0 ? A.debug + (size_t)gridDim.x * 16 : nullptr;
+#else
+    unsigned long long* dense_dbg = nullptr;
+#endif
+    const bool dense = dense_in && dense_maxima_f32<CLIP, true, EARLY>(T, tabH, tabA, redm, tid, &dPf, &dQf, &dRf, dense_dbg, early);  // (barrier inside)
     if (dense) {
         // (the values are wave-uniform already: no reductions, nothing written over the records; wave 0
         // files the float64 maxima and their arg-pairs for the combine below, zeros for the other waves)
@@ -1508,15 +1634,14 @@ __device__ void prior_body(const EvalArgs& A, int chain, char* smem, double* zo_
                 mP = lh * la;
                 aP = (uint32_t)h | ((uint32_t)a << 16);
             }
-            if (lane < WAVES) {
-                const bool me = lane == 0;
-                amx[lane * 8 + 0] = me ? mP : 0.0; amx[lane * 8 + 1] = me ? mQ : 0.0; amx[lane * 8 + 2] = me ? mR : 0.0;
-                amx[lane * 8 + 3] = me ? (double)aP : 0.0; amx[lane * 8 + 4] = me ? (double)aQ : 0.0;
-                amx[lane * 8 + 5] = me ? (double)aR : 0.0;
-                amx[lane * 8 + 6] = 0.0;   // (separable bounds: no pair walk, no per-pair corrections)
-            }
+            // (wave uniform, and this wave is the one that combines: the maxima stay in its registers -- through
+            // the waves' records and the eight-lane combine below they were 0.4 us of the record's serial chain)
         }
     } else {
+        if (no_walk && pfirst < A.P) {   // (not requested at entry: see no_walk)
+            pr0 = A.pairs[pfirst];
+            pw0[0] = A.pairw[4 * (size_t)pfirst]; pw0[1] = A.pairw[4 * (size_t)pfirst + 1]; pw0[2] = A.pairw[4 * (size_t)pfirst + 2];
+        }
         if (pfirst < A.P) take(pr0, true, pw0[0], pw0[1], pw0[2]);
         if (two_each && pfirst + 1 < A.P) take(pr1, true, pw1[0], pw1[1], pw1[2]);
         for (int p0 = tid + BLOCK; !two_each && p0 < A.P; p0 += PAIR_BATCH * BLOCK) {  // (see pair_maxima_f32)
@@ -1558,12 +1683,24 @@ __device__ void prior_body(const EvalArgs& A, int chain, char* smem, double* zo_
         }
     }
     DC_STAMP_PW(8);
-    __syncthreads();
+    // (separable bounds: nothing crosses waves here any more -- wave 0 keeps its maxima, the team sums were filed
+    // in front of dense_maxima_f32's barrier -- and the other waves go on to the rows' early poll)
+    if (!(slack && dense)) __syncthreads();
     DC_STAMP(3);
 
     // ---- team sums: see above (one wave, beside the pair loop) or, for T > 64, here
-    if (!sums_on_wave) {
-        for (int t = tid; t < T; t += BLOCK)
+    if (slack) {
+        if (tid == lz_tid) {   // (the only reader)
+            v[0] = v[1] = 0.0;
+#pragma unroll
+            for (int wv = 0; wv < WAVES; ++wv) {
+                v[0] += wsum[2 * wv];
+                v[1] += wsum[2 * wv + 1];
+            }
+        }
+    } else if (!sums_on_wave) {
+        if (tid < T) team_term(tid, pre[0], pre[1], pre[2], pre[3], pre[4], pre[5]);
+        for (int t = tid + BLOCK; t < T; t += BLOCK)
             team_term(t, A.cA[t], A.cD[t], A.cH[t], z[CLIP ? L.o_sat + t : L.o_adec + t],
                       z[CLIP ? L.o_sdt + t : L.o_ddec + t], CLIP ? z[L.o_hadec + t] : 0.0);
         block_sum<2>(v, scratch, tid);
@@ -1584,7 +1721,10 @@ __device__ void prior_body(const EvalArgs& A, int chain, char* smem, double* zo_
     double M = 0.0, Lh = 0.0, La = 0.0, pairc_all = 0.0;
     float cPf = 0.f, cQf = 0.f, cRf = 0.f;   // the workgroup's float32 maxima (walk: from the waves' records)
     uint32_t pP = 0, pQ = 0, pR = 0;
-    if (wave == 0) {
+    if (wave == 0 && dense) {
+        M = mP; Lh = mQ; La = mR;
+        pP = aP; pQ = aQ; pR = aR;
+    } else if (wave == 0) {
         // (unconditional reads of a clamped record, then selects: behind `src ? ... : 0` every read sat in
         // its own exec-masked block with its own wait)
         const bool src = lane < WAVES;
@@ -1684,6 +1824,7 @@ __device__ void prior_body(const EvalArgs& A, int chain, char* smem, double* zo_
             if (tid < 4) zput(&ill[3 * T + tid], red[tid]);
         }
     }
+    return dense_in;
 }
 
 // ---- the next position as data-tagged granules (persistent evaluation kernel).  One naturally
@@ -1954,63 +2095,46 @@ __device__ void tail_general(const EvalArgs& A, int chain, const double* zoL, co
                  CLIPC = col[ncol + 3];
     const double G_rho = SU;  // sum_i w_i dlogtau_i/drho
 
-    // ---- 3. first-order value corrections: float32 rounding of the tables
-    //   dL = - sum_t [ ha_raw eAg_t + (att_raw - ha_raw) eA_t + def_raw eDn_t ]
-    // and of rho:  dL = G_rho (rho_true - rho_f32);  then raw sums -> dL/d(team sites)
+    // ---- 3. per team, in ONE pass and in registers (round 4; three passes over LDS with a barrier each and the
+    // bounds' adjoint on a single thread between them were 2.6 us at 200 teams):
+    //   first-order value corrections for the float32 rounding of the tables
+    //     dL = - sum_t [ ha_raw eAg_t + (att_raw - ha_raw) eA_t + def_raw eDn_t ]
+    //   (and of rho:  dL = G_rho (rho_true - rho_f32), below);  raw sums -> dL/d(team sites);
+    //   the adjoint of the bounds (Appendix A.3) where the team is one of the (at most four) arg-extremal ones
+    //   -- every thread tests its own team, in the order the single thread added them;
+    //   the chain rule to z (adds and FMAs only); grad = gz - (fixture-sum terms)
+    const uint32_t pP = (uint32_t)zoL[ZO_PP], pQ = (uint32_t)zoL[ZO_PQ], pR = (uint32_t)zoL[ZO_PR];
+    const unsigned int flags = (unsigned int)zoL[ZO_FLAGS];
+    const bool any = A.P > 0, useP = any && M > 1.0, lhs = Lh >= La;
+    const double vP = G_rho * q * (-UB);          // UB = 1/M : d/d eta_h[P] = d/d eta_a[P] = -1/M
+    const double vL = G_rho * (1.0 - q) * (-LB);  // LB = -1/Lam : d/d eta = +1/Lam
+    const int hP = pP & 0xFFFFu, aP = pP >> 16;
+    const int hL = (lhs ? pQ : pR) & 0xFFFFu, aL = (lhs ? pQ : pR) >> 16;
+    const bool p1 = useP && !(flags & 1u), p2 = useP && !(flags & 2u);
+    const bool l1 = any && lhs && !(flags & 4u), l2 = any && !lhs && !(flags & 8u);
     double corr = 0.0;
-    for (int t = tid; t < T; t += BLOCK) {
+    DC_STAMP_SEQ(12);
+    auto team = [&](int t, double* ga_, double* gd_, double* gh_) {
         const double ra = g_att[t], rd = g_def[t], rh = g_ha[t];
         corr -= rh * eps[t] + (ra - rh) * eps[T + t] + rd * eps[2 * T + t];
-    }
-    __syncthreads();
-    for (int t = tid; t < T; t += BLOCK) {
-        g_att[t] = cL[t] - g_att[t];
-        g_def[t] = -(cL[T + t] - g_def[t]);
-        g_ha[t] = cL[2 * T + t] - g_ha[t];
-    }
-    __syncthreads();
-    if (tid == 0 && A.P > 0) {  // adjoint of the bounds (Appendix A.3)
-        const uint32_t pP = (uint32_t)zoL[ZO_PP], pQ = (uint32_t)zoL[ZO_PQ],
-                       pR = (uint32_t)zoL[ZO_PR];
-        const unsigned int flags = (unsigned int)zoL[ZO_FLAGS];
-        if (M > 1.0) {  // UB = 1/M : d/d eta_h[P] = d/d eta_a[P] = -1/M
-            const double v = G_rho * q * (-UB);
-            const int h = pP & 0xFFFFu, a = pP >> 16;
-            if (!(flags & 1u)) {
-                g_att[h] += v;
-                g_ha[h] += v;
-                g_def[a] -= v;
-            }
-            if (!(flags & 2u)) {
-                g_att[a] += v;
-                g_def[h] -= v;
-            }
-        }
-        const double v = G_rho * (1.0 - q) * (-LB);  // LB = -1/Lam : d/d eta = +1/Lam
-        if (Lh >= La) {
-            const int h = pQ & 0xFFFFu, a = pQ >> 16;
-            if (!(flags & 4u)) {
-                g_att[h] += v;
-                g_ha[h] += v;
-                g_def[a] -= v;
-            }
-        } else {
-            const int h = pR & 0xFFFFu, a = pR >> 16;
-            if (!(flags & 8u)) {
-                g_att[a] += v;
-                g_def[h] -= v;
-            }
-        }
-    }
-    __syncthreads();
-
-    // ---- 4. chain rule to z (adds and FMAs only); grad = gz - (fixture-sum terms)
+        double ga = cL[t] - ra, gd = -(cL[T + t] - rd), gh = cL[2 * T + t] - rh;
+        if (p1 && t == hP) { ga += vP; gh += vP; }
+        if (p1 && t == aP) gd -= vP;
+        if (p2 && t == aP) ga += vP;
+        if (p2 && t == hP) gd -= vP;
+        if (l1 && t == hL) { ga += vL; gh += vL; }
+        if (l1 && t == aL) gd -= vL;
+        if (l2 && t == aL) ga += vL;
+        if (l2 && t == hL) gd -= vL;
+        *ga_ = ga; *gd_ = gd; *gh_ = gh;
+    };
     if (!EXT) {
         // v: 0 sum g_def, 1 sum g_ha, 2 sum a~ g_att, 3 sum d~ g_def, 4 correction
-        double v[5] = {0, 0, 0, 0, corr};
+        double v[5] = {0, 0, 0, 0, 0};
         for (int t = tid; t < T; t += BLOCK) {
+            double ga, gd, gh;
+            team(t, &ga, &gd, &gh);
             const double ad = zL[L.o_adec + t], dd = zL[L.o_ddec + t];
-            const double ga = g_att[t], gd = g_def[t], gh = g_ha[t];
             grad[L.o_adec + t] = gz[L.o_adec + t] - s_a * ga;
             grad[L.o_ddec + t] = gz[L.o_ddec + t] - s_d * gd;
             v[0] += gd;
@@ -2018,7 +2142,10 @@ __device__ void tail_general(const EvalArgs& A, int chain, const double* zoL, co
             v[2] += ad * ga;
             v[3] += dd * gd;
         }
-        block_sum<5>(v, scratch, tid);
+        v[4] = corr;
+        DC_STAMP_SEQ(13);
+        block_sum<5, true>(v, scratch, tid);
+        DC_STAMP_SEQ(14);
         if (tid == 0) {
             grad[L.o_ha] = gz[L.o_ha] - v[1];
             grad[L.o_md] = gz[L.o_md] - v[0];
@@ -2031,10 +2158,14 @@ __device__ void tail_general(const EvalArgs& A, int chain, const double* zoL, co
         }
     } else {
         // v: 0 sum g_def, 1 sum g_ha, 2 sum sa g_att, 3 sum sd g_def, 4 sum ha~ g_ha, 5 corr
-        double v[6] = {0, 0, 0, 0, 0, corr};
+        double v[6] = {0, 0, 0, 0, 0, 0};
         for (int t = tid; t < T; t += BLOCK) {
+            double ga, gd, gh;
+            team(t, &ga, &gd, &gh);
+            // (the coefficient sums below read every team's: this thread's own entries, behind its own reads)
+            g_att[t] = ga;
+            g_def[t] = gd;
             const double sa = zL[L.o_sat + t], sd = zL[L.o_sdt + t], hd = zL[L.o_hadec + t];
-            const double ga = g_att[t], gd = g_def[t], gh = g_ha[t];
             grad[L.o_sat + t] = gz[L.o_sat + t] - s_a * ga;
             grad[L.o_sdt + t] = gz[L.o_sdt + t] - s_d * gd;
             grad[L.o_hadec + t] = gz[L.o_hadec + t] - s_h * gh;
@@ -2044,7 +2175,8 @@ __device__ void tail_general(const EvalArgs& A, int chain, const double* zoL, co
             v[3] += sd * gd;
             v[4] += hd * gh;
         }
-        block_sum<6>(v, scratch, tid);
+        v[5] = corr;
+        block_sum<6, true>(v, scratch, tid);   // (its barriers also publish g_att / g_def)
         for (int k = tid; k < 2 * K; k += BLOCK) {  // d/d beta_k: sum_t Xs[t,k] g_t
             const bool isd = k >= K;
             const int kk = isd ? k - K : k;
@@ -2250,7 +2382,34 @@ __host__ __device__ inline size_t acc_tail_lds_bytes(int T, int D, int K, int zo
 struct TailPre {
     double c0, z0, x0;
     int expect;   // contributions this thread's (first) accumulator row receives per evaluation
+    // larger leagues (BIG): the second round of the static sums and of the position, and the expected counts of
+    // the thread's four batched rows (tail_acc) -- requested behind the rows' poll they were two more memory
+    // round trips between the prior part and the epilogue (1.6 us from the last row add to the epilogue at 200 teams)
+    double c1, z1;
+    int ex[4];
 };
+constexpr int ROW_THREADS = (WAVES - 1) * 64;   // waves 0..6 take team rows, wave 7 the scalar rows
+// larger leagues: row k of a thread's batch of up to four (tail_acc).  Loads that bypass the L1 are served one
+// after the other PER LINE at the memory side, so a lane without a k-th row must not invent a request: it repeats
+// the address of the first lane of its own wave instruction (same instruction, same line: one request), and a
+// wave whose whole k-th instruction is past the end repeats its first row's.  (Measured at 200 teams: clamped to
+// the last row -- 300 threads on one line -- 0.6 us per evaluation; every lane its own first row again -- four
+// requests per line -- 1.7 us.)  The batch holds as many loads as the league needs (batched_loads).
+template <int RT = ROW_THREADS>
+__device__ __forceinline__ int batched_row(int b0, int k, int lane, int ncol) {
+    const int i0 = b0 + k * RT;
+    return i0 + lane < ncol ? i0 + lane : (i0 < ncol ? i0 : min(b0, ncol - 1));
+}
+template <int RT = ROW_THREADS>
+__device__ __forceinline__ int batched_loads(int b0_first, int ncol) {   // of the batch that starts at wave 0's b0
+    return min(4, (ncol - b0_first + RT - 1) / RT);
+}
+// EARLY (dc_eval past 64 teams, round 4): the rows are polled by waves 1..6 (team rows) and 7 (scalar rows) as
+// soon as each is through with the prior part -- while wave 0's first lane still works the bounds' record out
+// (0.85 us) -- instead of behind the barrier that ends it: at 200 teams the streaming workgroups are done at 4 us
+// and the prior part at 7, so the first poll finds every row complete, and its round trip (1.1 us with two rows
+// per thread) and what led up to it (0.4 us) leave the critical path.
+constexpr int EARLY_THREADS = (WAVES - 2) * 64;
 // the (first) accumulator row a thread of the tail takes: waves 0..6 the team rows, wave 7 the scalar
 // rows, lane = 16*scalar + shard
 __device__ __forceinline__ int tail_row_of(int tid, int ncol) {
@@ -2261,7 +2420,7 @@ __device__ __forceinline__ int tail_row_of(int tid, int ncol) {
 // the data-only part (z, static sums, covariates, expected counts): a plain launch requests it at
 // kernel entry, IN FRONT of the prior part -- requested behind it, the barrier that follows waited a
 // memory round trip (0.4 us) for it with the prior record already done
-template <bool ZL = false>
+template <bool ZL = false, bool BIG = false>
 __device__ __forceinline__ void tail_preload_static(const EvalArgs& A, int chain, TailPre& P) {
     const Layout& L = A.L;
     const int T = L.T, K = L.K, D = L.D;
@@ -2274,6 +2433,14 @@ __device__ __forceinline__ void tail_preload_static(const EvalArgs& A, int chain
     P.z0 = !ZL && i < D ? z[i] : 0.0;
     P.x0 = (!ZL && xs_staged && i < T * K) ? A.xs[i] : 0.0;
     P.expect = A.ga_expect[tail_row_of(tid, ncol)];
+    if (BIG) {
+        const int i1 = tid + BLOCK;
+        P.c1 = !ZL && i1 < ncol ? (i1 < T ? A.cA[i1] : (i1 < 2 * T ? A.cD[i1 - T] : A.cH[i1 - 2 * T])) : 0.0;
+        P.z1 = !ZL && i1 < D ? z[i1] : 0.0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            P.ex[k] = A.ga_expect[batched_row<EARLY_THREADS>(max((tid & ~63) - 64, 0), k, tid & 63, ncol)];
+    }
 }
 template <bool SMALLT, bool NUTS, bool ZL = false, int LNE>
 __device__ __forceinline__ void tail_preload(const EvalArgs& A, int chain, TailPre& P,
@@ -2283,7 +2450,7 @@ __device__ __forceinline__ void tail_preload(const EvalArgs& A, int chain, TailP
     const Layout& L = A.L;
     const int D = L.D;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (!static_done) tail_preload_static<ZL>(A, chain, P);
+    if (!static_done) tail_preload_static<ZL, !SMALLT>(A, chain, P);
     if (NUTS && SMALLT && want_leaf) {
         double* ns = nuts_of(A, chain);
         if (D <= 64 * LNE) {
@@ -2342,7 +2509,67 @@ __device__ __forceinline__ bool ga_take_row(const long long* row, int expect, Ga
 // last rows are complete, and the poll that follows starts a full round trip later than it would have.)
 // `set`: which of the chain's two row sets this evaluation used; CHECK_OTHER (persistent kernel): the
 // wait also covers the other set reading all zero (see ga_set_words)
-template <bool SMALLT, bool NUTS, bool EXT, bool ZL = false, int LNE>
+// the early poll itself: every wave but the first, once it has left prior_body (no barrier in between: okflag
+// was raised in front of the prior part).  Results into the tail's `col`, as tail_acc files them.
+__device__ __forceinline__ void tail_poll_early(const EvalArgs& A, int chain, char* smem, const TailPre& P, int* okflag) {
+    const Layout& L = A.L;
+    const int T = L.T, D = L.D;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ncol = 3 * T;
+    if (wave == 0) return;
+    double* col = reinterpret_cast<double*>(smem) + A.zo_stride + ncol + D;
+    long long* ga = A.gacc + (size_t)chain * 2 * ga_set_words(T);
+    bool ok = true;
+    DC_STAMP_WAVE(1, 11);
+    if (wave < WAVES - 1) {
+        for (int b0 = (wave - 1) * 64; b0 < ncol; b0 += 4 * EARLY_THREADS) {
+            int r[4], ex[4];
+            const int nload = max(2, batched_loads<EARLY_THREADS>(b0 - (wave - 1) * 64, ncol));
+            const bool pre_ex = b0 == (wave - 1) * 64;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                r[k] = batched_row<EARLY_THREADS>(b0, k, lane, ncol);
+                ex[k] = pre_ex ? P.ex[k] : A.ga_expect[r[k]];
+            }
+            GaWords w[4];
+            bool got = false;
+            for (int spin = 0; spin < ARRIVE_SPIN_LIMIT; ++spin) {
+                if (nload == 2)   // (wave uniform)
+                    ga_load2rows(ga + (size_t)r[0] * GA_ROW, ga + (size_t)r[1] * GA_ROW, w);
+                else if (nload == 3)
+                    ga_load3(ga + (size_t)r[0] * GA_ROW, ga + (size_t)r[1] * GA_ROW, ga + (size_t)r[2] * GA_ROW, w);
+                else
+                    ga_load4(ga + (size_t)r[0] * GA_ROW, ga + (size_t)r[1] * GA_ROW, ga + (size_t)r[2] * GA_ROW,
+                             ga + (size_t)r[3] * GA_ROW, w);
+                const bool mine = ga_count(w[0]) == ex[0] && ga_count(w[1]) == ex[1] &&
+                                  (nload < 3 || ga_count(w[2]) == ex[2]) && (nload < 4 || ga_count(w[3]) == ex[3]);
+                got = __ballot(!mine) == 0ull;
+                if (got) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            ok = got && ok;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int i2 = b0 + k * EARLY_THREADS + lane;
+                if (k < nload && i2 < ncol) col[i2] = ga_value(w[k]);
+            }
+        }
+    } else {  // scalar rows: sum the shards (as tail_acc)
+        GaWords w0;
+        ok = ga_take_row(ga + (size_t)tail_row_of(tid, ncol) * GA_ROW, P.expect, &w0);
+        double v = ga_value(w0);
+        v += dpp_f64<0xB1>(0.0, v);   // quad_perm [1,0,3,2]
+        v += dpp_f64<0x4E>(0.0, v);   // quad_perm [2,3,0,1]
+        v += dpp_f64<0x124>(0.0, v);  // row_ror:4
+        v += dpp_f64<0x128>(0.0, v);  // row_ror:8
+        if ((lane & 15) == 0) col[ncol + (lane >> 4)] = v;
+    }
+    poll_acquired();
+    DC_STAMP_WAVE(1, 6);
+    if (!ok && lane == 0) *okflag = 0;
+}
+// POLLED: tail_poll_early has taken the rows
+template <bool SMALLT, bool NUTS, bool EXT, bool ZL = false, bool POLLED = false, int LNE>
 __device__ __forceinline__ bool tail_acc(const EvalArgs& A, int chain, char* smem, const TailPre& P,
                                          const nd::LeafState<LNE>& leaf1,
                                          const double (&bigv)[nd::LEAF_STAGE_LOADS], int* okflag,
@@ -2352,7 +2579,6 @@ __device__ __forceinline__ bool tail_acc(const EvalArgs& A, int chain, char* sme
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ncol = 3 * T;
     static_assert(N_SCAL * GA_SHARDS == 64 && WAVES == 8, "wave 7 = the scalar rows");
-    constexpr int ROW_THREADS = (WAVES - 1) * 64;
 
     double* zoL = reinterpret_cast<double*>(smem);      // [zo_stride]  prior workgroup record
     double* cL = zoL + A.zo_stride;                     // [3T] cA | cD | cH
@@ -2376,31 +2602,43 @@ __device__ __forceinline__ bool tail_acc(const EvalArgs& A, int chain, char* sme
         const size_t ro = (size_t)tail_row_of(tid, ncol) * GA_ROW;
         // (persistent kernel: the next step's rows, re-armed one step ago, must read all zero too)
         // (larger leagues: a team-row thread takes its first row with the others, in one round trip)
-        const bool batched = !SMALLT && !check_other && wave < WAVES - 1 && ncol > ROW_THREADS;
-        bool ok = batched ||
+        const bool batched = !POLLED && !SMALLT && !check_other && wave < WAVES - 1 && ncol > ROW_THREADS;
+        bool ok = batched || POLLED ||
                   ga_take_row(ga + ro, P.expect, &w0,
                               check_other ? A.gacc + ((size_t)chain * 2 + (set ^ 1)) * ga_set_words(T) + ro : nullptr);
         if (!ZL && i < ncol) cL[i] = P.c0;
         if (!ZL && i < D) zL[i] = P.z0;
         if (!ZL && xs_staged && i < T * K) xsL[i] = P.x0;
-        if (wave < WAVES - 1) {
+        if (POLLED) {
+            // (nothing: col holds the rows)
+        } else if (wave < WAVES - 1) {
             if (!batched && i < ncol) col[i] = ga_value(w0);
-            // larger models: the remaining team rows, FOUR per thread and poll in flight together
-            // (wave-uniform trip count: the polls ballot; lanes past the last row poll it again)
-            for (int b0 = (tid & ~63) + (batched ? 0 : ROW_THREADS); b0 < ncol; b0 += 4 * ROW_THREADS) {
+            // larger models: the remaining team rows, up to FOUR per thread and poll in flight together
+            // (wave-uniform trip count: the polls ballot; lanes past the last row: batched_row)
+            // (SMALLT: at most 192 rows, all of them taken above -- and no trace of this loop in those kernels)
+            for (int b0 = (tid & ~63) + (batched ? 0 : ROW_THREADS); !SMALLT && b0 < ncol; b0 += 4 * ROW_THREADS) {
                 int r[4], ex[4];
+                const int nload = max(2, batched_loads(b0 - (tid & ~63), ncol));
+                // (the first batch's expected counts came with the prologue's loads: TailPre)
+                const bool pre_ex = false;   // (TailPre's counts follow the early poll's row mapping)
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    r[k] = min(b0 + k * ROW_THREADS + lane, ncol - 1);
-                    ex[k] = A.ga_expect[r[k]];
+                    r[k] = batched_row(b0, k, lane, ncol);
+                    ex[k] = pre_ex ? P.ex[k] : A.ga_expect[r[k]];
                 }
                 GaWords w[4];
                 bool got = false;
+                DC_STAMP(11);
                 for (int spin = 0; spin < ARRIVE_SPIN_LIMIT; ++spin) {
-                    ga_load4(ga + (size_t)r[0] * GA_ROW, ga + (size_t)r[1] * GA_ROW, ga + (size_t)r[2] * GA_ROW,
-                             ga + (size_t)r[3] * GA_ROW, w);
-                    const bool mine = ga_count(w[0]) == ex[0] && ga_count(w[1]) == ex[1] && ga_count(w[2]) == ex[2] &&
-                                      ga_count(w[3]) == ex[3];
+                    if (nload == 2)   // (wave uniform)
+                        ga_load2rows(ga + (size_t)r[0] * GA_ROW, ga + (size_t)r[1] * GA_ROW, w);
+                    else if (nload == 3)
+                        ga_load3(ga + (size_t)r[0] * GA_ROW, ga + (size_t)r[1] * GA_ROW, ga + (size_t)r[2] * GA_ROW, w);
+                    else
+                        ga_load4(ga + (size_t)r[0] * GA_ROW, ga + (size_t)r[1] * GA_ROW, ga + (size_t)r[2] * GA_ROW,
+                                 ga + (size_t)r[3] * GA_ROW, w);
+                    const bool mine = ga_count(w[0]) == ex[0] && ga_count(w[1]) == ex[1] &&
+                                      (nload < 3 || ga_count(w[2]) == ex[2]) && (nload < 4 || ga_count(w[3]) == ex[3]);
                     got = __ballot(!mine) == 0ull;
                     if (got) break;
                     __builtin_amdgcn_s_sleep(1);
@@ -2422,10 +2660,15 @@ __device__ __forceinline__ bool tail_acc(const EvalArgs& A, int chain, char* sme
         }
         if (!ok && lane == 0) *okflag = 0;
     }
+    DC_STAMP(14);
     if (!ZL) {
-        for (int i = tid + BLOCK; i < ncol; i += BLOCK)
+        if (!SMALLT) {
+            if (tid + BLOCK < ncol) cL[tid + BLOCK] = P.c1;
+            if (tid + BLOCK < D) zL[tid + BLOCK] = P.z1;
+        }
+        for (int i = tid + 2 * BLOCK; !SMALLT && i < ncol; i += BLOCK)   // (SMALLT: 3T <= 192)
             cL[i] = i < T ? A.cA[i] : (i < 2 * T ? A.cD[i - T] : A.cH[i - 2 * T]);
-        for (int i = tid + BLOCK; i < D; i += BLOCK) zL[i] = z[i];
+        for (int i = tid + (SMALLT ? 1 : 2) * BLOCK; i < D; i += BLOCK) zL[i] = z[i];
         if (xs_staged)
             for (int i = tid + BLOCK; i < T * K; i += BLOCK) xsL[i] = A.xs[i];
     }
@@ -2751,7 +2994,12 @@ __device__ __forceinline__ void class_terms(float rho, float c, float* l2, float
 // All fixtures of a lane are one pair (h, a): the library pads every pair's run to a multiple
 // of LANE_FIX with NULL fixtures -- same pair, goals (255, 255), weight 0 -- so a lane never
 // straddles a pair boundary and the rates and tau terms are computed once per lane.
-template <bool WEIGHTED, bool CLIP>
+// EXACT (dc_eval past 64 teams, round 4): the rate sum takes the EXACT products of the float32 table entries
+// (exact in float64) instead of their float32 roundings.  Up to 64 teams the prior part's pair walk books that
+// rounding per pair (prior_body, ZO_PAIRC); a complete pair table past 64 teams is not walked at all, and the
+// correction was simply missing there (1.2e-2 of U = 9e6 at 91 teams, uniform(-2, 2): as large as the whole
+// tolerance).  Four more float64 instructions per lane and tile.
+template <bool WEIGHTED, bool CLIP, bool EXACT = false>
 __device__ __forceinline__ LaneOut lane_uniform(const LaneData& Ld, float rho,
                                                 const float2* tabH, const float2* tabA) {
     const uint32_t h = Ld.hw[0] & 0xFFFFu, a = Ld.aw[0] & 0xFFFFu;
@@ -2834,7 +3082,10 @@ __device__ __forceinline__ LaneOut lane_uniform(const LaneData& Ld, float rho,
     // (round 3) float64: nall (lh + la) in float32 is rounded the same way in EVERY lane of a pair
     // (82 lanes per pair at N = 1e6) -- with the two corrections of prior_body / class_terms in, the
     // largest term of |U - U_float64| left (6e-3 at N = 1e6).  Five float64 instructions per lane.
-    o.slam = (double)nall * ((double)lh + (double)la);
+    if (EXACT)
+        o.slam = (double)nall * ((ch ? RATE_CLIP : (double)th.x * (double)ta.y) + (ca ? RATE_CLIP : (double)ta.x * (double)th.y));
+    else
+        o.slam = (double)nall * ((double)lh + (double)la);
     // a class with no fixture must not contribute (its log may be -inf): 0 * -inf = NaN
     o.slog = (n00 != 0.f ? n00 * l00 : 0.f) + (n10 != 0.f ? n10 * l10 : 0.f) +
              (n01 != 0.f ? n01 * l01 : 0.f) + (n11 != 0.f ? n11 * l11 : 0.f);
@@ -2939,8 +3190,19 @@ __global__ DC_LAUNCH_BOUNDS void dc_eval(const double* pz, const uint32_t* ph, c
         Ap.L = L;
         Ap.z = pz;
         Ap.z_stride = p_zstride;
-        tail_preload_static(Ap, chain, pre);
-        prior_body<CLIP, true, !STAGED>(Ap, chain, smem + tail_bytes, reinterpret_cast<double*>(smem));
+        if (STAGED) {
+            tail_preload_static<false, false>(Ap, chain, pre);
+            prior_body<CLIP, true, false>(Ap, chain, smem + tail_bytes, reinterpret_cast<double*>(smem));
+        } else {
+            if (tid == 0) *acc_tail_flag(Ap, smem) = 1;   // (the prior part's barriers lie in between)
+            auto entry_loads = [&]() { tail_preload_static<false, true>(Ap, chain, pre); };
+            prior_body<CLIP, true, true, false, decltype(entry_loads)>(
+                Ap, chain, smem + tail_bytes, reinterpret_cast<double*>(smem), nullptr, nullptr, nullptr, entry_loads);
+            // (Polled from inside the prior part instead -- behind the barrier of the bounds' top-two records, 0.7 us
+            // earlier -- the first poll comes back before the last row adds are visible and the second one a round
+            // trip later than this one: 10.8 us instead of 9.7 at 200 teams.  profiles/r04/teams_rework.txt)
+            tail_poll_early(Ap, chain, smem, pre, acc_tail_flag(Ap, smem));
+        }
         DC_STAMP(4);
         // The tail reads its arguments from the kernarg segment again (scalar loads behind an
         // opaque pointer): kept live in SGPRs from the kernel entry they were spilled.
@@ -2949,12 +3211,13 @@ __global__ DC_LAUNCH_BOUNDS void dc_eval(const double* pz, const uint32_t* ph, c
         nd::LeafState<1> leaf1{};            // D <= 64: the leaf's vectors in registers (waves 4, 5)
         double bigv[nd::LEAF_STAGE_LOADS];   // D > 64: waves 4..7 stage one 64-element slice each
         tail_preload<STAGED, NUTS>(reload_args<EVAL_PRE_BYTES>(), chain, pre, leaf1, bigv, true);
-        if (tid == 0) *acc_tail_flag(A, smem) = 1;
+        if (STAGED && tid == 0) *acc_tail_flag(A, smem) = 1;
         __syncthreads();
         DC_STAMP(5);
         const EvalArgs B = reload_args<EVAL_PRE_BYTES>();
-        // (tail_acc waits for the rows itself: every thread polls the row it will read)
-        if (!tail_acc<STAGED, NUTS, CLIP>(B, chain, smem, pre, leaf1, bigv, acc_tail_flag(B, smem))) {
+        // (tail_acc waits for the rows itself: every thread polls the row it will read; larger leagues:
+        // tail_poll_early has)
+        if (!tail_acc<STAGED, NUTS, CLIP, false, !STAGED>(B, chain, smem, pre, leaf1, bigv, acc_tail_flag(B, smem))) {
             // the streaming workgroups never arrived (bounded wait): poison the outputs
             double* grad = grad_of(A, chain);
             for (int i = tid; i < L.D; i += BLOCK) grad[i] = __builtin_nan("");
@@ -3032,7 +3295,7 @@ __global__ DC_LAUNCH_BOUNDS void dc_eval(const double* pz, const uint32_t* ph, c
             if (ld.hw[0] == 0xFFFFFFFFu) rho_dbg += 1.0f;  // forces the loads to have landed
             DC_STAMP(12);
 #endif
-            const LaneOut lo = lane_uniform<WEIGHTED, CLIP>(ld, rho, tabH, tabA);
+            const LaneOut lo = lane_uniform<WEIGHTED, CLIP, !STAGED>(ld, rho, tabH, tabA);
             // scalars: float32 over the lane's fixtures only, fixed point (q30) from there on
             // (a float32 sum over the whole wave-tile would cost ~1e-4 absolute in U)
             dSLAM += rint(ldexp(lo.slam, 30));

@@ -43,10 +43,12 @@ def run(n, model=MODEL_BASIC, max_wg=255, k=0, weighted=False):
     print("  shader clock over the streaming workgroups' lives: median %.2f GHz" % np.median(st[1:, 9] / life))
     last = int(np.argmax(st[:, 10]))
     print("  tail WG", last, " ".join(f"{names[k]}={rel[last, k]:.2f}" for k in range(11)),
-          f"epi:sums={rel[last, 11]:.2f} epi:puts={rel[last, 14]:.2f}")
+          f"epi:sums={rel[last, 11]:.2f} epi:puts={rel[last, 14]:.2f}",
+          f"| past 64 teams: early poll (wave 1) {rel[0, 11]:.2f} -> {rel[0, 6]:.2f}")
     pw = (buf[nwg * 16: (nwg + 1) * 16].astype(np.int64) - t0) * 0.01
     print("  prior part, per wave, arrival at the barrier that ends the bounds: " + " ".join(f"{v:.2f}" for v in pw[8:]))
-    print("  seq (thread 0): " + " ".join(f"{v:.2f}" for v in pw[:4]))
+    print("  prior part, per wave, own top-two jobs done (complete pair tables): " + " ".join(f"{v:.2f}" for v in pw[:8]))
+    print("  general epilogue (past 64 teams; overwrites waves 4..6 of the line before last): header read %.2f, teams done %.2f, sums done %.2f" % tuple(pw[12:15]))
     c.close()
 
 def run_nuts(n=1_000_000):

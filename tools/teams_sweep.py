@@ -9,8 +9,11 @@ if "ACTIVE_WAVES" in os.environ:   # experiment: a fixed partition (8 = all wave
     c.set_option("active_waves", int(os.environ["ACTIVE_WAVES"]))
 if "MAX_WG" in os.environ:
     c.set_option("max_wg", int(os.environ["MAX_WG"]))
+if "PAIR_ORDER" in os.environ:    # 0: fixtures in (home, away) order whatever the league's size (default: Z-order past 64 teams)
+    c.set_option("pair_order", int(os.environ["PAIR_ORDER"]))
+N = int(float(os.environ.get("N", "1e6")))
 for T in [int(t) for t in os.environ.get("TEAMS_LIST", "20,32,48,64,100,200").split(",")]:
-    h, a, x, y = synthetic_league(1_000_000, T)
+    h, a, x, y = synthetic_league(N, T)
     c.set_fixtures(MODEL_BASIC, h, a, x, y, T)
     D = c.dim
     z = torch.tensor(np.random.RandomState(7).uniform(-.5, .5, (64, D)), dtype=torch.float64, device=c.device)
@@ -20,4 +23,4 @@ for T in [int(t) for t in os.environ.get("TEAMS_LIST", "20,32,48,64,100,200").sp
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(); c.logp_grad_graph(64, z, U, g, replays=8); e1.record(); torch.cuda.synchronize()
         ts.append(e0.elapsed_time(e1) * 1e3 / 512)
-    print(f"T={T:4d} D={D:4d} pairs={T * (T - 1):6d}: {np.median(ts):7.2f} us/eval", flush=True)
+    print(f"N={N} T={T:4d} D={D:4d} pairs={T * (T - 1):6d}: {np.median(ts):7.2f} us/eval", flush=True)
