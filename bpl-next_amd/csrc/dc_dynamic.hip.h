@@ -1107,6 +1107,12 @@ __global__ __launch_bounds__(FUSED_DYN_BLOCK) void dyn_fused(DynArgs A) {
     const long long i_first = i_lo + tid;
     DynFx first{};
     if (!BIG) first = load_fx(i_first < A.n ? i_first : A.n - 1);
+    // (gathering form: this cell's incidence list is data -- its bounds are requested once the cells are out and
+    // its first four entries in the second barrier's shadow, all of it long landed when phase 4 wants it;
+    // requested there, the two dependent loads sat in front of the adjoint records' round trip.  Any earlier and
+    // the cells went out later: +0.3 us with the bounds among the position's loads, +0.5 with the entries
+    // requested right behind the cells.)
+    const bool gathers = !BIG && A.gather;
     const int o_std[6] = {L.o_s_att, L.o_s_def, L.o_s_ha, L.o_s_aa, L.o_s_hd, L.o_s_ad};
     double zstd[6];
 #pragma unroll
@@ -1157,6 +1163,11 @@ __global__ __launch_bounds__(FUSED_DYN_BLOCK) void dyn_fused(DynArgs A) {
     if (BIG && blockIdx.x * WAVES < (unsigned int)T)   // (a workgroup with teams)
         tree_arrive(A.tickets, TB_1, blockIdx.x, (unsigned int)((T + WAVES - 1) / WAVES));
     DYN_STAMP(1);
+    int inc_e0 = 0, inc_e1 = 0;
+    if (gathers && on) {
+        inc_e0 = A.inc_off[c];
+        inc_e1 = A.inc_off[c + 1];
+    }
     // corr_coef_raw's sigmoid (phase 3 needs it) -- while the other workgroups' cells travel.  The
     // rest of what does not depend on the fixtures runs in the barriers' shadows (a grid barrier is
     // ~2 us of memory-side round trips after the last arrival).
@@ -1341,6 +1352,12 @@ __global__ __launch_bounds__(FUSED_DYN_BLOCK) void dyn_fused(DynArgs A) {
     DYN_STAMP(4);
     if (BIG) tree_arrive(A.tickets, TB_2, blockIdx.x, nb);
     else grid_arrive(A.tickets + TK_B2);
+    // (the first four entries of this cell's incidence list, in the barrier's shadow: their bounds landed long ago)
+    unsigned int inc_w[4] = {0u, 0u, 0u, 0u};
+    if (gathers) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) inc_w[u] = A.inc[inc_e0 + u < inc_e1 ? inc_e0 + u : (inc_e1 > inc_e0 ? inc_e1 - 1 : 0)];
+    }
     // (second shadow: the u site.  u = sigmoid(zu) ~ Beta(2,4): one exp + one log1p serve the
     // value, its derivative, log u = -sp(-zu), log(1-u) = -sp(zu) and the Jacobian; then its part
     // of the gradient)
@@ -1537,18 +1554,27 @@ __global__ __launch_bounds__(FUSED_DYN_BLOCK) void dyn_fused(DynArgs A) {
 
     // ---- phase 4: this wave's team again
     double G6[A_N];
+    // (the sum and the three packed fixtures the bounds' adjoint needs travel in the SAME round of loads as the
+    // adjoint records / accumulators: requested behind them -- the records' loads end in a wait -- they were
+    // one more memory round trip)
+    const unsigned long long keyP = __hip_atomic_load(&scu[SC_IDXP], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long keyQ = __hip_atomic_load(&scu[SC_IDXQ], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long keyR = __hip_atomic_load(&scu[SC_IDXR], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    double g_rho_small = 0.0;
+    if (!BIG) g_rho_small = dc::ld_sc1(&A.sc[SC_GRHO]);
     if (!BIG && A.gather) {
         // this cell's fixtures, in list order: {dL/d eta_home, dL/d eta_away} of each, booked by the side the
         // team plays (the signs and the venue switch of the atomics' path above); all of a round's loads in
         // flight together (up to GATHER_MAX_INCIDENT entries: host)
 #pragma unroll
         for (int j = 0; j < A_N; ++j) G6[j] = 0.0;
-        const int e0 = on ? A.inc_off[c] : 0, e1 = on ? A.inc_off[c + 1] : 0;
+        const int e0 = inc_e0, e1 = inc_e1;
         for (int eb = e0; __ballot(eb < e1) != 0ull; eb += 4) {
             unsigned int w[4];
             dc::double2_t v[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) w[u] = A.inc[eb + u < e1 ? eb + u : (e1 > e0 ? e1 - 1 : 0)];
+            for (int u = 0; u < 4; ++u)
+                w[u] = eb == e0 ? inc_w[u] : A.inc[eb + u < e1 ? eb + u : (e1 > e0 ? e1 - 1 : 0)];
             dc::ld_sc1_x2_4(A.fadj + 2 * (size_t)(w[0] & 0x3FFFFFFFu), A.fadj + 2 * (size_t)(w[1] & 0x3FFFFFFFu),
                             A.fadj + 2 * (size_t)(w[2] & 0x3FFFFFFFu), A.fadj + 2 * (size_t)(w[3] & 0x3FFFFFFFu), v);
 #pragma unroll
@@ -1578,13 +1604,8 @@ __global__ __launch_bounds__(FUSED_DYN_BLOCK) void dyn_fused(DynArgs A) {
         for (int g_ = 0; g_ < SC_GROUPS; ++g_) sum += part[g_];
         b.G_rho = sum;
     } else {
-        b.G_rho = dc::ld_sc1(&A.sc[SC_GRHO]);
+        b.G_rho = g_rho_small;
     }
-    // (all three packed fixtures with the accumulators, in one round of loads: behind the
-    // comparisons that pick two of them each was a dependent round trip of its own)
-    const unsigned long long keyP = __hip_atomic_load(&scu[SC_IDXP], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned long long keyQ = __hip_atomic_load(&scu[SC_IDXQ], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned long long keyR = __hip_atomic_load(&scu[SC_IDXR], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     {
         // the bounds' adjoint reaches (at most) two fixtures: the one with the largest rate
         // product (when it binds, M > 1) through both rates, the one with the largest single
@@ -1698,7 +1719,9 @@ __global__ __launch_bounds__(FUSED_DYN_BLOCK) void dyn_fused(DynArgs A) {
         const dc::double2_t empty2 = {empty, empty};
         P2[0] = empty2; P2[1] = empty2; P2[2] = empty2;
     }
-    __syncthreads();
+    // (LDS traffic only -- s_last: __syncthreads() would wait for the stores above, a memory round trip in front
+    // of the last workgroup's final part)
+    dc::lds_barrier();
     if (!s_last) {
         DYN_STAMP_FLUSH;
         return;
