@@ -181,9 +181,14 @@ int bplhip_set_fixtures_neutral(bplhip_ctx* ctx, int64_t n, int32_t n_teams,
  *   "dyn_big_wgs" 0 (default) = the sliced single launch uses one workgroup per CU, and the
  *            dynamic model takes it past 1024 fixtures per team workgroup; > 0 = that many
  *            workgroups, and the dynamic model takes the sliced form whatever its size.
- *   "dense_pairs" 1 (default) = a complete pair table (every ordered pair h != a present) of 8192
- *            pairs or more takes the rho bounds from the top two table entries per role
- *            (O(teams)); 0 = always walk the pair table.
+ *   "dense_pairs" 1 (default) = a complete pair table (every ordered pair h != a present) of 4096
+ *            pairs or more -- every complete table past 64 teams -- takes the rho bounds from the
+ *            top two table entries per role (O(teams)); 0 = always walk the pair table.
+ *   "pair_order" -1 (default) = past 64 teams the fixtures are laid out along the Z-order curve over
+ *            (home, away), so that a workgroup's slice touches ~sqrt of its pairs' teams; up to 64
+ *            teams in (home, away) order.  0 / 1 = (home, away) / Z-order whatever the league's
+ *            size.  Applies at the next bplhip_set_fixtures; results do not depend on it beyond
+ *            the order of the float32 run sums.
  *   "max_wg" streaming workgroups per evaluation, 1..255 (default 255: with the prior workgroup
  *            one per CU; an accumulator row counts its contributors in 8 bits); applies at the next
  *            bplhip_set_fixtures
