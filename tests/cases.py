@@ -43,6 +43,12 @@ def fixtures(name):
         n = int(float(name.split("_")[1]))
         h, a, x, y = O.synthetic_league(n)
         return O.Fixtures(h, a, x, y, 20)
+    if name.startswith("widewc"):  # many teams, time weights AND covariates: widewc_N_T
+        _, n, T = name.split("_")
+        fx = fixtures(f"wide_{n}_{T}")
+        fx.weights = float32_weights(np.linspace(4, 0, int(n)), 1.0)
+        fx.covariates = np.random.RandomState(int(T)).normal(size=(int(T), 3))
+        return fx
     if name.startswith("wide"):  # many teams (> 64: the general tail epilogue): wide_N_T
         _, n, T = name.split("_")
         n, T = int(n), int(T)

@@ -83,6 +83,9 @@ CASES = [
     (O.MODEL_BASIC, "wide_4000_100"),
     (O.MODEL_EXTENDED, "wide_4000_100"),
     (O.MODEL_BASIC, "wide_30000_700"),
+    # ... with time weights and covariates (the lanes' exact rate products past 64 teams, weighted and clipped forms)
+    (O.MODEL_EXTENDED, "widewc_20000_80"),
+    (O.MODEL_EXTENDED, "widewc_60000_150"),
 ]
 
 
@@ -117,6 +120,44 @@ def test_near_bound_points(hip_ctx, model, name):
         _check(model, fx, f"{name}/{pname}", z, U, g, aux, cond=True)
         assert U == Ub[i] and np.array_equal(g, gb[i]) and np.array_equal(aux, auxb[i])
         _check(model, fx, f"{name}/{pname} [vec]", z, Uv[i], gv[i], auxv[i], cond=True)
+
+
+@pytest.mark.parametrize("model,name", [(O.MODEL_BASIC, "wide_4000_100"), (O.MODEL_EXTENDED, "widewc_20000_80"),
+                                        (O.MODEL_BASIC, "league_1e5")])
+def test_fixture_layouts_agree(hip_ctx, model, name):
+    """Option pair_order: the fixtures in (home, away) order (0) and along the Z-order curve over (home, away)
+    (1; the default past 64 teams) are the same evaluation -- same rho, bounds and arg-extremal pairs (the pair
+    table keeps its order: the tie rule), U and the gradient equal up to the order of the float32 run sums --
+    and both agree with the oracle.  (league_1e5: 20 teams, where the default is (home, away) order.)"""
+    import torch
+
+    fx = cases.fixtures(name)
+    pts = cases.z_points(model, fx)
+    cov = None
+    if model == O.MODEL_EXTENDED and fx.covariates is not None:
+        cov = (fx.covariates - fx.covariates.mean(axis=0)) / fx.covariates.std(axis=0)
+    w32 = None if fx.weights is None else fx.weights.astype(np.float32)
+    outs = {}
+    try:
+        for order in (0, 1):
+            hip_ctx.set_option("pair_order", order)
+            hip_ctx.set_fixtures(model, fx.home_idx.astype(np.uint16), fx.away_idx.astype(np.uint16),
+                                 fx.home_goals.astype(np.uint8), fx.away_goals.astype(np.uint8), fx.n_teams,
+                                 weights=w32, covariates_std=cov)
+            outs[order] = [tuple(t.cpu().numpy().copy() for t in
+                                 hip_ctx.logp_grad(torch.tensor(z, dtype=torch.float64, device=hip_ctx.device)))
+                           for _, z in pts]
+    finally:
+        hip_ctx.set_option("pair_order", -1)
+    for i, (pname, z) in enumerate(pts):
+        (U0, g0, a0), (U1, g1, a1) = outs[0][i], outs[1][i]
+        assert np.array_equal(a0, a1), "rho, LB, UB, q"
+        if np.isfinite(U0[0]):
+            tol = cases.u_tolerance(fx.n, float(U0[0]))
+            assert abs(U1[0] - U0[0]) <= 0.2 * tol, (pname, U0[0], U1[0])
+            assert np.abs(g1 - g0).max() <= 0.5 * (5e-7 * np.abs(g0).max() + 1e-7)
+        _check(model, fx, f"{name}/{pname} [(home, away)]", z, float(U0[0]), g0.reshape(-1), a0[0])
+        _check(model, fx, f"{name}/{pname} [Z-order]", z, float(U1[0]), g1.reshape(-1), a1[0])
 
 
 def test_full_size_1e6(hip_ctx):
