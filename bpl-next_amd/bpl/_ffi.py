@@ -45,9 +45,11 @@ ABI_SYMBOLS = (
     "bplhip_predict_set_posterior",
     "bplhip_predict_score_proba",
     "bplhip_predict_score_grid",
+    "bplhip_predict_score_grid_f32",
     "bplhip_predict_set_posterior_venue",
     "bplhip_predict_score_proba_venue",
     "bplhip_predict_score_grid_venue",
+    "bplhip_predict_score_grid_venue_f32",
     "bplhip_selftest_math",
     "bplhip_threefry_split",
     "bplhip_threefry_bits",
@@ -154,12 +156,16 @@ def load_library():
     lib.bplhip_predict_score_proba.restype = C.c_int
     lib.bplhip_predict_score_grid.argtypes = [vp, i64, vp, vp, i32, vp, vp]
     lib.bplhip_predict_score_grid.restype = C.c_int
+    lib.bplhip_predict_score_grid_f32.argtypes = [vp, i64, vp, vp, i32, vp, vp]
+    lib.bplhip_predict_score_grid_f32.restype = C.c_int
     lib.bplhip_predict_set_posterior_venue.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp, vp, i32, vp, vp]
     lib.bplhip_predict_set_posterior_venue.restype = C.c_int
     lib.bplhip_predict_score_proba_venue.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.bplhip_predict_score_proba_venue.restype = C.c_int
     lib.bplhip_predict_score_grid_venue.argtypes = [vp, i64, vp, vp, vp, vp, vp, i32, vp, vp]
     lib.bplhip_predict_score_grid_venue.restype = C.c_int
+    lib.bplhip_predict_score_grid_venue_f32.argtypes = [vp, i64, vp, vp, vp, vp, vp, i32, vp, vp]
+    lib.bplhip_predict_score_grid_venue_f32.restype = C.c_int
     lib.bplhip_selftest_math.argtypes = [vp, i32, i64, vp, vp]
     lib.bplhip_selftest_math.restype = C.c_int
     lib.bplhip_threefry_split.argtypes = [u32, u32, i32, C.POINTER(u32)]
@@ -498,21 +504,29 @@ class HipContext:
                     _np_ptr(out), self._stream()))
         return out
 
-    def predict_score_grid(self, home_idx, away_idx, max_goals: int, neutral=None, conf=None) -> np.ndarray:
-        """[m, max_goals+1, max_goals+1] scoreline probabilities of the m fixtures."""
+    def predict_score_grid(self, home_idx, away_idx, max_goals: int, neutral=None, conf=None,
+                           dtype=np.float64) -> np.ndarray:
+        """[m, max_goals+1, max_goals+1] scoreline probabilities of the m fixtures; dtype float64 (default) or
+        float32 (the reference's own: half the bytes over PCIe)."""
         h = np.ascontiguousarray(home_idx, dtype=np.uint16)
         a = np.ascontiguousarray(away_idx, dtype=np.uint16)
         if h.size != a.size:
             raise ValueError("home and away index arrays must have equal length")
+        dtype = np.dtype(dtype)
+        if dtype not in (np.dtype(np.float64), np.dtype(np.float32)):
+            raise ValueError("predict_score_grid: dtype is float64 or float32")
+        f32 = dtype == np.dtype(np.float32)
         g1 = int(max_goals) + 1
-        out = np.empty((h.size, g1, g1), dtype=np.float64)
+        out = np.empty((h.size, g1, g1), dtype=dtype)
         with self._torch.cuda.device(self.device):
             if neutral is None:
-                self._check(self._lib.bplhip_predict_score_grid(
+                fn = self._lib.bplhip_predict_score_grid_f32 if f32 else self._lib.bplhip_predict_score_grid
+                self._check(fn(
                     self._h, h.size, _np_ptr(h), _np_ptr(a), int(max_goals), _np_ptr(out), self._stream()))
             else:
                 nv, hc, ac = self._venue_args(h.size, neutral, conf)
-                self._check(self._lib.bplhip_predict_score_grid_venue(
+                fn = self._lib.bplhip_predict_score_grid_venue_f32 if f32 else self._lib.bplhip_predict_score_grid_venue
+                self._check(fn(
                     self._h, h.size, _np_ptr(h), _np_ptr(a), _np_ptr(nv),
                     None if hc is None else _np_ptr(hc), None if ac is None else _np_ptr(ac),
                     int(max_goals), _np_ptr(out), self._stream()))

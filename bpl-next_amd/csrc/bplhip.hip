@@ -2864,7 +2864,7 @@ static int predict_check_query(bplhip_ctx* c, const char* what, bool venue, int6
 
 static int predict_score_grid_any(bplhip_ctx* c, const char* what, bool venue, int64_t m, const uint16_t* home_idx,
                                   const uint16_t* away_idx, const uint8_t* neutral, const uint16_t* home_conf,
-                                  const uint16_t* away_conf, int32_t max_goals, double* out, void* stream) {
+                                  const uint16_t* away_conf, int32_t max_goals, void* out, bool f32, void* stream) {
     if (!c) return BPLHIP_EINVAL;
     if (max_goals < 0 || max_goals > dcp::GRID_MAX_GOALS)
         return fail(c, BPLHIP_EINVAL, "%s: max_goals=%d out of range [0,%d]", what, max_goals, dcp::GRID_MAX_GOALS);
@@ -2877,7 +2877,8 @@ static int predict_score_grid_any(bplhip_ctx* c, const char* what, bool venue, i
     const size_t cells = (size_t)m * (max_goals + 1) * (max_goals + 1);
     // u16 h, a, hc, ac then u8 neutral, rounded up to 8 bytes
     const size_t idx_bytes = ((size_t)m * 9 + 7) & ~(size_t)7;
-    HIP_TRY(c, c->dp_q.ensure(idx_bytes + cells * 8));
+    const size_t cell_bytes = f32 ? 4 : 8;
+    HIP_TRY(c, c->dp_q.ensure(idx_bytes + cells * cell_bytes));
     uint16_t* q = c->dp_q.as<uint16_t>();
     uint8_t* qn = reinterpret_cast<uint8_t*>(q + 4 * m);
     double* d_out = reinterpret_cast<double*>(c->dp_q.as<char>() + idx_bytes);
@@ -2918,12 +2919,13 @@ static int predict_score_grid_any(bplhip_ctx* c, const char* what, bool venue, i
     A.hc = q + 2 * m;
     A.ac = q + 3 * m;
     A.neutral = qn;
-    A.out = d_out;
+    A.out = f32 ? nullptr : d_out;
+    A.out32 = f32 ? reinterpret_cast<float*>(d_out) : nullptr;
     const dim3 grid((unsigned)((m + dcp::GRID_WAVES - 1) / dcp::GRID_WAVES)), block(64 * dcp::GRID_WAVES);
     if (venue) hipLaunchKernelGGL(dcp::predict_score_grid<true>, grid, block, 0, s, A);
     else hipLaunchKernelGGL(dcp::predict_score_grid<false>, grid, block, 0, s, A);
     HIP_TRY(c, hipGetLastError());
-    HIP_TRY(c, hipMemcpyAsync(out, d_out, cells * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(out, d_out, cells * cell_bytes, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
     return BPLHIP_OK;
 }
@@ -3055,7 +3057,14 @@ extern "C" int bplhip_predict_score_grid(bplhip_ctx* c, int64_t m, const uint16_
                                          const uint16_t* away_idx, int32_t max_goals, double* out,
                                          void* stream) {
     return guarded(c, "bplhip_predict_score_grid", [&] {
-        return predict_score_grid_any(c, "predict_score_grid", false, m, home_idx, away_idx, nullptr, nullptr, nullptr, max_goals, out, stream);
+        return predict_score_grid_any(c, "predict_score_grid", false, m, home_idx, away_idx, nullptr, nullptr, nullptr, max_goals, out, false, stream);
+    });
+}
+extern "C" int bplhip_predict_score_grid_f32(bplhip_ctx* c, int64_t m, const uint16_t* home_idx,
+                                             const uint16_t* away_idx, int32_t max_goals, float* out,
+                                             void* stream) {
+    return guarded(c, "bplhip_predict_score_grid_f32", [&] {
+        return predict_score_grid_any(c, "predict_score_grid_f32", false, m, home_idx, away_idx, nullptr, nullptr, nullptr, max_goals, out, true, stream);
     });
 }
 extern "C" int bplhip_predict_set_posterior_venue(bplhip_ctx* c, int32_t s, int32_t t, const double* attack,
@@ -3074,7 +3083,15 @@ extern "C" int bplhip_predict_score_grid_venue(bplhip_ctx* c, int64_t m, const u
                                                const uint16_t* home_conf, const uint16_t* away_conf,
                                                int32_t max_goals, double* out, void* stream) {
     return guarded(c, "bplhip_predict_score_grid_venue", [&] {
-        return predict_score_grid_any(c, "predict_score_grid_venue", true, m, home_idx, away_idx, neutral_venue, home_conf, away_conf, max_goals, out, stream);
+        return predict_score_grid_any(c, "predict_score_grid_venue", true, m, home_idx, away_idx, neutral_venue, home_conf, away_conf, max_goals, out, false, stream);
+    });
+}
+extern "C" int bplhip_predict_score_grid_venue_f32(bplhip_ctx* c, int64_t m, const uint16_t* home_idx,
+                                                   const uint16_t* away_idx, const uint8_t* neutral_venue,
+                                                   const uint16_t* home_conf, const uint16_t* away_conf,
+                                                   int32_t max_goals, float* out, void* stream) {
+    return guarded(c, "bplhip_predict_score_grid_venue_f32", [&] {
+        return predict_score_grid_any(c, "predict_score_grid_venue_f32", true, m, home_idx, away_idx, neutral_venue, home_conf, away_conf, max_goals, out, true, stream);
     });
 }
 extern "C" int bplhip_predict_score_proba_venue(bplhip_ctx* c, int64_t m, const uint16_t* home_idx,

@@ -136,6 +136,7 @@ struct GridArgs {
     const uint16_t* hc;      // with confederations: [M] each
     const uint16_t* ac;
     double* out;             // [M, G+1, G+1]
+    float* out32;            // ... or, when not null, the same grids as float32 (the reference's own dtype: half the copy back)
     float rk[64];            // 1 / (k + 1): by value, i.e. in the kernarg segment -- wave-uniform scalar loads
     double rfact[16];        // 1 / k!, k < 16 (the first tile's cells are scaled at the end)
 };
@@ -155,6 +156,7 @@ __global__ __launch_bounds__(64 * GRID_WAVES) void predict_score_grid(GridArgs A
     const int h = A.h[f], a = A.a[f], G = A.G, S = A.S;
     const int G1 = G + 1, nt = (G + 16) / 16;
     double* out = A.out + (size_t)f * G1 * G1;
+    float* out32 = A.out32 ? A.out32 + (size_t)f * G1 * G1 : nullptr;   // (wave uniform)
     const double inv_s = 1.0 / (double)S;
     constexpr float LOG2E = 1.44269504088896341f;
     const float* att_h = A.attack + (size_t)h * S;
@@ -316,7 +318,10 @@ __global__ __launch_bounds__(64 * GRID_WAVES) void predict_score_grid(GridArgs A
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int xo = x0 + 4 * d + j, y = y0 + i;
-                if (xo <= G && y <= G) out[(size_t)xo * G1 + y] = accd[j] * inv_s;
+                if (xo <= G && y <= G) {
+                    if (out32) out32[(size_t)xo * G1 + y] = (float)(accd[j] * inv_s);
+                    else out[(size_t)xo * G1 + y] = accd[j] * inv_s;
+                }
             }
         }
 }

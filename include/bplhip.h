@@ -332,6 +332,13 @@ int bplhip_predict_score_proba(bplhip_ctx* ctx, int64_t m, const uint16_t* home_
 int bplhip_predict_score_grid(bplhip_ctx* ctx, int64_t m, const uint16_t* home_idx,
                               const uint16_t* away_idx, int32_t max_goals, double* out,
                               void* stream);
+/* ... the same grids as HOST f32[m, max_goals+1, max_goals+1] -- the dtype the reference's
+ * predict_score_grid_proba returns (jax float32, bpl/base.py:74-111): the float64 accumulators
+ * are rounded once at the store, and half as many bytes come back over PCIe (the copy back is
+ * most of a large query: 97 280 grids of 16 x 16 are 199 MB as float64). */
+int bplhip_predict_score_grid_f32(bplhip_ctx* ctx, int64_t m, const uint16_t* home_idx,
+                                  const uint16_t* away_idx, int32_t max_goals, float* out,
+                                  void* stream);
 
 /* The same three entry points for the venue-aware rate form of the neutral-venue family:
  * `_calculate_expected_goals` of bpl/neutral_dixon_coles.py:399-423 (four per-team offsets that
@@ -365,6 +372,10 @@ int bplhip_predict_score_grid_venue(bplhip_ctx* ctx, int64_t m, const uint16_t* 
                                     const uint16_t* away_idx, const uint8_t* neutral_venue,
                                     const uint16_t* home_conf, const uint16_t* away_conf,
                                     int32_t max_goals, double* out, void* stream);
+int bplhip_predict_score_grid_venue_f32(bplhip_ctx* ctx, int64_t m, const uint16_t* home_idx,
+                                        const uint16_t* away_idx, const uint8_t* neutral_venue,
+                                        const uint16_t* home_conf, const uint16_t* away_conf,
+                                        int32_t max_goals, float* out, void* stream);
 
 /* Self-test of the library's own float64 device math (csrc/dc_kernels.hip.h, namespace
  * dc::lean -- the short exp / log / log1p / reciprocal the float64 kernels use on their critical

@@ -397,6 +397,10 @@ def test_device_predict_matches_float64_restatement(fitted, model_cls):
         assert xs[3, 0] == 3 and ys[0, 3] == 3
         err = np.abs(grid - want)
         assert (err <= 3e-6 * want + 1e-12).all(), (depth, err.max())
+        # float32 output (bplhip_predict_score_grid_f32; the reference's own dtype): the float64 accumulators
+        # rounded once, at the store
+        g32 = model._device().predict_score_grid(h[:60], a[:60], depth, dtype=np.float32)
+        assert g32.dtype == np.float32 and np.array_equal(g32, grid.astype(np.float32))
     # the reductions of the grid
     out = model.predict_outcome_proba(dd["home_team"][:40], dd["away_team"][:40])
     g = ref.predict_score_grid(h[:40], a[:40], MAX_GOALS)

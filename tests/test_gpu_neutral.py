@@ -242,6 +242,9 @@ def _venue_check(m, h, a, nv, conf, x, y):
                                       None if conf is None else (conf[0][:40], conf[1][:40]))
         err = np.abs(grid - want)
         assert (err <= 3e-6 * want + 1e-12).all(), (depth, err.max(), (err / (want + 1e-300)).max())
+        g32 = m._device().predict_score_grid(h[:40], a[:40], depth, neutral=nv[:40],
+                                             conf=None if conf is None else (conf[0][:40], conf[1][:40]), dtype=np.float32)
+        assert g32.dtype == np.float32 and np.array_equal(g32, np.asarray(grid).astype(np.float32))   # (bplhip_predict_score_grid_venue_f32)
     return ref
 
 

@@ -36,3 +36,6 @@ big = np.tile(np.array(pairs), (256, 1))  # 97 280 fixtures
 t0 = time.perf_counter(); gb = c.predict_score_grid(big[:, 0], big[:, 1], MG - 1); tb = time.perf_counter() - t0
 print(f"predict_score_grid: {len(big)} fixtures ({gb.size * 8 / 1e6:.0f} MB of grids): {tb * 1e3:.1f} ms end to end, "
       f"{len(big) * MG * MG * S / tb / 1e12:.2f} T cell-draws/s")
+t0 = time.perf_counter(); g32 = c.predict_score_grid(big[:, 0], big[:, 1], MG - 1, dtype=np.float32); t32 = time.perf_counter() - t0
+print(f"predict_score_grid, float32 output: {len(big)} fixtures ({g32.size * 4 / 1e6:.0f} MB of grids): {t32 * 1e3:.1f} ms end to end; "
+      f"equal to the rounded float64 grids: {bool(np.array_equal(g32, gb.astype(np.float32)))}")
