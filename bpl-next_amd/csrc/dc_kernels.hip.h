@@ -1949,6 +1949,25 @@ __device__ void tail_waves(const EvalArgs& A, int chain, const double* zoL, cons
     // covariate coefficients: sum_t Xs[t,k] g_t for every k, four sums in flight; lane j of a
     // batch stores its coefficient
     auto cov_grad = [&](int o, double gt) {
+        if (K <= 8 && xsL != nullptr) {   // (wave uniform)
+            // up to eight coefficients in ONE pass: lane 8 k + j takes coefficient k over teams j, j + 8, ...
+            // (g_t from lane t by a wave shuffle, the covariates from the LDS copy), then three DPP steps fold
+            // the eight lanes of a coefficient.  Four wave-wide float64 sums per round of four coefficients were
+            // 0.6 us of the extended model's 8.2 with five covariates (a what-if build without them: 7.6).
+            const int k = t >> 3, j = t & 7;
+            double sk = 0.0;
+            for (int tb = 0; tb < T; tb += 8) {   // (wave-uniform trip count)
+                const int tt = tb + j;
+                const double g = __shfl(gt, tt < 64 ? tt : 63);
+                const double xv = k < K && tt < T ? xsL[(size_t)tt * K + k] : 0.0;
+                sk += xv * g;
+            }
+            sk += dpp_f64<0x141>(0.0, sk);   // row_half_mirror: lane j <-> 7 - j
+            sk += dpp_f64<0xB1>(0.0, sk);    // quad_perm [1,0,3,2]
+            sk += dpp_f64<0x4E>(0.0, sk);    // quad_perm [2,3,0,1]
+            if (j == 0 && k < K) put(o + k, gz[o + k] - sk);
+            return;
+        }
         for (int k0 = 0; k0 < K; k0 += 4) {
             double v[4];
 #pragma unroll
