@@ -21,6 +21,11 @@ def _league(n, teams=20):
     ("basic 3800", 3_800, False, 0, False, 20),
     ("extended 1e6, 5 covariates, weighted", 1_000_000, True, 5, True, 20),
     ("basic 2e5, 100 teams (separable bounds, general tail)", 200_000, False, 0, False, 100),
+    # (round 4's tail past 64 teams: rows polled beside the record, two per thread at 200 teams; no barrier behind
+    # separable bounds; the pair walk of an incomplete table; exact rate products with weights and covariates)
+    ("basic 4e5, 200 teams", 400_000, False, 0, False, 200),
+    ("basic 5e4, 300 teams (incomplete pair table)", 50_000, False, 0, False, 300),
+    ("extended 3e5, 150 teams, 3 covariates, weighted", 300_000, True, 3, True, 150),
 ])
 def test_repeats_are_bit_identical(hip_ctx, name, n, extended, k, weighted, teams):
     import torch
