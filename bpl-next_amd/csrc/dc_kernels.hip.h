@@ -923,6 +923,56 @@ __device__ __forceinline__ Top2<F> wave_top2(int T, int lane, Get get) {
     R.m2 = b2 ? R.m2 : (F)0;
     return R;
 }
+// two float32 arrays at once (the prior part's waves that take two jobs: one pass over the table entries for
+// both, the maxima of both reduced step by step together -- a wave issues a dependent DPP + max only every ~20
+// cycles; two jobs one after the other were the longest pole of the bounds past 64 teams).  Results as wave_top2's.
+template <class Get2>
+__device__ __forceinline__ void wave_top2_pair_f32(int T, int lane, Get2 get2, Top2<float>* RA, Top2<float>* RB) {
+    float a1[2] = {0.f, 0.f}, a2[2] = {0.f, 0.f};
+    int j1[2] = {-1, -1}, j2[2] = {-1, -1};
+    for (int b = 0; b < T; b += 256) {
+        float v[4][2];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) get2(min(b + 64 * k + lane, T - 1), &v[k][0], &v[k][1]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int t = b + 64 * k + lane;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const bool first = t < T && v[k][q] > a1[q], second = t < T && !first && v[k][q] > a2[q];
+                a2[q] = first ? a1[q] : second ? v[k][q] : a2[q];
+                j2[q] = first ? j1[q] : second ? t : j2[q];
+                a1[q] = first ? v[k][q] : a1[q];
+                j1[q] = first ? t : j1[q];
+            }
+        }
+    }
+    Top2<float> R[2];
+    float m0 = a1[0], m1 = a1[1], d0 = 0.f;
+    wave_max3_f32(m0, m1, d0);
+    R[0].m1 = m0; R[1].m1 = m1;
+    float c[2];
+    int jc[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const unsigned long long b1 = __ballot(a1[q] == R[q].m1 && j1[q] >= 0);
+        const int win = b1 ? __ffsll((long long)b1) - 1 : 0;
+        R[q].i1 = b1 ? __builtin_amdgcn_readlane(j1[q], win) : -1;
+        c[q] = lane == win ? a2[q] : a1[q];
+        jc[q] = lane == win ? j2[q] : j1[q];
+    }
+    float n0 = c[0], n1 = c[1], d1 = 0.f;
+    wave_max3_f32(n0, n1, d1);
+    R[0].m2 = n0; R[1].m2 = n1;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const unsigned long long b2 = __ballot(c[q] == R[q].m2 && jc[q] >= 0);
+        R[q].i2 = b2 ? __builtin_amdgcn_readlane(jc[q], b2 ? __ffsll((long long)b2) - 1 : 0) : -1;
+        R[q].m2 = b2 ? R[q].m2 : 0.f;
+    }
+    *RA = R[0];
+    *RB = R[1];
+}
 // max over h != a of x_h * y_a from the top two of x and of y; *ph, *pa: the pair (or -1)
 template <class F>
 __device__ __forceinline__ F dense_pair_max(F x1, int ix1, F x2, int ix2, F y1, int iy1, F y2, int iy2,
@@ -969,8 +1019,23 @@ __device__ __forceinline__ bool dense_maxima_f32(int T, const float2* tabH, cons
         if (wave < DENSE_ARRAYS) job(wave);
     } else if (wave >= DENSE_ARRAYS) {
         static_assert(WAVES == 8 && DENSE_ARRAYS == 5, "float32 arrays 0..4 on waves 5, 5, 6, 6, 7");
-        job(2 * (wave - DENSE_ARRAYS));
-        if (wave < WAVES - 1) job(2 * (wave - DENSE_ARRAYS) + 1);
+        if (wave < WAVES - 1) {   // arrays (0, 1) on wave 5, (2, 3) on wave 6: both in one pass
+            const int j0 = 2 * (wave - DENSE_ARRAYS);
+            Top2<float> Ra, Rb;
+            wave_top2_pair_f32(T, lane, [&](int t, float* va, float* vb) {
+                const float2 th = tabH[t], ta = tabA[t];
+                *va = j0 == 0 ? th.x : th.y;
+                *vb = j0 == 0 ? ta.x : th.x * th.y;
+            }, &Ra, &Rb);
+            if (lane == 0) {
+                rec[j0 * 4 + 0] = Ra.m1; rec[j0 * 4 + 1] = Ra.m2;
+                rec[j0 * 4 + 2] = __int_as_float(Ra.i1); rec[j0 * 4 + 3] = __int_as_float(Ra.i2);
+                rec[j0 * 4 + 4] = Rb.m1; rec[j0 * 4 + 5] = Rb.m2;
+                rec[j0 * 4 + 6] = __int_as_float(Rb.i1); rec[j0 * 4 + 7] = __int_as_float(Rb.i2);
+            }
+        } else {
+            job(2 * (wave - DENSE_ARRAYS));   // (wave 7: array 4)
+        }
     }
 #ifdef DC_STAMPS
     if (PRIOR && lane == 0 && dbg) dbg[wave] = __builtin_amdgcn_s_memrealtime();
