@@ -9,17 +9,23 @@ from bpl._ffi import HipContext, MODEL_BASIC, MODEL_EXTENDED, default_nuts_cfg
 
 REPLAYS = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
 c = HipContext(0)
-for name, n, model, k, weighted in (("basic 1e6", 1_000_000, MODEL_BASIC, 0, False),
-                                    ("basic 3800", 3_800, MODEL_BASIC, 0, False),
-                                    ("extended 1e6 K=5", 1_000_000, MODEL_EXTENDED, 5, False),
-                                    ("extended 1e6 K=5 weighted", 1_000_000, MODEL_EXTENDED, 5, True),
-                                    ("basic 1e7", 10_000_000, MODEL_BASIC, 0, False)):
-    h, a, x, y = synthetic_league(n, 20)
+for name, n, model, k, weighted, T in (("basic 1e6", 1_000_000, MODEL_BASIC, 0, False, 20),
+                                       ("basic 3800", 3_800, MODEL_BASIC, 0, False, 20),
+                                       ("extended 1e6 K=5", 1_000_000, MODEL_EXTENDED, 5, False, 20),
+                                       ("extended 1e6 K=5 weighted", 1_000_000, MODEL_EXTENDED, 5, True, 20),
+                                       ("basic 1e7", 10_000_000, MODEL_BASIC, 0, False, 20),
+                                       # past 64 teams (round 4: rows polled beside the record, no barrier behind
+                                       # separable bounds, fused top-two jobs; an incomplete pair table: the walk)
+                                       ("basic 2e5, 100 teams", 200_000, MODEL_BASIC, 0, False, 100),
+                                       ("basic 4e5, 200 teams", 400_000, MODEL_BASIC, 0, False, 200),
+                                       ("basic 5e4, 300 teams", 50_000, MODEL_BASIC, 0, False, 300),
+                                       ("extended 3e5, 150 teams K=3 w", 300_000, MODEL_EXTENDED, 3, True, 150)):
+    h, a, x, y = synthetic_league(n, T)
     cov = None
     if k:
-        cov = np.random.RandomState(0).normal(size=(20, k)); cov = (cov - cov.mean(0)) / cov.std(0)
+        cov = np.random.RandomState(0).normal(size=(T, k)); cov = (cov - cov.mean(0)) / cov.std(0)
     w = np.exp(-np.linspace(5.0, 0.0, n)).astype(np.float32) if weighted else None
-    c.set_fixtures(model, h, a, x, y, 20, weights=w, covariates_std=cov)
+    c.set_fixtures(model, h, a, x, y, T, weights=w, covariates_std=cov)
     D = c.dim
     z = torch.tensor(np.random.RandomState(7).uniform(-.5, .5, (64, D)), dtype=torch.float64, device=c.device)
     U = torch.zeros(64, dtype=torch.float64, device=c.device); g = torch.zeros_like(z)
