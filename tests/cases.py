@@ -19,6 +19,20 @@ def fixtures(name):
         fx, _ = O.fixtures_from_training_data(O.dummy_data_recipe())
         fx.covariates = np.random.RandomState(0).normal(size=(20, 5))
         return fx
+    if name.startswith("dummy_covk_"):   # the reference's recipe with K covariates: dummy_covk_K
+        k = int(name.split("_")[2])
+        fx, _ = O.fixtures_from_training_data(O.dummy_data_recipe())
+        fx.covariates = np.random.RandomState(100 + k).normal(size=(20, k))
+        return fx
+    if name.startswith("ragged64cov_"):   # 64 teams (the widest one-lane-per-team epilogue), K covariates
+        k = int(name.split("_")[1])
+        rs = np.random.RandomState(640 + k)
+        n, T = 9000, 64
+        h = rs.randint(0, T, n)
+        a = (h + 1 + rs.randint(0, T - 1, n)) % T
+        fx = O.Fixtures(h, a, rs.poisson(1.4, n), rs.poisson(1.1, n), T)
+        fx.covariates = rs.normal(size=(T, k))
+        return fx
     if name == "dummy_w":
         fx, _ = O.fixtures_from_training_data(O.dummy_data_recipe())
         fx.weights = float32_weights(np.linspace(5, 0, 380), 1.0)

@@ -83,6 +83,13 @@ CASES = [
     (O.MODEL_BASIC, "wide_4000_100"),
     (O.MODEL_EXTENDED, "wide_4000_100"),
     (O.MODEL_BASIC, "wide_30000_700"),
+    # covariate counts around the epilogue's one-pass coefficient sums (K <= 8: lane = coefficient x team residue;
+    # more: four wave sums per round), at 20 and at 64 teams
+    (O.MODEL_EXTENDED, "dummy_covk_1"),
+    (O.MODEL_EXTENDED, "dummy_covk_8"),
+    (O.MODEL_EXTENDED, "dummy_covk_9"),
+    (O.MODEL_EXTENDED, "ragged64cov_3"),
+    (O.MODEL_EXTENDED, "ragged64cov_8"),
     # ... with time weights and covariates (the lanes' exact rate products past 64 teams, weighted and clipped forms)
     (O.MODEL_EXTENDED, "widewc_20000_80"),
     (O.MODEL_EXTENDED, "widewc_60000_150"),
