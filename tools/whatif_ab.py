@@ -1,6 +1,9 @@
 """Timing only (the variants compute garbage): evaluation time of the basic and the extended model (5 covariates),
 N = 1e6, per library built with -DDC_WHATIF=n -- which part of an evaluation is on its critical path?
-python tools/whatif_ab.py libbplhip.so libbplhip_whatif7.so ...   (three interleaved rounds, a process per library)"""
+python tools/whatif_ab.py libbplhip.so libbplhip_whatif7.so ...   (three interleaved rounds, a process per library)
+Build a variant:  git apply tools/whatif.patch && hipcc <the Makefile's FLAGS> -DDC_WHATIF=7 -o bpl-next_amd/bpl/libbplhip_whatif7.so
+bpl-next_amd/csrc/bplhip.hip && git checkout bpl-next_amd/csrc/dc_kernels.hip.h   (variants: the patch's comments and
+profiles/r04/whatif.txt; 21-24 concern leagues of more than 64 teams: time them with BPLHIP_LIB=... tools/teams_sweep.py)"""
 import os, sys, subprocess
 CHILD = r'''
 import sys, os
